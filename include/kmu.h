@@ -1,0 +1,236 @@
+/*
+ * kmu.h -- C-ABI boundary of the MI355X (gfx950) k-mer generation + counting + sketching hot path.
+ *
+ * This is the drop-in boundary for the hot path of jean-pierreBoth/kmerutils (a Rust crate with no FFI of its
+ * own): every entry point below replaces a *Rust* interface of the reference, cited as `file:line` relative
+ * to the reference tree.  A Rust closure cannot cross an FFI, so the `fhash` closures the reference actually
+ * uses are enumerated in `kmu_fhash`.  INTEGRATION.md shows the `extern "C"` block and the
+ * `impl SeqSketcherT<Kmer> for ...` shim a maintainer would add on the Rust side.
+ *
+ * Conventions
+ *  - plain C scalars / pointers / sizes only; no torch, no C++ types.
+ *  - every call returns 0 (KMU_OK) or a negative kmu_status; kmu_last_error() gives the text.
+ *  - the caller owns every input and output buffer.  `mem` says where they live:
+ *      KMU_MEM_HOST   : host pointers; the library stages H2D / D2H itself (synchronous call).
+ *      KMU_MEM_DEVICE : HIP device pointers (e.g. a torch tensor's data_ptr()); kernels are enqueued on the
+ *                       context's stream and the call returns after the stream has been synchronised unless
+ *                       the context was created with `async_device = 1`.
+ *  - sequences are handed over as one concatenated byte array + (n_seq+1) uint64 offsets:
+ *      KMU_INPUT_ASCII  : bases[offsets[i] .. offsets[i+1]) are the ASCII letters of sequence i
+ *      KMU_INPUT_PACKED2: offsets are in *bases*; sequence i starts at byte `packed_byte_offsets[i]`
+ *                         and is packed exactly as reference `Sequence::new(raw,2)`
+ *                         (src/base/sequence.rs:48-73: 4 bases / byte, first base in bits 7..6).
+ *  - a kmu_ctx is used from one thread at a time; distinct contexts may run concurrently.
+ */
+#ifndef KMU_H
+#define KMU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMU_VERSION_MAJOR 0
+#define KMU_VERSION_MINOR 1
+
+typedef struct kmu_ctx kmu_ctx;
+typedef struct kmu_counter kmu_counter;
+
+typedef enum kmu_status {
+    KMU_OK = 0,
+    KMU_E_BAD_K = -1,        /* reference: panic in KmerSeqIterator::new, src/base/kmergenerator.rs:48-53 */
+    KMU_E_BAD_ALPHABET = -2,
+    KMU_E_EMPTY_SEQ = -3,    /* reference: ilog2(0) panic, src/sketching/nbkmerguess.rs:8 */
+    KMU_E_NON_ACGT = -4,     /* reference: Alphabet2b::encode panics, src/base/alphabet.rs:125 */
+    KMU_E_OOM = -5,
+    KMU_E_HIP = -6,
+    KMU_E_BAD_ARG = -7,
+    KMU_E_TABLE_FULL = -8,
+    KMU_E_UNSUPPORTED = -9,
+    KMU_E_NO_DEVICE = -10
+} kmu_status;
+
+typedef enum kmu_mem { KMU_MEM_HOST = 0, KMU_MEM_DEVICE = 1 } kmu_mem;
+typedef enum kmu_input_kind { KMU_INPUT_ASCII = 0, KMU_INPUT_PACKED2 = 1 } kmu_input_kind;
+
+/* k-mer value types of the reference (src/base/kmer32bit.rs:22, kmer16b32bit.rs:21, kmer64bit.rs:24,
+ * src/aautils/kmeraa.rs:146,280).  The type fixes Kmer::Val (u32 / u64) and the bit layout of `.0`. */
+typedef enum kmu_kmer_type {
+    KMU_KMER32BIT = 0,    /* k <= 14, u32, k stored in bits 31..28            */
+    KMU_KMER16B32BIT = 1, /* k == 16, u32                                     */
+    KMU_KMER64BIT = 2,    /* k <= 31, (u64, u8); k = 32 is broken upstream    */
+    KMU_KMERAA32BIT = 3,  /* amino acids, 5 bits, k <= 6, u32                 */
+    KMU_KMERAA64BIT = 4   /* amino acids, 5 bits, k <= 12, u64                */
+} kmu_kmer_type;
+
+/* The closures `fhash: Fn(&Kmer) -> Kmer::Val` that reference callers really pass. */
+typedef enum kmu_fhash {
+    KMU_FHASH_IDENTITY_RAW = 0,   /* kmer.0                      src/sketching/seqsketchjaccard.rs:775,883 */
+    KMU_FHASH_VALUE_MASKED = 1,   /* get_compressed_value() & mask   src/sketching/setsketchert.rs:1098-1104,
+                                                                     src/aautils/setsketchert.rs:1235-1241 */
+    KMU_FHASH_CANON_RAW = 2,      /* min(kmer, revcomp).0        src/base/kmercount.rs:313 */
+    KMU_FHASH_CANON_INVHASH = 3,  /* intNN_hash(min(kmer,revcomp).0)  src/bin/datasketcher.rs:222-226,
+                                                                      src/sketching/seqsketchjaccard.rs:931-935 */
+    KMU_FHASH_INVHASH_RAW = 4,    /* intNN_hash(kmer.0)          src/sketching/seqminhash.rs:38,49 */
+    KMU_FHASH_CANON_VALUE = 5,    /* min(kmer, revcomp).get_compressed_value()  src/base/kmercount.rs:313-316 */
+    KMU_FHASH_CANON_NTHASH = 6,   /* canonical ntHash, 2-bit seed table  src/base/kmer.rs:76-95 (any k) */
+    KMU_FHASH_CANON_NTHASH_8B = 7 /* canonical ntHash with the reference's ASCII table, bug-compatible:
+                                     'G' and 'T' map to seed 0   src/base/nthash.rs:48-57,214-228 */
+} kmu_fhash;
+
+typedef enum kmu_algo {
+    KMU_ALGO_PROB3A = 0, /* ProbMinHash3a  (probminhash crate), src/sketching/seqsketchjaccard.rs:211-260 */
+    KMU_ALGO_SUPER = 1,  /* SuperMinHash   (probminhash crate), src/sketching/setsketchert.rs:255-297 */
+    KMU_ALGO_SUPER2 = 2, /* SuperMinHash2  (integer sketch),   src/sketching/setsketchert.rs:963-1004 */
+    KMU_ALGO_BOTTOMK = 3 /* MinHashCount / MinInvHashCountKmer, src/sketching/minhash.rs:62-99,219-265 */
+} kmu_algo;
+
+typedef enum kmu_sig_type { KMU_SIG_U32 = 0, KMU_SIG_U64 = 1, KMU_SIG_F32 = 2, KMU_SIG_F64 = 3 } kmu_sig_type;
+
+/* std::hash::Hasher used to seed the per-element RNG */
+typedef enum kmu_hasher {
+    KMU_HASHER_NOHASH = 0, /* src/nohasher.rs:11-49: finish() = byte-swapped key on little-endian hosts */
+    KMU_HASHER_FNV1A = 1,  /* fnv::FnvHasher, src/sketching/seqsketchjaccard.rs:346-349 */
+    KMU_HASHER_INT64HASH = 2 /* BOTTOMK only: int64_hash(value as u64), MinInvHashCountKmer minhash.rs:223-233 */
+} kmu_hasher;
+
+typedef enum kmu_sketch_mode {
+    KMU_MODE_PER_SEQ = 0, /* sketch_compressedkmer: one signature per sequence      setsketchert.rs:121-157 */
+    KMU_MODE_ALL_SEQS = 1 /* sketch_compressedkmer_seqs: one signature for all       setsketchert.rs:160-202 */
+} kmu_sketch_mode;
+
+/* flags */
+#define KMU_FLAG_RAND08 0x1u /* index draws as rand 0.8 `Uniform<usize>` (64-bit widening multiply) instead of
+                                rand 0.9 (32-bit when the range fits u32); see DESIGN.md "unpinned" */
+
+typedef struct kmu_device_cfg {
+    int32_t device_id;     /* HIP device ordinal */
+    int32_t async_device;  /* 1: KMU_MEM_DEVICE calls return without synchronising the stream */
+    void *stream;          /* hipStream_t to enqueue on, or NULL to let the library create one */
+    uint64_t workspace_bytes; /* 0 = grow on demand */
+} kmu_device_cfg;
+
+typedef struct kmu_sketch_params {
+    int32_t algo;        /* kmu_algo */
+    int32_t kmer_type;   /* kmu_kmer_type */
+    int32_t kmer_size;
+    int32_t sketch_size; /* m */
+    int32_t sig_type;    /* kmu_sig_type; PROB3A/BOTTOMK: must match Kmer::Val width; SUPER: F32/F64 */
+    int32_t hasher;      /* kmu_hasher */
+    int32_t fhash;       /* kmu_fhash */
+    int32_t block_size;  /* 0 = whole sequence; >0 = BlockSeqSketcher (src/sketching/seqblocksketch.rs:97-149) */
+    int32_t mode;        /* kmu_sketch_mode */
+    int32_t input_kind;  /* kmu_input_kind */
+    int32_t mem;         /* kmu_mem */
+    uint32_t flags;
+} kmu_sketch_params;
+
+typedef struct kmu_hash_params {
+    int32_t kmer_type;
+    int32_t kmer_size;
+    int32_t fhash;
+    int32_t input_kind;
+    int32_t mem;
+    uint32_t flags;
+} kmu_hash_params;
+
+typedef struct kmu_count_params {
+    int32_t kmer_type;     /* DNA types only */
+    int32_t kmer_size;
+    int32_t counter_bits;  /* 8 or 16 (reference default 8: saturates at 255, src/base/kmercount.rs:1615) */
+    int32_t reserved;
+    uint64_t capacity_hint; /* expected number of distinct canonical k-mers */
+} kmu_count_params;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+const char *kmu_version(void);
+int kmu_device_count(void);
+int kmu_create(const kmu_device_cfg *cfg, kmu_ctx **out);
+void kmu_destroy(kmu_ctx *ctx);
+const char *kmu_last_error(const kmu_ctx *ctx); /* ctx may be NULL: last error of a failed kmu_create */
+int kmu_synchronize(kmu_ctx *ctx);
+void *kmu_stream(kmu_ctx *ctx); /* the hipStream_t kernels are enqueued on */
+
+/* per-kernel device timing with hipEvents on the context stream (bench.py roofline object) */
+int kmu_profile_enable(kmu_ctx *ctx, int on);
+int kmu_profile_reset(kmu_ctx *ctx);
+/* returns number of kernels known; fills up to `cap` entries */
+typedef struct kmu_kernel_stat {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} kmu_kernel_stat;
+int kmu_profile_get(kmu_ctx *ctx, kmu_kernel_stat *stats, int cap);
+
+/* ---- L0: alphabet + Sequence::new(raw, 2)  (src/base/alphabet.rs:119-127,162-168; sequence.rs:25-106) ---- */
+/* number of bytes b with !is_acgt(b) per sequence (alphabet.rs:28-31); counts_out[n_seq] */
+int kmu_count_non_acgt(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
+                       uint64_t *counts_out);
+/* pack every sequence as Sequence::new(raw,2).  packed_offsets_out[n_seq+1] (bytes) is written first;
+ * packed_out must hold sum(ceil(L_i/4)) bytes.  Returns KMU_E_NON_ACGT if any byte is not in ACGTacgt. */
+int kmu_pack2b(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
+               uint8_t *packed_out, uint64_t *packed_offsets_out);
+
+/* ---- L1/L2: k-mer generation + canonicalise + hash, one value per k-mer start position -------------
+ * KmerSeqIterator::next (src/base/kmergenerator.rs:75-106) followed by the fhash closure.
+ * out[offsets[i] + p] (uint64, zero-extended for u32 types) for p in [0, L_i-k+1); other entries untouched.
+ * For KMU_INPUT_PACKED2 `packed_offsets` gives the byte offset of every sequence (may be NULL for ASCII). */
+int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                    const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out);
+
+/* ---- L3 sketching: SeqSketcherT::sketch_compressedkmer{,_seqs}  (src/sketching/setsketchert.rs:54-80),
+ * SeqSketcher::sketch_probminhash3a / sketch_superminhash (src/sketching/seqsketchjaccard.rs:211,328),
+ * BlockSeqSketcher::blocksketch_sequences (src/sketching/seqblocksketch.rs:152-167),
+ * SeqSketcherAAT (src/aautils/setsketchert.rs:42-72) ------------------------------------------------
+ * sig_out: PER_SEQ, block_size == 0 : n_seq rows of sketch_size signatures, row i <-> sequence i
+ *          PER_SEQ, block_size  > 0 : rows block_row_offsets[i] .. block_row_offsets[i+1], one row per block
+ *                                     (block_row_offsets from kmu_block_layout; may be NULL if block_size==0)
+ *          ALL_SEQS                 : 1 row
+ * BOTTOMK: sig_out rows are sketch_size uint64 hashes ascending, padded with UINT64_MAX; counts_out (may be
+ *          NULL) gets sketch_size uint32 multiplicities per row. */
+int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_t *bases, const uint64_t *offsets,
+               const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *block_row_offsets, void *sig_out,
+               uint32_t *counts_out);
+/* nb_blocks_i = ceil(L_i / block_size) (seqblocksketch.rs:108-112); block_row_offsets_out[n_seq+1], host memory,
+ * offsets in host memory */
+int kmu_block_layout(const uint64_t *offsets, uint32_t n_seq, uint32_t block_size, uint64_t *block_row_offsets_out);
+
+/* fallback for arbitrary closures: the host evaluates fhash, the device does multiset + sketch only.
+ * hashed[offsets[i] .. offsets[i+1]) are the hashed k-mers of sequence i (uint32 or uint64 per p->sig_type /
+ * kmer_type width). */
+int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const void *hashed, const uint64_t *offsets,
+                      uint32_t n_seq, void *sig_out, uint32_t *counts_out);
+
+/* ---- L3 counting: KmerCountT (src/base/kmercount.rs:48-59), KmerCounter::insert_kmer :241-267,
+ * count_kmer_threaded_one_to_many :881-974, KmerCounterPool :424-565 --------------------------------- */
+int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out);
+void kmu_count_destroy(kmu_counter *c);
+int kmu_count_reset(kmu_counter *c);
+/* insert every canonical k-mer (min(kmer, revcomp), kmercount.rs:938) of every sequence */
+int kmu_count_add_reads(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets,
+                        const uint64_t *packed_offsets, uint32_t n_seq, int input_kind, int mem);
+/* insert pre-computed canonical compressed values (KmerCountT::insert_kmer, one call per value) */
+int kmu_count_add_kmers(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int mem);
+/* KmerCountT::get_count (kmercount.rs:270-277): 0 never seen, 1 singleton, else min(multiplicity, 2^bits-1) */
+int kmu_count_query(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int mem, uint32_t *counts_out);
+int kmu_count_nb_distinct(kmu_counter *c, uint64_t *out); /* kmercount.rs:280-282 */
+int kmu_count_nb_unique(kmu_counter *c, uint64_t *out);   /* kmercount.rs:285-287 */
+/* dump of (canonical k-mer, count) for count >= min_count (dump_kmer_counter, kmercount.rs:500-525 uses 2).
+ * Call with kmers_out == NULL to get the number of records in *n_out; records are sorted by k-mer value. */
+int kmu_count_dump(kmu_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,
+                   uint64_t *n_out);
+/* multi-GPU merge (one process per GPU): export the entries whose owner (int64_hash(kmer) % n_parts,
+ * kmercount.rs:412-420) is `part` as device/host arrays, and merge entries received from peers.
+ * The exchange itself is done by the host layer (RCCL all_to_all over xGMI). */
+int kmu_count_export_part(kmu_counter *c, uint32_t part, uint32_t n_parts, uint64_t *kmers_out, uint32_t *counts_out,
+                          uint64_t cap, int mem, uint64_t *n_out);
+int kmu_count_merge_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *counts, uint64_t n, int mem);
+/* drop every entry not owned by `part` (after the exchange each rank keeps only its key range) */
+int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMU_H */

@@ -1,0 +1,65 @@
+"""ctypes mirror of include/kmu.h (enums + parameter structs).  Shared by the product loader (lib.py) and by
+the test-only oracle loader (oracle/oracle.py); holds no compute."""
+import ctypes as C
+
+# kmu_status
+OK = 0
+E_BAD_K, E_BAD_ALPHABET, E_EMPTY_SEQ, E_NON_ACGT, E_OOM, E_HIP, E_BAD_ARG, E_TABLE_FULL, E_UNSUPPORTED, E_NO_DEVICE = (
+    -1, -2, -3, -4, -5, -6, -7, -8, -9, -10)
+STATUS_NAMES = {0: "KMU_OK", -1: "KMU_E_BAD_K", -2: "KMU_E_BAD_ALPHABET", -3: "KMU_E_EMPTY_SEQ", -4: "KMU_E_NON_ACGT",
+                -5: "KMU_E_OOM", -6: "KMU_E_HIP", -7: "KMU_E_BAD_ARG", -8: "KMU_E_TABLE_FULL",
+                -9: "KMU_E_UNSUPPORTED", -10: "KMU_E_NO_DEVICE"}
+
+MEM_HOST, MEM_DEVICE = 0, 1
+INPUT_ASCII, INPUT_PACKED2 = 0, 1
+KMER32BIT, KMER16B32BIT, KMER64BIT, KMERAA32BIT, KMERAA64BIT = 0, 1, 2, 3, 4
+(FHASH_IDENTITY_RAW, FHASH_VALUE_MASKED, FHASH_CANON_RAW, FHASH_CANON_INVHASH, FHASH_INVHASH_RAW, FHASH_CANON_VALUE,
+ FHASH_CANON_NTHASH, FHASH_CANON_NTHASH_8B) = range(8)
+ALGO_PROB3A, ALGO_SUPER, ALGO_SUPER2, ALGO_BOTTOMK = 0, 1, 2, 3
+SIG_U32, SIG_U64, SIG_F32, SIG_F64 = 0, 1, 2, 3
+HASHER_NOHASH, HASHER_FNV1A, HASHER_INT64HASH = 0, 1, 2
+MODE_PER_SEQ, MODE_ALL_SEQS = 0, 1
+FLAG_RAND08 = 0x1
+
+
+def kmer_val_bytes(kmer_type):
+    return 8 if kmer_type in (KMER64BIT, KMERAA64BIT) else 4
+
+
+def kmer_type_for_k(k, aa=False):
+    """The reference's choice of k-mer type for a k (kmer32bit.rs:68, kmer16b32bit.rs, kmer64bit.rs, kmeraa.rs)."""
+    if aa:
+        return KMERAA32BIT if k <= 6 else KMERAA64BIT
+    if k <= 14:
+        return KMER32BIT
+    if k == 16:
+        return KMER16B32BIT
+    return KMER64BIT
+
+
+class DeviceCfg(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("async_device", C.c_int32), ("stream", C.c_void_p),
+                ("workspace_bytes", C.c_uint64)]
+
+
+class SketchParams(C.Structure):
+    _fields_ = [("algo", C.c_int32), ("kmer_type", C.c_int32), ("kmer_size", C.c_int32), ("sketch_size", C.c_int32),
+                ("sig_type", C.c_int32), ("hasher", C.c_int32), ("fhash", C.c_int32), ("block_size", C.c_int32),
+                ("mode", C.c_int32), ("input_kind", C.c_int32), ("mem", C.c_int32), ("flags", C.c_uint32)]
+
+
+class HashParams(C.Structure):
+    _fields_ = [("kmer_type", C.c_int32), ("kmer_size", C.c_int32), ("fhash", C.c_int32), ("input_kind", C.c_int32),
+                ("mem", C.c_int32), ("flags", C.c_uint32)]
+
+
+class CountParams(C.Structure):
+    _fields_ = [("kmer_type", C.c_int32), ("kmer_size", C.c_int32), ("counter_bits", C.c_int32),
+                ("reserved", C.c_int32), ("capacity_hint", C.c_uint64)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+SIG_NP = {SIG_U32: "uint32", SIG_U64: "uint64", SIG_F32: "float32", SIG_F64: "float64"}

@@ -1,0 +1,1119 @@
+/*
+ * kmu_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See kmu_oracle.h for the parity status.
+ *
+ * Plain C99, single thread, written to be *literal*: same data structures and the same order of operations as
+ * the reference (per-read hash map -> ProbMinHash3a with MaxValueTracker and a to_be_processed list; streaming
+ * SuperMinHash with q/p/b arrays; heap-based bottom-k; first/second sighting counting).  Citations are
+ * `file:line` relative to the reference tree (jean-pierreBoth/kmerutils v0.0.14).
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off; no -ffast-math: f64 results must be IEEE exact)
+ */
+#include "kmu_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ====================================================================================================
+ * L0  alphabet + Sequence::new(raw,2)
+ * ==================================================================================================== */
+
+/* Alphabet2b::encode, src/base/alphabet.rs:119-127 (case-insensitive; anything else panics) */
+int kmo_encode2b(uint8_t c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+    }
+}
+
+/* Alphabet2b::decode, src/base/alphabet.rs:130-138 */
+uint8_t kmo_decode2b(uint8_t code) { return (uint8_t) "ACGT"[code & 3]; }
+
+/* count_non_acgt, src/base/alphabet.rs:28-31 */
+uint64_t kmo_count_non_acgt(const uint8_t *raw, uint64_t n) {
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; i++) bad += (kmo_encode2b(raw[i]) < 0);
+    return bad;
+}
+
+/* Sequence::new(raw, 2), src/base/sequence.rs:48-73 + Alphabet2b::base_pack alphabet.rs:162-168:
+ * 4 bases per byte, base i of a group in bits (7-2i)..(6-2i); incomplete last byte padded with 'A' (= 0). */
+int64_t kmo_pack2b(const uint8_t *raw, uint64_t n, uint8_t *out) {
+    uint64_t nb_full = n / 4, rem = n - 4 * nb_full;
+    for (uint64_t i = 0; i < nb_full; i++) {
+        uint8_t packed = 0;
+        for (int j = 0; j < 4; j++) {
+            int c = kmo_encode2b(raw[4 * i + j]);
+            if (c < 0) return -1;
+            packed |= (uint8_t) (c << (6 - 2 * j));
+        }
+        out[i] = packed;
+    }
+    if (rem > 0) {
+        uint8_t last[4] = {'A', 'A', 'A', 'A'};
+        for (uint64_t j = 0; j < rem; j++) last[j] = raw[4 * nb_full + j];
+        uint8_t packed = 0;
+        for (int j = 0; j < 4; j++) {
+            int c = kmo_encode2b(last[j]);
+            if (c < 0) return -1;
+            packed |= (uint8_t) (c << (6 - 2 * j));
+        }
+        out[nb_full] = packed;
+        return (int64_t) nb_full + 1;
+    }
+    return (int64_t) nb_full;
+}
+
+/* Sequence::encode_and_add / update_byte, src/base/sequence.rs:388-492: invalid bytes are skipped */
+int64_t kmo_pack2b_filtered(const uint8_t *raw, uint64_t n, uint8_t *out) {
+    uint64_t kept = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        int c = kmo_encode2b(raw[i]);
+        if (c < 0) continue;
+        if ((kept & 3) == 0) out[kept >> 2] = 0;
+        out[kept >> 2] |= (uint8_t) (c << (6 - 2 * (kept & 3)));
+        kept++;
+    }
+    return (int64_t) kept;
+}
+
+/* Sequence::get_base, src/base/sequence.rs:120-136 (2-bit branch); IterSequence::next :632 reads the same bits */
+uint8_t kmo_get_base(const uint8_t *packed, uint64_t pos) {
+    unsigned bit_offset = 2u * (unsigned) (pos % 4);
+    return (uint8_t) (3u & (packed[pos / 4] >> (8 - bit_offset - 2)));
+}
+
+/* aautils Alphabet::encode, src/aautils/kmeraa.rs:85-109 (upper case only, Q = 15, no 14) */
+int kmo_encode_aa(uint8_t c) {
+    switch (c) {
+    case 'A': return 1;  case 'C': return 2;  case 'D': return 3;  case 'E': return 4;  case 'F': return 5;
+    case 'G': return 6;  case 'H': return 7;  case 'I': return 8;  case 'K': return 9;  case 'L': return 10;
+    case 'M': return 11; case 'N': return 12; case 'P': return 13; case 'Q': return 15; case 'R': return 16;
+    case 'S': return 17; case 'T': return 18; case 'V': return 19; case 'W': return 20; case 'Y': return 21;
+    default: return -1;
+    }
+}
+
+/* ====================================================================================================
+ * L1  k-mer value types.  `raw` is the tuple field `.0` zero-extended to 64 bits.
+ * ==================================================================================================== */
+
+static int kmer_is_aa(int t) { return t == KMU_KMERAA32BIT || t == KMU_KMERAA64BIT; }
+static int kmer_val_bytes(int t) { return (t == KMU_KMER64BIT || t == KMU_KMERAA64BIT) ? 8 : 4; }
+
+static int kmer_check_k(int t, int k) {
+    if (k <= 0) return KMU_E_BAD_K;
+    switch (t) {
+    case KMU_KMER32BIT: return k <= 14 ? 0 : KMU_E_BAD_K;    /* kmer32bit.rs:68-71, get_nb_base_max :150 */
+    case KMU_KMER16B32BIT: return k == 16 ? 0 : KMU_E_BAD_K; /* kmergenerator.rs:218-220 */
+    case KMU_KMER64BIT: return k <= 31 ? 0 : KMU_E_BAD_K;    /* k = 32: push mask is 0 (kmer64bit.rs:75) */
+    case KMU_KMERAA32BIT: return k <= 6 ? 0 : KMU_E_BAD_K;   /* kmeraa.rs:146-274 */
+    case KMU_KMERAA64BIT: return k <= 12 ? 0 : KMU_E_BAD_K;  /* kmeraa.rs:353-355 get_nb_base_max = 12 */
+    default: return KMU_E_BAD_ARG;
+    }
+}
+
+/* KmerBuilder::build: kmer32bit.rs:212-216, kmer16b32bit.rs:127-131, kmer64bit.rs:167-171, kmeraa.rs:394-396 */
+uint64_t kmo_kmer_build(int t, uint64_t val, int k) {
+    if (t == KMU_KMER32BIT) return (uint32_t) (((uint32_t) k << 28) | (uint32_t) val);
+    if (t == KMU_KMER16B32BIT || t == KMU_KMERAA32BIT) return (uint32_t) val;
+    return val;
+}
+
+/* KmerT::push: kmer32bit.rs:98-113, kmer16b32bit.rs:57-61, kmer64bit.rs:68-80, kmeraa.rs:165-178,301-312 */
+uint64_t kmo_kmer_push(int t, uint64_t raw, int k, uint8_t base) {
+    switch (t) {
+    case KMU_KMER32BIT: {
+        uint32_t r = (uint32_t) raw;
+        uint32_t nb_mask = r & 0xF0000000u;
+        uint32_t value_mask = (1u << (2 * k)) - 1u;
+        uint32_t nk = ((r << 2) & value_mask) | (base & 3u);
+        return nk | nb_mask;
+    }
+    case KMU_KMER16B32BIT: return (uint32_t) (((uint32_t) raw << 2) | (base & 3u));
+    case KMU_KMER64BIT: {
+        uint64_t value_mask = (1ull << (2 * k)) - 1ull;
+        return ((raw << 2) & value_mask) | (base & 3ull);
+    }
+    case KMU_KMERAA32BIT: { /* base is already the 5-bit code here */
+        uint32_t value_mask = (1u << (5 * k)) - 1u;
+        return (((uint32_t) raw << 5) & value_mask) | (base & 31u);
+    }
+    case KMU_KMERAA64BIT: {
+        uint64_t value_mask = (1ull << (5 * k)) - 1ull;
+        return ((raw << 5) & value_mask) | (base & 31ull);
+    }
+    }
+    return 0;
+}
+
+static uint32_t bitrev32(uint32_t x) {
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+}
+static uint64_t bitrev64(uint64_t x) {
+    return ((uint64_t) bitrev32((uint32_t) x) << 32) | bitrev32((uint32_t) (x >> 32));
+}
+
+/* KmerT::reverse_complement: kmer32bit.rs:119-137, kmer16b32bit.rs:43-54, kmer64bit.rs:83-96 */
+uint64_t kmo_kmer_revcomp(int t, uint64_t raw, int k) {
+    switch (t) {
+    case KMU_KMER32BIT: {
+        uint32_t r = (uint32_t) raw;
+        uint32_t nb_mask = r & 0xF0000000u;
+        uint32_t rc = ~r;
+        rc = bitrev32(rc);
+        rc = ((rc & 0x55555555u) << 1) | ((rc & 0xAAAAAAAAu) >> 1);
+        rc >>= 32 - 2 * (nb_mask >> 28); /* rotate_left(4) of the mask = k */
+        rc = (rc & 0x0FFFFFFFu) | nb_mask;
+        return rc;
+    }
+    case KMU_KMER16B32BIT: {
+        uint32_t rc = ~(uint32_t) raw;
+        rc = bitrev32(rc);
+        rc = ((rc & 0x55555555u) << 1) | ((rc & 0xAAAAAAAAu) >> 1);
+        return rc;
+    }
+    case KMU_KMER64BIT: {
+        uint64_t rc = ~raw;
+        rc = bitrev64(rc);
+        rc = ((rc & 0x5555555555555555ull) << 1) | ((rc & 0xAAAAAAAAAAAAAAAAull) >> 1);
+        rc >>= 64 - 2 * k;
+        return rc;
+    }
+    }
+    return raw; /* AA: reverse_complement panics (kmeraa.rs:180-182,315-317); callers must not canonicalise */
+}
+
+/* CompressedKmerT::get_compressed_value: kmer32bit.rs:173-178, kmer16b32bit.rs:94-96, kmer64bit.rs:133-135 */
+uint64_t kmo_kmer_value(int t, uint64_t raw) { return t == KMU_KMER32BIT ? (raw & 0x0FFFFFFFull) : raw; }
+
+/* Ord: kmer32bit.rs:47-55 (k nibble first, then value), kmer64bit.rs:45-53 (same k => value) */
+int kmo_kmer_less(int t, uint64_t a, uint64_t b) {
+    if (t == KMU_KMER32BIT) {
+        uint32_t ka = (uint32_t) a & 0xF0000000u, kb = (uint32_t) b & 0xF0000000u;
+        if (ka != kb) return ka < kb;
+        return ((uint32_t) a & 0x0FFFFFFFu) < ((uint32_t) b & 0x0FFFFFFFu);
+    }
+    return a < b;
+}
+
+/* ====================================================================================================
+ * hashes
+ * ==================================================================================================== */
+
+/* probminhash::invhash::int32_hash (UNPINNED: third-party; Thomas Wang's hash32shift) */
+uint32_t kmo_int32_hash(uint32_t key) {
+    key = ~key + (key << 15);
+    key = key ^ (key >> 12);
+    key = key + (key << 2);
+    key = key ^ (key >> 4);
+    key = key * 2057u;
+    key = key ^ (key >> 16);
+    return key;
+}
+
+/* probminhash::invhash::int64_hash (UNPINNED: third-party; Thomas Wang's hash64shift) */
+uint64_t kmo_int64_hash(uint64_t key) {
+    key = ~key + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+/* NoHashHasher, src/nohasher.rs:22-48: big-endian assembly of the value's native (little-endian) bytes */
+uint64_t kmo_nohash_finish(uint64_t v, int width_bytes) {
+    if (width_bytes == 4) return (uint64_t) __builtin_bswap32((uint32_t) v);
+    return __builtin_bswap64(v);
+}
+
+/* fnv::FnvHasher over the little-endian bytes of the value (fnv 1.0, FNV-1a 64) */
+uint64_t kmo_fnv1a(uint64_t v, int width_bytes) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int i = 0; i < width_bytes; i++) {
+        h ^= (v >> (8 * i)) & 0xFF;
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+static uint64_t hasher_finish(int hasher, uint64_t v, int width_bytes) {
+    if (hasher == KMU_HASHER_FNV1A) return kmo_fnv1a(v, width_bytes);
+    if (hasher == KMU_HASHER_INT64HASH) return kmo_int64_hash(v); /* MinInvHashCountKmer, minhash.rs:223-233 */
+    return kmo_nohash_finish(v, width_bytes);
+}
+
+static uint64_t rotl64(uint64_t x, unsigned r) { r &= 63; return r ? (x << r) | (x >> (64 - r)) : x; }
+static uint64_t rotr64(uint64_t x, unsigned r) { r &= 63; return r ? (x >> r) | (x << (64 - r)) : x; }
+
+/* ntHash seeds, src/base/nthash.rs:17-20 */
+#define SEED_A 0x3c8bfbb395c60474ull
+#define SEED_C 0x3193c18562a02b4cull
+#define SEED_G 0x20323ed082572324ull
+#define SEED_T 0x295549f54be24456ull
+/* BASE_MAPPING_2B, nthash.rs:28-30: [A,C,G,T, T,G,C,A] */
+static const uint64_t NT_2B[8] = {SEED_A, SEED_C, SEED_G, SEED_T, SEED_T, SEED_G, SEED_C, SEED_A};
+
+/* BASE_MAPPING_8B, nthash.rs:48-57, restated by *index*: the literal table holds
+ *   [65]=A [67]=C [80]=G [83]=T | complements (+24): [89]=T [91]=G [104]=C [107]=A, everything else 0.
+ * i.e. ASCII 'G' (71) and 'T' (84) -- and their complements at 95 / 108 -- map to 0: a quirk of the reference
+ * table that its own roll==init tests (nthash.rs:333,379) cannot see.  Reproduced as is. */
+static uint64_t nt8b(unsigned idx) {
+    switch (idx) {
+    case 65: return SEED_A;  case 67: return SEED_C;  case 80: return SEED_G;  case 83: return SEED_T;
+    case 89: return SEED_T;  case 91: return SEED_G;  case 104: return SEED_C; case 107: return SEED_A;
+    default: return 0; /* the Rust table has 112 entries; indices >= 112 would panic -- never reached for ACGT */
+    }
+}
+
+/* nthash_init_8b, nthash.rs:153-161 */
+uint64_t kmo_nthash_init_8b(const uint8_t *kmer, int k) {
+    uint64_t h = 0;
+    for (int i = 0; i < k; i++) h ^= rotl64(nt8b(kmer[i]), (unsigned) (k - i - 1) % 64);
+    return h;
+}
+/* nthash_cycle_8b, nthash.rs:172-176 */
+uint64_t kmo_nthash_cycle_8b(uint64_t h, int k, uint8_t old_base, uint8_t new_base) {
+    return rotl64(h, 1) ^ rotl64(nt8b(old_base), (unsigned) k % 64) ^ nt8b(new_base);
+}
+/* nthash_canonical_init_8b, nthash.rs:214-228 */
+uint64_t kmo_nthash_canonical_init_8b(const uint8_t *kmer, int k, uint64_t *fh, uint64_t *rh, uint8_t *strand) {
+    uint64_t f = 0, r = 0;
+    for (int i = 0; i < k; i++) {
+        f ^= rotl64(nt8b(kmer[i]), (unsigned) (k - i - 1) % 64);
+        r ^= rotl64(nt8b(24u + kmer[i]), (unsigned) i % 64);
+    }
+    *fh = f; *rh = r;
+    if (f <= r) { if (strand) *strand = 0; return f; }
+    if (strand) *strand = 1;
+    return r;
+}
+/* nthash_canonical_cycle_8b, nthash.rs:232-246 (= nthash_cycle_8b + nthash_rcomp_cycle_8b :198-202) */
+uint64_t kmo_nthash_canonical_cycle_8b(int k, uint8_t old_base, uint8_t new_base, uint64_t *fh, uint64_t *rh,
+                                       uint8_t *strand) {
+    *fh = kmo_nthash_cycle_8b(*fh, k, old_base, new_base);
+    *rh = rotr64(*rh, 1) ^ rotr64(nt8b(24u + old_base), 1) ^ rotl64(nt8b(24u + new_base), (unsigned) (k - 1) % 64);
+    if (*fh <= *rh) { if (strand) *strand = 0; return *fh; }
+    if (strand) *strand = 1;
+    return *rh;
+}
+/* NtHash::nthash_canonical_init for 2-bit k-mers, src/base/kmer.rs:76-95 (value right-aligned, first base most
+ * significant); defined for every k (rotations taken mod 64 like the 8-bit functions) */
+uint64_t kmo_nthash_canonical_2b(uint64_t val, int k, uint64_t *fh, uint64_t *rh, uint8_t *strand) {
+    uint64_t f = 0, r = 0;
+    for (int i = 0; i < k; i++) {
+        unsigned base = (unsigned) (val >> (2 * (k - 1 - i))) & 3u;
+        f ^= rotl64(NT_2B[base], (unsigned) (k - i - 1));
+        r ^= rotl64(NT_2B[4 + base], (unsigned) i);
+    }
+    if (fh) *fh = f;
+    if (rh) *rh = r;
+    if (f <= r) { if (strand) *strand = 0; return f; }
+    if (strand) *strand = 1;
+    return r;
+}
+/* from_one_hash_val_to_mult_hash, nthash.rs:63-72 (MULTISHIFT 27, MULTISEED :10-13; wrapping multiply) */
+void kmo_nthash_mult(uint64_t ksize, uint64_t *hashed, int n) {
+    for (int i = 1; i < n; i++) {
+        uint64_t t = hashed[0] * ((uint64_t) i ^ (ksize * 0x90b45d39fb6da1faull));
+        t ^= t >> 27;
+        hashed[i] = t;
+    }
+}
+
+/* ====================================================================================================
+ * L2  forward k-mer iteration + fhash closures
+ * ==================================================================================================== */
+
+/* one sequence's forward k-mers as `.0` values: KmerSeqIterator::next, src/base/kmergenerator.rs:75-106
+ * (first k-mer assembled base by base :88-101, then push :83-86); AA: src/aautils/kmeraa.rs:568-627.
+ * `codes` are 2-bit (DNA) or 5-bit (AA) codes.  Returns the number of k-mers = max(0, L-k+1). */
+static uint64_t gen_kmers_codes(int t, int k, const uint8_t *codes, uint64_t L, uint64_t *out) {
+    if (L < (uint64_t) k) return 0;
+    int bits = kmer_is_aa(t) ? 5 : 2;
+    uint64_t val = 0;
+    for (int i = 0; i < k; i++) val |= (uint64_t) codes[i] << (bits * (k - 1 - i));
+    uint64_t raw = kmo_kmer_build(t, val, k);
+    uint64_t n = 0;
+    out[n++] = raw;
+    for (uint64_t p = (uint64_t) k; p < L; p++) {
+        raw = kmo_kmer_push(t, raw, k, codes[p]);
+        out[n++] = raw;
+    }
+    return n;
+}
+
+static int seq_to_codes(int t, const uint8_t *bases, uint64_t L, int input_kind, uint8_t *codes) {
+    if (kmer_is_aa(t)) {
+        for (uint64_t i = 0; i < L; i++) {
+            int c = kmo_encode_aa(bases[i]);
+            if (c < 0) return KMU_E_BAD_ALPHABET;
+            codes[i] = (uint8_t) c;
+        }
+        return 0;
+    }
+    if (input_kind == KMU_INPUT_PACKED2) {
+        for (uint64_t i = 0; i < L; i++) codes[i] = kmo_get_base(bases, i);
+        return 0;
+    }
+    for (uint64_t i = 0; i < L; i++) {
+        int c = kmo_encode2b(bases[i]);
+        if (c < 0) return KMU_E_NON_ACGT;
+        codes[i] = (uint8_t) c;
+    }
+    return 0;
+}
+
+static uint64_t value_mask_bits(int t, int k) {
+    int bits = (kmer_is_aa(t) ? 5 : 2) * k;
+    return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+}
+
+/* apply one of the fhash closures (A.4 of SURVEY.md) to a k-mer `.0` value */
+static uint64_t apply_fhash(int fhash, int t, int k, uint64_t raw) {
+    int w = kmer_val_bytes(t);
+    switch (fhash) {
+    case KMU_FHASH_IDENTITY_RAW: return raw;
+    case KMU_FHASH_VALUE_MASKED: return kmo_kmer_value(t, raw) & value_mask_bits(t, k);
+    case KMU_FHASH_INVHASH_RAW: return w == 4 ? kmo_int32_hash((uint32_t) raw) : kmo_int64_hash(raw);
+    default: break;
+    }
+    /* canonical variants: kmer.reverse_complement().min(kmer), kmercount.rs:313, datasketcher.rs:222-226 */
+    uint64_t rc = kmo_kmer_revcomp(t, raw, k);
+    uint64_t canon = kmo_kmer_less(t, rc, raw) ? rc : raw;
+    switch (fhash) {
+    case KMU_FHASH_CANON_RAW: return canon;
+    case KMU_FHASH_CANON_VALUE: return kmo_kmer_value(t, canon);
+    case KMU_FHASH_CANON_INVHASH: return w == 4 ? kmo_int32_hash((uint32_t) canon) : kmo_int64_hash(canon);
+    case KMU_FHASH_CANON_NTHASH: return kmo_nthash_canonical_2b(kmo_kmer_value(t, raw), k, 0, 0, 0);
+    default: return canon;
+    }
+}
+
+static int fhash_valid(int fhash, int t) {
+    if (fhash < 0 || fhash > KMU_FHASH_CANON_NTHASH_8B) return 0;
+    if (kmer_is_aa(t)) return fhash == KMU_FHASH_IDENTITY_RAW || fhash == KMU_FHASH_VALUE_MASKED ||
+                              fhash == KMU_FHASH_INVHASH_RAW;
+    return 1;
+}
+
+/* hashed k-mers of one sequence. `asc` = ASCII bytes (needed by NTHASH_8B only), may be NULL otherwise. */
+static int64_t seq_hashed_kmers(int t, int k, int fhash, const uint8_t *codes, const uint8_t *asc, uint64_t L,
+                                uint64_t *out) {
+    uint64_t n = gen_kmers_codes(t, k, codes, L, out);
+    if (fhash == KMU_FHASH_CANON_NTHASH_8B) {
+        if (!asc) return KMU_E_BAD_ARG;
+        /* literal rolling use of the reference functions: init once, then cycle (nthash.rs:214-246) */
+        uint64_t fh, rh;
+        for (uint64_t p = 0; p < n; p++) {
+            if (p == 0) out[p] = kmo_nthash_canonical_init_8b(asc, k, &fh, &rh, 0);
+            else out[p] = kmo_nthash_canonical_cycle_8b(k, asc[p - 1], asc[p - 1 + k], &fh, &rh, 0);
+        }
+        return (int64_t) n;
+    }
+    for (uint64_t p = 0; p < n; p++) out[p] = apply_fhash(fhash, t, k, out[p]);
+    return (int64_t) n;
+}
+
+static const uint8_t *seq_ptr(const uint8_t *bases, const uint64_t *offsets, const uint64_t *packed_offsets,
+                              int input_kind, uint32_t i) {
+    return input_kind == KMU_INPUT_PACKED2 ? bases + packed_offsets[i] : bases + offsets[i];
+}
+
+int kmo_kmer_hashes(const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                    const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out) {
+    int rc = kmer_check_k(p->kmer_type, p->kmer_size);
+    if (rc) return rc;
+    if (!fhash_valid(p->fhash, p->kmer_type)) return KMU_E_BAD_ARG;
+    if (p->input_kind == KMU_INPUT_PACKED2 && (!packed_offsets || p->fhash == KMU_FHASH_CANON_NTHASH_8B))
+        return KMU_E_BAD_ARG;
+    for (uint32_t i = 0; i < n_seq; i++) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        uint8_t *codes = (uint8_t *) malloc(L + 1);
+        const uint8_t *src = seq_ptr(bases, offsets, packed_offsets, p->input_kind, i);
+        rc = seq_to_codes(p->kmer_type, src, L, p->input_kind, codes);
+        if (rc) { free(codes); return rc; }
+        int64_t n = seq_hashed_kmers(p->kmer_type, p->kmer_size, p->fhash, codes,
+                                     p->input_kind == KMU_INPUT_ASCII ? src : 0, L, out + offsets[i]);
+        free(codes);
+        if (n < 0) return (int) n;
+    }
+    return 0;
+}
+
+/* ====================================================================================================
+ * RNG + distributions (UNPINNED: third-party crates rand 0.9 / rand_xoshiro 0.7 / probminhash 0.1)
+ * ==================================================================================================== */
+
+/* Xoshiro256PlusPlus::seed_from_u64 = four SplitMix64 outputs (rand_xoshiro) */
+void kmo_xoshiro_seed(uint64_t seed, uint64_t s[4]) {
+    uint64_t x = seed;
+    for (int i = 0; i < 4; i++) {
+        x += 0x9e3779b97f4a7c15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        s[i] = z ^ (z >> 31);
+    }
+}
+uint64_t kmo_xoshiro_next(uint64_t s[4]) {
+    uint64_t result = rotl64(s[0] + s[3], 23) + s[0];
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+static uint32_t xoshiro_next_u32(uint64_t s[4]) { return (uint32_t) (kmo_xoshiro_next(s) >> 32); }
+
+/* Uniform::<f64>::new(0.,1.).sample: 52 random mantissa bits in [1,2) minus 1 (scale = 1, low = 0) */
+static double unif01_f64(uint64_t s[4]) {
+    uint64_t bits = (kmo_xoshiro_next(s) >> 12) | 0x3FF0000000000000ull;
+    double d;
+    memcpy(&d, &bits, 8);
+    return d - 1.0;
+}
+/* Uniform::<f32>::new(0.,1.).sample: 23 bits from next_u32 */
+static float unif01_f32(uint64_t s[4]) {
+    uint32_t bits = (xoshiro_next_u32(s) >> 9) | 0x3F800000u;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f - 1.0f;
+}
+/* Uniform::<usize>::new(low, high).sample.
+ * rand 0.9: a 32-bit sample when high-1 fits u32; widening multiply, reject while lo < (2^32 - range) % range.
+ * rand 0.8 (KMU_FLAG_RAND08): 64-bit sample, accept when lo <= zone, zone = MAX - (MAX - range + 1) % range. */
+static uint64_t unif_usize(uint64_t s[4], uint64_t low, uint64_t high, uint32_t flags) {
+    uint64_t range = high - low;
+    if (flags & KMU_FLAG_RAND08) {
+        uint64_t ints_to_reject = (UINT64_MAX - range + 1) % range;
+        uint64_t zone = UINT64_MAX - ints_to_reject;
+        for (;;) {
+            unsigned __int128 m = (unsigned __int128) kmo_xoshiro_next(s) * range;
+            uint64_t hi = (uint64_t) (m >> 64), lo = (uint64_t) m;
+            if (lo <= zone) return low + hi;
+        }
+    }
+    if (high - 1 <= 0xFFFFFFFFull) {
+        uint32_t r32 = (uint32_t) range;
+        uint32_t thresh = (uint32_t) (0u - r32) % r32;
+        for (;;) {
+            uint64_t m = (uint64_t) xoshiro_next_u32(s) * r32;
+            uint32_t hi = (uint32_t) (m >> 32), lo = (uint32_t) m;
+            if (lo >= thresh) return low + hi;
+        }
+    } else {
+        uint64_t thresh = (0ull - range) % range;
+        for (;;) {
+            unsigned __int128 m = (unsigned __int128) kmo_xoshiro_next(s) * range;
+            uint64_t hi = (uint64_t) (m >> 64), lo = (uint64_t) m;
+            if (lo >= thresh) return low + hi;
+        }
+    }
+}
+
+/* exp(x) - 1 for 0 <= x <= ln 2, fixed 22-term Horner with no fused operations.  Shared *formula* with the HIP
+ * kernels (kmu_device.h) so that the one comparison it feeds is evaluated identically on both sides.  The
+ * reference calls libm's exp_m1 there; the two can differ by an ulp, which would matter only if a sample fell
+ * within 1 ulp of the acceptance boundary (probability ~1e-16 per call). */
+static double expm1_small(double x) {
+    static const double inv_fact[23] = {
+        1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+        1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+        1.0 / 1307674368000.0, 1.0 / 20922789888000.0, 1.0 / 355687428096000.0, 1.0 / 6402373705728000.0,
+        1.0 / 121645100408832000.0, 1.0 / 2432902008176640000.0, 1.0 / 51090942171709440000.0,
+        1.0 / 1124000727777607680000.0};
+    double acc = inv_fact[22];
+    for (int i = 21; i >= 1; i--) acc = acc * x + inv_fact[i];
+    return acc * x;
+}
+
+/* probminhash ExpRestricted01 (exponential law restricted to [0,1), Ertl ProbMinHash Alg. 4) */
+typedef struct { double lambda, c1, c2, c3; } exp01_t;
+static void exp01_init(exp01_t *e, double lambda) {
+    e->lambda = lambda;
+    e->c1 = (exp(lambda) - 1.0) / lambda;
+    e->c2 = log(2.0 / (1.0 + exp(-lambda))) / lambda;
+    e->c3 = (1.0 - exp(-lambda)) / lambda;
+}
+static double exp01_sample(const exp01_t *e, uint64_t s[4]) {
+    double x = e->c1 * unif01_f64(s);
+    if (x < 1.0) return x;
+    for (;;) {
+        x = unif01_f64(s);
+        if (x < e->c2) return x;
+        double y = 0.5 * unif01_f64(s);
+        if (y > 1.0 - x) {
+            x = 1.0 - x;
+            y = 1.0 - y;
+        }
+        if (x <= e->c3 * (1.0 - y)) return x;
+        if (e->c1 * y <= 1.0 - x) return x;
+        if (y * e->c1 * e->lambda <= expm1_small(e->lambda * (1.0 - x))) return x;
+    }
+}
+
+/* ====================================================================================================
+ * per-read weighted multiset: FnvHashMap<Val, u64>, seqsketchjaccard.rs:226-234 / setsketchert.rs:130-138.
+ * Insertion-ordered open-addressing map (iteration order of the reference's map is arbitrary; the sketch is
+ * order-independent except for exact f64 ties, resolved here towards the smaller key).
+ * ==================================================================================================== */
+typedef struct {
+    uint64_t *keys;
+    double *w;
+    uint64_t n, cap_items;
+    int64_t *slots; /* index into keys or -1 */
+    uint64_t nslots;
+} mset_t;
+
+static void mset_init(mset_t *m, uint64_t expected) {
+    m->cap_items = expected < 16 ? 16 : expected;
+    m->keys = (uint64_t *) malloc(m->cap_items * 8);
+    m->w = (double *) malloc(m->cap_items * 8);
+    m->n = 0;
+    m->nslots = 32;
+    while (m->nslots < 2 * m->cap_items) m->nslots <<= 1;
+    m->slots = (int64_t *) malloc(m->nslots * 8);
+    memset(m->slots, 0xFF, m->nslots * 8);
+}
+static void mset_free(mset_t *m) { free(m->keys); free(m->w); free(m->slots); }
+static void mset_clear(mset_t *m) { m->n = 0; memset(m->slots, 0xFF, m->nslots * 8); }
+static void mset_grow(mset_t *m) {
+    m->cap_items *= 2;
+    m->keys = (uint64_t *) realloc(m->keys, m->cap_items * 8);
+    m->w = (double *) realloc(m->w, m->cap_items * 8);
+    free(m->slots);
+    m->nslots *= 2;
+    m->slots = (int64_t *) malloc(m->nslots * 8);
+    memset(m->slots, 0xFF, m->nslots * 8);
+    for (uint64_t i = 0; i < m->n; i++) {
+        uint64_t h = kmo_int64_hash(m->keys[i] ^ 0x5bd1e995ull) & (m->nslots - 1);
+        while (m->slots[h] >= 0) h = (h + 1) & (m->nslots - 1);
+        m->slots[h] = (int64_t) i;
+    }
+}
+static void mset_add(mset_t *m, uint64_t key, double w) {
+    uint64_t h = kmo_int64_hash(key ^ 0x5bd1e995ull) & (m->nslots - 1);
+    while (m->slots[h] >= 0) {
+        if (m->keys[m->slots[h]] == key) { m->w[m->slots[h]] += w; return; }
+        h = (h + 1) & (m->nslots - 1);
+    }
+    if (m->n == m->cap_items) { mset_grow(m); mset_add(m, key, w); return; }
+    m->slots[h] = (int64_t) m->n;
+    m->keys[m->n] = key;
+    m->w[m->n] = w;
+    m->n++;
+}
+
+/* ====================================================================================================
+ * ProbMinHash3a (UNPINNED third-party: probminhash::probminhasher::ProbMinHash3a; Ertl arXiv 1911.00675)
+ * call sites: seqsketchjaccard.rs:235-240, setsketchert.rs:139-144, seqblocksketch.rs:125,137-138
+ * ==================================================================================================== */
+
+/* MaxValueTracker: binary tree over m leaves, parent(k) = m + k/2, root = values[2m-2] */
+typedef struct { int m; int last; double *v; } mvt_t;
+static void mvt_init(mvt_t *t, int m) {
+    t->m = m;
+    t->last = 2 * m - 2;
+    t->v = (double *) malloc((size_t) (2 * m - 1) * 8);
+    for (int i = 0; i <= t->last; i++) t->v[i] = 1.7976931348623157e308; /* f64::MAX */
+}
+static void mvt_update(mvt_t *t, int k, double value) {
+    /* nodes (2j, 2j+1) are siblings with parent m + j; leaves and internal nodes share one array */
+    double cur = value;
+    int ck = k;
+    if (!(cur < t->v[ck])) return;
+    for (;;) {
+        t->v[ck] = cur;
+        int pidx = t->m + ck / 2;
+        if (pidx > t->last) break;
+        int sib = ck ^ 1;
+        if (t->v[sib] >= t->v[pidx] && t->v[ck] >= t->v[pidx]) break; /* parent already holds this max */
+        if (cur < t->v[sib]) cur = t->v[sib];
+        ck = pidx;
+        if (!(cur < t->v[ck])) break;
+    }
+}
+static double mvt_max(const mvt_t *t) { return t->v[t->last]; }
+
+typedef struct { uint64_t key; double winv; uint64_t rng[4]; } pmh_pending_t;
+
+int kmo_probminhash3a(const uint64_t *keys, const double *weights, uint64_t n, int key_bytes, int m, uint32_t flags,
+                      uint64_t *sig_out, double *h_out) {
+    if (m < 2) return KMU_E_BAD_ARG;
+    exp01_t e;
+    exp01_init(&e, log((double) m / (double) (m - 1)));
+    mvt_t trk;
+    mvt_init(&trk, m);
+    for (int i = 0; i < m; i++) sig_out[i] = 0; /* initobj = Val::default() */
+    pmh_pending_t *pend = (pmh_pending_t *) malloc((n ? n : 1) * sizeof(pmh_pending_t));
+    uint64_t npend = 0;
+    double qmax;
+    /* strict `<` against the slot value as in the crate, except that an exact tie goes to the smaller key so
+     * that the result does not depend on the (arbitrary) map iteration order */
+#define PMH_TRY(k_, h_, key_)                                                                        \
+    do {                                                                                             \
+        if ((h_) < trk.v[k_] || ((h_) == trk.v[k_] && (key_) < sig_out[k_])) {                      \
+            sig_out[k_] = (key_);                                                                    \
+            mvt_update(&trk, (int) (k_), (h_));                                                      \
+        }                                                                                            \
+    } while (0)
+    for (uint64_t i = 0; i < n; i++) {
+        double winv = 1.0 / weights[i];
+        uint64_t s[4];
+        kmo_xoshiro_seed(kmo_nohash_finish(keys[i], key_bytes), s);
+        double h = winv * exp01_sample(&e, s);
+        qmax = mvt_max(&trk);
+        if (h < qmax) {
+            uint64_t k = unif_usize(s, 0, (uint64_t) m, flags);
+            PMH_TRY(k, h, keys[i]);
+            qmax = mvt_max(&trk);
+            if (winv < qmax) {
+                pend[npend].key = keys[i];
+                pend[npend].winv = winv;
+                memcpy(pend[npend].rng, s, 32);
+                npend++;
+            }
+        }
+    }
+    uint64_t round = 2;
+    while (npend > 0) {
+        uint64_t insert_pos = 0;
+        for (uint64_t j = 0; j < npend; j++) {
+            pmh_pending_t *it = &pend[j];
+            double h = it->winv * (double) (round - 1);
+            if (h < mvt_max(&trk)) {
+                h = h + it->winv * exp01_sample(&e, it->rng);
+                uint64_t k = unif_usize(it->rng, 0, (uint64_t) m, flags);
+                PMH_TRY(k, h, it->key);
+                qmax = mvt_max(&trk);
+                if (it->winv * (double) round < qmax) {
+                    if (insert_pos != j) pend[insert_pos] = *it;
+                    insert_pos++;
+                }
+            }
+        }
+        npend = insert_pos;
+        round++;
+    }
+#undef PMH_TRY
+    if (h_out) for (int i = 0; i < m; i++) h_out[i] = trk.v[i];
+    free(pend);
+    free(trk.v);
+    return 0;
+}
+
+/* ====================================================================================================
+ * SuperMinHash (UNPINNED third-party: probminhash::superminhasher::SuperMinHash; Ertl arXiv 1706.05698 Alg. 3)
+ * call sites: seqsketchjaccard.rs:346-360 (FnvHasher), setsketchert.rs:267-284 (NoHashHasher)
+ * ==================================================================================================== */
+typedef struct {
+    int m, mode; /* mode: 0 f64, 1 f32, 2 u64 (SuperMinHash2), 3 u32 (SuperMinHash2) */
+    double *hs;   /* float modes: hsketch (f32 values are kept exactly representable) */
+    uint64_t *hi; /* integer modes */
+    int64_t *q, *b;
+    int *p;
+    int64_t item_rank;
+    int a_upper, lg;
+} smh_t;
+
+#define SMH_INIT_VALUE 4294967295.0 /* F::from(u32::MAX): "something large" that still casts to usize */
+
+static int ceil_log2(int m) { int b = 0; while ((1 << b) < m) b++; return b; }
+
+static void smh_init(smh_t *s, int m, int mode) {
+    s->m = m; s->mode = mode; s->lg = ceil_log2(m);
+    s->hs = (double *) malloc((size_t) m * 8);
+    s->hi = (uint64_t *) malloc((size_t) m * 8);
+    s->q = (int64_t *) malloc((size_t) m * 8);
+    s->b = (int64_t *) calloc((size_t) m, 8);
+    s->p = (int *) calloc((size_t) m, sizeof(int));
+    for (int i = 0; i < m; i++) {
+        s->hs[i] = mode == 1 ? (double) (float) SMH_INIT_VALUE : SMH_INIT_VALUE;
+        s->hi[i] = mode == 3 ? 0xFFFFFFFFull : ~0ull;
+        s->q[i] = -1;
+    }
+    s->b[m - 1] = m;
+    s->a_upper = m - 1;
+    s->item_rank = 0;
+}
+static void smh_free(smh_t *s) { free(s->hs); free(s->hi); free(s->q); free(s->b); free(s->p); }
+
+/* SuperMinHash::sketch.  Integer modes = SuperMinHash2 (feature sminhash2), LOW CONFIDENCE:
+ * restated as the same (j, r) stream with r an integer draw of the signature width W and the slot value the
+ * fixed-point image of r + j:  (j << (W - ceil_log2 m)) | (r >> ceil_log2 m).  Provisional. */
+static void smh_sketch(smh_t *s, uint64_t hval, uint32_t flags) {
+    uint64_t rng[4];
+    kmo_xoshiro_seed(hval, rng);
+    int m = s->m;
+    int64_t irank = s->item_rank;
+    int j = 0;
+    while (j <= s->a_upper) {
+        double r = 0;
+        uint64_t ri = 0;
+        switch (s->mode) {
+        case 0: r = unif01_f64(rng); break;
+        case 1: r = (double) unif01_f32(rng); break;
+        case 2: ri = kmo_xoshiro_next(rng); break;
+        default: ri = xoshiro_next_u32(rng); break;
+        }
+        int k = (int) unif_usize(rng, (uint64_t) j, (uint64_t) m, flags);
+        if (s->q[j] != irank) { s->q[j] = irank; s->p[j] = j; }
+        if (s->q[k] != irank) { s->q[k] = irank; s->p[k] = k; }
+        int tmp = s->p[j]; s->p[j] = s->p[k]; s->p[k] = tmp;
+        int slot = s->p[j];
+        int better, j2;
+        if (s->mode <= 1) {
+            double rpj = s->mode == 1 ? (double) ((float) r + (float) j) : r + (double) j;
+            better = rpj < s->hs[slot];
+            double fl = floor(s->hs[slot]);
+            j2 = fl >= (double) (m - 1) ? m - 1 : (int) fl;
+            if (better) s->hs[slot] = rpj;
+        } else {
+            int W = s->mode == 2 ? 64 : 32;
+            uint64_t rpj = s->lg == 0 ? ri : (((uint64_t) j << (W - s->lg)) | (ri >> s->lg));
+            better = rpj < s->hi[slot];
+            uint64_t fl = s->lg == 0 ? 0 : (s->hi[slot] >> (W - s->lg));
+            j2 = fl >= (uint64_t) (m - 1) ? m - 1 : (int) fl;
+            if (better) s->hi[slot] = rpj;
+        }
+        if (better && j < j2) {
+            s->b[j2] -= 1;
+            s->b[j] += 1;
+            while (s->b[s->a_upper] == 0) s->a_upper -= 1;
+        }
+        j++;
+    }
+    s->item_rank += 1;
+}
+
+/* ====================================================================================================
+ * bottom-k with multiplicities: MinHashCount::push, src/sketching/minhash.rs:62-99 (u16 counts) and
+ * MinInvHashCountKmer::push :219-265 (u8 counts).  Literal: max-heap + map, `<=` acceptance.
+ * ==================================================================================================== */
+typedef struct { uint64_t *h; uint32_t *c; int n, size; } botk_t;
+static void botk_init(botk_t *b, int size) {
+    b->h = (uint64_t *) malloc((size_t) (size + 1) * 8);
+    b->c = (uint32_t *) malloc((size_t) (size + 1) * 4);
+    b->n = 0; b->size = size;
+}
+static void botk_free(botk_t *b) { free(b->h); free(b->c); }
+static void botk_push(botk_t *b, uint64_t new_hash, uint32_t count_mask) {
+    /* kept sorted ascending: b->h[n-1] is the heap's max */
+    int add = (b->n == 0) || (new_hash <= b->h[b->n - 1]) || (b->n < b->size);
+    if (!add) return;
+    int lo = 0, hi = b->n;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (b->h[mid] < new_hash) lo = mid + 1; else hi = mid; }
+    if (lo < b->n && b->h[lo] == new_hash) { b->c[lo] = (b->c[lo] + 1) & count_mask; return; }
+    memmove(b->h + lo + 1, b->h + lo, (size_t) (b->n - lo) * 8);
+    memmove(b->c + lo + 1, b->c + lo, (size_t) (b->n - lo) * 4);
+    b->h[lo] = new_hash; b->c[lo] = 1; b->n++;
+    if (b->n > b->size) b->n--; /* pop the max and its count */
+}
+
+/* ====================================================================================================
+ * L3  sketch drivers (same contract as kmu_sketch / kmu_sketch_hashed)
+ * ==================================================================================================== */
+
+static size_t sig_bytes(int sig_type) { return (sig_type == KMU_SIG_U32 || sig_type == KMU_SIG_F32) ? 4 : 8; }
+
+static int sketch_params_check(const kmu_sketch_params *p) {
+    if (p->algo != KMU_ALGO_BOTTOMK && p->sketch_size < 2) return KMU_E_BAD_ARG;
+    if (p->sketch_size < 1) return KMU_E_BAD_ARG;
+    int w = kmer_val_bytes(p->kmer_type);
+    switch (p->algo) {
+    case KMU_ALGO_PROB3A:
+        if (p->sig_type != (w == 4 ? KMU_SIG_U32 : KMU_SIG_U64)) return KMU_E_BAD_ARG;
+        if (p->hasher != KMU_HASHER_NOHASH) return KMU_E_BAD_ARG; /* every call site uses NoHashHasher */
+        break;
+    case KMU_ALGO_SUPER:
+        if (p->sig_type != KMU_SIG_F32 && p->sig_type != KMU_SIG_F64) return KMU_E_BAD_ARG;
+        break;
+    case KMU_ALGO_SUPER2:
+        if (p->sig_type != KMU_SIG_U32 && p->sig_type != KMU_SIG_U64) return KMU_E_BAD_ARG;
+        break;
+    case KMU_ALGO_BOTTOMK:
+        if (p->sig_type != KMU_SIG_U64) return KMU_E_BAD_ARG;
+        break;
+    default: return KMU_E_BAD_ARG;
+    }
+    if (p->block_size < 0) return KMU_E_BAD_ARG;
+    if (p->block_size > 0 && (p->algo != KMU_ALGO_PROB3A || p->mode != KMU_MODE_PER_SEQ)) return KMU_E_UNSUPPORTED;
+    return 0;
+}
+
+/* sketch one stream of hashed k-mers (values of Kmer::Val) into row `row` */
+typedef struct {
+    const kmu_sketch_params *p;
+    int w; /* bytes of Kmer::Val */
+    mset_t ms;
+    smh_t smh;
+    botk_t bk;
+    int open;
+} sk_state_t;
+
+static void sk_begin(sk_state_t *st, const kmu_sketch_params *p, uint64_t expected) {
+    st->p = p;
+    st->w = kmer_val_bytes(p->kmer_type);
+    if (p->algo == KMU_ALGO_PROB3A) mset_init(&st->ms, expected);
+    else if (p->algo == KMU_ALGO_SUPER) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_F32 ? 1 : 0);
+    else if (p->algo == KMU_ALGO_SUPER2) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_U32 ? 3 : 2);
+    else botk_init(&st->bk, p->sketch_size);
+    st->open = 1;
+}
+static void sk_feed(sk_state_t *st, const uint64_t *hashed, uint64_t n) {
+    const kmu_sketch_params *p = st->p;
+    if (p->algo == KMU_ALGO_PROB3A) {
+        for (uint64_t i = 0; i < n; i++) mset_add(&st->ms, hashed[i], 1.0);
+    } else if (p->algo == KMU_ALGO_SUPER || p->algo == KMU_ALGO_SUPER2) {
+        for (uint64_t i = 0; i < n; i++) smh_sketch(&st->smh, hasher_finish(p->hasher, hashed[i], st->w), p->flags);
+    } else {
+        /* MinHashCount counts are u16, MinInvHashCountKmer (hasher = int64_hash) u8; both wrap in release */
+        uint32_t cmask = p->hasher == KMU_HASHER_INT64HASH ? 0xFFu : 0xFFFFu;
+        for (uint64_t i = 0; i < n; i++) botk_push(&st->bk, hasher_finish(p->hasher, hashed[i], st->w), cmask);
+    }
+}
+static int sk_end(sk_state_t *st, void *sig_row, uint32_t *count_row) {
+    const kmu_sketch_params *p = st->p;
+    int m = p->sketch_size, rc = 0;
+    if (p->algo == KMU_ALGO_PROB3A) {
+        uint64_t *sig = (uint64_t *) malloc((size_t) m * 8);
+        if (st->ms.n == 0) { for (int i = 0; i < m; i++) sig[i] = 0; } /* empty map: signature = [initobj; m] */
+        else rc = kmo_probminhash3a(st->ms.keys, st->ms.w, st->ms.n, st->w, m, p->flags, sig, 0);
+        if (st->w == 4) for (int i = 0; i < m; i++) ((uint32_t *) sig_row)[i] = (uint32_t) sig[i];
+        else memcpy(sig_row, sig, (size_t) m * 8);
+        free(sig);
+        mset_free(&st->ms);
+    } else if (p->algo == KMU_ALGO_SUPER) {
+        if (p->sig_type == KMU_SIG_F32) for (int i = 0; i < m; i++) ((float *) sig_row)[i] = (float) st->smh.hs[i];
+        else memcpy(sig_row, st->smh.hs, (size_t) m * 8);
+        smh_free(&st->smh);
+    } else if (p->algo == KMU_ALGO_SUPER2) {
+        if (p->sig_type == KMU_SIG_U32) for (int i = 0; i < m; i++) ((uint32_t *) sig_row)[i] = (uint32_t) st->smh.hi[i];
+        else memcpy(sig_row, st->smh.hi, (size_t) m * 8);
+        smh_free(&st->smh);
+    } else {
+        for (int i = 0; i < m; i++) {
+            ((uint64_t *) sig_row)[i] = i < st->bk.n ? st->bk.h[i] : UINT64_MAX;
+            if (count_row) count_row[i] = i < st->bk.n ? st->bk.c[i] : 0;
+        }
+        botk_free(&st->bk);
+    }
+    st->open = 0;
+    return rc;
+}
+
+int kmo_sketch(const kmu_sketch_params *p, const uint8_t *bases, const uint64_t *offsets,
+               const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *block_row_offsets, void *sig_out,
+               uint32_t *counts_out) {
+    int rc = kmer_check_k(p->kmer_type, p->kmer_size);
+    if (rc) return rc;
+    rc = sketch_params_check(p);
+    if (rc) return rc;
+    if (!fhash_valid(p->fhash, p->kmer_type)) return KMU_E_BAD_ARG;
+    if (p->input_kind == KMU_INPUT_PACKED2 && (!packed_offsets || p->fhash == KMU_FHASH_CANON_NTHASH_8B))
+        return KMU_E_BAD_ARG;
+    if (p->block_size > 0 && !block_row_offsets) return KMU_E_BAD_ARG;
+    int m = p->sketch_size, k = p->kmer_size;
+    size_t row_bytes = (size_t) m * sig_bytes(p->sig_type);
+    sk_state_t st;
+    st.open = 0;
+    if (p->mode == KMU_MODE_ALL_SEQS) sk_begin(&st, p, 1024);
+    for (uint32_t i = 0; i < n_seq; i++) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        if (L == 0) { /* get_nbkmer_guess -> ilog2(0) panics, nbkmerguess.rs:8; blocks: assert seqblocksketch.rs:107 */
+            if (st.open) sk_end(&st, sig_out, counts_out);
+            return KMU_E_EMPTY_SEQ;
+        }
+        uint8_t *codes = (uint8_t *) malloc(L + 1);
+        uint64_t *hk = (uint64_t *) malloc((L + 1) * 8);
+        const uint8_t *src = seq_ptr(bases, offsets, packed_offsets, p->input_kind, i);
+        rc = seq_to_codes(p->kmer_type, src, L, p->input_kind, codes);
+        int64_t n = rc ? rc : seq_hashed_kmers(p->kmer_type, k, p->fhash, codes,
+                                               p->input_kind == KMU_INPUT_ASCII ? src : 0, L, hk);
+        if (n < 0) { free(codes); free(hk); if (st.open) sk_end(&st, sig_out, counts_out); return (int) n; }
+        if (p->mode == KMU_MODE_ALL_SEQS) {
+            sk_feed(&st, hk, (uint64_t) n);
+        } else if (p->block_size > 0) {
+            /* blocksketch_sequence, seqblocksketch.rs:97-149: nb_blocks = ceil(L / B); block j takes the next B
+             * k-mers of one continuous iterator; trailing blocks may be short or empty (-> all-zero signature) */
+            uint64_t B = (uint64_t) p->block_size;
+            uint64_t nb_blocks = (L % B == 0) ? L / B : 1 + L / B;
+            if (block_row_offsets[i + 1] - block_row_offsets[i] != nb_blocks) { free(codes); free(hk); return KMU_E_BAD_ARG; }
+            for (uint64_t j = 0; j < nb_blocks; j++) {
+                uint64_t b0 = j * B, b1 = b0 + B;
+                if (b0 > (uint64_t) n) b0 = (uint64_t) n;
+                if (b1 > (uint64_t) n) b1 = (uint64_t) n;
+                sk_begin(&st, p, B);
+                sk_feed(&st, hk + b0, b1 - b0);
+                rc = sk_end(&st, (uint8_t *) sig_out + (block_row_offsets[i] + j) * row_bytes, 0);
+            }
+        } else {
+            sk_begin(&st, p, (uint64_t) n);
+            sk_feed(&st, hk, (uint64_t) n);
+            rc = sk_end(&st, (uint8_t *) sig_out + (size_t) i * row_bytes,
+                        counts_out ? counts_out + (size_t) i * (size_t) m : 0);
+        }
+        free(codes);
+        free(hk);
+        if (rc) return rc;
+    }
+    if (p->mode == KMU_MODE_ALL_SEQS) return sk_end(&st, sig_out, counts_out);
+    return 0;
+}
+
+int kmo_sketch_hashed(const kmu_sketch_params *p, const void *hashed, const uint64_t *offsets, uint32_t n_seq,
+                      void *sig_out, uint32_t *counts_out) {
+    int rc = sketch_params_check(p);
+    if (rc) return rc;
+    if (p->block_size > 0) return KMU_E_UNSUPPORTED;
+    int w = kmer_val_bytes(p->kmer_type), m = p->sketch_size;
+    size_t row_bytes = (size_t) m * sig_bytes(p->sig_type);
+    sk_state_t st;
+    if (p->mode == KMU_MODE_ALL_SEQS) sk_begin(&st, p, 1024);
+    for (uint32_t i = 0; i < n_seq; i++) {
+        uint64_t n = offsets[i + 1] - offsets[i];
+        uint64_t *hk = (uint64_t *) malloc((n + 1) * 8);
+        for (uint64_t j = 0; j < n; j++)
+            hk[j] = w == 4 ? ((const uint32_t *) hashed)[offsets[i] + j] : ((const uint64_t *) hashed)[offsets[i] + j];
+        if (p->mode == KMU_MODE_ALL_SEQS) sk_feed(&st, hk, n);
+        else {
+            sk_begin(&st, p, n);
+            sk_feed(&st, hk, n);
+            rc = sk_end(&st, (uint8_t *) sig_out + (size_t) i * row_bytes,
+                        counts_out ? counts_out + (size_t) i * (size_t) m : 0);
+        }
+        free(hk);
+        if (rc) return rc;
+    }
+    if (p->mode == KMU_MODE_ALL_SEQS) return sk_end(&st, sig_out, counts_out);
+    return 0;
+}
+
+/* ====================================================================================================
+ * L3  counting: KmerCounter::insert_kmer, src/base/kmercount.rs:241-267, get_count :270-277.
+ * The reference's cuckoo/Bloom filters are randomised per process (RandomState / thread_rng), so only the
+ * observable contract can be restated: first sighting -> singleton set (+ nb_distinct), second -> moved to the
+ * counter with value 2, then ++ saturating at 2^bits - 1; this oracle is the zero-false-positive limit.
+ * ==================================================================================================== */
+struct kmo_counter {
+    kmu_count_params p;
+    uint64_t *keys;
+    uint32_t *cnt;
+    uint8_t *used;
+    uint64_t nslots, n;
+};
+
+kmo_counter *kmo_count_create(const kmu_count_params *p) {
+    if (kmer_check_k(p->kmer_type, p->kmer_size) || kmer_is_aa(p->kmer_type)) return 0;
+    if (p->counter_bits != 8 && p->counter_bits != 16) return 0;
+    kmo_counter *c = (kmo_counter *) calloc(1, sizeof(*c));
+    c->p = *p;
+    c->nslots = 1024;
+    while (c->nslots < 2 * p->capacity_hint) c->nslots <<= 1;
+    c->keys = (uint64_t *) malloc(c->nslots * 8);
+    c->cnt = (uint32_t *) calloc(c->nslots, 4);
+    c->used = (uint8_t *) calloc(c->nslots, 1);
+    return c;
+}
+void kmo_count_destroy(kmo_counter *c) {
+    if (!c) return;
+    free(c->keys); free(c->cnt); free(c->used); free(c);
+}
+static void count_insert(kmo_counter *c, uint64_t v, uint32_t add);
+static void count_grow(kmo_counter *c) {
+    uint64_t on = c->nslots;
+    uint64_t *ok = c->keys; uint32_t *oc = c->cnt; uint8_t *ou = c->used;
+    c->nslots *= 2;
+    c->keys = (uint64_t *) malloc(c->nslots * 8);
+    c->cnt = (uint32_t *) calloc(c->nslots, 4);
+    c->used = (uint8_t *) calloc(c->nslots, 1);
+    c->n = 0;
+    for (uint64_t i = 0; i < on; i++) if (ou[i]) count_insert(c, ok[i], oc[i]);
+    free(ok); free(oc); free(ou);
+}
+static void count_insert(kmo_counter *c, uint64_t v, uint32_t add) {
+    if (2 * (c->n + 1) > c->nslots) count_grow(c);
+    uint64_t h = kmo_int64_hash(v) & (c->nslots - 1);
+    while (c->used[h]) {
+        if (c->keys[h] == v) { uint64_t s = (uint64_t) c->cnt[h] + add; c->cnt[h] = s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) s; return; }
+        h = (h + 1) & (c->nslots - 1);
+    }
+    c->used[h] = 1; c->keys[h] = v; c->cnt[h] = add; c->n++;
+}
+int kmo_count_add_kmers(kmo_counter *c, const uint64_t *canon, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) count_insert(c, canon[i], 1);
+    return 0;
+}
+int kmo_count_add_reads(kmo_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq) {
+    kmu_hash_params hp = {c->p.kmer_type, c->p.kmer_size, KMU_FHASH_CANON_VALUE, KMU_INPUT_ASCII, KMU_MEM_HOST, 0};
+    for (uint32_t i = 0; i < n_seq; i++) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        if (L < (uint64_t) hp.kmer_size) {
+            if (kmo_count_non_acgt(bases + offsets[i], L)) return KMU_E_NON_ACGT;
+            continue;
+        }
+        uint64_t *hk = (uint64_t *) malloc(L * 8);
+        uint64_t off2[2] = {0, L};
+        int rc = kmo_kmer_hashes(&hp, bases + offsets[i], off2, 0, 1, hk);
+        if (rc) { free(hk); return rc; }
+        kmo_count_add_kmers(c, hk, L - (uint64_t) hp.kmer_size + 1);
+        free(hk);
+    }
+    return 0;
+}
+static uint32_t count_clamp(const kmo_counter *c, uint32_t v) {
+    uint32_t mx = c->p.counter_bits == 8 ? 255u : 65535u;
+    return v > mx ? mx : v;
+}
+int kmo_count_query(kmo_counter *c, const uint64_t *canon, uint64_t n, uint32_t *counts_out) {
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t h = kmo_int64_hash(canon[i]) & (c->nslots - 1);
+        counts_out[i] = 0;
+        while (c->used[h]) {
+            if (c->keys[h] == canon[i]) { counts_out[i] = count_clamp(c, c->cnt[h]); break; }
+            h = (h + 1) & (c->nslots - 1);
+        }
+    }
+    return 0;
+}
+uint64_t kmo_count_nb_distinct(kmo_counter *c) { return c->n; }
+uint64_t kmo_count_nb_unique(kmo_counter *c) {
+    uint64_t u = 0;
+    for (uint64_t i = 0; i < c->nslots; i++) u += (c->used[i] && c->cnt[i] == 1);
+    return u;
+}
+typedef struct { uint64_t k; uint32_t c; } kc_t;
+static int kc_cmp(const void *a, const void *b) {
+    uint64_t x = ((const kc_t *) a)->k, y = ((const kc_t *) b)->k;
+    return x < y ? -1 : (x > y);
+}
+int kmo_count_dump(kmo_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,
+                   uint64_t *n_out) {
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < c->nslots; i++) n += (c->used[i] && c->cnt[i] >= min_count);
+    *n_out = n;
+    if (!kmers_out) return 0;
+    if (cap < n) return KMU_E_BAD_ARG;
+    kc_t *v = (kc_t *) malloc((n ? n : 1) * sizeof(kc_t));
+    uint64_t j = 0;
+    for (uint64_t i = 0; i < c->nslots; i++)
+        if (c->used[i] && c->cnt[i] >= min_count) { v[j].k = c->keys[i]; v[j].c = count_clamp(c, c->cnt[i]); j++; }
+    qsort(v, n, sizeof(kc_t), kc_cmp);
+    for (j = 0; j < n; j++) { kmers_out[j] = v[j].k; counts_out[j] = v[j].c; }
+    free(v);
+    return 0;
+}

@@ -1,0 +1,207 @@
+"""ctypes loader for the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  It is the checker /
+the reported CPU baseline, never the thing shipped: kmerutils_amd never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from kmerutils_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libkmu_oracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "kmu_oracle.c")
+        if not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
+            build()
+        _lib = C.CDLL(_SO)
+        L = _lib
+        u8p, u64p, u32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p
+        L.kmo_encode2b.argtypes = [C.c_uint8]; L.kmo_encode2b.restype = C.c_int
+        L.kmo_encode_aa.argtypes = [C.c_uint8]; L.kmo_encode_aa.restype = C.c_int
+        L.kmo_count_non_acgt.argtypes = [vp, C.c_uint64]; L.kmo_count_non_acgt.restype = C.c_uint64
+        L.kmo_pack2b.argtypes = [vp, C.c_uint64, vp]; L.kmo_pack2b.restype = C.c_int64
+        L.kmo_pack2b_filtered.argtypes = [vp, C.c_uint64, vp]; L.kmo_pack2b_filtered.restype = C.c_int64
+        L.kmo_get_base.argtypes = [vp, C.c_uint64]; L.kmo_get_base.restype = C.c_uint8
+        for f in ("kmo_kmer_build",):
+            getattr(L, f).argtypes = [C.c_int, C.c_uint64, C.c_int]; getattr(L, f).restype = C.c_uint64
+        L.kmo_kmer_push.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_uint8]; L.kmo_kmer_push.restype = C.c_uint64
+        L.kmo_kmer_revcomp.argtypes = [C.c_int, C.c_uint64, C.c_int]; L.kmo_kmer_revcomp.restype = C.c_uint64
+        L.kmo_kmer_value.argtypes = [C.c_int, C.c_uint64]; L.kmo_kmer_value.restype = C.c_uint64
+        L.kmo_kmer_less.argtypes = [C.c_int, C.c_uint64, C.c_uint64]; L.kmo_kmer_less.restype = C.c_int
+        L.kmo_int32_hash.argtypes = [C.c_uint32]; L.kmo_int32_hash.restype = C.c_uint32
+        L.kmo_int64_hash.argtypes = [C.c_uint64]; L.kmo_int64_hash.restype = C.c_uint64
+        L.kmo_nohash_finish.argtypes = [C.c_uint64, C.c_int]; L.kmo_nohash_finish.restype = C.c_uint64
+        L.kmo_fnv1a.argtypes = [C.c_uint64, C.c_int]; L.kmo_fnv1a.restype = C.c_uint64
+        L.kmo_nthash_init_8b.argtypes = [vp, C.c_int]; L.kmo_nthash_init_8b.restype = C.c_uint64
+        L.kmo_nthash_cycle_8b.argtypes = [C.c_uint64, C.c_int, C.c_uint8, C.c_uint8]
+        L.kmo_nthash_cycle_8b.restype = C.c_uint64
+        L.kmo_nthash_canonical_init_8b.argtypes = [vp, C.c_int, u64p, u64p, u8p]
+        L.kmo_nthash_canonical_init_8b.restype = C.c_uint64
+        L.kmo_nthash_canonical_cycle_8b.argtypes = [C.c_int, C.c_uint8, C.c_uint8, u64p, u64p, u8p]
+        L.kmo_nthash_canonical_cycle_8b.restype = C.c_uint64
+        L.kmo_nthash_canonical_2b.argtypes = [C.c_uint64, C.c_int, u64p, u64p, u8p]
+        L.kmo_nthash_canonical_2b.restype = C.c_uint64
+        L.kmo_nthash_mult.argtypes = [C.c_uint64, vp, C.c_int]; L.kmo_nthash_mult.restype = None
+        L.kmo_xoshiro_seed.argtypes = [C.c_uint64, vp]; L.kmo_xoshiro_seed.restype = None
+        L.kmo_xoshiro_next.argtypes = [vp]; L.kmo_xoshiro_next.restype = C.c_uint64
+        L.kmo_kmer_hashes.argtypes = [C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp]
+        L.kmo_kmer_hashes.restype = C.c_int
+        L.kmo_sketch.argtypes = [C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
+        L.kmo_sketch.restype = C.c_int
+        L.kmo_sketch_hashed.argtypes = [C.POINTER(A.SketchParams), vp, vp, C.c_uint32, vp, vp]
+        L.kmo_sketch_hashed.restype = C.c_int
+        L.kmo_probminhash3a.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_uint32, vp, vp]
+        L.kmo_probminhash3a.restype = C.c_int
+        L.kmo_count_create.argtypes = [C.POINTER(A.CountParams)]; L.kmo_count_create.restype = vp
+        L.kmo_count_destroy.argtypes = [vp]; L.kmo_count_destroy.restype = None
+        L.kmo_count_add_reads.argtypes = [vp, vp, vp, C.c_uint32]; L.kmo_count_add_reads.restype = C.c_int
+        L.kmo_count_add_kmers.argtypes = [vp, vp, C.c_uint64]; L.kmo_count_add_kmers.restype = C.c_int
+        L.kmo_count_query.argtypes = [vp, vp, C.c_uint64, vp]; L.kmo_count_query.restype = C.c_int
+        L.kmo_count_nb_distinct.argtypes = [vp]; L.kmo_count_nb_distinct.restype = C.c_uint64
+        L.kmo_count_nb_unique.argtypes = [vp]; L.kmo_count_nb_unique.restype = C.c_uint64
+        L.kmo_count_dump.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64, u64p]; L.kmo_count_dump.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(A.STATUS_NAMES.get(code, str(code)))
+        self.code = code
+
+
+def concat(seqs):
+    """list of bytes -> (bases uint8[total], offsets uint64[n+1])"""
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
+    if bases.size == 0:
+        bases = np.zeros(1, np.uint8)
+    return bases, offsets
+
+
+def pack2b(raw):
+    raw = np.frombuffer(bytes(raw), dtype=np.uint8)
+    out = np.zeros((raw.size + 3) // 4 + 1, np.uint8)
+    n = lib().kmo_pack2b(_p(raw) if raw.size else None, raw.size, _p(out))
+    if n < 0:
+        raise OracleError(A.E_NON_ACGT)
+    return out[:n].copy()
+
+
+def kmer_hashes(bases, offsets, kmer_type, k, fhash, input_kind=A.INPUT_ASCII, packed_offsets=None):
+    hp = A.HashParams(kmer_type, k, fhash, input_kind, A.MEM_HOST, 0)
+    out = np.zeros(max(int(offsets[-1]), 1), dtype=np.uint64)
+    rc = lib().kmo_kmer_hashes(C.byref(hp), _p(bases), _p(offsets), _p(packed_offsets), len(offsets) - 1, _p(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def block_layout(offsets, block_size):
+    L = np.diff(offsets.astype(np.int64))
+    nb = (L + block_size - 1) // block_size
+    out = np.zeros(len(offsets), np.uint64)
+    out[1:] = np.cumsum(nb)
+    return out
+
+
+def sketch(bases, offsets, params, packed_offsets=None, want_counts=False):
+    n = len(offsets) - 1
+    m = params.sketch_size
+    bro = None
+    if params.mode == A.MODE_ALL_SEQS:
+        rows = 1
+    elif params.block_size > 0:
+        bro = block_layout(offsets, params.block_size)
+        rows = int(bro[-1])
+    else:
+        rows = n
+    sig = np.zeros((rows, m), dtype=A.SIG_NP[params.sig_type])
+    counts = np.zeros((rows, m), np.uint32) if want_counts else None
+    p = A.SketchParams.from_buffer_copy(params)
+    p.mem = A.MEM_HOST
+    rc = lib().kmo_sketch(C.byref(p), _p(bases), _p(offsets), _p(packed_offsets), n, _p(bro), _p(sig), _p(counts))
+    if rc:
+        raise OracleError(rc)
+    return (sig, counts) if want_counts else sig
+
+
+def sketch_hashed(hashed, offsets, params, want_counts=False):
+    n = len(offsets) - 1
+    rows = 1 if params.mode == A.MODE_ALL_SEQS else n
+    sig = np.zeros((rows, params.sketch_size), dtype=A.SIG_NP[params.sig_type])
+    counts = np.zeros((rows, params.sketch_size), np.uint32) if want_counts else None
+    rc = lib().kmo_sketch_hashed(C.byref(params), _p(hashed), _p(offsets), n, _p(sig), _p(counts))
+    if rc:
+        raise OracleError(rc)
+    return (sig, counts) if want_counts else sig
+
+
+def probminhash3a(keys, weights, key_bytes, m, flags=0):
+    keys = np.ascontiguousarray(keys, np.uint64)
+    weights = np.ascontiguousarray(weights, np.float64)
+    sig = np.zeros(m, np.uint64)
+    h = np.zeros(m, np.float64)
+    rc = lib().kmo_probminhash3a(_p(keys), _p(weights), keys.size, key_bytes, m, flags, _p(sig), _p(h))
+    if rc:
+        raise OracleError(rc)
+    return sig, h
+
+
+class Counter:
+    def __init__(self, kmer_type, k, counter_bits=8, capacity_hint=1024):
+        self.p = A.CountParams(kmer_type, k, counter_bits, 0, capacity_hint)
+        self.h = lib().kmo_count_create(C.byref(self.p))
+        if not self.h:
+            raise OracleError(A.E_BAD_ARG)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().kmo_count_destroy(self.h)
+            self.h = None
+
+    def add_reads(self, bases, offsets):
+        rc = lib().kmo_count_add_reads(self.h, _p(bases), _p(offsets), len(offsets) - 1)
+        if rc:
+            raise OracleError(rc)
+
+    def add_kmers(self, canon):
+        canon = np.ascontiguousarray(canon, np.uint64)
+        lib().kmo_count_add_kmers(self.h, _p(canon), canon.size)
+
+    def query(self, canon):
+        canon = np.ascontiguousarray(canon, np.uint64)
+        out = np.zeros(canon.size, np.uint32)
+        lib().kmo_count_query(self.h, _p(canon), canon.size, _p(out))
+        return out
+
+    def nb_distinct(self):
+        return int(lib().kmo_count_nb_distinct(self.h))
+
+    def nb_unique(self):
+        return int(lib().kmo_count_nb_unique(self.h))
+
+    def dump(self, min_count=2):
+        n = C.c_uint64(0)
+        lib().kmo_count_dump(self.h, min_count, None, None, 0, C.byref(n))
+        k = np.zeros(max(n.value, 1), np.uint64)
+        c = np.zeros(max(n.value, 1), np.uint32)
+        lib().kmo_count_dump(self.h, min_count, _p(k), _p(c), n.value, C.byref(n))
+        return k[:n.value], c[:n.value]

@@ -1,0 +1,244 @@
+"""Pin the CPU oracle against every exact known-answer test the reference holds for the hot path
+(SURVEY.md section 4 / 8c).  Vectors live in tests/golden/reference_kats.json with their reference citations."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+DNA = "ACGT"
+AA = {1: "A", 2: "C", 3: "D", 4: "E", 5: "F", 6: "G", 7: "H", 8: "I", 9: "K", 10: "L", 11: "M", 12: "N", 13: "P",
+      15: "Q", 16: "R", 17: "S", 18: "T", 19: "V", 20: "W", 21: "Y"}
+
+
+def decode_dna(val, k):
+    return "".join(DNA[(val >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def decode_aa(val, k):
+    return "".join(AA[(val >> (5 * (k - 1 - i))) & 31] for i in range(k))
+
+
+def from_str(O, kmer_type, s):
+    """Kmer32bit::from_str / Kmer64bit::from_str: new(k) then push every base"""
+    k = len(s)
+    raw = O.lib().kmo_kmer_build(kmer_type, 0, k)
+    for c in s.encode():
+        raw = O.lib().kmo_kmer_push(kmer_type, raw, k, O.lib().kmo_encode2b(c))
+    return raw
+
+
+def test_alphabet_and_packing(oracle):
+    L = oracle.lib()
+    assert L.kmo_encode2b(ord("G")) == KAT["alphabet2b"]["G"]
+    assert [L.kmo_encode2b(ord(c)) for c in "ACGTacgt"] == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert L.kmo_encode2b(ord("N")) == -1
+    for v in KAT["pack2b"]:
+        packed = oracle.pack2b(v["raw"].encode())
+        assert len(packed) == v["bytes"]
+        assert packed[0] == v["byte0"]  # ACGT -> 0x1B
+        if "byte1_top2" in v:
+            assert (packed[1] >> 6) & 3 == v["byte1_top2"]
+            assert packed[1] & 0x3F == 0  # tail padded with 'A' = 0 (sequence.rs:66-71)
+        assert len(v["raw"]) % 4 == v["last"]
+        for i, c in enumerate(v["raw"]):
+            assert L.kmo_get_base(packed.ctypes.data, i) == L.kmo_encode2b(ord(c))
+    with pytest.raises(oracle.OracleError):
+        oracle.pack2b(b"ACNT")
+    assert L.kmo_count_non_acgt(np.frombuffer(b"ACNTxacgt", np.uint8).ctypes.data, 9) == 2
+
+
+def test_encode_and_add_filters(oracle):
+    L = oracle.lib()
+    for v in KAT["encode_and_add"]:
+        raw = np.frombuffer(v["raw"].encode(), np.uint8)
+        out = np.zeros(16, np.uint8)
+        kept = L.kmo_pack2b_filtered(raw.ctypes.data, raw.size, out.ctypes.data)
+        s = "".join(DNA[L.kmo_get_base(out.ctypes.data, i)] for i in range(kept))
+        assert s == v["kept"]
+
+
+def test_revcomp_bit_patterns(oracle):
+    L = oracle.lib()
+    for a, b in zip(KAT["revcomp16"]["in"], KAT["revcomp16"]["out"]):
+        assert L.kmo_kmer_revcomp(A.KMER16B32BIT, int(a, 2), 16) == int(b, 2)
+    for v in KAT["revcomp_str"]:
+        for t in (A.KMER32BIT, A.KMER64BIT):
+            k = len(v["in"])
+            rc = L.kmo_kmer_revcomp(t, from_str(oracle, t, v["in"]), k)
+            assert rc == from_str(oracle, t, v["out"])
+    o = KAT["ord32"]
+    a, b = from_str(oracle, A.KMER32BIT, o["a"]), from_str(oracle, A.KMER32BIT, o["b"])
+    assert bool(L.kmo_kmer_less(A.KMER32BIT, b, a)) == o["a_gt_b"]
+    assert not L.kmo_kmer_less(A.KMER32BIT, a, a)
+
+
+@pytest.mark.parametrize("name,kmer_type,k", [("seq80", A.KMER16B32BIT, 16), ("seq50", A.KMER16B32BIT, 16),
+                                              ("seq50", A.KMER32BIT, 11), ("seq50", A.KMER64BIT, 21),
+                                              ("seq48", A.KMER64BIT, 21), ("seq48", A.KMER16B32BIT, 16)])
+def test_kmer_iteration_decodes_to_substrings(oracle, name, kmer_type, k):
+    """kmergenerator.rs:596-732, 897-972: every k-mer decodes to seq[i..i+k]; the iterator stops after L-k+1"""
+    s = KAT[name]
+    bases, off = oracle.concat([s.encode()])
+    out = oracle.kmer_hashes(bases, off, kmer_type, k, A.FHASH_IDENTITY_RAW)
+    n = len(s) - k + 1
+    for i in range(n):
+        raw = int(out[i])
+        if kmer_type == A.KMER32BIT:
+            assert raw >> 28 == k  # k lives in the top nibble (kmer32bit.rs:212-216)
+            raw &= 0x0FFFFFFF
+        assert decode_dna(raw, k) == s[i:i + k]
+    assert not out[n:].any()
+    # same through the packed Sequence::new(raw,2) input
+    packed = oracle.pack2b(s.encode())
+    out2 = oracle.kmer_hashes(packed, off, kmer_type, k, A.FHASH_IDENTITY_RAW, A.INPUT_PACKED2,
+                              np.zeros(2, np.uint64))
+    assert (out2 == out).all()
+
+
+def test_range_iterator(oracle):
+    v = KAT["range_iter"]
+    s = KAT[v["seq"]][v["begin"]:v["end"]]
+    bases, off = oracle.concat([s.encode()])
+    out = oracle.kmer_hashes(bases, off, A.KMER16B32BIT, v["k"], A.FHASH_IDENTITY_RAW)
+    n = len(s) - v["k"] + 1
+    assert n == v["n_kmers"]
+    for i in range(n):
+        assert decode_dna(int(out[i]), v["k"]) == KAT[v["seq"]][v["begin"] + i: v["begin"] + i + v["k"]]
+
+
+def test_3mer_multiplicity_table(oracle):
+    """kmergenerator.rs:777-850"""
+    s = KAT["seq48"]
+    bases, off = oracle.concat([s.encode()])
+    out = oracle.kmer_hashes(bases, off, A.KMER32BIT, 3, A.FHASH_VALUE_MASKED)[:len(s) - 2]
+    vals, cnt = np.unique(out, return_counts=True)
+    got = {decode_dna(int(v), 3): int(c) for v, c in zip(vals, cnt)}
+    assert got == KAT["kmer3_multiplicity"]["table"]
+
+
+def test_weighted_kmer64(oracle):
+    """kmergenerator.rs:853-894: k=15 on the repeated string, the first 9+... k-mers have weight 2"""
+    s = KAT["seq72_repeat"]
+    bases, off = oracle.concat([s.encode()])
+    out = oracle.kmer_hashes(bases, off, A.KMER64BIT, 15, A.FHASH_IDENTITY_RAW)[:len(s) - 14]
+    vals, cnt = np.unique(out, return_counts=True)
+    for v, c in zip(vals, cnt):
+        sub = decode_dna(int(v), 15)
+        assert sum(1 for i in range(len(s) - 14) if s[i:i + 15] == sub) == c
+    assert set(cnt.tolist()) == {1, 2}
+
+
+def test_nthash_roll_equals_init(oracle):
+    """nthash.rs:303-381: rolled hash == re-initialised hash at every position, forward and canonical"""
+    L = oracle.lib()
+    import ctypes as C
+    s = KAT["seq80"].encode()
+    k = 16
+    buf = np.frombuffer(s, np.uint8)
+    h = L.kmo_nthash_init_8b(buf.ctypes.data, k)
+    fh, rh, st = C.c_uint64(), C.c_uint64(), C.c_uint8()
+    hc = L.kmo_nthash_canonical_init_8b(buf.ctypes.data, k, C.byref(fh), C.byref(rh), C.byref(st))
+    for i in range(1, len(s) - k):
+        h = L.kmo_nthash_cycle_8b(h, k, s[i - 1], s[i - 1 + k])
+        assert h == L.kmo_nthash_init_8b(buf[i:].ctypes.data, k)
+        hc = L.kmo_nthash_canonical_cycle_8b(k, s[i - 1], s[i - 1 + k], C.byref(fh), C.byref(rh), C.byref(st))
+        f2, r2, s2 = C.c_uint64(), C.c_uint64(), C.c_uint8()
+        assert hc == L.kmo_nthash_canonical_init_8b(buf[i:].ctypes.data, k, C.byref(f2), C.byref(r2), C.byref(s2))
+        assert (fh.value, rh.value, st.value) == (f2.value, r2.value, s2.value)
+    # the per-position contract of KMU_FHASH_CANON_NTHASH_8B is exactly that
+    bases, off = oracle.concat([s])
+    out = oracle.kmer_hashes(bases, off, A.KMER16B32BIT, k, A.FHASH_CANON_NTHASH_8B)
+    for i in range(len(s) - k + 1):
+        assert out[i] == L.kmo_nthash_canonical_init_8b(buf[i:].ctypes.data, k, C.byref(fh), C.byref(rh), None)
+
+
+def test_nthash_2bit_derived_kat(oracle):
+    """SURVEY.md 8(a6) derived KAT for the proper seed table: first 16-mer of seq80"""
+    L = oracle.lib()
+    import ctypes as C
+    s = KAT["seq80"][:16]
+    val = 0
+    for c in s:
+        val = (val << 2) | DNA.index(c)
+    fh, rh, st = C.c_uint64(), C.c_uint64(), C.c_uint8()
+    h = L.kmo_nthash_canonical_2b(val, 16, C.byref(fh), C.byref(rh), C.byref(st))
+    assert fh.value == 0x9840eab169670ddf and rh.value == 0x684a2ec1114d51c5
+    assert h == rh.value and st.value == 1
+
+
+def test_aa_kmers(oracle):
+    aa = KAT["aa"]
+    r = aa["range"]
+    s = aa["seq149"][r["begin"]:r["end"]]
+    for t in (A.KMERAA32BIT, A.KMERAA64BIT):
+        bases, off = oracle.concat([s.encode()])
+        out = oracle.kmer_hashes(bases, off, t, r["k"], A.FHASH_IDENTITY_RAW)
+        got = [decode_aa(int(out[i]), r["k"]) for i in range(len(s) - r["k"] + 1)]
+        assert got == r["kmers"]
+    e = aa["end"]
+    bases, off = oracle.concat([e["seq"].encode()])
+    out = oracle.kmer_hashes(bases, off, A.KMERAA64BIT, e["k"], A.FHASH_IDENTITY_RAW)
+    assert decode_aa(int(out[len(e["seq"]) - e["k"]]), e["k"]) == e["last"]
+    # k = 12 works through the iterator (60-bit values)
+    s12 = aa["seq149"]
+    bases, off = oracle.concat([s12.encode()])
+    out = oracle.kmer_hashes(bases, off, A.KMERAA64BIT, 12, A.FHASH_VALUE_MASKED)
+    for i in (0, 7, len(s12) - 12):
+        assert decode_aa(int(out[i]), 12) == s12[i:i + 12]
+    with pytest.raises(oracle.OracleError):
+        oracle.kmer_hashes(*oracle.concat([b"MTEQB"]), A.KMERAA32BIT, 3, A.FHASH_IDENTITY_RAW)  # 'B' panics
+
+
+def test_counting_semantics(oracle):
+    """kmercount.rs:1524-1559, 1580-1617"""
+    s = KAT["seq80"]
+    bases, off = oracle.concat([s.encode()])
+    vk = oracle.kmer_hashes(bases, off, A.KMER16B32BIT, 16, A.FHASH_IDENTITY_RAW)[:65]
+    rng = np.random.default_rng(7)
+    c = oracle.Counter(A.KMER16B32BIT, 16, 8, 1024)
+    c.add_kmers(vk[:2])
+    c.add_kmers(vk[rng.integers(2, 65, 100000)])
+    c.add_kmers(vk[1:2])
+    exp = KAT["count"]
+    assert c.query(vk[:2]).tolist() == [exp["kmer0_count"], exp["kmer1_count"]]
+    c2 = oracle.Counter(A.KMER16B32BIT, 16, 8, 1024)
+    c2.add_kmers(vk[rng.integers(32, 65, 100000)])
+    got = c2.query(vk)
+    assert (got[:32] == exp["never_inserted"]).all() and (got[32:] == exp["saturated"]).all()
+    assert c2.nb_distinct() == len(set(vk[32:].tolist())) and c2.nb_unique() == 0
+    c3 = oracle.Counter(A.KMER16B32BIT, 16, 16, 1024)
+    c3.add_kmers(np.repeat(vk[:1], 70000))
+    assert c3.query(vk[:1])[0] == 65535
+
+
+def test_canonical_fhash_modes(oracle):
+    L = oracle.lib()
+    s = KAT["seq80"]
+    rcs = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    for t, k in ((A.KMER32BIT, 8), (A.KMER16B32BIT, 16), (A.KMER64BIT, 31)):
+        b1, o1 = oracle.concat([s.encode()])
+        b2, o2 = oracle.concat([rcs.encode()])
+        n = len(s) - k + 1
+        for fh in (A.FHASH_CANON_RAW, A.FHASH_CANON_INVHASH, A.FHASH_CANON_VALUE, A.FHASH_CANON_NTHASH):
+            h1 = oracle.kmer_hashes(b1, o1, t, k, fh)[:n]
+            h2 = oracle.kmer_hashes(b2, o2, t, k, fh)[:n]
+            assert (h1 == h2[::-1]).all()  # strand invariance
+        raw = oracle.kmer_hashes(b1, o1, t, k, A.FHASH_IDENTITY_RAW)[:n]
+        ch = oracle.kmer_hashes(b1, o1, t, k, A.FHASH_CANON_INVHASH)[:n]
+        for i in range(n):
+            r = int(raw[i])
+            rc = L.kmo_kmer_revcomp(t, r, k)
+            canon = rc if L.kmo_kmer_less(t, rc, r) else r
+            want = L.kmo_int32_hash(canon) if A.kmer_val_bytes(t) == 4 else L.kmo_int64_hash(canon)
+            assert int(ch[i]) == want
+    # hashers
+    assert L.kmo_nohash_finish(0x01020304, 4) == 0x04030201
+    assert L.kmo_nohash_finish(0x0102030405060708, 8) == 0x0807060504030201
+    h = 0xcbf29ce484222325
+    for byte in (0x04, 0x03, 0x02, 0x01):
+        h = ((h ^ byte) * 0x100000001b3) & (2**64 - 1)
+    assert L.kmo_fnv1a(0x01020304, 4) == h
