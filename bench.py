@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X: Gbases/s of the k-mer + sketch (+ count) hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over the whole synthetic read set resident in HBM:
+    default workload `ont_k31`: 746 333 ONT-shaped reads / 4.38 Gbases per GPU (BASELINE config 3's read set) at the
+    metric's k = 31: ProbMinHash3a, 200 sketches per read (u64 signatures, fhash = int64_hash(min(kmer, revcomp)))
+    + kmercount of every canonical 31-mer (table reset included), + for N > 1 the owner-partition exchange.
+Weak scaling: every rank holds its own read shard of that size (same genome, different read seed); value is the
+whole-job aggregate.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ont_k31", choices=["ont_k31", "ont_k31_sketch", "ont_k31_count", "c3_k8",
+                                                                "c2_count", "c1_super"])
+    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU")
+    ap.add_argument("--bases", type=float, default=0, help="override total bases per GPU")
+    ap.add_argument("--genome", type=int, default=100_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads timed on the host oracle (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sketch-size", type=int, default=0)
+    return ap.parse_args()
+
+
+def workload_cfg(args):
+    from kmerutils_amd import _abi as A
+    w = args.workload
+    cfg = dict(name=w, n_reads=746_333, total_bases=4.38e9, fixed_len=None, errors=(0.04, 0.02, 0.02), k=31,
+               kmer_type=A.KMER64BIT, m=200, algo=A.ALGO_PROB3A, sig=A.SIG_U64, hasher=A.HASHER_NOHASH,
+               fhash=A.FHASH_CANON_INVHASH, sketch=True, count=True, seed=0xC3, genome=args.genome)
+    if w == "ont_k31_sketch":
+        cfg.update(count=False)
+    elif w == "ont_k31_count":
+        cfg.update(sketch=False)
+    elif w == "c3_k8":
+        cfg.update(k=8, kmer_type=A.KMER32BIT, sig=A.SIG_U32, count=False)
+    elif w == "c2_count":
+        cfg.update(n_reads=1_000_000, total_bases=1.5e8, fixed_len=150, errors=(0.005, 0, 0), k=21, sketch=False,
+                   seed=0xC2, genome=10_000_000)
+    elif w == "c1_super":
+        cfg.update(n_reads=10_000, total_bases=1e7, fixed_len=1000, errors=(0, 0, 0), k=16, kmer_type=A.KMER16B32BIT,
+                   m=64, algo=A.ALGO_SUPER, sig=A.SIG_F64, count=False, seed=0xC1, genome=20_000_000)
+    if args.reads:
+        cfg["total_bases"] = cfg["total_bases"] * args.reads / cfg["n_reads"]
+        cfg["n_reads"] = args.reads
+    if args.bases:
+        cfg["total_bases"] = args.bases
+    if args.sketch_size:
+        cfg["m"] = args.sketch_size
+    return cfg
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from kmerutils_amd import _abi as A
+    from kmerutils_amd import dist as kdist
+    from kmerutils_amd import lib, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    cfg = workload_cfg(args)
+
+    # ---- synthetic reads, generated in HBM (same genome on every rank, rank-specific reads) -----------------
+    t_gen = time.time()
+    n_reads = cfg["n_reads"]
+    torch.manual_seed(cfg["seed"])
+    bases, offsets, lens = _gen(synth, cfg, dev, rank)
+    total_bases = int(offsets[-1].item())
+    nk = int(np.maximum(lens - cfg["k"] + 1, 0).sum())
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+
+    stream = torch.cuda.Stream(device=dev)
+    ctx = lib.Context(local_rank, stream=stream.cuda_stream, async_device=True)
+    p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0,
+                       A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_DEVICE, 0)
+    sig_dtype = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
+                 A.SIG_F64: torch.float64}[cfg["sig"]]
+    sig = torch.zeros((n_reads, cfg["m"]), dtype=sig_dtype, device=dev) if cfg["sketch"] else None
+    counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024)) if cfg["count"] else None
+
+    def step():
+        if cfg["sketch"]:
+            ctx.sketch(bases, offsets, p, out=sig)
+        if cfg["count"]:
+            counter.reset()
+            counter.add_reads(bases, offsets)
+            if world > 1:
+                ctx.synchronize()
+                kdist.merge_counters(counter, device=dev)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+        barrier()
+        t1 = time.perf_counter()
+        ctx.profile_enable(False)
+    elapsed = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tb = torch.tensor([total_bases], dtype=torch.float64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        job_bases = float(tb.item())
+    else:
+        job_bases = float(total_bases)
+    stats = ctx.profile_get()
+
+    # ---- sanity of what was computed (not timed) ---------------------------------------------------------
+    checks = {}
+    if cfg["sketch"]:
+        checks["sig_checksum"] = int(sig.view(torch.int64 if sig.element_size() == 8 else torch.int32).sum().item())
+    if cfg["count"] and world == 1:
+        checks["nb_distinct"] = counter.nb_distinct()
+
+    if rank == 0:
+        value = job_bases * args.steps / elapsed / 1e9
+        # ---- roofline of the dominant kernel (HBM-bound integer path) -------------------------------------
+        alg_bytes = {
+            "k_sketch_pmh3a": total_bases + n_reads * cfg["m"] * (8 if cfg["sig"] in (A.SIG_U64, A.SIG_F64) else 4),
+            "k_sketch_super": total_bases + n_reads * cfg["m"] * (8 if cfg["sig"] in (A.SIG_U64, A.SIG_F64) else 4),
+            "k_count_add_flat": total_bases + nk * 16,
+        }
+        kern = {}
+        for name, (launches, ms) in stats.items():
+            if launches:
+                avg = ms / launches
+                ent = {"launches": launches, "avg_ms": avg}
+                if name in alg_bytes:
+                    ent["alg_bytes"] = alg_bytes[name]
+                    ent["GBps"] = alg_bytes[name] / (avg * 1e-3) / 1e9
+                kern[name] = ent
+        dom = max((n for n in kern if n in alg_bytes), key=lambda n: kern[n]["avg_ms"] * kern[n]["launches"],
+                  default=None)
+        roofline = None
+        if dom:
+            ach = kern[dom]["GBps"]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"],
+                        "alg_bytes_per_launch": kern[dom]["alg_bytes"]}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(cfg, bases, offsets, lens, args.cpu_sample_reads)
+        out = {
+            "metric": "Gbases/sec k-mer+sketch throughput, k=31, 200 sketches/read",
+            "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": _describe(cfg, n_reads, total_bases), "reads_per_gpu": n_reads,
+                       "bases_per_gpu": total_bases, "kmers_per_gpu": nk, "k": cfg["k"], "sketch_size": cfg["m"],
+                       "sketch": cfg["sketch"], "count": cfg["count"], "parallelism": "reads sharded x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
+            "checks": checks, "gen_seconds": t_gen,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _gen(synth, cfg, dev, rank):
+    import torch
+    # same genome on every rank (genome seed), rank-specific read sampling
+    bases, offsets, lens = synth.ont_reads_device(cfg["n_reads"], cfg["total_bases"], cfg["genome"],
+                                                  cfg["seed"], dev, errors=cfg["errors"], fixed_len=cfg["fixed_len"],
+                                                  read_seed=cfg["seed"] * 1000 + rank)
+    return bases, offsets, lens
+
+
+def _describe(cfg, n_reads, total_bases):
+    ops = []
+    if cfg["sketch"]:
+        ops.append("%s m=%d" % ("ProbMinHash3a" if cfg["algo"] == 0 else "SuperMinHash", cfg["m"]))
+    if cfg["count"]:
+        ops.append("kmercount 8-bit")
+    shape = "%d x %d bp reads" % (n_reads, cfg["fixed_len"]) if cfg["fixed_len"] else \
+        "%d ONT-shaped reads (log-normal lengths, 8%% errors)" % n_reads
+    return "%s: %s, %.3g bases, k=%d, %s" % (cfg["name"], shape, total_bases, cfg["k"], " + ".join(ops))
+
+
+def cpu_baseline(cfg, bases, offsets, lens, sample_reads):
+    """The oracle (a C restatement of the reference algorithm, single thread = `kind: port`) timed on this box's host
+    cores over a bounded sample of the same workload."""
+    from kmerutils_amd import _abi as A
+    from oracle import oracle as O
+    O.lib()
+    if not sample_reads:
+        # aim at roughly 10-20 s of single-thread work
+        target_bases = 6e7 if (cfg["sketch"] and cfg["count"]) else 1e8
+        csum = np.cumsum(lens)
+        sample_reads = int(min(len(lens), max(16, np.searchsorted(csum, target_bases) + 1)))
+    nb = int(offsets[sample_reads].item())
+    hb = bases[:nb].cpu().numpy()
+    ho = offsets[:sample_reads + 1].cpu().numpy().astype(np.uint64)
+    p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0, 0,
+                       0, 0, 0)
+    t0 = time.perf_counter()
+    if cfg["sketch"]:
+        O.sketch(hb, ho, p)
+    t_sk = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if cfg["count"]:
+        c = O.Counter(cfg["kmer_type"], cfg["k"], 8, max(1024, nb))
+        c.add_reads(hb, ho)
+    t_ct = time.perf_counter() - t0
+    tot = t_sk + t_ct
+    return {"value": nb / tot / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads (%d bases) of the same read set; sketch %.2f s + count %.2f s, oracle C "
+                      "restatement, gcc -O2, 1 thread" % (sample_reads, nb, t_sk, t_ct),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

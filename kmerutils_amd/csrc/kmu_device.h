@@ -1,0 +1,345 @@
+// kmu_device.h -- device-side primitives shared by every gfx950 kernel of libkmu.
+//
+// Everything here is integer / f64 arithmetic that must agree bit for bit with the reference (citations are
+// file:line in jean-pierreBoth/kmerutils) or with the third-party crates it calls (probminhash, rand,
+// rand_xoshiro: restated from their published algorithms, see DESIGN.md "unpinned").
+// Compile with -ffp-contract=off: h = hbase + winv * x must not become an FMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kmu.h"
+
+#define KMU_WAVE 64
+
+namespace kmu {
+
+// ---------------------------------------------------------------------------------------------------
+// alphabet (src/base/alphabet.rs:119-127): A/a 0, C/c 1, G/g 2, T/t 3
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t code2b(uint32_t c) {
+    uint32_t x = (c >> 1) & 3u; // A 0, C 1, T 2, G 3
+    return x ^ (x >> 1);        // A 0, C 1, G 2, T 3
+}
+__device__ __forceinline__ bool is_acgt(uint32_t c) {
+    uint32_t u = c & 0xDFu;
+    return (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+}
+// 16 ASCII bytes -> one packed word, first base in bits 31..30 (the MSB-first order of Sequence::new,
+// src/base/sequence.rs:48-73, widened from a byte to a 32-bit word); `bad` gets one bit per invalid byte
+__device__ __forceinline__ uint32_t pack16_ascii(uint4 v, uint32_t &bad) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t out = 0;
+    bad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t c = (w[i] >> (8 * j)) & 0xFFu;
+            int idx = 4 * i + j;
+            out |= code2b(c) << (30 - 2 * idx);
+            bad |= (is_acgt(c) ? 0u : 1u) << idx;
+        }
+    }
+    return out;
+}
+// amino acids (src/aautils/kmeraa.rs:85-109): 5-bit codes, upper case only, Q = 15, no 14; 0 = invalid
+__device__ __forceinline__ uint32_t code_aa(uint32_t c) {
+    // index by (c - 'A'): A B C D E F G H I J K L M N O P Q R S T U V W X Y Z
+    const uint8_t tab[26] = {1, 0, 2, 3, 4, 5, 6, 7, 8, 0, 9, 10, 11, 12, 0, 13, 15, 16, 17, 18, 0, 19, 20, 0, 21, 0};
+    uint32_t i = c - 'A';
+    return i < 26u ? tab[i] : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k-mer values (A.2/A.3 of SURVEY.md)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t revcomp_val(uint64_t val, int k) {
+    // kmer64bit.rs:83-96 / kmer32bit.rs:119-137 / kmer16b32bit.rs:43-54 on the right-aligned 2k-bit value
+    uint64_t rc = ~val;
+    rc = __brevll(rc);
+    rc = ((rc & 0x5555555555555555ull) << 1) | ((rc & 0xAAAAAAAAAAAAAAAAull) >> 1);
+    return rc >> (64 - 2 * k);
+}
+
+// probminhash::invhash (Thomas Wang hash32shift / hash64shift)
+__device__ __forceinline__ uint32_t int32_hash(uint32_t key) {
+    key = ~key + (key << 15);
+    key = key ^ (key >> 12);
+    key = key + (key << 2);
+    key = key ^ (key >> 4);
+    key = key * 2057u;
+    key = key ^ (key >> 16);
+    return key;
+}
+__device__ __forceinline__ uint64_t int64_hash(uint64_t key) {
+    key = ~key + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, unsigned r) {
+    r &= 63u;
+    return (x << r) | (x >> ((64u - r) & 63u));
+}
+
+// ntHash seeds (src/base/nthash.rs:17-20), BASE_MAPPING_2B order [A,C,G,T]
+__device__ __forceinline__ uint64_t nt_seed(uint32_t code) {
+    const uint64_t s[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x20323ed082572324ull,
+                           0x295549f54be24456ull};
+    return s[code & 3u];
+}
+// forward / reverse seeds of the reference's *ASCII* table (nthash.rs:48-57): only 'A' and 'C' carry a seed,
+// 'G' (71) and 'T' (84) hit zero entries; complement row: A -> SEED_T, C -> SEED_G, G/T -> 0.
+__device__ __forceinline__ uint64_t nt8b_fwd(uint32_t code) {
+    return code == 0 ? 0x3c8bfbb395c60474ull : (code == 1 ? 0x3193c18562a02b4cull : 0ull);
+}
+__device__ __forceinline__ uint64_t nt8b_rev(uint32_t code) {
+    return code == 0 ? 0x295549f54be24456ull : (code == 1 ? 0x20323ed082572324ull : 0ull);
+}
+// canonical ntHash of a right-aligned k-mer value: kmer.rs:76-95 (2-bit seeds) or nthash.rs:214-228 (8-bit
+// table, upper-case input).  Closed form per position; equals the rolled value (nthash.rs:333,379).
+template <bool TABLE8B>
+__device__ __forceinline__ uint64_t nthash_canonical(uint64_t val, int k) {
+    uint64_t f = 0, r = 0;
+    for (int i = 0; i < k; i++) {
+        uint32_t b = (uint32_t) (val >> (2 * (k - 1 - i))) & 3u;
+        if (TABLE8B) {
+            f ^= rotl64(nt8b_fwd(b), (unsigned) (k - i - 1));
+            r ^= rotl64(nt8b_rev(b), (unsigned) i);
+        } else {
+            f ^= rotl64(nt_seed(b), (unsigned) (k - i - 1));
+            r ^= rotl64(nt_seed(3u - b), (unsigned) i);
+        }
+    }
+    return f <= r ? f : r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k-mer type dependent pieces, selected at compile time.  `val` is always the right-aligned value.
+// ---------------------------------------------------------------------------------------------------
+struct KmerCfg {
+    int kmer_type; // kmu_kmer_type
+    int k;
+    int fhash; // kmu_fhash
+};
+
+// raw `.0` from the value (KmerBuilder::build)
+__device__ __forceinline__ uint64_t raw_from_val(int kmer_type, int k, uint64_t val) {
+    return kmer_type == KMU_KMER32BIT ? (val | ((uint64_t) k << 28)) : val;
+}
+__device__ __forceinline__ bool is_u32_type(int kmer_type) {
+    return kmer_type == KMU_KMER32BIT || kmer_type == KMU_KMER16B32BIT || kmer_type == KMU_KMERAA32BIT;
+}
+
+// fhash closure on a forward k-mer value (and its reverse complement, already computed by the caller for DNA)
+__device__ __forceinline__ uint64_t apply_fhash(const KmerCfg &c, uint64_t val, uint64_t rcval) {
+    const bool w32 = is_u32_type(c.kmer_type);
+    switch (c.fhash) {
+    case KMU_FHASH_IDENTITY_RAW: return raw_from_val(c.kmer_type, c.k, val);
+    case KMU_FHASH_VALUE_MASKED: return val; // value is already masked to bits*k
+    case KMU_FHASH_INVHASH_RAW: {
+        uint64_t raw = raw_from_val(c.kmer_type, c.k, val);
+        return w32 ? (uint64_t) int32_hash((uint32_t) raw) : int64_hash(raw);
+    }
+    default: break;
+    }
+    uint64_t canon = rcval < val ? rcval : val; // same k => Ord compares values (kmer32bit.rs:47-55)
+    switch (c.fhash) {
+    case KMU_FHASH_CANON_RAW: return raw_from_val(c.kmer_type, c.k, canon);
+    case KMU_FHASH_CANON_VALUE: return canon;
+    case KMU_FHASH_CANON_INVHASH: {
+        uint64_t raw = raw_from_val(c.kmer_type, c.k, canon);
+        return w32 ? (uint64_t) int32_hash((uint32_t) raw) : int64_hash(raw);
+    }
+    case KMU_FHASH_CANON_NTHASH: return nthash_canonical<false>(val, c.k);
+    case KMU_FHASH_CANON_NTHASH_8B: return nthash_canonical<true>(val, c.k);
+    default: return canon;
+    }
+}
+
+// std::hash::Hasher::finish of the key: NoHashHasher (src/nohasher.rs:22-48), FnvHasher, or int64_hash
+__device__ __forceinline__ uint64_t hasher_finish(int hasher, uint64_t v, bool w32) {
+    if (hasher == KMU_HASHER_FNV1A) {
+        uint64_t h = 0xcbf29ce484222325ull;
+        int n = w32 ? 4 : 8;
+        for (int i = 0; i < n; i++) {
+            h ^= (v >> (8 * i)) & 0xFFull;
+            h *= 0x100000001b3ull;
+        }
+        return h;
+    }
+    if (hasher == KMU_HASHER_INT64HASH) return int64_hash(v);
+    if (w32) return (uint64_t) __builtin_bswap32((uint32_t) v);
+    return __builtin_bswap64(v);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RNG: Xoshiro256PlusPlus::seed_from_u64 (4 x SplitMix64) + rand's uniform samplers
+// ---------------------------------------------------------------------------------------------------
+struct Xoshiro {
+    uint64_t s0, s1, s2, s3;
+    __device__ __forceinline__ void seed(uint64_t x) {
+        uint64_t z;
+        x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; s0 = z ^ (z >> 31);
+        x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; s1 = z ^ (z >> 31);
+        x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; s2 = z ^ (z >> 31);
+        x += 0x9e3779b97f4a7c15ull; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; s3 = z ^ (z >> 31);
+    }
+    __device__ __forceinline__ uint64_t next() {
+        uint64_t result = rotl64(s0 + s3, 23) + s0;
+        uint64_t t = s1 << 17;
+        s2 ^= s0;
+        s3 ^= s1;
+        s1 ^= s2;
+        s0 ^= s3;
+        s2 ^= t;
+        s3 = rotl64(s3, 45);
+        return result;
+    }
+    __device__ __forceinline__ uint32_t next_u32() { return (uint32_t) (next() >> 32); }
+    // Uniform::<f64>::new(0.,1.): 52 mantissa bits in [1,2) minus 1
+    __device__ __forceinline__ double unif01() {
+        return __longlong_as_double((long long) ((next() >> 12) | 0x3FF0000000000000ull)) - 1.0;
+    }
+    __device__ __forceinline__ float unif01_f32() { return __uint_as_float((next_u32() >> 9) | 0x3F800000u) - 1.0f; }
+    // Uniform::<usize>::new(low, high), high - 1 <= u32::MAX (always true here: ranges are sketch sizes)
+    __device__ __forceinline__ uint32_t unif_index(uint32_t low, uint32_t high, bool rand08) {
+        uint32_t range = high - low;
+        if (rand08) {
+            uint64_t r64 = range;
+            uint64_t ints_to_reject = (0xFFFFFFFFFFFFFFFFull - r64 + 1ull) % r64;
+            uint64_t zone = 0xFFFFFFFFFFFFFFFFull - ints_to_reject;
+            for (;;) {
+                uint64_t v = next();
+                uint64_t hi = __umul64hi(v, r64), lo = v * r64;
+                if (lo <= zone) return low + (uint32_t) hi;
+            }
+        }
+        uint32_t thresh = (0u - range) % range;
+        for (;;) {
+            uint64_t m = (uint64_t) next_u32() * range;
+            if ((uint32_t) m >= thresh) return low + (uint32_t) (m >> 32);
+        }
+    }
+};
+
+// exp(x) - 1 on [0, ln 2]: the same fixed 22-term Horner as the oracle's expm1_small (no fused operations)
+__device__ __forceinline__ double expm1_small(double x) {
+    const double inv_fact[23] = {
+        1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+        1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+        1.0 / 1307674368000.0, 1.0 / 20922789888000.0, 1.0 / 355687428096000.0, 1.0 / 6402373705728000.0,
+        1.0 / 121645100408832000.0, 1.0 / 2432902008176640000.0, 1.0 / 51090942171709440000.0,
+        1.0 / 1124000727777607680000.0};
+    double acc = inv_fact[22];
+    for (int i = 21; i >= 1; i--) acc = acc * x + inv_fact[i];
+    return acc * x;
+}
+
+// probminhash ExpRestricted01: constants computed once on the host with libm (same expressions as the crate)
+struct Exp01 {
+    double lambda, c1, c2, c3;
+};
+__device__ __forceinline__ double exp01_sample(const Exp01 &e, Xoshiro &rng) {
+    double x = e.c1 * rng.unif01();
+    if (x < 1.0) return x;
+    for (;;) {
+        x = rng.unif01();
+        if (x < e.c2) return x;
+        double y = 0.5 * rng.unif01();
+        if (y > 1.0 - x) {
+            x = 1.0 - x;
+            y = 1.0 - y;
+        }
+        if (x <= e.c3 * (1.0 - y)) return x;
+        if (e.c1 * y <= 1.0 - x) return x;
+        if (y * e.c1 * e.lambda <= expm1_small(e.lambda * (1.0 - x))) return x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
+__device__ __forceinline__ uint32_t shfl_down_u32(uint32_t v, int d) { return (uint32_t) __shfl_down((int) v, d, 64); }
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, 64); }
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint64_t o = ((uint64_t) (uint32_t) __shfl_xor((int) (v >> 32), d, 64) << 32) |
+                     (uint32_t) __shfl_xor((int) (uint32_t) v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Streaming one sequence through a wave: 64 lanes x 16 bases per step.
+//
+// Sequence data are read as aligned 16-byte chunks (global_load_dwordx4, 1 KiB per wave-instruction); every
+// lane turns its chunk into one packed 32-bit word of 2-bit codes and picks up the two following words from
+// its neighbours with wave shuffles, so a lane can roll the 16 k-mers that start inside its chunk (k <= 32)
+// without LDS staging and without a barrier.
+// ---------------------------------------------------------------------------------------------------
+struct SeqView {
+    const uint8_t *base; // ASCII: bases array; PACKED2: packed array
+    uint64_t begin;      // ASCII: byte index of the first base; PACKED2: byte index of the first packed byte
+    uint64_t len;        // number of bases
+    uint64_t total;      // size in bytes of the whole `base` array (for guarded edge loads)
+    int packed;          // 1 = KMU_INPUT_PACKED2
+};
+
+// one aligned 16-byte chunk at byte index `idx` (multiple of 16) with edge guards
+__device__ __forceinline__ uint4 load_chunk16(const uint8_t *base, uint64_t idx, uint64_t total) {
+    if (idx + 16 <= total) return *reinterpret_cast<const uint4 *>(base + idx);
+    uint32_t w[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; // 'A' padding, masked by callers
+    for (int i = 0; i < 16; i++)
+        if (idx + i < total) {
+            w[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+            w[i >> 2] |= (uint32_t) base[idx + i] << (8 * (i & 3));
+        }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Packed word number `widx` of the sequence's *aligned code stream*: ASCII: bases [16*widx, 16*widx+16) of the
+// 16-byte aligned stream that starts at (begin & ~15); PACKED2: 4 packed bytes starting at (begin&~3)+4*widx.
+// `bad` gets a mask of non-ACGT bytes that lie inside the sequence.
+__device__ __forceinline__ uint32_t load_code_word(const SeqView &s, uint64_t widx, uint32_t &bad) {
+    bad = 0;
+    if (s.packed) {
+        uint64_t b0 = (s.begin & ~3ull) + 4 * widx;
+        uint32_t w = 0;
+        if (b0 + 4 <= s.total) {
+            w = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(s.base + b0));
+        } else {
+            for (int i = 0; i < 4; i++)
+                if (b0 + i < s.total) w |= (uint32_t) s.base[b0 + i] << (24 - 8 * i);
+        }
+        return w;
+    }
+    uint64_t a0 = (s.begin & ~15ull) + 16 * widx;
+    if (a0 >= s.total) return 0;
+    uint4 v = load_chunk16(s.base, a0, s.total);
+    uint32_t b;
+    uint32_t w = pack16_ascii(v, b);
+    // keep only the bits of bytes inside [begin, begin+len)
+    uint64_t lo = s.begin > a0 ? s.begin - a0 : 0;               // first valid byte in chunk
+    uint64_t end = s.begin + s.len;
+    uint64_t hi = end > a0 ? (end - a0 > 16 ? 16 : end - a0) : 0; // one past the last valid byte
+    uint32_t m = (hi > lo) ? (uint32_t) (((1ull << hi) - 1ull) & ~((1ull << lo) - 1ull)) : 0u;
+    bad = b & m;
+    return w;
+}
+// number of leading code slots of the aligned stream that precede the first base of the sequence
+__device__ __forceinline__ uint32_t seq_lead(const SeqView &s) {
+    return s.packed ? (uint32_t) (s.begin & 3ull) * 4u : (uint32_t) (s.begin & 15ull);
+}
+
+} // namespace kmu

@@ -1,0 +1,251 @@
+// kmu_sketch_super.hip -- SuperMinHash / SuperMinHash2 per-sequence kernels for gfx950.
+//
+// Reference loop (src/sketching/setsketchert.rs:255-297, seqsketchjaccard.rs:328-380): for every k-mer occurrence
+// `sminhash.sketch(&fhash(kmer))`: seed an RNG from hasher(value), then for j = 0.. draw r in [0,1) and
+// k in [j,m), swap p[j]<->p[k] (Fisher-Yates prefix) and offer r + j to slot p[j]; stop at j > a_upper, the
+// largest floor() among the current slot values (Ertl, arXiv 1706.05698 Alg. 3).
+// The result is the per-slot minimum over all (item, j) candidates, so items are independent: here every lane
+// owns one item at a time and all lanes of the workgroup advance j in lock step; the slot minima live in LDS and
+// are updated with ds_min_u64 on the order-preserving bit pattern of the (positive) value; a_upper is refreshed
+// from them every few steps (any stale upper bound is valid).  Each lane's partial permutation is an LDS column
+// (entry-major, one byte or two per entry) that is restored to the identity after the item through a swap log.
+#include <algorithm>
+
+#include "kmu_ctx.hpp"
+#include "kmu_stream.h"
+
+namespace kmu {
+
+struct SuperArgs {
+    const uint8_t *bases;
+    const uint64_t *offsets;
+    const uint64_t *packed_offsets;
+    uint32_t n_seq;
+    int packed;
+    uint64_t total_bytes;
+    KmerCfg cfg;
+    int m;
+    int lg;       // ceil(log2 m)
+    int hasher;
+    int rand08;
+    int mode;     // 0 f64, 1 f32, 2 u64 (SuperMinHash2), 3 u32 (SuperMinHash2)
+    int val_w32;  // Kmer::Val is 32 bits
+    uint32_t chunk; // items staged per chunk
+    void *sig_out;
+    uint32_t *queue;
+    uint32_t *err;
+};
+
+__device__ __forceinline__ uint64_t super_init_bits(int mode) {
+    switch (mode) {
+    case 0: return (uint64_t) __double_as_longlong(4294967295.0); // F::from(u32::MAX)
+    case 1: return (uint64_t) __float_as_uint(4294967296.0f);
+    case 2: return 0xFFFFFFFFFFFFFFFFull;
+    default: return 0xFFFFFFFFull;
+    }
+}
+// min(floor(value), m-1) of a slot bit pattern
+__device__ __forceinline__ uint32_t super_floor(uint64_t bits, int mode, int m, int lg) {
+    uint32_t f;
+    switch (mode) {
+    case 0: { double v = __longlong_as_double((long long) bits); f = v >= (double) (m - 1) ? (uint32_t) (m - 1) : (uint32_t) v; break; }
+    case 1: { float v = __uint_as_float((uint32_t) bits); f = v >= (float) (m - 1) ? (uint32_t) (m - 1) : (uint32_t) v; break; }
+    case 2: { uint64_t v = lg ? bits >> (64 - lg) : 0; f = v >= (uint64_t) (m - 1) ? (uint32_t) (m - 1) : (uint32_t) v; break; }
+    default: { uint64_t v = lg ? bits >> (32 - lg) : 0; f = v >= (uint64_t) (m - 1) ? (uint32_t) (m - 1) : (uint32_t) v; break; }
+    }
+    return f;
+}
+
+template <typename PT>
+__global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int wave = tid >> 6, nwaves = nthreads >> 6;
+    const int m = a.m;
+    uint64_t *hs = reinterpret_cast<uint64_t *>(smem);          // m slot minima
+    uint64_t *items = hs + m;                                     // a.chunk staged RNG seeds
+    uint32_t *misc = reinterpret_cast<uint32_t *>(items + a.chunk); // [0] read, [1] a_upper
+    PT *perm = reinterpret_cast<PT *>(misc + 4);                  // [m][nthreads]
+    PT *slog = perm + (size_t) m * nthreads;                      // [m][nthreads]
+    const bool aa = a.cfg.kmer_type == KMU_KMERAA32BIT || a.cfg.kmer_type == KMU_KMERAA64BIT;
+    const uint64_t init_bits = super_init_bits(a.mode);
+
+    for (int e = 0; e < m; e++) perm[(size_t) e * nthreads + tid] = (PT) e;
+    for (int s = tid; s < m; s += nthreads) hs[s] = init_bits;
+    if (tid == 0) misc[1] = (uint32_t) (m - 1);
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) misc[0] = atomicAdd(a.queue, 1u);
+        __syncthreads();
+        const uint32_t r = misc[0];
+        if (r >= a.n_seq) break;
+        SeqView sv;
+        sv.base = a.bases;
+        sv.len = a.offsets[r + 1] - a.offsets[r];
+        sv.packed = a.packed;
+        if (a.packed) {
+            sv.begin = a.packed_offsets[r];
+            sv.total = a.total_bytes ? a.total_bytes
+                                     : (a.packed_offsets[a.n_seq - 1] + (a.offsets[a.n_seq] - a.offsets[a.n_seq - 1] + 3) / 4);
+        } else {
+            sv.begin = a.offsets[r];
+            sv.total = a.total_bytes ? a.total_bytes : a.offsets[a.n_seq];
+        }
+        const uint64_t L = sv.len;
+        const uint64_t nk = L >= (uint64_t) a.cfg.k ? L - a.cfg.k + 1 : 0;
+        if (L == 0 && tid == 0) atomicOr(a.err, 8u);
+        if (nk == 0 && wave_validate_seq(sv, wave, nwaves, aa)) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
+        const uint32_t lead = aa ? 0 : seq_lead(sv);
+        for (uint64_t c0 = 0; c0 < nk; c0 += a.chunk) {
+            const uint64_t c1 = c0 + a.chunk < nk ? c0 + a.chunk : nk;
+            // ---- stage the RNG seeds hasher(fhash(kmer)) of positions [c0, c1) ------------------------------
+            uint32_t bad = 0;
+            auto visit = [&](uint64_t p, uint64_t val, uint64_t rc) {
+                items[p - c0] = hasher_finish(a.hasher, apply_fhash(a.cfg, val, rc), a.val_w32 != 0);
+            };
+            if (aa) {
+                for (uint64_t st = c0 / 64 + wave; st < (c1 + 63) / 64; st += nwaves)
+                    bad |= wave_step_kmers_aa(sv, a.cfg.k, st, c0, c1, visit);
+            } else {
+                // the last chunk also walks the words that only hold the read's tail, to validate them
+                uint64_t st1 = c1 == nk ? (seq_num_words(sv) + 63) / 64 : (c1 - 1 + lead) / 1024 + 1;
+                for (uint64_t st = (c0 + lead) / 1024 + wave; st < st1; st += nwaves)
+                    bad |= wave_step_kmers(sv, a.cfg.k, st, c0, c1, visit);
+            }
+            if (bad) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
+            __syncthreads();
+            // ---- every lane sketches one staged item per batch; j advances in lock step ----------------------
+            const uint32_t n_items = (uint32_t) (c1 - c0);
+            for (uint32_t b0 = 0; b0 < n_items; b0 += nthreads) {
+                const bool have = b0 + tid < n_items;
+                Xoshiro rng;
+                if (have) rng.seed(items[b0 + tid]);
+                uint32_t j = 0, round = 0;
+                bool active = have;
+                for (;;) {
+                    uint32_t a_upper = *(volatile uint32_t *) &misc[1];
+                    if (active && j > a_upper) active = false;
+                    if (!__any(active)) break;
+                    if (active) {
+                        double rd = 0.0;
+                        float rf = 0.f;
+                        uint64_t ri = 0;
+                        switch (a.mode) {
+                        case 0: rd = rng.unif01(); break;
+                        case 1: rf = rng.unif01_f32(); break;
+                        case 2: ri = rng.next(); break;
+                        default: ri = rng.next_u32(); break;
+                        }
+                        uint32_t k = rng.unif_index(j, (uint32_t) m, a.rand08 != 0);
+                        PT pj = perm[(size_t) j * nthreads + tid];
+                        PT pk = perm[(size_t) k * nthreads + tid];
+                        perm[(size_t) j * nthreads + tid] = pk;
+                        perm[(size_t) k * nthreads + tid] = pj;
+                        slog[(size_t) j * nthreads + tid] = (PT) k;
+                        uint64_t bits;
+                        switch (a.mode) {
+                        case 0: bits = (uint64_t) __double_as_longlong(rd + (double) j); break;
+                        case 1: bits = (uint64_t) __float_as_uint(rf + (float) j); break;
+                        case 2: bits = a.lg ? (((uint64_t) j << (64 - a.lg)) | (ri >> a.lg)) : ri; break;
+                        default: bits = a.lg ? ((((uint64_t) j << (32 - a.lg)) | (ri >> a.lg)) & 0xFFFFFFFFull) : ri; break;
+                        }
+                        atomicMin((unsigned long long *) &hs[pk], (unsigned long long) bits);
+                        j++;
+                    }
+                    round++; // wave-uniform (all lanes of the wave run this loop together)
+                    if ((round & 3u) == 0u || round == 1u) { // refresh a_upper = max_s min(floor(hs[s]), m-1)
+                        uint32_t mx = 0;
+                        for (int s = lane_id(); s < m; s += 64) {
+                            uint32_t f = super_floor(*(volatile uint64_t *) &hs[s], a.mode, m, a.lg);
+                            mx = f > mx ? f : mx;
+                        }
+                        mx = (uint32_t) wave_max_u64(mx);
+                        if (lane_id() == 0) atomicMin(&misc[1], mx);
+                    }
+                }
+                // restore this lane's permutation column to the identity
+                for (uint32_t jj = 0; jj < j; jj++) {
+                    PT k = slog[(size_t) jj * nthreads + tid];
+                    perm[(size_t) jj * nthreads + tid] = (PT) jj;
+                    perm[(size_t) k * nthreads + tid] = k;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- signature -------------------------------------------------------------------------------------
+        for (int t = tid; t < m; t += nthreads) {
+            uint64_t v = hs[t];
+            switch (a.mode) {
+            case 0: reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * m + t] = v; break;
+            case 2: reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * m + t] = v; break;
+            default: reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * m + t] = (uint32_t) v; break;
+            }
+            hs[t] = init_bits;
+        }
+        if (tid == 0) misc[1] = (uint32_t) (m - 1);
+        __syncthreads();
+    }
+}
+
+int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err) {
+    SuperArgs a;
+    memset(&a, 0, sizeof a);
+    a.bases = ds.bases;
+    a.offsets = ds.offsets;
+    a.packed_offsets = ds.packed_offsets;
+    a.n_seq = ds.n_seq;
+    a.packed = ds.packed;
+    a.total_bytes = ds.total_bytes;
+    a.cfg = KmerCfg{p->kmer_type, p->kmer_size, p->fhash};
+    a.m = p->sketch_size;
+    a.lg = 0;
+    while ((1 << a.lg) < a.m) a.lg++;
+    a.hasher = p->hasher;
+    a.rand08 = (p->flags & KMU_FLAG_RAND08) ? 1 : 0;
+    if (p->algo == KMU_ALGO_SUPER) a.mode = p->sig_type == KMU_SIG_F32 ? 1 : 0;
+    else a.mode = p->sig_type == KMU_SIG_U32 ? 3 : 2;
+    a.val_w32 = kmer_val_bytes(p->kmer_type) == 4;
+    a.sig_out = d_sig;
+    a.err = d_err;
+    void *q;
+    KMU_TRY(dev_buf(ctx, "queue", 64, &q));
+    KMU_HIP(ctx, hipMemsetAsync(q, 0, 64, ctx->stream));
+    a.queue = (uint32_t *) q;
+    a.chunk = 2048;
+    const bool wide = a.m > 256;
+    const size_t pt = wide ? 2 : 1;
+    const size_t lds_max = 160 * 1024;
+    auto fn = wide ? (const void *) k_sketch_super<uint16_t> : (const void *) k_sketch_super<uint8_t>;
+    // per-lane permutation + swap-log columns dominate the LDS footprint: shrink the workgroup for large m
+    int threads = 256;
+    size_t lds = 0;
+    for (; threads >= 64; threads -= 64) {
+        lds = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + 2 * pt * a.m * threads;
+        lds = (lds + 15) & ~(size_t) 15;
+        if (lds <= lds_max) break;
+    }
+    if (threads < 64) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS (%zu B)", a.m, lds);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) != hipSuccess) {
+            (void) hipGetLastError();
+            return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d needs %zu B of LDS", a.m, lds);
+        }
+    }
+    int blocks_per_cu = std::max<int>(1, std::min<int>(8, (int) (lds_max / lds)));
+    int grid = (int) std::min<uint64_t>((uint64_t) ds.n_seq, (uint64_t) ctx->num_cus * blocks_per_cu);
+    if (grid < 1) grid = 1;
+    {
+        KernelTimer t(ctx, "k_sketch_super");
+        if (wide) hipLaunchKernelGGL(k_sketch_super<uint16_t>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(k_sketch_super<uint8_t>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+
+int launch_bottomk(kmu_ctx *ctx, const kmu_sketch_params *, const DevSeqs &, void *, uint32_t *, uint32_t *) {
+    return fail(ctx, KMU_E_UNSUPPORTED, "bottom-k sketch is not built yet");
+}
+
+} // namespace kmu

@@ -1,0 +1,119 @@
+"""Multi-GPU orchestration: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).
+
+Sketching shards reads -- independent units, exactly the reference's rayon map
+(src/sketching/seqsketchjaccard.rs:245-248) -- with NO data-path collective: every rank sketches a contiguous
+read range and the rows are concatenated in read order (the rank re-ordering of seqsketchjaccard.rs:250-259).
+
+Counting has one real exchange step.  The reference partitions the *key space* over threads
+(`int64_hash(kmer) % n`, src/base/kmercount.rs:412-420, :942) and ships every k-mer occurrence to its owner
+through channels.  Here every rank first counts its own read shard locally (duplicates collapse on the GPU), then
+ONE all-to-all moves each distinct (k-mer, count) entry to its owner rank, which adds it into its table.  After the
+merge rank r holds the exact counts of the keys with owner == r, i.e. the KmerCounterPool layout
+(kmercount.rs:424-565) with one counter per GPU.
+
+PyTorch is plumbing here: process group, all_to_all; the compute is in libkmu.
+"""
+import numpy as np
+
+
+def shard_reads_by_bases(lens, world_size):
+    """Contiguous read ranges [(r0, r1)] balanced by total bases (ONT lengths are skewed: balancing by read count
+    would leave ranks idle).  Every read belongs to exactly one range; ranges may be empty."""
+    lens = np.asarray(lens, dtype=np.int64)
+    csum = np.concatenate([[0], np.cumsum(lens)])
+    total = int(csum[-1])
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r // world_size
+        bounds.append(int(np.searchsorted(csum, target, side="left")))
+    bounds.append(len(lens))
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return [(bounds[i], bounds[i + 1]) for i in range(world_size)]
+
+
+def _all_to_all_var(send_list, recv_sizes, dtype, device, group=None):
+    """variable-size all-to-all of 1-D tensors; all_to_all_single on RCCL, isend/irecv pairs elsewhere (gloo has no
+    all_to_all)"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    recv = [torch.empty(int(n), dtype=dtype, device=device) for n in recv_sizes]
+    if dist.get_backend(group) == "nccl":
+        sendbuf = torch.cat(send_list) if send_list else torch.empty(0, dtype=dtype, device=device)
+        recvbuf = torch.empty(int(sum(recv_sizes)), dtype=dtype, device=device)
+        dist.all_to_all_single(recvbuf, sendbuf, [int(n) for n in recv_sizes], [int(t.numel()) for t in send_list],
+                               group=group)
+        off = 0
+        for i, n in enumerate(recv_sizes):
+            recv[i] = recvbuf[off:off + int(n)]
+            off += int(n)
+        return recv
+    reqs = []
+    for peer in range(world):
+        if peer == rank:
+            recv[peer].copy_(send_list[peer])
+            continue
+        if send_list[peer].numel():
+            reqs.append(dist.isend(send_list[peer].contiguous(), peer, group=group))
+        if recv[peer].numel():
+            reqs.append(dist.irecv(recv[peer], peer, group=group))
+    for r in reqs:
+        r.wait()
+    return recv
+
+
+def merge_counters(counter, device=None, group=None, chunk_entries=1 << 27):
+    """The exchange step of distributed counting.  `counter` is a kmerutils_amd.lib.Counter (or any object with
+    export_part / reset / merge_entries).  On return the local table holds exactly the keys owned by this rank with
+    their global multiplicities.  Returns the number of entries received."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return 0
+    parts = [counter.export_part(p, world, device) for p in range(world)]
+    tk = [torch.as_tensor(k.view(np.int64) if isinstance(k, np.ndarray) else k) for k, _ in parts]
+    tc = [torch.as_tensor(c.view(np.int32) if isinstance(c, np.ndarray) else c) for _, c in parts]
+    dev = tk[0].device
+    send_n = torch.tensor([t.numel() for t in tk], dtype=torch.int64, device=dev)
+    all_n = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_n, send_n, group=group)
+    recv_n = [int(all_n[p][rank].item()) for p in range(world)]
+    max_pair = int(max(int(x.max().item()) for x in all_n))
+    counter.reset()
+    received = 0
+    # chunked so that no single collective moves more than chunk_entries per peer
+    for c0 in range(0, max(max_pair, 1), chunk_entries):
+        sk = [t[c0:c0 + chunk_entries] for t in tk]
+        sc = [t[c0:c0 + chunk_entries] for t in tc]
+        rn = [max(0, min(n - c0, chunk_entries)) for n in recv_n]
+        rk = _all_to_all_var(sk, rn, torch.int64, dev, group)
+        rc = _all_to_all_var(sc, rn, torch.int32, dev, group)
+        for k, c in zip(rk, rc):
+            if k.numel():
+                if dev.type == "cpu":
+                    counter.merge_entries(k.numpy().view(np.uint64), c.numpy().view(np.uint32))
+                else:
+                    counter.merge_entries(k.contiguous(), c.contiguous())
+                received += int(k.numel())
+    return received
+
+
+def gather_rows(local_rows, group=None):
+    """Concatenate per-rank signature slabs in rank (= read) order on every rank.  Used by the host API; the bench
+    never needs it (each rank keeps its own slab)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_rows.device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    mx = int(max(int(x.item()) for x in ns))
+    pad = torch.zeros((mx,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
+    pad[:local_rows.shape[0]] = local_rows
+    outs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:int(k.item())] for o, k in zip(outs, ns)], 0)

@@ -1,0 +1,336 @@
+"""ctypes binding of libkmu.so (the C-ABI of include/kmu.h).
+
+The product path: every compute call goes to hand-written gfx950 kernels.  There is no CPU fallback -- if the
+shared library is missing or no HIP device is present this module raises, loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libkmu.so")
+_lib = None
+
+# every symbol include/kmu.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "kmu_version", "kmu_device_count", "kmu_create", "kmu_destroy", "kmu_last_error", "kmu_synchronize", "kmu_stream",
+    "kmu_profile_enable", "kmu_profile_reset", "kmu_profile_get", "kmu_count_non_acgt", "kmu_pack2b",
+    "kmu_kmer_hashes", "kmu_sketch", "kmu_block_layout", "kmu_sketch_hashed", "kmu_count_create", "kmu_count_destroy",
+    "kmu_count_reset", "kmu_count_add_reads", "kmu_count_add_kmers", "kmu_count_query", "kmu_count_nb_distinct",
+    "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
+    "kmu_count_retain_part",
+]
+
+
+class KmuError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s: %s" % (A.STATUS_NAMES.get(code, str(code)), msg))
+        self.code = code
+
+
+def load():
+    """Load libkmu.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError("kmerutils_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    L.kmu_version.restype = C.c_char_p
+    L.kmu_device_count.restype = C.c_int
+    L.kmu_create.argtypes = [C.POINTER(A.DeviceCfg), C.POINTER(vp)]
+    L.kmu_destroy.argtypes = [vp]
+    L.kmu_destroy.restype = None
+    L.kmu_last_error.argtypes = [vp]
+    L.kmu_last_error.restype = C.c_char_p
+    L.kmu_synchronize.argtypes = [vp]
+    L.kmu_stream.argtypes = [vp]
+    L.kmu_stream.restype = vp
+    L.kmu_profile_enable.argtypes = [vp, C.c_int]
+    L.kmu_profile_reset.argtypes = [vp]
+    L.kmu_profile_get.argtypes = [vp, C.POINTER(A.KernelStat), C.c_int]
+    L.kmu_count_non_acgt.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp]
+    L.kmu_pack2b.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, vp]
+    L.kmu_kmer_hashes.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp]
+    L.kmu_sketch.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
+    L.kmu_block_layout.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.kmu_sketch_hashed.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, C.c_uint32, vp, vp]
+    L.kmu_count_create.argtypes = [vp, C.POINTER(A.CountParams), C.POINTER(vp)]
+    L.kmu_count_destroy.argtypes = [vp]
+    L.kmu_count_destroy.restype = None
+    L.kmu_count_reset.argtypes = [vp]
+    L.kmu_count_add_reads.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, C.c_int]
+    L.kmu_count_add_kmers.argtypes = [vp, vp, C.c_uint64, C.c_int]
+    L.kmu_count_query.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
+    L.kmu_count_nb_distinct.argtypes = [vp, u64p]
+    L.kmu_count_nb_unique.argtypes = [vp, u64p]
+    L.kmu_count_dump.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64, u64p]
+    L.kmu_count_export_part.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, u64p]
+    L.kmu_count_merge_entries.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
+    L.kmu_count_retain_part.argtypes = [vp, C.c_uint32, C.c_uint32]
+    _lib = L
+    return L
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    """(pointer, is_device) of a numpy array, a torch tensor, or None"""
+    if x is None:
+        return None, False
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return C.c_void_p(x.data_ptr()), x.is_cuda
+    assert x.flags["C_CONTIGUOUS"]
+    return x.ctypes.data_as(C.c_void_p), False
+
+
+class Context:
+    """kmu_ctx: one HIP device + stream.  Use from one thread at a time."""
+
+    def __init__(self, device_id=0, stream=None, async_device=False):
+        self.L = load()
+        cfg = A.DeviceCfg(device_id, 1 if async_device else 0, stream, 0)
+        h = C.c_void_p()
+        rc = self.L.kmu_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise KmuError(rc, self.L.kmu_last_error(None).decode())
+        self.h = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kmu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise KmuError(rc, self.L.kmu_last_error(self.h).decode())
+
+    def synchronize(self):
+        self._check(self.L.kmu_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self.L.kmu_stream(self.h)
+
+    # ---- profiling ----
+    def profile_enable(self, on=True):
+        self._check(self.L.kmu_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.L.kmu_profile_reset(self.h))
+
+    def profile_get(self):
+        arr = (A.KernelStat * 32)()
+        n = self.L.kmu_profile_get(self.h, arr, 32)
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n, 32))}
+
+    def _wait_producers(self, *xs):
+        """Device buffers are consumed on this context's stream: if they were produced on another torch stream,
+        wait for it first (a no-op when the context was created on torch's current stream)."""
+        for x in xs:
+            if x is not None and _is_torch(x) and x.is_cuda:
+                import torch
+                cur = torch.cuda.current_stream(x.device)
+                if cur.cuda_stream != (self.stream or 0):
+                    cur.synchronize()
+                return
+
+    # ---- helpers ----
+    @staticmethod
+    def _mem(*xs):
+        dev = [d for (_, d) in (_ptr(x) for x in xs if x is not None)]
+        if any(dev) and not all(dev):
+            raise ValueError("all buffers of one call must live on the same side (host or device)")
+        return A.MEM_DEVICE if dev and dev[0] else A.MEM_HOST
+
+    def count_non_acgt(self, bases, offsets):
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets)
+        if mem == A.MEM_DEVICE:
+            import torch
+            out = torch.zeros(max(n, 1), dtype=torch.int64, device=bases.device)
+        else:
+            out = np.zeros(max(n, 1), np.uint64)
+        self._check(self.L.kmu_count_non_acgt(self.h, _ptr(bases)[0], _ptr(offsets)[0], n, mem, _ptr(out)[0]))
+        return out[:n]
+
+    def pack2b(self, bases, offsets):
+        n = len(offsets) - 1
+        L = np.diff(offsets.astype(np.int64))
+        poff = np.zeros(n + 1, np.uint64)
+        out = np.zeros(int(((L + 3) // 4).sum()) + 16, np.uint8)
+        self._check(self.L.kmu_pack2b(self.h, _ptr(bases)[0], _ptr(offsets)[0], n, A.MEM_HOST, _ptr(out)[0],
+                                      _ptr(poff)[0]))
+        return out[:int(poff[-1])], poff
+
+    def kmer_hashes(self, bases, offsets, kmer_type, k, fhash, input_kind=A.INPUT_ASCII, packed_offsets=None,
+                    out=None):
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets)
+        self._wait_producers(bases)
+        hp = A.HashParams(kmer_type, k, fhash, input_kind, mem, 0)
+        if out is None:
+            if mem == A.MEM_DEVICE:
+                import torch
+                out = torch.zeros(max(int(offsets[-1].item()), 1), dtype=torch.int64, device=bases.device)
+            else:
+                out = np.zeros(max(int(offsets[-1]), 1), np.uint64)
+        self._check(self.L.kmu_kmer_hashes(self.h, C.byref(hp), _ptr(bases)[0], _ptr(offsets)[0],
+                                           _ptr(packed_offsets)[0], n, _ptr(out)[0]))
+        return out
+
+    def block_layout(self, offsets_host, block_size):
+        n = len(offsets_host) - 1
+        out = np.zeros(n + 1, np.uint64)
+        rc = self.L.kmu_block_layout(_ptr(offsets_host)[0], n, block_size, _ptr(out)[0])
+        self._check(rc)
+        return out
+
+    def sketch(self, bases, offsets, params, packed_offsets=None, block_row_offsets=None, n_rows=None, out=None,
+               counts_out=None, want_counts=False):
+        """kmu_sketch.  Host (numpy) or device (torch cuda) buffers.  Returns sig [rows, m] (and counts)."""
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets)
+        self._wait_producers(bases)
+        p = A.SketchParams.from_buffer_copy(params)
+        p.mem = mem
+        m = p.sketch_size
+        if p.block_size > 0:
+            if block_row_offsets is None:
+                if mem != A.MEM_HOST:
+                    raise ValueError("device block sketching needs block_row_offsets (+ n_rows)")
+                block_row_offsets = self.block_layout(np.ascontiguousarray(offsets, np.uint64), p.block_size)
+            rows = int(n_rows if n_rows is not None else block_row_offsets[-1])
+        else:
+            rows = 1 if p.mode == A.MODE_ALL_SEQS else n
+        if out is None:
+            if mem == A.MEM_DEVICE:
+                import torch
+                tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
+                       A.SIG_F64: torch.float64}[p.sig_type]
+                out = torch.zeros((max(rows, 1), m), dtype=tdt, device=bases.device)
+                if want_counts and counts_out is None:
+                    counts_out = torch.zeros((max(rows, 1), m), dtype=torch.int32, device=bases.device)
+            else:
+                out = np.zeros((max(rows, 1), m), dtype=A.SIG_NP[p.sig_type])
+                if want_counts and counts_out is None:
+                    counts_out = np.zeros((max(rows, 1), m), np.uint32)
+        self._check(self.L.kmu_sketch(self.h, C.byref(p), _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0],
+                                      n, _ptr(block_row_offsets)[0], _ptr(out)[0], _ptr(counts_out)[0]))
+        out = out[:rows]
+        if want_counts:
+            return out, counts_out[:rows]
+        return out
+
+    def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20):
+        return Counter(self, kmer_type, k, counter_bits, capacity_hint)
+
+
+class Counter:
+    """kmu_counter: exact canonical k-mer multiplicities on the device (KmerCountT contract)."""
+
+    def __init__(self, ctx, kmer_type, k, counter_bits=8, capacity_hint=1 << 20):
+        self.ctx = ctx
+        self.L = ctx.L
+        self.p = A.CountParams(kmer_type, k, counter_bits, 0, capacity_hint)
+        h = C.c_void_p()
+        ctx._check(self.L.kmu_count_create(ctx.h, C.byref(self.p), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.L.kmu_count_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx._check(self.L.kmu_count_reset(self.h))
+
+    def add_reads(self, bases, offsets, input_kind=A.INPUT_ASCII, packed_offsets=None):
+        mem = Context._mem(bases, offsets)
+        self.ctx._wait_producers(bases)
+        self.ctx._check(self.L.kmu_count_add_reads(self.h, _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0],
+                                                   len(offsets) - 1, input_kind, mem))
+
+    def add_kmers(self, canon):
+        mem = Context._mem(canon)
+        self.ctx._wait_producers(canon)
+        n = canon.numel() if _is_torch(canon) else canon.size
+        self.ctx._check(self.L.kmu_count_add_kmers(self.h, _ptr(canon)[0], n, mem))
+
+    def query(self, canon):
+        mem = Context._mem(canon)
+        if mem == A.MEM_DEVICE:
+            import torch
+            n = canon.numel()
+            out = torch.zeros(max(n, 1), dtype=torch.int32, device=canon.device)
+        else:
+            canon = np.ascontiguousarray(canon, np.uint64)
+            n = canon.size
+            out = np.zeros(max(n, 1), np.uint32)
+        self.ctx._check(self.L.kmu_count_query(self.h, _ptr(canon)[0], n, mem, _ptr(out)[0]))
+        return out[:n]
+
+    def nb_distinct(self):
+        v = C.c_uint64(0)
+        self.ctx._check(self.L.kmu_count_nb_distinct(self.h, C.byref(v)))
+        return v.value
+
+    def nb_unique(self):
+        v = C.c_uint64(0)
+        self.ctx._check(self.L.kmu_count_nb_unique(self.h, C.byref(v)))
+        return v.value
+
+    def dump(self, min_count=2):
+        n = C.c_uint64(0)
+        self.ctx._check(self.L.kmu_count_dump(self.h, min_count, None, None, 0, C.byref(n)))
+        k = np.zeros(max(n.value, 1), np.uint64)
+        c = np.zeros(max(n.value, 1), np.uint32)
+        self.ctx._check(self.L.kmu_count_dump(self.h, min_count, _ptr(k)[0], _ptr(c)[0], n.value, C.byref(n)))
+        return k[:n.value], c[:n.value]
+
+    def export_part(self, part, n_parts, device=None):
+        """entries owned by `part`: (kmers, counts) as numpy arrays, or torch cuda tensors when device is given"""
+        n = C.c_uint64(0)
+        self.ctx._check(self.L.kmu_count_export_part(self.h, part, n_parts, None, None, 0, A.MEM_HOST, C.byref(n)))
+        if device is not None:
+            import torch
+            k = torch.zeros(max(n.value, 1), dtype=torch.int64, device=device)
+            c = torch.zeros(max(n.value, 1), dtype=torch.int32, device=device)
+            mem = A.MEM_DEVICE
+        else:
+            k = np.zeros(max(n.value, 1), np.uint64)
+            c = np.zeros(max(n.value, 1), np.uint32)
+            mem = A.MEM_HOST
+        self.ctx._check(self.L.kmu_count_export_part(self.h, part, n_parts, _ptr(k)[0], _ptr(c)[0], n.value, mem,
+                                                     C.byref(n)))
+        return k[:n.value], c[:n.value]
+
+    def merge_entries(self, kmers, counts):
+        mem = Context._mem(kmers, counts)
+        self.ctx._wait_producers(kmers)
+        n = kmers.numel() if _is_torch(kmers) else kmers.size
+        self.ctx._check(self.L.kmu_count_merge_entries(self.h, _ptr(kmers)[0], _ptr(counts)[0], n, mem))
+
+    def retain_part(self, part, n_parts):
+        self.ctx._check(self.L.kmu_count_retain_part(self.h, part, n_parts))

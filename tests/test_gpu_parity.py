@@ -1,0 +1,279 @@
+"""GPU parity: the HIP path (through the C-ABI of libkmu.so) against the CPU oracle on the same seeded inputs.
+Bit-exact for every integer / byte / index output; the f32/f64 SuperMinHash values are compared bit for bit as
+well (same IEEE operations in the same order, -ffp-contract=off)."""
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+from kmerutils_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kmerutils_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def ragged_dna(seed, lens):
+    rng = np.random.default_rng(seed)
+    seqs = [bytes(synth.ACGT[rng.integers(0, 4, L)]) for L in lens]
+    return seqs
+
+
+RAGGED = [1, 2, 7, 15, 16, 17, 30, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 150, 151, 1000, 1023, 1024, 1025, 1039,
+          1040, 1041, 2047, 2048, 2079, 5000, 12345]
+
+
+@pytest.mark.parametrize("kmer_type,k", [(A.KMER32BIT, 3), (A.KMER32BIT, 8), (A.KMER32BIT, 14), (A.KMER16B32BIT, 16),
+                                         (A.KMER64BIT, 17), (A.KMER64BIT, 21), (A.KMER64BIT, 31)])
+def test_kmer_hashes_all_fhash(ctx, oracle, kmer_type, k):
+    seqs = ragged_dna(100 + k, RAGGED)
+    bases, off = oracle.concat(seqs)
+    for fh in range(8):
+        want = oracle.kmer_hashes(bases, off, kmer_type, k, fh)
+        got = ctx.kmer_hashes(bases, off, kmer_type, k, fh)
+        assert np.array_equal(got, want), "fhash %d" % fh
+
+
+def test_kmer_hashes_packed_and_lowercase(ctx, oracle):
+    seqs = ragged_dna(5, RAGGED)
+    bases, off = oracle.concat(seqs)
+    packed, poff = ctx.pack2b(bases, off)
+    # packing itself: Sequence::new(raw, 2)
+    for i, s in enumerate(seqs):
+        assert bytes(packed[int(poff[i]):int(poff[i + 1])]) == bytes(oracle.pack2b(s))
+    for kmer_type, k in ((A.KMER32BIT, 11), (A.KMER16B32BIT, 16), (A.KMER64BIT, 31)):
+        for fh in (A.FHASH_IDENTITY_RAW, A.FHASH_CANON_INVHASH, A.FHASH_CANON_NTHASH):
+            want = oracle.kmer_hashes(bases, off, kmer_type, k, fh)
+            got = ctx.kmer_hashes(packed, off, kmer_type, k, fh, A.INPUT_PACKED2, poff)
+            assert np.array_equal(got, want)
+    lower = np.frombuffer(bytes(bases).lower(), np.uint8).copy()
+    assert np.array_equal(ctx.kmer_hashes(lower, off, A.KMER64BIT, 21, A.FHASH_CANON_INVHASH),
+                          oracle.kmer_hashes(bases, off, A.KMER64BIT, 21, A.FHASH_CANON_INVHASH))
+
+
+def test_non_acgt_and_errors(ctx, oracle):
+    from kmerutils_amd.lib import KmuError
+    seqs = [b"ACGTACGTNACGT", b"ACGT" * 10, b"acgtxx", b"A" * 100 + b"N"]
+    bases, off = oracle.concat(seqs)
+    assert ctx.count_non_acgt(bases, off).tolist() == [1, 0, 2, 1]
+    with pytest.raises(KmuError) as e:
+        ctx.kmer_hashes(bases, off, A.KMER32BIT, 5, A.FHASH_IDENTITY_RAW)
+    assert e.value.code == A.E_NON_ACGT
+    with pytest.raises(KmuError) as e:
+        ctx.pack2b(bases, off)
+    assert e.value.code == A.E_NON_ACGT
+    good, goff = oracle.concat([b"ACGT" * 10])
+    for kt, k in ((A.KMER32BIT, 15), (A.KMER16B32BIT, 15), (A.KMER64BIT, 32), (A.KMERAA64BIT, 13)):
+        with pytest.raises(KmuError) as e:
+            ctx.kmer_hashes(good, goff, kt, k, A.FHASH_IDENTITY_RAW)
+        assert e.value.code == A.E_BAD_K
+    # empty sequence: the reference panics (nbkmerguess.rs:8)
+    eb, eo = oracle.concat([b"ACGTACGTACGT", b""])
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, 5, 16, A.SIG_U32, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    with pytest.raises(KmuError) as e:
+        ctx.sketch(eb, eo, p)
+    assert e.value.code == A.E_EMPTY_SEQ
+    with pytest.raises(oracle.OracleError):
+        oracle.sketch(eb, eo, p)
+
+
+def test_aa_kmers(ctx, oracle):
+    res, off = synth.protein_seqs(200, 11, median=120)
+    for kt, k in ((A.KMERAA32BIT, 4), (A.KMERAA32BIT, 6), (A.KMERAA64BIT, 8), (A.KMERAA64BIT, 12)):
+        for fh in (A.FHASH_IDENTITY_RAW, A.FHASH_VALUE_MASKED, A.FHASH_INVHASH_RAW):
+            assert np.array_equal(ctx.kmer_hashes(res, off, kt, k, fh), oracle.kmer_hashes(res, off, kt, k, fh))
+    from kmerutils_amd.lib import KmuError
+    bad, boff = oracle.concat([b"MTEQBELIK"])
+    with pytest.raises(KmuError) as e:
+        ctx.kmer_hashes(bad, boff, A.KMERAA32BIT, 3, A.FHASH_IDENTITY_RAW)
+    assert e.value.code == A.E_BAD_ALPHABET
+
+
+PMH_CASES = [
+    # (kmer_type, k, m, fhash, lens)
+    (A.KMER32BIT, 8, 200, A.FHASH_CANON_INVHASH, [5, 8, 9, 200, 1000, 5900, 20000]),
+    (A.KMER32BIT, 5, 64, A.FHASH_IDENTITY_RAW, [3, 4, 5, 6, 50, 3000]),
+    (A.KMER16B32BIT, 16, 100, A.FHASH_CANON_INVHASH, [15, 16, 17, 1000, 9000]),
+    (A.KMER64BIT, 31, 200, A.FHASH_CANON_INVHASH, [30, 31, 32, 150, 6000, 9000, 30000, 70000]),
+    (A.KMER64BIT, 21, 2, A.FHASH_CANON_NTHASH, [21, 500]),
+    (A.KMER64BIT, 31, 257, A.FHASH_CANON_RAW, [4000, 100]),
+]
+
+
+@pytest.mark.parametrize("kmer_type,k,m,fhash,lens", PMH_CASES)
+def test_probminhash3a_parity(ctx, oracle, kmer_type, k, m, fhash, lens):
+    seqs = ragged_dna(1000 + k + m, lens)
+    # a low-complexity read: heavy weights
+    seqs.append(b"ACGT" * 700 + b"A" * 900 + bytes(synth.ACGT[np.random.default_rng(3).integers(0, 4, 400)]))
+    bases, off = oracle.concat(seqs)
+    sig_t = A.SIG_U32 if A.kmer_val_bytes(kmer_type) == 4 else A.SIG_U64
+    for flags in (0, A.FLAG_RAND08):
+        p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, m, sig_t, A.HASHER_NOHASH, fhash, 0, 0, 0, 0, flags)
+        want = oracle.sketch(bases, off, p)
+        got = ctx.sketch(bases, off, p)
+        assert got.dtype == want.dtype
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, "rows differ: %s" % bad[:5]
+    # reads shorter than k: all-zero signature (empty map -> [initobj; m])
+    short = [i for i, L in enumerate(lens) if L < k]
+    for i in short:
+        assert not got[i].any()
+
+
+def test_probminhash3a_ont_batch_and_device_memory(ctx, oracle):
+    import torch
+    bases, off = synth.ont_reads(300, 2_000_000, 0xC3)
+    for kt, k, sig in ((A.KMER32BIT, 8, A.SIG_U32), (A.KMER64BIT, 31, A.SIG_U64)):
+        p = A.SketchParams(A.ALGO_PROB3A, kt, k, 200, sig, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        want = oracle.sketch(bases, off, p)
+        got = ctx.sketch(bases, off, p)
+        assert np.array_equal(got, want)
+        # same through device-resident buffers (torch tensors), twice: determinism
+        tb = torch.from_numpy(bases).cuda()
+        to = torch.from_numpy(off.astype(np.int64)).cuda()
+        g1 = ctx.sketch(tb, to, p).cpu().numpy()
+        g2 = ctx.sketch(tb, to, p).cpu().numpy()
+        assert np.array_equal(g1.view(want.dtype), want) and np.array_equal(g1, g2)
+
+
+def test_block_sketch_parity(ctx, oracle):
+    seqs = ragged_dna(77, [10, 999, 1000, 1001, 2500, 7, 8, 30000])
+    bases, off = oracle.concat(seqs)
+    for B in (1000, 257, 4096):
+        p = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, 8, 50, A.SIG_U32, 0, A.FHASH_CANON_INVHASH, B, 0, 0, 0, 0)
+        want = oracle.sketch(bases, off, p)
+        got = ctx.sketch(bases, off, p)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        # empty trailing blocks give all-zero rows (seqblocksketch.rs:137-145)
+        bro = oracle.block_layout(off, B)
+        assert np.array_equal(ctx.block_layout(off, B), bro)
+
+
+SUPER_CASES = [
+    (A.ALGO_SUPER, A.KMER16B32BIT, 16, 64, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH),
+    (A.ALGO_SUPER, A.KMER16B32BIT, 16, 64, A.SIG_F32, A.HASHER_FNV1A, A.FHASH_CANON_INVHASH),
+    (A.ALGO_SUPER, A.KMER32BIT, 10, 100, A.SIG_F64, A.HASHER_FNV1A, A.FHASH_IDENTITY_RAW),
+    (A.ALGO_SUPER, A.KMER64BIT, 31, 128, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH),
+    (A.ALGO_SUPER, A.KMER64BIT, 21, 300, A.SIG_F32, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED),
+    (A.ALGO_SUPER2, A.KMER64BIT, 21, 128, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH),
+    (A.ALGO_SUPER2, A.KMER16B32BIT, 16, 50, A.SIG_U32, A.HASHER_FNV1A, A.FHASH_CANON_INVHASH),
+]
+
+
+@pytest.mark.parametrize("algo,kmer_type,k,m,sig,hasher,fhash", SUPER_CASES)
+def test_superminhash_parity(ctx, oracle, algo, kmer_type, k, m, sig, hasher, fhash):
+    seqs = ragged_dna(500 + m, [k - 1, k, k + 1, 100, 1000, 1000, 3000, 10000])
+    bases, off = oracle.concat(seqs)
+    for flags in (0, A.FLAG_RAND08):
+        p = A.SketchParams(algo, kmer_type, k, m, sig, hasher, fhash, 0, 0, 0, 0, flags)
+        want = oracle.sketch(bases, off, p)
+        got = ctx.sketch(bases, off, p)
+        assert got.dtype == want.dtype
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def test_superminhash_aa(ctx, oracle):
+    res, off = synth.protein_seqs(300, 0xC5, median=250)
+    for kt, k, m in ((A.KMERAA64BIT, 12, 128), (A.KMERAA32BIT, 5, 400)):
+        p = A.SketchParams(A.ALGO_SUPER, kt, k, m, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0, 0, 0, 0, 0)
+        assert np.array_equal(ctx.sketch(res, off, p), oracle.sketch(res, off, p))
+        p2 = A.SketchParams(A.ALGO_PROB3A, kt, k, 64, A.SIG_U64 if kt == A.KMERAA64BIT else A.SIG_U32, 0,
+                            A.FHASH_VALUE_MASKED, 0, 0, 0, 0, 0)
+        assert np.array_equal(ctx.sketch(res, off, p2), oracle.sketch(res, off, p2))
+
+
+@pytest.mark.parametrize("kmer_type,k", [(A.KMER64BIT, 21), (A.KMER64BIT, 31), (A.KMER16B32BIT, 16), (A.KMER32BIT, 12)])
+def test_count_parity(ctx, oracle, kmer_type, k):
+    bases, off = synth.illumina_reads(3000, 20000, 0xC2)  # ~22x coverage: multiplicities well above 2
+    extra, eoff = oracle.concat([b"A" * 400, b"ACGT" * 5, b"AC", b"T" * 399])
+    bases = np.concatenate([bases, extra])
+    off = np.concatenate([off, eoff[1:] + off[-1]])
+    oc = oracle.Counter(kmer_type, k, 8, 1 << 16)
+    oc.add_reads(bases, off)
+    gc = ctx.counter(kmer_type, k, 8, 1 << 16)
+    gc.add_reads(bases, off)
+    assert gc.nb_distinct() == oc.nb_distinct()
+    assert gc.nb_unique() == oc.nb_unique()
+    wk, wc = oc.dump(2)
+    gk, gcn = gc.dump(2)
+    assert np.array_equal(gk, wk) and np.array_equal(gcn, wc)
+    assert wc.max() == 255  # poly-A saturates the 8-bit counter
+    canon = oracle.kmer_hashes(bases, off, kmer_type, k, A.FHASH_CANON_VALUE)
+    q = np.concatenate([canon[:5000], np.arange(1000, dtype=np.uint64) * 7919 + 3])
+    assert np.array_equal(gc.query(q), oc.query(q))
+    # a second batch accumulates; packed input goes through the per-read kernel
+    packed, poff = ctx.pack2b(bases, off)
+    gc.add_reads(packed, off, A.INPUT_PACKED2, poff)
+    oc.add_reads(bases, off)
+    assert np.array_equal(gc.query(q), oc.query(q))
+    # key-partition export / merge / retain (multi-GPU merge building blocks)
+    g2 = ctx.counter(kmer_type, k, 16, 1 << 16)
+    tot = 0
+    for part in range(3):
+        kk, cc = gc.export_part(part, 3)
+        tot += kk.size
+        g2.merge_entries(kk, cc)
+    assert tot == gc.nb_distinct() == g2.nb_distinct()
+    o16 = oracle.Counter(kmer_type, k, 16, 1 << 16)
+    o16.add_reads(bases, off)
+    o16.add_reads(bases, off)
+    assert np.array_equal(g2.query(q), o16.query(q))
+    gc.retain_part(1, 3)
+    k1, c1 = g2.export_part(1, 3)
+    assert gc.nb_distinct() == k1.size
+
+
+def test_count_reference_kat(ctx, oracle):
+    """kmercount.rs:1524-1559 / 1580-1617 through the GPU counter"""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+    s = kat["seq80"]
+    bases, off = oracle.concat([s.encode()])
+    vk = oracle.kmer_hashes(bases, off, A.KMER16B32BIT, 16, A.FHASH_IDENTITY_RAW)[:65]
+    rng = np.random.default_rng(7)
+    c = ctx.counter(A.KMER16B32BIT, 16, 8, 1024)
+    c.add_kmers(vk[:2].copy())
+    c.add_kmers(vk[rng.integers(2, 65, 1_000_000)])
+    c.add_kmers(vk[1:2].copy())
+    assert c.query(vk[:2].copy()).tolist() == [1, 2]
+    c2 = ctx.counter(A.KMER16B32BIT, 16, 8, 1024)
+    c2.add_kmers(vk[rng.integers(32, 65, 1_000_000)])
+    got = c2.query(vk.copy())
+    assert (got[:32] == 0).all() and (got[32:] == 255).all()
+
+
+def test_full_size_properties(ctx):
+    """size-independent checks at a larger scale than the oracle is run at: determinism, strand invariance of the
+    canonical sketch, and count conservation (sum of counts == number of k-mers)."""
+    import torch
+    dev = torch.device("cuda:0")
+    bases, off, lens = synth.ont_reads_device(20000, 20000 * 6000, 5_000_000, 0xC3, dev)
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 200, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    s1 = ctx.sketch(bases, off, p)
+    s2 = ctx.sketch(bases, off, p)
+    assert torch.equal(s1, s2)
+    # reverse-complement every read (on the device): canonical hashing => identical signatures
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    n = len(lens)
+    rid = torch.repeat_interleave(torch.arange(n, device=dev), torch.from_numpy(lens).to(dev))
+    pos = torch.arange(bases.numel(), device=dev) - off[rid]
+    src = off[rid] + (torch.from_numpy(lens).to(dev)[rid] - 1 - pos)
+    rc = comp[bases[src].long()]
+    rcb = torch.empty(bases.numel() + 64, dtype=torch.uint8, device=dev)
+    rcb[:bases.numel()] = rc
+    s3 = ctx.sketch(rcb[:bases.numel()], off, p)
+    assert torch.equal(s1, s3)
+    nk = int(np.maximum(lens - 30, 0).sum())
+    c = ctx.counter(A.KMER64BIT, 31, 16, nk)
+    c.add_reads(bases, off)
+    k_all, c_all = c.export_part(0, 1)
+    assert int(c_all.astype(np.int64).sum()) == nk
+    assert k_all.size == c.nb_distinct()
