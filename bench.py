@@ -184,8 +184,8 @@ def main():
         if dom:
             ach = kern[dom]["GBps"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"],
-                        "alg_bytes_per_launch": kern[dom]["alg_bytes"]}
+                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cfg, total_bases, dom),
+                        "avg_launch_ms": kern[dom]["avg_ms"], "alg_bytes_per_launch": kern[dom]["alg_bytes"]}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(cfg, bases, offsets, lens, args.cpu_sample_reads)
@@ -204,6 +204,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(cfg, total_bases, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected
+    as MI355X_MICROARCH.md prescribes; scripts/summarize_prof.py).  PMC counters cannot be read from inside the timed
+    run, so the figure is only reported when the committed profile is of this exact workload and size; else null."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(path))
+        if d.get("workload") == cfg["name"] and abs(d.get("bases_per_gpu", 0) - total_bases) < 1e-3 * total_bases:
+            return d["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def _gen(synth, cfg, dev, rank):

@@ -1,0 +1,63 @@
+"""Host-side mirror of the reference's counting interface (src/base/kmercount.rs) on top of libkmu.
+
+  KmerCountT            trait, kmercount.rs:48-59    insert_kmer / get_count / get_nb_distinct / get_nb_unique
+  KmerCounter           kmercount.rs:70-123
+  KmerCounterPool       kmercount.rs:424-565         one counter per thread -> here one counter per GPU
+  count_kmer_threaded_one_to_many   kmercount.rs:881-974
+The reference's cuckoo + counting-Bloom pair is approximate and randomised per process; the device table is exact,
+i.e. the reference's own contract without its ~3 % false positives (counts saturate at 2^nb_bits - 1).
+"""
+import numpy as np
+
+from . import _abi as A
+from . import lib
+from .sketching import _as_arrays, default_context
+
+
+class KmerCounter:
+    """KmerCounter::new(fpr, capacity, nb_bits), kmercount.rs:83-98 (fpr is accepted and ignored: the table is exact)"""
+
+    def __init__(self, kmer_size, capacity, nb_bits=8, fpr=0.03, kmer_type=None, ctx=None):
+        self.ctx = ctx or default_context()
+        self.kmer_type = kmer_type if kmer_type is not None else A.kmer_type_for_k(kmer_size)
+        self.kmer_size = kmer_size
+        self._c = lib.Counter(self.ctx, self.kmer_type, kmer_size, nb_bits, capacity)
+
+    def insert_kmer(self, compressed_values):
+        """KmerCountT::insert_kmer for one value or an array of `get_compressed_value()` values"""
+        v = np.atleast_1d(np.asarray(compressed_values, dtype=np.uint64)).copy()
+        self._c.add_kmers(v)
+
+    def insert_reads(self, vseq):
+        """every canonical k-mer of every read: kmer.reverse_complement().min(kmer), kmercount.rs:313,938"""
+        bases, offsets = _as_arrays(vseq)
+        self._c.add_reads(bases, offsets)
+
+    def get_count(self, compressed_values):
+        v = np.atleast_1d(np.asarray(compressed_values, dtype=np.uint64)).copy()
+        return self._c.query(v)
+
+    def get_nb_distinct(self):
+        return self._c.nb_distinct()
+
+    def get_nb_unique(self):
+        return self._c.nb_unique()
+
+    def get_above2_count(self):
+        """(kmer, count) with count >= 2, sorted by k-mer (dump_kmer_counter, kmercount.rs:500-525)"""
+        return self._c.dump(2)
+
+    @property
+    def raw(self):
+        return self._c
+
+
+def count_kmer_threaded_one_to_many(seqvec, nb_threads, count_size, kmer_size, capacity=None, ctx=None):
+    """kmercount.rs:881-974.  `nb_threads` is accepted for signature compatibility (the GPU needs no key-space
+    dispatch inside one device); `count_size` = bits per counter (8 or 16).  Returns a KmerCounter."""
+    bases, offsets = _as_arrays(seqvec)
+    if capacity is None:
+        capacity = max(1024, int(offsets[-1]))
+    kc = KmerCounter(kmer_size, capacity, count_size, ctx=ctx)
+    kc.insert_reads((bases, offsets))
+    return kc

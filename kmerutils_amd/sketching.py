@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's sketching interface, on top of libkmu (the C-ABI).
+
+Names and argument meaning follow the reference so that callers (gsearch-style code, the parity tests) read the same:
+  SeqSketcherParams            src/sketcharg.rs:40-78
+  SketchAlgo / DataType        src/sketcharg.rs:13-33
+  ProbHash3aSketch             src/sketching/setsketchert.rs:85-203      (trait SeqSketcherT :54-80)
+  SuperHashSketch              src/sketching/setsketchert.rs:211-336
+  SuperHash2Sketch             src/sketching/setsketchert.rs:904-1046
+  SeqSketcher                  src/sketching/seqsketchjaccard.rs:117-415 (sketch_probminhash3a :211, _superminhash :328)
+  BlockSeqSketcher             src/sketching/seqblocksketch.rs:79-227
+A Rust closure `fhash` cannot cross the FFI: pass one of the FHASH_* modes (the closures the reference's own callers
+use, include/kmu.h `kmu_fhash`).  Sequences are given as a list of `bytes` (ASCII), or as (bases, offsets) arrays
+(numpy on the host, torch tensors on the device).  Errors surface as KmuError where the reference panics.
+"""
+import numpy as np
+
+from . import _abi as A
+from . import lib
+
+
+class SketchAlgo:
+    PROB3A, SUPER, SUPER2, BOTTOMK = A.ALGO_PROB3A, A.ALGO_SUPER, A.ALGO_SUPER2, A.ALGO_BOTTOMK
+
+
+class DataType:
+    DNA, AA = 0, 1
+
+
+class SeqSketcherParams:
+    """SeqSketcherParams::new(kmer_size, sketch_size, algo, data_t), src/sketcharg.rs:49-56"""
+
+    def __init__(self, kmer_size, sketch_size, algo=SketchAlgo.PROB3A, data_t=DataType.DNA):
+        self.kmer_size, self.sketch_size, self.algo, self.data_t = kmer_size, sketch_size, algo, data_t
+
+    def get_kmer_size(self):
+        return self.kmer_size
+
+    def get_sketch_size(self):
+        return self.sketch_size
+
+    def get_algo(self):
+        return self.algo
+
+
+def _as_arrays(seqs):
+    """list of bytes -> (bases, offsets); arrays pass through"""
+    if isinstance(seqs, (tuple, list)) and len(seqs) == 2 and not isinstance(seqs[0], (bytes, bytearray)):
+        return seqs[0], seqs[1]
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(bytes(s) for s in seqs), dtype=np.uint8).copy()
+    if bases.size == 0:
+        bases = np.zeros(16, np.uint8)
+    return bases, offsets
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=0):
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = lib.Context(device_id)
+    return _default_ctx[device_id]
+
+
+class _SketcherBase:
+    algo = None
+
+    def __init__(self, params, kmer_type=None, ctx=None):
+        self.params = params
+        aa = params.data_t == DataType.AA
+        self.kmer_type = kmer_type if kmer_type is not None else A.kmer_type_for_k(params.kmer_size, aa)
+        self.ctx = ctx or default_context()
+
+    def get_kmer_size(self):
+        return self.params.kmer_size
+
+    def get_sketch_size(self):
+        return self.params.sketch_size
+
+    def get_algo(self):
+        return self.algo
+
+    def _sig_type(self):
+        raise NotImplementedError
+
+    def _hasher(self):
+        return A.HASHER_NOHASH
+
+    def _params(self, fhash, mode, block_size=0, flags=0):
+        return A.SketchParams(self.algo, self.kmer_type, self.params.kmer_size, self.params.sketch_size,
+                              self._sig_type(), self._hasher(), fhash, block_size, mode, A.INPUT_ASCII, A.MEM_HOST, flags)
+
+    def sketch_compressedkmer(self, vseq, fhash, flags=0):
+        """one signature per sequence, in order (SeqSketcherT::sketch_compressedkmer, setsketchert.rs:66-72)"""
+        bases, offsets = _as_arrays(vseq)
+        return self.ctx.sketch(bases, offsets, self._params(fhash, A.MODE_PER_SEQ, flags=flags))
+
+    def sketch_compressedkmer_seqs(self, vseq, fhash, flags=0):
+        """ONE signature for the whole list (outer length 1), setsketchert.rs:74-79"""
+        bases, offsets = _as_arrays(vseq)
+        return self.ctx.sketch(bases, offsets, self._params(fhash, A.MODE_ALL_SEQS, flags=flags))
+
+
+class ProbHash3aSketch(_SketcherBase):
+    """type Sig = Kmer::Val (setsketchert.rs:107)"""
+    algo = SketchAlgo.PROB3A
+
+    def _sig_type(self):
+        return A.SIG_U32 if A.kmer_val_bytes(self.kmer_type) == 4 else A.SIG_U64
+
+
+class SuperHashSketch(_SketcherBase):
+    """type Sig = f32 / f64 (setsketchert.rs:237); NoHashHasher (:267)"""
+    algo = SketchAlgo.SUPER
+
+    def __init__(self, params, sig="f64", kmer_type=None, ctx=None):
+        super().__init__(params, kmer_type, ctx)
+        self.sig = sig
+
+    def _sig_type(self):
+        return A.SIG_F32 if self.sig == "f32" else A.SIG_F64
+
+
+class SuperHash2Sketch(_SketcherBase):
+    """type Sig = u32 / u64, caller-chosen hasher (setsketchert.rs:904-945)"""
+    algo = SketchAlgo.SUPER2
+
+    def __init__(self, params, sig="u64", hasher=A.HASHER_NOHASH, kmer_type=None, ctx=None):
+        super().__init__(params, kmer_type, ctx)
+        self.sig, self.hasher = sig, hasher
+
+    def _sig_type(self):
+        return A.SIG_U32 if self.sig == "u32" else A.SIG_U64
+
+    def _hasher(self):
+        return self.hasher
+
+
+class SeqSketcher:
+    """SeqSketcher{kmer_size, sketch_size}, src/sketching/seqsketchjaccard.rs:117-140"""
+
+    def __init__(self, kmer_size, sketch_size, ctx=None):
+        self.kmer_size, self.sketch_size = kmer_size, sketch_size
+        self.ctx = ctx or default_context()
+
+    def get_kmer_size(self):
+        return self.kmer_size
+
+    def get_sketch_size(self):
+        return self.sketch_size
+
+    def sketch_probminhash3a(self, vseq, fhash, kmer_type=None, flags=0):
+        """seqsketchjaccard.rs:211-260: Vec<Vec<Kmer::Val>>, row i <-> sequence i"""
+        kt = kmer_type if kmer_type is not None else A.kmer_type_for_k(self.kmer_size)
+        sig = A.SIG_U32 if A.kmer_val_bytes(kt) == 4 else A.SIG_U64
+        p = A.SketchParams(A.ALGO_PROB3A, kt, self.kmer_size, self.sketch_size, sig, A.HASHER_NOHASH, fhash, 0,
+                           A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_HOST, flags)
+        bases, offsets = _as_arrays(vseq)
+        return self.ctx.sketch(bases, offsets, p)
+
+    def sketch_superminhash(self, vseq, fhash, sig="f64", kmer_type=None, flags=0):
+        """seqsketchjaccard.rs:328-380: SuperMinHash<S, Kmer::Val, fnv::FnvHasher>"""
+        kt = kmer_type if kmer_type is not None else A.kmer_type_for_k(self.kmer_size)
+        p = A.SketchParams(A.ALGO_SUPER, kt, self.kmer_size, self.sketch_size,
+                           A.SIG_F32 if sig == "f32" else A.SIG_F64, A.HASHER_FNV1A, fhash, 0, A.MODE_PER_SEQ,
+                           A.INPUT_ASCII, A.MEM_HOST, flags)
+        bases, offsets = _as_arrays(vseq)
+        return self.ctx.sketch(bases, offsets, p)
+
+
+class BlockSeqSketcher:
+    """BlockSeqSketcher{block_size, kmer_size, sketch_size}, src/sketching/seqblocksketch.rs:79-95 (Kmer32bit only)"""
+
+    def __init__(self, block_size, kmer_size, sketch_size, ctx=None):
+        self.block_size, self.kmer_size, self.sketch_size = block_size, kmer_size, sketch_size
+        self.ctx = ctx or default_context()
+
+    def blocksketch_sequences(self, vseq, fhash, first_numseq=0):
+        """seqblocksketch.rs:152-167.  Returns (rows [n_blocks_total, sketch_size] u32, numseq, numblock): row j is
+        BlockSketched{numseq[j], numblock[j], sketch = rows[j]}"""
+        bases, offsets = _as_arrays(vseq)
+        p = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, self.kmer_size, self.sketch_size, A.SIG_U32, A.HASHER_NOHASH,
+                           fhash, self.block_size, A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_HOST, 0)
+        off_h = np.ascontiguousarray(offsets, np.uint64)
+        bro = self.ctx.block_layout(off_h, self.block_size)
+        rows = self.ctx.sketch(bases, offsets, p, block_row_offsets=bro)
+        nb = np.diff(bro.astype(np.int64))
+        numseq = np.repeat(np.arange(len(nb), dtype=np.uint32) + first_numseq, nb)
+        numblock = np.concatenate([np.arange(k, dtype=np.uint32) for k in nb]) if len(nb) else np.zeros(0, np.uint32)
+        return rows, numseq, numblock
+
+
+def jaccard_from_signatures(siga, sigb):
+    """probminhash::jaccard::compute_probminhash_jaccard (called at seqsketchjaccard.rs:95-101): fraction of equal
+    slots"""
+    siga, sigb = np.asarray(siga), np.asarray(sigb)
+    return float((siga == sigb).mean())

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output directories (gpurun_out/<name>_{trace,fetch,write}) into the small summaries committed
+under profiles/: kernel stats (our kernels + the largest others) and per-launch HBM traffic from the PMC passes.
+
+usage: scripts/summarize_prof.py <tag> <trace_dir> [<fetch_dir> <write_dir>]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    tag, trace = sys.argv[1], sys.argv[2]
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    rows = list(csv.DictReader(open(glob.glob(os.path.join(trace, "*", "*_kernel_stats.csv"))[0])))
+    with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats summary (kmu:: kernels + the 5 largest others)\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        others = 0
+        for r in rows:
+            ours = r["Name"].startswith("kmu::")
+            if ours or others < 5:
+                others += 0 if ours else 1
+                f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (r["Name"][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                                     r["Percentage"], r["MinNs"], r["MaxNs"]))
+    pmc = {}
+    if len(sys.argv) >= 5:
+        for name, d in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+            acc = collections.defaultdict(float)
+            cnt = collections.Counter()
+            for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
+                if r["Counter_Name"] == name and r["Kernel_Name"].startswith("kmu::"):
+                    k = r["Kernel_Name"].split("(")[0].replace("kmu::", "")
+                    acc[k] += float(r["Counter_Value"])
+                    cnt[k] += 1
+            for k in acc:
+                pmc.setdefault(k, {})[name + "_KB_per_launch"] = acc[k] / cnt[k]
+        for k, v in pmc.items():
+            f_kb, w_kb = v.get("FETCH_SIZE_KB_per_launch", 0), v.get("WRITE_SIZE_KB_per_launch", 0)
+            # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming
+            # read -> doubled for the streaming kernels; the random 4/8-byte atomic pattern of the count-insert kernel
+            # is uncalibrated and left as reported.
+            streaming = not k.startswith("k_count_add")
+            v["fetch_correction"] = 2.0 if streaming else 1.0
+            v["hbm_bytes_per_launch"] = (f_kb * v["fetch_correction"] + w_kb) * 1024.0
+        json.dump(pmc, open(os.path.join(out_dir, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
+    print(open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag)).read())
+    print(json.dumps(pmc, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""The N > 1 path on CPU: world_size-2 gloo process group, read sharding and the owner-partition exchange of
+kmerutils_amd.dist, with a test-only counter double backed by the oracle standing in for the GPU table."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+from kmerutils_amd import dist as kdist
+from kmerutils_amd import synth
+
+
+def test_shard_reads_by_bases():
+    rng = np.random.default_rng(1)
+    lens = synth.ont_lengths(5000, rng)
+    for w in (1, 2, 3, 8):
+        sh = kdist.shard_reads_by_bases(lens, w)
+        assert sh[0][0] == 0 and sh[-1][1] == len(lens)
+        assert all(sh[i][1] == sh[i + 1][0] for i in range(w - 1))
+        per = np.array([lens[a:b].sum() for a, b in sh])
+        assert per.max() - per.min() <= 2 * lens.max()
+    assert kdist.shard_reads_by_bases([], 2) == [(0, 0), (0, 0)]
+    assert kdist.shard_reads_by_bases([5], 4)[-1][1] == 1
+
+
+class OracleCounterDouble:
+    """test-only stand-in with the lib.Counter surface used by dist.merge_counters"""
+
+    def __init__(self, O, kmer_type, k):
+        self.O, self.kt, self.k = O, kmer_type, k
+        self.c = O.Counter(kmer_type, k, 16, 1 << 12)
+
+    def add_reads(self, bases, offsets):
+        self.c.add_reads(bases, offsets)
+
+    def export_part(self, part, n_parts, device=None):
+        k, c = self.c.dump(1)
+        L = self.O.lib()
+        own = np.array([L.kmo_int64_hash(int(x)) % n_parts for x in k], dtype=np.int64) == part
+        return k[own].copy(), c[own].copy()
+
+    def reset(self):
+        self.c = self.O.Counter(self.kt, self.k, 16, 1 << 12)
+
+    def merge_entries(self, k, c):
+        self.c.add_kmers(np.repeat(k, c.astype(np.int64)))
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bases, off = synth.illumina_reads(400, 3000, 0xC4)  # every rank builds the same read set ...
+        lens = np.diff(off.astype(np.int64))
+        r0, r1 = kdist.shard_reads_by_bases(lens, world)[rank]  # ... and counts only its contiguous shard
+        sb = bases[int(off[r0]):int(off[r1])].copy()
+        so = (off[r0:r1 + 1] - off[r0]).astype(np.uint64)
+        cd = OracleCounterDouble(O, A.KMER64BIT, 21)
+        cd.add_reads(sb, so)
+        got = kdist.merge_counters(cd, device=None, chunk_entries=257)  # several exchange rounds
+        # reference result: the global counter restricted to the keys this rank owns
+        g = O.Counter(A.KMER64BIT, 21, 16, 1 << 12)
+        g.add_reads(bases, off)
+        gk, gc = g.dump(1)
+        L = O.lib()
+        own = np.array([L.kmo_int64_hash(int(x)) % world for x in gk], dtype=np.int64) == rank
+        mk, mc = cd.c.dump(1)
+        ok = np.array_equal(mk, gk[own]) and np.array_equal(mc, gc[own]) and got > 0
+        # signature slabs are concatenated in rank (= read) order
+        import torch
+        rows = torch.arange((r1 - r0) * 4, dtype=torch.int64).reshape(r1 - r0, 4) + 1000 * rank
+        allrows = kdist.gather_rows(rows)
+        ok = ok and allrows.shape[0] == len(lens) and int(allrows[0, 0]) == 0
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_merge_counters_world2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(0) is True and ret.get(1) is True

@@ -1,0 +1,150 @@
+"""Oracle-side checks of the sketchers, mirroring the *statistical* assertions the reference holds for them
+(they never pin signature bits), plus structural properties that must hold exactly:
+order independence, duplicate idempotence, strand invariance, block partitioning."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+from kmerutils_amd import synth
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def rc(s):
+    return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+
+
+def rnd(rng, n):
+    return bytes(synth.ACGT[rng.integers(0, 4, n)])
+
+
+def test_pminhash_small_kmers_like_reference(oracle):
+    """seqsketchjaccard.rs:742-851: k=5, m=4000 on two short strings; J(a, revcomp(a)) == 1 with the canonical hash"""
+    a = KAT["seq80"].encode()
+    b = (KAT["seq80"][:40] + "ACGTACGGTTACCATGAGGGCATTACAGCGGATTACAGGA").encode()
+    bases, off = oracle.concat([a, b, rc(a)])
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, 5, 4000, A.SIG_U32, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    s = oracle.sketch(bases, off, p)
+    assert (s[0] == s[2]).all()  # ">= 1.0 for revcomp-invariant hash" (:785)
+    # exact weighted (probability) Jaccard J_P of the two multisets vs the estimate
+    ha = oracle.kmer_hashes(bases, off, A.KMER32BIT, 5, A.FHASH_CANON_INVHASH)
+    ka, ca = np.unique(ha[:76], return_counts=True)
+    kb, cb = np.unique(ha[80:80 + 76], return_counts=True)
+    wa, wb = dict(zip(ka, ca / ca.sum())), dict(zip(kb, cb / cb.sum()))
+    jp = 0.0
+    for x in set(wa) & set(wb):
+        jp += 1.0 / sum(max(wa.get(y, 0) / wa[x], wb.get(y, 0) / wb[x]) for y in set(wa) | set(wb))
+    est = (s[0] == s[1]).mean()
+    assert abs(est - jp) < 0.05, (est, jp)
+    # identity hash: sequence vs its reverse complement share few k-mers ("<= 0.1", :850)
+    pi = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, 5, 4000, A.SIG_U32, 0, A.FHASH_IDENTITY_RAW, 0, 0, 0, 0, 0)
+    si = oracle.sketch(bases, off, pi)
+    assert (si[0] == si[2]).mean() <= 0.2
+
+
+@pytest.mark.parametrize("algo,kt,k,m,sig,hasher", [
+    (A.ALGO_PROB3A, A.KMER16B32BIT, 16, 1000, A.SIG_U32, A.HASHER_NOHASH),     # seqsketchjaccard.rs:854-911
+    (A.ALGO_PROB3A, A.KMER64BIT, 24, 1000, A.SIG_U64, A.HASHER_NOHASH),        # :914-944
+    (A.ALGO_SUPER, A.KMER16B32BIT, 16, 1000, A.SIG_F64, A.HASHER_FNV1A),       # :947-1005
+    (A.ALGO_SUPER, A.KMER64BIT, 31, 1000, A.SIG_F32, A.HASHER_NOHASH),
+    (A.ALGO_SUPER2, A.KMER64BIT, 21, 1000, A.SIG_U64, A.HASHER_NOHASH),
+])
+def test_half_overlap_estimates(oracle, algo, kt, k, m, sig, hasher):
+    """|J_est - J_true| small on two random reads sharing a known fraction of k-mers; J == 1 against the reverse
+    complement with a canonical hash (setsketchert.rs:1125,1146 use |d - 0.5| < 0.1)"""
+    rng = np.random.default_rng(42 + k)
+    common, ua, ub = rnd(rng, 6000), rnd(rng, 3000), rnd(rng, 3000)
+    a, b = common + ua, common + ub
+    bases, off = oracle.concat([a, b, rc(a)])
+    p = A.SketchParams(algo, kt, k, m, sig, hasher, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    s = oracle.sketch(bases, off, p)
+    assert (s[0] == s[2]).all()
+    h = oracle.kmer_hashes(bases, off, kt, k, A.FHASH_CANON_INVHASH)
+    A_, B_ = set(h[:len(a) - k + 1].tolist()), set(h[len(a):len(a) + len(b) - k + 1].tolist())
+    jt = len(A_ & B_) / len(A_ | B_)
+    est = (s[0] == s[1]).mean()
+    assert abs(est - jt) < 0.07, (est, jt)  # sigma = sqrt(J(1-J)/m) = 0.016
+
+
+def test_probminhash3a_order_independence_and_weights(oracle):
+    rng = np.random.default_rng(3)
+    keys = rng.integers(0, 2**62, 3000, dtype=np.uint64)
+    w = rng.integers(1, 50, 3000).astype(np.float64)
+    s1, h1 = oracle.probminhash3a(keys, w, 8, 200)
+    perm = rng.permutation(3000)
+    s2, h2 = oracle.probminhash3a(keys[perm], w[perm], 8, 200)
+    assert (s1 == s2).all() and (h1 == h2).all()
+    assert (h1 > 0).all() and (h1 < 1.0).all()
+    # heavier keys win more slots: the slot share of the top-weight decile is far above 10 %
+    heavy = set(keys[np.argsort(w)[-300:]].tolist())
+    share = np.mean([int(x) in heavy for x in s1])
+    assert share > 0.15
+    # a single key fills every slot
+    s3, _ = oracle.probminhash3a(keys[:1], w[:1], 8, 64)
+    assert (s3 == keys[0]).all()
+
+
+def test_superminhash_duplicates_are_idempotent(oracle):
+    rng = np.random.default_rng(5)
+    a = rnd(rng, 2000)
+    bases, off = oracle.concat([a, a + a[-30:] + a])  # every k-mer of a again (plus junction k-mers)
+    p = A.SketchParams(A.ALGO_SUPER, A.KMER32BIT, 12, 64, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    s = oracle.sketch(bases, off, p)
+    assert (s[1] <= s[0]).all() and (s[1] == s[0]).mean() > 0.9
+    assert (s >= 0).all() and (s < 64).all()
+
+
+def test_block_sketch_matches_per_block_sketch(oracle):
+    """seqblocksketch.rs:108-146: block j = the k-mers starting in [jB, (j+1)B); empty trailing block -> zeros"""
+    rng = np.random.default_rng(9)
+    s = rnd(rng, 2503)
+    B, k, m = 1000, 8, 40
+    bases, off = oracle.concat([s])
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, k, m, A.SIG_U32, 0, A.FHASH_CANON_INVHASH, B, 0, 0, 0, 0)
+    blk = oracle.sketch(bases, off, p)
+    assert blk.shape == (3, m)
+    p0 = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, k, m, A.SIG_U32, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    for j in range(3):
+        sub = s[j * B: (j + 1) * B + k - 1]
+        b2, o2 = oracle.concat([sub])
+        assert (oracle.sketch(b2, o2, p0)[0] == blk[j]).all()
+    # L = 2000, B = 1000, k = 8: blocks hold 1000 and 993 k-mers; L = 1003: second block holds k-mers 1000..995 = none
+    b3, o3 = oracle.concat([rnd(rng, 1003)])
+    blk3 = oracle.sketch(b3, o3, p)
+    assert blk3.shape == (2, m) and not blk3[1].any()
+
+
+def test_all_seqs_mode_equals_concatenated_multiset(oracle):
+    rng = np.random.default_rng(13)
+    reads = [rnd(rng, 500) for _ in range(5)]
+    bases, off = oracle.concat(reads)
+    for algo, sig in ((A.ALGO_PROB3A, A.SIG_U32), (A.ALGO_SUPER, A.SIG_F64)):
+        p = A.SketchParams(algo, A.KMER32BIT, 10, 64, sig, 0, A.FHASH_CANON_INVHASH, 0, A.MODE_ALL_SEQS, 0, 0, 0)
+        one = oracle.sketch(bases, off, p)
+        assert one.shape == (1, 64)
+        h = oracle.kmer_hashes(bases, off, A.KMER32BIT, 10, A.FHASH_CANON_INVHASH)
+        hk = np.concatenate([h[int(off[i]):int(off[i + 1]) - 9] for i in range(5)]).astype(np.uint32)
+        p2 = A.SketchParams(algo, A.KMER32BIT, 10, 64, sig, 0, A.FHASH_CANON_INVHASH, 0, A.MODE_PER_SEQ, 0, 0, 0)
+        ref = oracle.sketch_hashed(hk, np.array([0, hk.size], np.uint64), p2)
+        assert (ref == one).all()
+
+
+def test_bottomk_is_the_k_smallest_with_total_multiplicities(oracle):
+    """minhash.rs:62-99: streaming max-heap + map == the `size` smallest distinct hashes with their full counts"""
+    rng = np.random.default_rng(17)
+    s = rnd(rng, 3000) + b"ACGTACGTACGTACGTACGT" * 30
+    bases, off = oracle.concat([s])
+    for hasher, fh in ((A.HASHER_NOHASH, A.FHASH_CANON_INVHASH), (A.HASHER_INT64HASH, A.FHASH_CANON_VALUE)):
+        p = A.SketchParams(A.ALGO_BOTTOMK, A.KMER16B32BIT, 16, 50, A.SIG_U64, hasher, fh, 0, 0, 0, 0, 0)
+        sig, cnt = oracle.sketch(bases, off, p, want_counts=True)
+        v = oracle.kmer_hashes(bases, off, A.KMER16B32BIT, 16, fh)[:len(s) - 15]
+        L = oracle.lib()
+        hh = np.array([L.kmo_nohash_finish(int(x), 4) if hasher == A.HASHER_NOHASH else L.kmo_int64_hash(int(x))
+                       for x in v], dtype=np.uint64)
+        u, c = np.unique(hh, return_counts=True)
+        assert (sig[0] == u[:50]).all()
+        mask = 0xFF if hasher == A.HASHER_INT64HASH else 0xFFFF
+        assert (cnt[0] == (c[:50] & mask)).all()
