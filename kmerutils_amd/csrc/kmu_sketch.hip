@@ -36,7 +36,12 @@ struct SketchArgs {
     int sig_bytes;   // 4 or 8
     uint32_t block_size;
     uint32_t table_slots; // S
-    uint32_t part_cap;    // max k-mers handled by one pass
+    uint32_t list_cap;    // dense list capacity = max distinct keys of one pass
+    uint32_t part_target; // k-mers aimed at per pass (list_cap minus a fluctuation margin)
+    uint32_t tile_words;  // staged code words per tile (16 bases each)
+    uint32_t idx_thresh;  // rand 0.9 Uniform<usize>(0, m): reject while lo < (2^32 - m) % m
+    uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
+    uint32_t ablate;      // diagnostics only (KMU_PMH_ABLATE): 1 skip pass B math, 2 skip table insert, 4 skip hashing
     Exp01 e01;
     void *sig_out;
     uint32_t *queue; // atomic read counter
@@ -51,31 +56,37 @@ __device__ __forceinline__ uint32_t mix32(uint64_t key) {
 }
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t) (((uint64_t) a * b) >> 32); }
 
-// LDS multiset insert: keys[] (u64, KEY_EMPTY = free) + cnt[] (u32).  Returns false when the table is full.
-__device__ __forceinline__ bool table_insert(uint64_t *keys, uint32_t *cnt, uint32_t S, uint64_t key, uint32_t h) {
+// misc words in LDS
+enum { M_READ = 0, M_SENT = 1, M_LIST = 2, M_FLAGS = 3, M_QMAX = 4 /* 4,5: u64 */, M_WORDS = 8 };
+
+// LDS multiset insert: keys[] (u64, KEY_EMPTY = free) + cnt[] (u32).  Returns 0 = key was present, 1 = this lane
+// claimed a free slot (*slot), 2 = table full.
+__device__ __forceinline__ int table_insert(uint64_t *keys, uint32_t *cnt, uint32_t S, uint64_t key, uint32_t h,
+                                            uint32_t *slot) {
     uint32_t s = mulhi32(h, S);
     for (uint32_t probes = 0; probes < S; probes++) {
         unsigned long long old = atomicCAS((unsigned long long *) &keys[s], (unsigned long long) KEY_EMPTY,
                                            (unsigned long long) key);
         if (old == KEY_EMPTY || old == key) {
             atomicAdd(&cnt[s], 1u);
-            return true;
+            *slot = s;
+            return old == KEY_EMPTY ? 1 : 0;
         }
         s = s + 1 == S ? 0 : s + 1;
     }
-    return false;
+    return 2;
 }
 
 // slot update: keep (h, key) minimal per slot; exact ties go to the smaller key (order independence)
 __device__ __forceinline__ void slot_update(uint64_t *hmin, uint64_t *sig, uint32_t k, double h, uint64_t key) {
     const uint64_t hb = (uint64_t) __double_as_longlong(h);
     for (;;) {
-        uint64_t cur = *(volatile uint64_t *) &hmin[k];
+        uint64_t cur = __hip_atomic_load(&hmin[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == H_BUSY) continue;
         if (hb > cur) return;
-        if (hb == cur && key >= *(volatile uint64_t *) &sig[k]) return;
+        if (hb == cur && key >= __hip_atomic_load(&sig[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
         if (atomicCAS((unsigned long long *) &hmin[k], (unsigned long long) cur, (unsigned long long) H_BUSY) == cur) {
-            *(volatile uint64_t *) &sig[k] = key;
+            __hip_atomic_store(&sig[k], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __threadfence_block();
             atomicExch((unsigned long long *) &hmin[k], (unsigned long long) hb);
             return;
@@ -87,27 +98,96 @@ __device__ __forceinline__ void slot_update(uint64_t *hmin, uint64_t *sig, uint3
 __device__ __forceinline__ uint64_t wave_qmax(const uint64_t *hmin, int m) {
     uint64_t q = 0;
     for (int i = lane_id(); i < m; i += 64) {
-        uint64_t v = *(volatile const uint64_t *) &hmin[i];
+        uint64_t v = __hip_atomic_load(&hmin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (v == H_BUSY) v = H_INIT;
         q = v > q ? v : q;
     }
     return wave_max_u64(q);
 }
 
-// ProbMinHash3a for one key of weight w: every generated point (h, slot) is offered to the slot minima.
-// `qmax_bits` is any upper bound of the current q_max; pruning with it never changes the arg-min.
-__device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t *hmin, uint64_t *sig, bool have,
-                                                   uint64_t key, uint32_t w) {
+__device__ __forceinline__ uint32_t draw_slot(const SketchArgs &a, Xoshiro &rng) {
+    if (a.rand08) {
+        for (;;) {
+            uint64_t v = rng.next();
+            uint64_t hi = __umul64hi(v, (uint64_t) a.m), lo = v * (uint64_t) a.m;
+            if (lo <= a.idx_zone) return (uint32_t) hi;
+        }
+    }
+    for (;;) {
+        uint64_t mm = (uint64_t) rng.next_u32() * (uint32_t) a.m;
+        if ((uint32_t) mm >= a.idx_thresh) return (uint32_t) (mm >> 32);
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + i * 0x9e3779b97f4a7c15ull; // SplitMix64 is counter based: output i depends on seed + i*G only
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+// the rejection part of ExpRestricted01::sample (reached with probability 1 - 1/c1)
+__device__ __forceinline__ double exp01_rest(const Exp01 &e, Xoshiro &rng) {
+    for (;;) {
+        double x = rng.unif01();
+        if (x < e.c2) return x;
+        double y = 0.5 * rng.unif01();
+        if (y > 1.0 - x) {
+            x = 1.0 - x;
+            y = 1.0 - y;
+        }
+        if (x <= e.c3 * (1.0 - y)) return x;
+        if (e.c1 * y <= 1.0 - x) return x;
+        if (y * e.c1 * e.lambda <= expm1_small(e.lambda * (1.0 - x))) return x;
+    }
+}
+
+// ProbMinHash3a for one key of weight w per lane: every generated point (h, slot) is offered to the slot minima.
+// `qmax` is any upper bound of the current q_max (shared word, refreshed by whoever still has live lanes); pruning
+// with a stale bound never changes the arg-min.  RNG draw order per key = the crate's: round 1 draws the slot only
+// when h < q_max (otherwise the key is dropped), later rounds always draw it.
+// The first xoshiro256++ output needs only state words s0 and s3 (= SplitMix64 outputs 1 and 4 of the seed): the
+// other two are computed only for the minority of keys whose first point survives the q_max test.
+__device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t *hmin, uint64_t *sig, uint64_t *qmax_sh,
+                                                   bool refresh, bool have, uint64_t key, uint32_t w) {
+    uint64_t qb;
+    if (refresh) {
+        qb = wave_qmax(hmin, a.m);
+        if (lane_id() == 0) atomicMin((unsigned long long *) qmax_sh, (unsigned long long) qb);
+    } else {
+        qb = __hip_atomic_load(qmax_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     Xoshiro rng;
     double winv = 0.0;
-    bool alive = have;
-    if (have) {
-        rng.seed(hasher_finish(KMU_HASHER_NOHASH, key, a.sig_bytes == 4));
-        winv = 1.0 / (double) w;
-    }
+    bool alive = false;
     uint32_t i = 1;
-    uint64_t qb = wave_qmax(hmin, a.m);
+    if (have) {
+        const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, a.sig_bytes == 4);
+        winv = 1.0 / (double) w;
+        rng.s0 = splitmix_at(seed, 1);
+        rng.s3 = splitmix_at(seed, 4);
+        const uint64_t r1 = rotl64(rng.s0 + rng.s3, 23) + rng.s0;
+        const double u1 = __longlong_as_double((long long) ((r1 >> 12) | 0x3FF0000000000000ull)) - 1.0;
+        double x = a.e01.c1 * u1;
+        const double qmax = __longlong_as_double((long long) qb);
+        const bool slow = !(x < 1.0);
+        if (slow || winv * x < qmax) {
+            rng.s1 = splitmix_at(seed, 2);
+            rng.s2 = splitmix_at(seed, 3);
+            (void) rng.next(); // the draw already used
+            if (slow) x = exp01_rest(a.e01, rng);
+            const double h = winv * x;
+            if (h < qmax) {
+                uint32_t k = draw_slot(a, rng);
+                slot_update(hmin, sig, k, h, key);
+                alive = winv < qmax; // keep iff winv * 1 < q_max
+            }
+            i = 2;
+        }
+    }
     while (__any(alive)) {
+        qb = wave_qmax(hmin, a.m);
+        if (lane_id() == 0) atomicMin((unsigned long long *) qmax_sh, (unsigned long long) qb);
         if (alive) {
             double qmax = __longlong_as_double((long long) qb);
             double hbase = winv * (double) (i - 1);
@@ -116,18 +196,17 @@ __device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t
             } else {
                 double x = exp01_sample(a.e01, rng);
                 double h = hbase + winv * x;
-                uint32_t k = rng.unif_index(0, (uint32_t) a.m, a.rand08 != 0);
+                uint32_t k = draw_slot(a, rng); // rounds >= 2 always draw the slot
                 if (h < qmax) slot_update(hmin, sig, k, h, key);
-                else if (i == 1) alive = false; // first point already beyond q_max: the reference drops the key
                 if (!(winv * (double) i < qmax)) alive = false;
                 i++;
             }
         }
-        if (__any(alive)) qb = wave_qmax(hmin, a.m);
     }
 }
 
-// One workgroup = one read at a time (or one block of a read in block mode).
+// One workgroup = one read at a time (all blocks of it in block mode).
+template <bool AA>
 __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t S = a.table_slots;
@@ -135,21 +214,28 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     uint64_t *hmin = keys + S;
     uint64_t *sig = hmin + a.m;
     uint32_t *cnt = reinterpret_cast<uint32_t *>(sig + a.m);
-    uint32_t *misc = cnt + S; // [0] current read, [1] count of KEY_EMPTY-valued keys, [2] flags
+    uint32_t *misc = cnt + S;
+    uint32_t *words = misc + M_WORDS;
+    uint16_t *list = reinterpret_cast<uint16_t *>(words + a.tile_words + 4);
+    uint64_t *qmax_sh = reinterpret_cast<uint64_t *>(&misc[M_QMAX]);
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
-    const bool aa = a.cfg.kmer_type == KMU_KMERAA32BIT || a.cfg.kmer_type == KMU_KMERAA64BIT;
+    const int k = a.cfg.k;
+    const uint32_t tile_pos = (a.tile_words - 2) * 16; // k-mer start positions covered by one staged tile
 
     for (uint32_t s = tid; s < S; s += nthreads) { keys[s] = KEY_EMPTY; cnt[s] = 0; }
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
-    if (tid == 0) { misc[1] = 0; misc[2] = 0; }
+    if (tid == 0) { misc[M_SENT] = 0; misc[M_LIST] = 0; misc[M_FLAGS] = 0; *qmax_sh = H_INIT; }
     __syncthreads();
 
+    if (tid == 0) misc[M_READ] = atomicAdd(a.queue, 1u);
+    __syncthreads();
     for (;;) {
-        if (tid == 0) misc[0] = atomicAdd(a.queue, 1u);
-        __syncthreads();
-        const uint32_t r = misc[0];
+        const uint32_t r = misc[M_READ];
+        __syncthreads(); // everyone holds r before thread 0 posts the next one
         if (r >= a.n_seq) break;
+        uint32_t r_next = 0;
+        if (tid == 0) r_next = atomicAdd(a.queue, 1u); // its latency hides under this read's work
         SeqView sv;
         sv.base = a.bases;
         sv.len = a.offsets[r + 1] - a.offsets[r];
@@ -163,10 +249,10 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             sv.total = a.total_bytes ? a.total_bytes : a.offsets[a.n_seq];
         }
         const uint64_t L = sv.len;
-        const uint64_t nk_all = L >= (uint64_t) a.cfg.k ? L - a.cfg.k + 1 : 0;
+        const uint64_t nk_all = L >= (uint64_t) k ? L - k + 1 : 0;
         if (L == 0 && tid == 0) atomicOr(a.err, 8u);
-        if (nk_all == 0 && wave_validate_seq(sv, wave, nwaves, aa)) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
-        const uint64_t nsteps = aa ? (L + 63) / 64 : (seq_num_words(sv) + 63) / 64;
+        if (nk_all == 0 && wave_validate_seq(sv, wave, nwaves, AA)) atomicOr(a.err, AA ? DERR_BAD_AA : DERR_NON_ACGT);
+        const uint32_t lead = AA ? 0u : seq_lead(sv);
         // blocks of the read (src/sketching/seqblocksketch.rs:108-146); whole read = one block
         const uint64_t B = a.block_size ? a.block_size : (nk_all ? nk_all : 1);
         const uint64_t nblocks = a.block_size ? (L + B - 1) / B : 1;
@@ -175,57 +261,111 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             if (pb > nk_all) pb = nk_all;
             if (pe > nk_all) pe = nk_all;
             const uint64_t nk = pe - pb;
-            const uint32_t P = nk ? (uint32_t) ((nk + a.part_cap - 1) / a.part_cap) : 0;
-            // table region used by this block: small reads only touch (and later sweep) a prefix of the table
-            uint32_t Seff = S;
-            if (P == 1) {
-                uint64_t want = ((nk * 8) / 5 + 64 + 63) & ~63ull;
-                Seff = want < S ? (uint32_t) want : S;
-            }
-            // only the steps that hold positions [pb, pe + k - 1) matter
-            uint64_t st0 = 0, st1 = nsteps;
-            if (a.block_size && !aa) {
-                uint32_t lead = seq_lead(sv);
-                st0 = (pb + lead) / 1024;
-                st1 = nk ? ((pe - 1 + lead) / 1024 + 1) : st0;
-            } else if (a.block_size) {
-                st0 = pb / 64;
-                st1 = nk ? ((pe - 1) / 64 + 1) : st0;
-            }
+            const uint32_t P = nk ? (uint32_t) ((nk + a.part_target - 1) / a.part_target) : 0;
+            const uint64_t ntiles = AA ? 1 : (nk + tile_pos - 1) / tile_pos;
+            uint32_t bad = 0;
+            bool full = false;
             for (uint32_t part = 0; part < P; part++) {
-                // ---- pass A: multiset of the keys of this partition -------------------------------------
-                uint32_t bad = 0;
-                bool full = false;
-                auto visit = [&](uint64_t, uint64_t val, uint64_t rc) {
-                    uint64_t key = apply_fhash(a.cfg, val, rc);
-                    uint32_t h = mix32(key);
-                    if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) return;
-                    if (key == KEY_EMPTY) { atomicAdd(&misc[1], 1u); return; }
-                    if (!table_insert(keys, cnt, Seff, key, h)) full = true;
-                };
-                for (uint64_t st = st0 + wave; st < st1; st += nwaves) {
-                    if (aa) bad |= wave_step_kmers_aa(sv, a.cfg.k, st, pb, pe, visit);
-                    else bad |= wave_step_kmers(sv, a.cfg.k, st, pb, pe, visit);
+                // ---- pass A: multiset of the keys of this partition (seqsketchjaccard.rs:226-234) -----------
+                for (uint64_t tile = 0; tile < ntiles; tile++) {
+                    const uint64_t tp0 = AA ? pb : pb + tile * tile_pos;
+                    const uint64_t tp1 = AA ? pe : (tp0 + tile_pos < pe ? tp0 + tile_pos : pe);
+                    uint64_t wfirst = 0;
+                    if (!AA) {
+                        wfirst = (tp0 + lead) >> 4;
+                        if (!(part > 0 && ntiles == 1)) { // a single-tile read stays staged across partitions
+                            if (tile > 0 || part > 0) __syncthreads(); // previous tile still being read
+                            const uint64_t wlast = (tp1 - 1 + lead + (uint64_t) k - 1) >> 4;
+                            const uint32_t nw = (uint32_t) (wlast - wfirst + 1) + 2;
+                            for (uint32_t t = tid; t < nw; t += nthreads) {
+                                uint32_t b;
+                                words[t] = load_code_word(sv, wfirst + t, b);
+                                bad |= b;
+                            }
+                            __syncthreads();
+                        }
+                    }
+                    for (uint64_t pw = tp0 + (uint64_t) wave * 64; pw < tp1; pw += nthreads) { // wave-uniform trip count
+                        const uint64_t p = pw + lane_id();
+                        bool claimed = false;
+                        uint32_t cslot = 0;
+                        if (p < tp1) {
+                            uint64_t val, rc = 0;
+                            if (AA) {
+                                val = 0;
+                                for (int j = 0; j < k; j++) {
+                                    uint32_t c = code_aa(sv.base[sv.begin + p + j]);
+                                    bad |= c == 0;
+                                    val = (val << 5) | c;
+                                }
+                            } else {
+                                const uint32_t q = (uint32_t) (p + lead - 16 * wfirst);
+                                const uint32_t idx = q >> 4, sh = (q & 15u) * 2u;
+                                const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
+                                const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
+                                val = v >> (64 - 2 * k);
+                                rc = revcomp_val(val, k);
+                            }
+                            bool go = !(a.ablate & 4u);
+                            uint64_t key = 0;
+                            uint32_t h = 0;
+                            if (go) {
+                                key = apply_fhash(a.cfg, val, rc);
+                                h = mix32(key);
+                                if (a.ablate & 2u) go = false;
+                                if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) go = false;
+                            } else if (val == 0x1234567ull) full = true;
+                            if (go) {
+                                if (key == KEY_EMPTY) atomicAdd(&misc[M_SENT], 1u);
+                                else {
+                                    int rcode = table_insert(keys, cnt, S, key, h, &cslot);
+                                    claimed = rcode == 1;
+                                    if (rcode == 2) full = true;
+                                }
+                            } else if (h == 0x12345u) full = true;
+                        }
+                        // one LDS atomic per wave appends all newly claimed slots to the dense list
+                        const uint64_t cmask = __ballot(claimed);
+                        if (cmask) {
+                            const int leader = __ffsll((unsigned long long) cmask) - 1;
+                            uint32_t basepos = 0;
+                            if (lane_id() == leader) basepos = atomicAdd(&misc[M_LIST], (uint32_t) __popcll(cmask));
+                            basepos = bcast_u32(basepos, leader);
+                            if (claimed) {
+                                uint32_t pos = basepos + (uint32_t) __popcll(cmask & ((1ull << lane_id()) - 1ull));
+                                if (pos < a.list_cap) list[pos] = (uint16_t) cslot;
+                                else full = true;
+                            }
+                        }
+                    }
                 }
-                if (bad) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
-                if (full) atomicOr(a.err, DERR_TABLE_FULL);
                 __syncthreads();
-                // ---- pass B: every distinct key generates its points; table is swept clean ---------------
-                for (uint32_t base = wave * 64; base < Seff; base += nwaves * 64) {
-                    uint32_t s = base + lane_id();
-                    uint64_t key = keys[s];
-                    uint32_t w = cnt[s];
-                    bool have = key != KEY_EMPTY;
-                    if (have) { keys[s] = KEY_EMPTY; cnt[s] = 0; }
-                    if (__any(have)) pmh3a_consume_wave(a, hmin, sig, have, key, w);
-                }
-                if (wave == 0 && misc[1] != 0) { // the key whose value equals the sentinel
-                    uint32_t w = misc[1];
-                    pmh3a_consume_wave(a, hmin, sig, lane_id() == 0, KEY_EMPTY, w);
-                }
+                const uint32_t n_list = misc[M_LIST] < a.list_cap ? misc[M_LIST] : a.list_cap;
+                const uint32_t n_sent = misc[M_SENT];
                 __syncthreads();
-                if (tid == 0) misc[1] = 0;
+                if (tid == 0) { misc[M_LIST] = 0; misc[M_SENT] = 0; }
+                // ---- pass B: every distinct key generates its points; its table slot is freed -----------------
+                uint32_t chunk = 0;
+                for (uint32_t base = 0; base < n_list; base += nthreads, chunk++) {
+                    const uint32_t i = base + tid;
+                    const bool have = i < n_list;
+                    uint64_t key = 0;
+                    uint32_t w = 1;
+                    if (have) {
+                        const uint32_t s = list[i];
+                        key = keys[s];
+                        w = cnt[s];
+                        keys[s] = KEY_EMPTY;
+                        cnt[s] = 0;
+                    }
+                    if (__any(have) && !(a.ablate & 1u)) pmh3a_consume_wave(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
+                }
+                if (wave == 0 && n_sent != 0) // the key whose value equals the table sentinel
+                    pmh3a_consume_wave(a, hmin, sig, qmax_sh, true, lane_id() == 0, KEY_EMPTY, n_sent);
+                __syncthreads();
             }
+            if (bad) atomicOr(a.err, AA ? DERR_BAD_AA : DERR_NON_ACGT);
+            if (full) atomicOr(a.err, DERR_TABLE_FULL);
             // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
             {
                 uint64_t row = a.block_rows ? a.block_rows[r] + blk : (uint64_t) r;
@@ -236,9 +376,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                     hmin[t] = H_INIT;
                     sig[t] = 0;
                 }
+                if (tid == 0) *qmax_sh = H_INIT;
             }
             __syncthreads();
         }
+        if (tid == 0) misc[M_READ] = r_next;
         __syncthreads();
     }
 }
@@ -298,6 +440,12 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.rand08 = (p->flags & KMU_FLAG_RAND08) ? 1 : 0;
     a.sig_bytes = kmer_val_bytes(p->kmer_type);
     a.block_size = (uint32_t) p->block_size;
+    {
+        uint32_t m32 = (uint32_t) a.m;
+        a.idx_thresh = (0u - m32) % m32;
+        uint64_t m64 = (uint64_t) a.m;
+        a.idx_zone = 0xFFFFFFFFFFFFFFFFull - (0xFFFFFFFFFFFFFFFFull - m64 + 1ull) % m64;
+    }
     // ExpRestricted01::new(lambda), lambda = ln(m / (m-1)) -- same libm expressions as the crate / the oracle
     double lambda = std::log((double) a.m / (double) (a.m - 1));
     a.e01.lambda = lambda;
@@ -306,21 +454,27 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.e01.c3 = (1.0 - std::exp(-lambda)) / lambda;
     a.sig_out = d_sig;
     a.err = d_err;
-    // LDS budget: keys 8S + cnt 4S + 16 m + 64
+    { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
+    const bool aa = kmer_is_aa(p->kmer_type);
+    auto fn = aa ? (const void *) k_sketch_pmh3a<true> : (const void *) k_sketch_pmh3a<false>;
     size_t lds_max = 160 * 1024;
-    if (hipFuncSetAttribute((const void *) k_sketch_pmh3a, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) !=
-        hipSuccess) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) != hipSuccess) {
         (void) hipGetLastError();
         lds_max = 64 * 1024;
     }
-    size_t fixed = (size_t) 16 * a.m + 64;
-    if (fixed + 12 * 256 > lds_max) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS", a.m);
-    uint32_t S = (uint32_t) (((lds_max - fixed) / 12) & ~63ull);
+    // LDS budget: slot minima 16 m | misc 32 B | staged code words 4 (tile_words + 4) | table 12 S | list 2 * 0.75 S
+    a.tile_words = aa ? 4 : (lds_max > 64 * 1024 ? 4096 + 2 : 1024 + 2);
+    size_t fixed = (size_t) 16 * a.m + 4 * M_WORDS + 4 * ((size_t) a.tile_words + 4) + 64;
+    if (fixed + 13.5 * 256 > lds_max) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS", a.m);
+    uint32_t S = (uint32_t) ((double) (lds_max - fixed) / 13.5);
+    S &= ~63u;
+    if (S > 65536) S = 65536; // slot indices are stored as u16
     const char *env = getenv("KMU_PMH_SLOTS");
     if (env && atoi(env) >= 256) S = std::min<uint32_t>(S, (uint32_t) atoi(env) & ~63u);
     a.table_slots = S;
-    a.part_cap = (uint32_t) ((uint64_t) S * 5 / 8);
-    size_t lds = (size_t) 12 * S + fixed;
+    a.list_cap = (S / 4) * 3;
+    a.part_target = a.list_cap - a.list_cap / 10;
+    size_t lds = (size_t) 12 * S + 2 * (size_t) a.list_cap + fixed;
     void *q;
     KMU_TRY(dev_buf(ctx, "queue", 64, &q));
     KMU_HIP(ctx, hipMemsetAsync(q, 0, 64, ctx->stream));
@@ -333,7 +487,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     if (grid < 1) grid = 1;
     {
         KernelTimer t(ctx, "k_sketch_pmh3a");
-        hipLaunchKernelGGL(k_sketch_pmh3a, dim3(grid), dim3(threads), lds, ctx->stream, a);
+        if (aa) hipLaunchKernelGGL(k_sketch_pmh3a<true>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(k_sketch_pmh3a<false>, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
     KMU_HIP(ctx, hipGetLastError());
     return KMU_OK;
