@@ -3,10 +3,17 @@
 // Reference (src/base/kmercount.rs:241-277): a cuckoo filter holds k-mers seen once, a counting Bloom filter
 // the counts >= 2; both are randomised per process, so the observable contract is "exact multiplicity of the
 // canonical k-mer, reported saturated at 2^bits - 1" (plus ~3 % false positives the reference itself treats as
-// noise).  Here: one exact open-addressing table in HBM (8-byte canonical value + 4-byte count per slot), updated
-// with one 64-bit CAS + one 32-bit atomic add per k-mer occurrence.  The bases are consumed as ONE flat stream of
-// aligned 16-byte words (perfect coalescing and load balance whatever the read lengths); each lane finds the
-// read that owns its word by binary search in `offsets` and masks the k-mers that would straddle a read end.
+// noise).  Here: one exact table in HBM -- keys[2^q] (canonical value, all-ones = free) + counts[2^q] (u32) --
+// cut into REGIONS of 4096 slots; a key lives in the region named by the top bits of fmix64(key) and is probed
+// linearly inside it (wrapping at the region end), so a region is an independent little hash table that fits LDS.
+//
+// Two ways to add k-mers:
+//  * big batches (the throughput path): a radix-partitioned build.  The bases are consumed as ONE flat stream of
+//    aligned 16-byte words; exact per-unit histograms give every workgroup private, contiguous output ranges, so
+//    the k-mers are scattered region by region (one or two levels, <= 2048-way each) with plain stores and no
+//    global atomics; then one workgroup per region builds the region in LDS (ds_cmpst / ds_add) and streams it
+//    out.  HBM sees only streaming reads/writes: bases, 8 B per k-mer per level, and the table image.
+//  * small batches / single values / merges: direct insertion with one 64-bit CAS + one 32-bit atomic add.
 #include <algorithm>
 #include <vector>
 
@@ -18,14 +25,17 @@ struct kmu_counter {
     kmu_count_params p{};
     uint64_t nslots = 0; // power of two
     int lg = 0;
+    int rbits = 0;       // log2 of the region size
     uint64_t *keys = nullptr;
     uint32_t *counts = nullptr;
     uint64_t *scalars = nullptr; // device: [0] distinct, [1] unique, [2] cursor
+    bool empty = true;           // table content not materialised yet (every slot is logically free)
 };
 
 namespace kmu {
 
 static constexpr uint64_t CKEY_EMPTY = 0xFFFFFFFFFFFFFFFFull; // canonical values are < 2^62
+static constexpr int REGION_BITS_MAX = 12;                    // 4096 slots = 48 KiB of LDS per region
 
 __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
     x ^= x >> 33;
@@ -39,14 +49,17 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
 struct CountTable {
     uint64_t *keys;
     uint32_t *counts;
-    uint64_t mask;
-    int shift; // 64 - lg
+    int shift;      // 64 - lg
+    uint32_t rmask; // region size - 1
 };
 
 // KmerCounter::insert_kmer (kmercount.rs:241-267), exact form: count[v] += add
 __device__ __forceinline__ bool count_insert(const CountTable &t, uint64_t v, uint32_t add) {
-    uint64_t idx = fmix64(v) >> t.shift;
-    for (uint64_t probes = 0; probes <= t.mask; probes++) {
+    const uint64_t idx0 = fmix64(v) >> t.shift;
+    const uint64_t base = idx0 & ~(uint64_t) t.rmask;
+    uint32_t off = (uint32_t) idx0 & t.rmask;
+    for (uint32_t probes = 0; probes <= t.rmask; probes++) {
+        const uint64_t idx = base | off;
         uint64_t cur = __hip_atomic_load(&t.keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == CKEY_EMPTY) {
             cur = atomicCAS((unsigned long long *) &t.keys[idx], (unsigned long long) CKEY_EMPTY, (unsigned long long) v);
@@ -56,61 +69,63 @@ __device__ __forceinline__ bool count_insert(const CountTable &t, uint64_t v, ui
             atomicAdd(&t.counts[idx], add);
             return true;
         }
-        idx = (idx + 1) & t.mask;
+        off = (off + 1) & t.rmask;
     }
     return false;
 }
 
 __device__ __forceinline__ uint32_t count_lookup(const CountTable &t, uint64_t v) {
-    uint64_t idx = fmix64(v) >> t.shift;
-    for (uint64_t probes = 0; probes <= t.mask; probes++) {
+    const uint64_t idx0 = fmix64(v) >> t.shift;
+    const uint64_t base = idx0 & ~(uint64_t) t.rmask;
+    uint32_t off = (uint32_t) idx0 & t.rmask;
+    for (uint32_t probes = 0; probes <= t.rmask; probes++) {
+        const uint64_t idx = base | off;
         uint64_t cur = t.keys[idx];
         if (cur == v) return t.counts[idx];
         if (cur == CKEY_EMPTY) return 0;
-        idx = (idx + 1) & t.mask;
+        off = (off + 1) & t.rmask;
     }
     return 0;
 }
 
-// largest i with offsets[i] <= g  (offsets[0] = 0, offsets[n] = total > g)
-__device__ __forceinline__ uint32_t find_read(const uint64_t *offsets, uint32_t n, uint64_t g) {
+// largest i with offsets[i] <= g, g wave-uniform; 64-ary search, one coalesced probe per round
+__device__ __forceinline__ uint32_t wave_find_read(const uint64_t *offsets, uint32_t n, uint64_t g) {
     uint32_t lo = 0, hi = n; // invariant offsets[lo] <= g < offsets[hi]
+    const uint32_t lane = (uint32_t) lane_id();
     while (hi - lo > 1) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if (offsets[mid] <= g) lo = mid;
-        else hi = mid;
+        const uint32_t step = (hi - lo + 63) / 64;
+        const uint64_t idx = (uint64_t) lo + (uint64_t) (lane + 1) * step;
+        const bool le = idx < hi && offsets[idx] <= g;
+        const uint32_t c = (uint32_t) __popcll(__ballot(le));
+        const uint64_t nhi = (uint64_t) lo + (uint64_t) (c + 1) * step;
+        lo = lo + c * step;
+        hi = nhi < hi ? (uint32_t) nhi : hi;
     }
     return lo;
 }
 
-// flat stream over all bases (ASCII input)
-__global__ void __launch_bounds__(256) k_count_add_flat(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
-                                                        int k, CountTable t, uint32_t *err) {
-    const uint64_t total = offsets[n_seq];
-    const uint64_t nwords = (total + 15) / 16;
-    const uint64_t nsteps = (nwords + 63) / 64;
-    const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+// One wave step (64 words = 1024 bases) of the flat base stream: f(canon) for every k-mer that lies inside one read.
+// Returns a non-zero mask if this lane saw a non-ACGT byte.
+template <typename F>
+__device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
+                                                    uint64_t total, int k, uint64_t st, F &&f) {
     SeqView s;
     s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
     const int lane = lane_id();
-    const int sh = 64 - 2 * k;
-    uint32_t anybad = 0, full = 0;
-    for (uint64_t st = wave_global; st < nsteps; st += nwaves_global) {
-        const uint64_t widx = st * 64 + lane;
-        uint32_t bad, bad2;
-        uint32_t w0 = load_code_word(s, widx, bad);
-        uint32_t ex = load_code_word(s, st * 64 + 64 + (uint64_t) (lane & 1), bad2);
-        uint32_t e0 = bcast_u32(ex, 0), e1 = bcast_u32(ex, 1);
-        uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
-        if (lane == 63) { w1 = e0; w2 = e1; }
-        if (lane == 62) { w2 = e0; }
-        anybad |= bad;
-        const uint64_t g0 = widx * 16;
-        if (g0 >= total) continue;
-        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
-        uint32_t r = find_read(offsets, n_seq, g0);
+    const uint64_t widx = st * 64 + lane;
+    uint32_t bad, bad2;
+    uint32_t w0 = load_code_word(s, widx, bad);
+    uint32_t ex = load_code_word(s, st * 64 + 64 + (uint64_t) (lane & 1), bad2);
+    uint32_t e0 = bcast_u32(ex, 0), e1 = bcast_u32(ex, 1);
+    uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
+    if (lane == 63) { w1 = e0; w2 = e1; }
+    if (lane == 62) { w2 = e0; }
+    uint32_t r = wave_find_read(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1);
+    const uint64_t g0 = widx * 16;
+    if (g0 < total) {
         uint64_t rend = offsets[r + 1];
+        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+        const int sh = 64 - 2 * k;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint64_t g = g0 + j;
@@ -119,16 +134,31 @@ __global__ void __launch_bounds__(256) k_count_add_flat(const uint8_t *bases, co
                 uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
                 uint64_t val = v >> sh;
                 uint64_t rc = revcomp_val(val, k);
-                uint64_t canon = rc < val ? rc : val; // kmer.reverse_complement().min(kmer), kmercount.rs:938
-                if (!count_insert(t, canon, 1u)) full = 1;
+                f(rc < val ? rc : val); // kmer.reverse_complement().min(kmer), kmercount.rs:938
             }
         }
     }
+    return bad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct insertion kernels (small batches, packed input, explicit k-mer lists, merges)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count_add_flat(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
+                                                        int k, CountTable t, uint32_t *err) {
+    const uint64_t total = offsets[n_seq];
+    const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
+    const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    uint32_t anybad = 0, full = 0;
+    for (uint64_t st = wave_global; st < nsteps; st += nwaves_global)
+        anybad |= flat_step_canon(bases, offsets, n_seq, total, k, st, [&](uint64_t canon) {
+            if (!count_insert(t, canon, 1u)) full = 1;
+        });
     if (anybad) atomicOr(err, DERR_NON_ACGT);
     if (full) atomicOr(err, DERR_TABLE_FULL);
 }
 
-// per-read form (packed input): one wave per read step
 __global__ void __launch_bounds__(256) k_count_add_reads(const uint8_t *bases, const uint64_t *offsets,
                                                          const uint64_t *packed_offsets, uint32_t n_seq, int packed,
                                                          uint64_t total_bytes, int k, CountTable t, uint32_t *err) {
@@ -175,10 +205,10 @@ __global__ void __launch_bounds__(256) k_count_query(const uint64_t *kmers, uint
     }
 }
 
-// [0] += occupied slots, [1] += slots with count == 1, [3] += slots with count >= min_count in partition
-__global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t *scalars) {
+// [0] += occupied slots, [1] += slots with count == 1
+__global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslots, uint64_t *scalars) {
     uint64_t d = 0, u = 0;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t) gridDim.x * blockDim.x) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         if (t.keys[i] != CKEY_EMPTY) {
             d++;
             u += t.counts[i] == 1u;
@@ -200,21 +230,248 @@ __device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_p
 }
 
 // compact (kmer, count) with count >= min_count (and owner == part when n_parts > 0); cap-limited
-__global__ void __launch_bounds__(256) k_count_select(CountTable t, uint32_t min_count, uint32_t maxc, int w32,
-                                                      uint32_t part, uint32_t n_parts, uint64_t cap, uint64_t *kmers,
-                                                      uint32_t *counts, uint64_t *cursor) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= t.mask; i += (uint64_t) gridDim.x * blockDim.x) {
-        uint64_t key = t.keys[i];
-        if (key == CKEY_EMPTY) continue;
-        uint32_t c = t.counts[i];
-        if (c < min_count) continue;
-        if (n_parts && kmer_owner(key, w32, n_parts) != part) continue;
-        uint64_t pos = atomicAdd((unsigned long long *) cursor, 1ull);
-        if (kmers && pos < cap) {
-            kmers[pos] = key;
-            counts[pos] = c > maxc ? maxc : c;
+__global__ void __launch_bounds__(256) k_count_select(CountTable t, uint64_t nslots, uint32_t min_count, uint32_t maxc,
+                                                      int w32, uint32_t part, uint32_t n_parts, uint64_t cap,
+                                                      uint64_t *kmers, uint32_t *counts, uint64_t *cursor) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    const uint64_t rounds = (nslots + stride - 1) / stride; // wave-uniform trip count (ballot inside)
+    for (uint64_t it = 0; it < rounds; it++) {
+        const uint64_t i = it * stride + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+        bool take = false;
+        uint64_t key = 0;
+        uint32_t c = 0;
+        if (i < nslots) {
+            key = t.keys[i];
+            if (key != CKEY_EMPTY) {
+                c = t.counts[i];
+                take = c >= min_count && !(n_parts && kmer_owner(key, w32, n_parts) != part);
+            }
+        }
+        // one global atomic per wave
+        const uint64_t m = __ballot(take);
+        if (m) {
+            const int leader = __ffsll((unsigned long long) m) - 1;
+            uint64_t base = 0;
+            if (lane_id() == leader) base = atomicAdd((unsigned long long *) cursor, (unsigned long long) __popcll(m));
+            base = ((uint64_t) bcast_u32((uint32_t) (base >> 32), leader) << 32) | bcast_u32((uint32_t) base, leader);
+            if (take) {
+                uint64_t pos = base + (uint64_t) __popcll(m & ((1ull << lane_id()) - 1ull));
+                if (kmers && pos < cap) {
+                    kmers[pos] = key;
+                    counts[pos] = c > maxc ? maxc : c;
+                }
+            }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix-partitioned build
+// ------------------------------------------------------------------------------------------------
+struct PartPlan {
+    int region_bits; // number of regions = 2^region_bits
+    int b1, b2;      // level-1 / level-2 fan-out bits (b2 = 0: one level)
+    uint32_t units1; // level-1 units (workgroups), each a contiguous range of wave steps
+    uint32_t steps_per_unit;
+    uint32_t chunks2; // level-2 units per level-1 partition
+};
+
+__device__ __forceinline__ uint32_t region_of(uint64_t canon, int region_bits) {
+    return region_bits ? (uint32_t) (fmix64(canon) >> (64 - region_bits)) : 0u;
+}
+
+// level 1, pass 1: per-unit histogram of the level-1 digit (also validates the bases)
+__global__ void __launch_bounds__(256) k_part_hist1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
+                                                    PartPlan pl, uint32_t *hist1, uint32_t *err) {
+    extern __shared__ uint32_t lh[];
+    const uint32_t bins1 = 1u << pl.b1;
+    for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    const uint64_t total = offsets[n_seq];
+    const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
+    const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
+    const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint32_t bad = 0;
+    for (uint64_t st = s0 + wave; st < s1; st += nwaves)
+        bad |= flat_step_canon(bases, offsets, n_seq, total, k, st, [&](uint64_t canon) {
+            atomicAdd(&lh[region_of(canon, pl.region_bits) >> pl.b2], 1u);
+        });
+    if (bad) atomicOr(err, DERR_NON_ACGT);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) hist1[(uint64_t) blockIdx.x * bins1 + b] = lh[b];
+}
+
+// level 1 scan, step a: one workgroup per bin -> exclusive prefix over the units + bin total
+__global__ void __launch_bounds__(256) k_part_scan1a(const uint32_t *hist1, PartPlan pl, uint64_t *offs1, uint64_t *tot1) {
+    __shared__ uint64_t part[256];
+    const uint32_t bins1 = 1u << pl.b1, b = blockIdx.x, U = pl.units1;
+    const uint32_t per = (U + 255) / 256;
+    const uint32_t u0 = threadIdx.x * per < U ? threadIdx.x * per : U, u1 = u0 + per < U ? u0 + per : U;
+    uint64_t sum = 0;
+    for (uint32_t u = u0; u < u1; u++) sum += hist1[(uint64_t) u * bins1 + b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 256; i++) { uint64_t v = part[i]; part[i] = run; run += v; }
+        tot1[b] = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t u = u0; u < u1; u++) {
+        offs1[(uint64_t) u * bins1 + b] = run;
+        run += hist1[(uint64_t) u * bins1 + b];
+    }
+}
+
+// level 1 scan, step b: exclusive scan of the bin totals (single workgroup); binstart1[bins1] = number of k-mers
+__global__ void __launch_bounds__(256) k_part_scan1b(const uint64_t *tot1, PartPlan pl, uint64_t *binstart1) {
+    __shared__ uint64_t part[256];
+    const uint32_t bins1 = 1u << pl.b1;
+    const uint32_t per = (bins1 + 255) / 256;
+    const uint32_t b0 = threadIdx.x * per < bins1 ? threadIdx.x * per : bins1, b1 = b0 + per < bins1 ? b0 + per : bins1;
+    uint64_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += tot1[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 256; i++) { uint64_t v = part[i]; part[i] = run; run += v; }
+        binstart1[bins1] = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t b = b0; b < b1; b++) { binstart1[b] = run; run += tot1[b]; }
+}
+
+// level 1, pass 2: scatter the canonical k-mers into their level-1 partitions (private ranges per unit)
+__global__ void __launch_bounds__(256) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
+                                                       PartPlan pl, const uint64_t *offs1, const uint64_t *binstart1,
+                                                       uint64_t *out) {
+    extern __shared__ uint64_t cur[];
+    const uint32_t bins1 = 1u << pl.b1;
+    for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x)
+        cur[b] = binstart1[b] + offs1[(uint64_t) blockIdx.x * bins1 + b];
+    __syncthreads();
+    const uint64_t total = offsets[n_seq];
+    const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
+    const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
+    const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (uint64_t st = s0 + wave; st < s1; st += nwaves)
+        (void) flat_step_canon(bases, offsets, n_seq, total, k, st, [&](uint64_t canon) {
+            uint32_t b = region_of(canon, pl.region_bits) >> pl.b2;
+            uint64_t pos = atomicAdd((unsigned long long *) &cur[b], 1ull);
+            out[pos] = canon;
+        });
+}
+
+// level 2 unit (p1, c): its slice of partition p1
+__device__ __forceinline__ void unit2_range(const uint64_t *binstart1, PartPlan pl, uint32_t unit, uint64_t *i0, uint64_t *i1) {
+    const uint32_t p1 = unit / pl.chunks2, c = unit % pl.chunks2;
+    const uint64_t s = binstart1[p1], len = binstart1[p1 + 1] - s;
+    *i0 = s + len * c / pl.chunks2;
+    *i1 = s + len * (c + 1) / pl.chunks2;
+}
+
+__global__ void __launch_bounds__(256) k_part_hist2(const uint64_t *in, const uint64_t *binstart1, PartPlan pl,
+                                                    uint32_t *hist2) {
+    extern __shared__ uint32_t lh[];
+    const uint32_t bins2 = 1u << pl.b2;
+    for (uint32_t b = threadIdx.x; b < bins2; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    uint64_t i0, i1;
+    unit2_range(binstart1, pl, blockIdx.x, &i0, &i1);
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+        atomicAdd(&lh[region_of(in[i], pl.region_bits) & (bins2 - 1)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins2; b += blockDim.x) hist2[(uint64_t) blockIdx.x * bins2 + b] = lh[b];
+}
+
+// level 2 scan: one workgroup per level-1 partition; order = (bin2 major, chunk minor)
+__global__ void __launch_bounds__(256) k_part_scan2(const uint32_t *hist2, const uint64_t *binstart1, PartPlan pl,
+                                                    uint64_t *offs2, uint64_t *leafstart) {
+    __shared__ uint64_t part[256];
+    const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2, p1 = blockIdx.x, C = pl.chunks2;
+    const uint32_t per = (bins2 + 255) / 256;
+    const uint32_t b0 = threadIdx.x * per < bins2 ? threadIdx.x * per : bins2, b1 = b0 + per < bins2 ? b0 + per : bins2;
+    uint64_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++)
+        for (uint32_t c = 0; c < C; c++) sum += hist2[((uint64_t) p1 * C + c) * bins2 + b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = binstart1[p1];
+        for (int i = 0; i < 256; i++) { uint64_t v = part[i]; part[i] = run; run += v; }
+        if (p1 == bins1 - 1) leafstart[(uint64_t) bins1 * bins2] = binstart1[bins1];
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t b = b0; b < b1; b++) {
+        leafstart[(uint64_t) p1 * bins2 + b] = run;
+        for (uint32_t c = 0; c < C; c++) {
+            offs2[((uint64_t) p1 * C + c) * bins2 + b] = run;
+            run += hist2[((uint64_t) p1 * C + c) * bins2 + b];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_part_scatter2(const uint64_t *in, const uint64_t *binstart1, PartPlan pl,
+                                                       const uint64_t *offs2, uint64_t *out) {
+    extern __shared__ uint64_t cur[];
+    const uint32_t bins2 = 1u << pl.b2;
+    for (uint32_t b = threadIdx.x; b < bins2; b += blockDim.x) cur[b] = offs2[(uint64_t) blockIdx.x * bins2 + b];
+    __syncthreads();
+    uint64_t i0, i1;
+    unit2_range(binstart1, pl, blockIdx.x, &i0, &i1);
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const uint64_t canon = in[i];
+        const uint32_t b = region_of(canon, pl.region_bits) & (bins2 - 1);
+        const uint64_t pos = atomicAdd((unsigned long long *) &cur[b], 1ull);
+        out[pos] = canon;
+    }
+}
+
+// build: one workgroup per region.  The region (keys + counts) lives in LDS while its k-mers are inserted, then it
+// is streamed out.  `fresh` = the table holds nothing yet (every region is written, no region is read).
+__global__ void __launch_bounds__(256) k_part_build(const uint64_t *items, const uint64_t *leafstart, uint32_t n_regions,
+                                                    CountTable t, int fresh, uint32_t *err) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t R = t.rmask + 1;
+    uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *lc = reinterpret_cast<uint32_t *>(lk + R);
+    uint32_t full = 0;
+    for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        const uint64_t gbase = (uint64_t) r * R;
+        if (fresh) {
+            for (uint32_t s = threadIdx.x; s < R; s += blockDim.x) { lk[s] = CKEY_EMPTY; lc[s] = 0; }
+        } else {
+            for (uint32_t s = threadIdx.x; s < R; s += blockDim.x) { lk[s] = t.keys[gbase + s]; lc[s] = t.counts[gbase + s]; }
+        }
+        __syncthreads();
+        const uint64_t i0 = leafstart[r], i1 = leafstart[r + 1];
+        for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            const uint64_t v = items[i];
+            uint32_t off = (uint32_t) (fmix64(v) >> t.shift) & t.rmask;
+            bool done = false;
+            for (uint32_t probes = 0; probes < R; probes++) {
+                unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY,
+                                                   (unsigned long long) v);
+                if (old == CKEY_EMPTY || old == v) {
+                    atomicAdd(&lc[off], 1u);
+                    done = true;
+                    break;
+                }
+                off = (off + 1) & t.rmask;
+            }
+            if (!done) full = 1;
+        }
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < R; s += blockDim.x) { t.keys[gbase + s] = lk[s]; t.counts[gbase + s] = lc[s]; }
+        __syncthreads();
+    }
+    if (full) atomicOr(err, DERR_TABLE_FULL);
 }
 
 } // namespace kmu
@@ -225,8 +482,8 @@ static CountTable table_of(const kmu_counter *c) {
     CountTable t;
     t.keys = c->keys;
     t.counts = c->counts;
-    t.mask = c->nslots - 1;
     t.shift = 64 - c->lg;
+    t.rmask = (1u << c->rbits) - 1u;
     return t;
 }
 static uint32_t max_count(const kmu_counter *c) { return c->p.counter_bits == 8 ? 255u : 65535u; }
@@ -236,14 +493,104 @@ static int grid_for(const kmu_ctx *ctx, uint64_t n, int per_block) {
     return (int) std::max<uint64_t>(1, std::min(blocks, cap));
 }
 
+// make the logical "all free" state physical before anything reads or updates slots in place
+static int materialize(kmu_counter *c) {
+    if (!c->empty) return KMU_OK;
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipMemsetAsync(c->keys, 0xFF, c->nslots * 8, ctx->stream));
+    KMU_HIP(ctx, hipMemsetAsync(c->counts, 0, c->nslots * 4, ctx->stream));
+    c->empty = false;
+    return KMU_OK;
+}
+
+// the radix-partitioned build over device-resident ASCII reads
+static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    PartPlan pl;
+    pl.region_bits = c->lg - c->rbits;
+    if (pl.region_bits <= 11) { pl.b1 = pl.region_bits; pl.b2 = 0; }
+    else { pl.b1 = (pl.region_bits + 1) / 2; pl.b2 = pl.region_bits - pl.b1; }
+    if (pl.b1 > 11 || pl.b2 > 11) return fail(ctx, KMU_E_UNSUPPORTED, "table too large for the two-level partitioned build");
+    const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
+    const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
+    uint32_t units1 = (uint32_t) std::min<uint64_t>(nsteps, (uint64_t) ctx->num_cus * 8);
+    if (units1 < 1) units1 = 1;
+    pl.steps_per_unit = (uint32_t) ((nsteps + units1 - 1) / units1);
+    units1 = (uint32_t) ((nsteps + pl.steps_per_unit - 1) / pl.steps_per_unit);
+    pl.units1 = units1;
+    pl.chunks2 = pl.b2 ? std::max<uint32_t>(1u, 16384u / bins1) : 1u;
+    const uint32_t units2 = bins1 * pl.chunks2;
+    const uint64_t n_regions = 1ull << pl.region_bits;
+
+    void *A, *B = nullptr, *hist1, *offs1, *tot1, *binstart1, *hist2 = nullptr, *offs2 = nullptr, *leafstart = nullptr;
+    KMU_TRY(dev_buf(ctx, "cnt.partA", total_bases * 8 + 64, &A));
+    KMU_TRY(dev_buf(ctx, "cnt.hist1", (size_t) units1 * bins1 * 4, &hist1));
+    KMU_TRY(dev_buf(ctx, "cnt.offs1", (size_t) units1 * bins1 * 8, &offs1));
+    KMU_TRY(dev_buf(ctx, "cnt.tot1", (size_t) bins1 * 8, &tot1));
+    KMU_TRY(dev_buf(ctx, "cnt.binstart1", (size_t) (bins1 + 1) * 8, &binstart1));
+    if (pl.b2) {
+        KMU_TRY(dev_buf(ctx, "cnt.partB", total_bases * 8 + 64, &B));
+        KMU_TRY(dev_buf(ctx, "cnt.hist2", (size_t) units2 * bins2 * 4, &hist2));
+        KMU_TRY(dev_buf(ctx, "cnt.offs2", (size_t) units2 * bins2 * 8, &offs2));
+        KMU_TRY(dev_buf(ctx, "cnt.leafstart", (size_t) (n_regions + 1) * 8, &leafstart));
+    }
+    const int k = c->p.kmer_size;
+    {
+        KernelTimer tm(ctx, "k_part_hist1");
+        hipLaunchKernelGGL(k_part_hist1, dim3(units1), dim3(256), bins1 * 4, ctx->stream, ds.bases, ds.offsets, ds.n_seq, k,
+                           pl, (uint32_t *) hist1, d_err);
+    }
+    {
+        KernelTimer tm(ctx, "k_part_scan1");
+        hipLaunchKernelGGL(k_part_scan1a, dim3(bins1), dim3(256), 0, ctx->stream, (const uint32_t *) hist1, pl,
+                           (uint64_t *) offs1, (uint64_t *) tot1);
+        hipLaunchKernelGGL(k_part_scan1b, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *) tot1, pl,
+                           (uint64_t *) binstart1);
+    }
+    {
+        KernelTimer tm(ctx, "k_part_scatter1");
+        hipLaunchKernelGGL(k_part_scatter1, dim3(units1), dim3(256), bins1 * 8, ctx->stream, ds.bases, ds.offsets, ds.n_seq,
+                           k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1, (uint64_t *) A);
+    }
+    const uint64_t *items = (const uint64_t *) A;
+    const uint64_t *leaves = (const uint64_t *) binstart1;
+    if (pl.b2) {
+        {
+            KernelTimer tm(ctx, "k_part_hist2");
+            hipLaunchKernelGGL(k_part_hist2, dim3(units2), dim3(256), bins2 * 4, ctx->stream, (const uint64_t *) A,
+                               (const uint64_t *) binstart1, pl, (uint32_t *) hist2);
+        }
+        {
+            KernelTimer tm(ctx, "k_part_scan2");
+            hipLaunchKernelGGL(k_part_scan2, dim3(bins1), dim3(256), 0, ctx->stream, (const uint32_t *) hist2,
+                               (const uint64_t *) binstart1, pl, (uint64_t *) offs2, (uint64_t *) leafstart);
+        }
+        {
+            KernelTimer tm(ctx, "k_part_scatter2");
+            hipLaunchKernelGGL(k_part_scatter2, dim3(units2), dim3(256), bins2 * 8, ctx->stream, (const uint64_t *) A,
+                               (const uint64_t *) binstart1, pl, (const uint64_t *) offs2, (uint64_t *) B);
+        }
+        items = (const uint64_t *) B;
+        leaves = (const uint64_t *) leafstart;
+    }
+    {
+        const uint32_t R = 1u << c->rbits;
+        const size_t lds = (size_t) R * 12;
+        int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * 3 * 8);
+        KernelTimer tm(ctx, "k_part_build");
+        hipLaunchKernelGGL(k_part_build, dim3(grid), dim3(256), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
+                           table_of(c), c->empty ? 1 : 0, d_err);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    c->empty = false;
+    return KMU_OK;
+}
+
 extern "C" {
 
 int kmu_count_reset(kmu_counter *c) {
     if (!c) return KMU_E_BAD_ARG;
-    kmu_ctx *ctx = c->ctx;
-    KMU_HIP(ctx, hipSetDevice(ctx->device));
-    KMU_HIP(ctx, hipMemsetAsync(c->keys, 0xFF, c->nslots * 8, ctx->stream));
-    KMU_HIP(ctx, hipMemsetAsync(c->counts, 0, c->nslots * 4, ctx->stream));
+    c->empty = true; // materialised lazily: a partitioned build writes every region itself
     return KMU_OK;
 }
 
@@ -261,18 +608,19 @@ int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out)
     c->lg = 10;
     while ((1ull << c->lg) < want) c->lg++;
     c->nslots = 1ull << c->lg;
+    c->rbits = std::min(c->lg, REGION_BITS_MAX);
     hipError_t e1 = hipMalloc((void **) &c->keys, c->nslots * 8);
     hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **) &c->counts, c->nslots * 4) : e1;
     hipError_t e3 = e2 == hipSuccess ? hipMalloc((void **) &c->scalars, 64) : e2;
     if (e3 != hipSuccess) {
         if (c->keys) (void) hipFree(c->keys);
         if (c->counts) (void) hipFree(c->counts);
+        unsigned long long ns = c->nslots;
         delete c;
         (void) hipGetLastError();
-        return fail(ctx, KMU_E_OOM, "cannot allocate a %llu-slot count table", (unsigned long long) (1ull << c->lg));
+        return fail(ctx, KMU_E_OOM, "cannot allocate a %llu-slot count table", ns);
     }
-    int rc = kmu_count_reset(c);
-    if (rc) { kmu_count_destroy(c); return rc; }
+    c->empty = true;
     *out = c;
     return KMU_OK;
 }
@@ -297,19 +645,38 @@ int kmu_count_add_reads(kmu_counter *c, const uint8_t *bases, const uint64_t *of
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
     if (n_seq) {
-        CountTable t = table_of(c);
+        bool partitioned = false;
+        uint64_t total_bases = 0;
+        const char *force = getenv("KMU_COUNT_PATH"); // "direct" / "partitioned": diagnostics
         if (!ds.packed) {
-            int grid = ctx->num_cus * 8;
-            KernelTimer tm(ctx, "k_count_add_flat");
-            hipLaunchKernelGGL(k_count_add_flat, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, n_seq,
-                               c->p.kmer_size, t, d_err);
-        } else {
-            int grid = (int) std::min<uint64_t>(n_seq, (uint64_t) ctx->num_cus * 8);
-            KernelTimer tm(ctx, "k_count_add_reads");
-            hipLaunchKernelGGL(k_count_add_reads, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets,
-                               ds.packed_offsets, n_seq, ds.packed, ds.total_bytes, c->p.kmer_size, t, d_err);
+            if (mem == KMU_MEM_HOST) total_bases = offsets[n_seq];
+            else {
+                KMU_HIP(ctx, hipMemcpyAsync(&total_bases, ds.offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            // the streaming build pays off once the batch is a sizeable fraction of the table
+            partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
+            if (force && !strcmp(force, "direct")) partitioned = false;
+            if (force && !strcmp(force, "partitioned")) partitioned = total_bases > 0;
         }
-        KMU_HIP(ctx, hipGetLastError());
+        if (partitioned) {
+            KMU_TRY(partitioned_add(c, ds, total_bases, d_err));
+        } else {
+            KMU_TRY(materialize(c));
+            CountTable t = table_of(c);
+            if (!ds.packed) {
+                int grid = ctx->num_cus * 8;
+                KernelTimer tm(ctx, "k_count_add_flat");
+                hipLaunchKernelGGL(k_count_add_flat, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, n_seq,
+                                   c->p.kmer_size, t, d_err);
+            } else {
+                int grid = (int) std::min<uint64_t>(n_seq, (uint64_t) ctx->num_cus * 8);
+                KernelTimer tm(ctx, "k_count_add_reads");
+                hipLaunchKernelGGL(k_count_add_reads, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets,
+                                   ds.packed_offsets, n_seq, ds.packed, ds.total_bytes, c->p.kmer_size, t, d_err);
+            }
+            KMU_HIP(ctx, hipGetLastError());
+        }
     }
     if (!(mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
     return finish_call(ctx, mem);
@@ -319,6 +686,7 @@ static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *co
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     if (n == 0) return KMU_OK;
+    KMU_TRY(materialize(c));
     const uint64_t *d_k = kmers;
     const uint32_t *d_c = counts;
     if (mem == KMU_MEM_HOST) {
@@ -359,6 +727,7 @@ int kmu_count_query(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     if (n == 0) return KMU_OK;
+    KMU_TRY(materialize(c));
     const uint64_t *d_k = canon_kmers;
     uint32_t *d_o = counts_out;
     if (mem == KMU_MEM_HOST) {
@@ -382,11 +751,16 @@ int kmu_count_query(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int
 static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique) {
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (c->empty) {
+        if (distinct) *distinct = 0;
+        if (unique) *unique = 0;
+        return KMU_OK;
+    }
     KMU_HIP(ctx, hipMemsetAsync(c->scalars, 0, 64, ctx->stream));
     {
         KernelTimer tm(ctx, "k_count_stats");
         hipLaunchKernelGGL(k_count_stats, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), 0, ctx->stream, table_of(c),
-                           c->scalars);
+                           c->nslots, c->scalars);
     }
     KMU_HIP(ctx, hipGetLastError());
     uint64_t h[2];
@@ -407,10 +781,14 @@ int kmu_count_nb_unique(kmu_counter *c, uint64_t *out) {
 }
 
 // shared by dump / export: select into device buffers, then hand over
-static int select_entries(kmu_counter *c, uint32_t min_count, uint32_t part, uint32_t n_parts, uint64_t *kmers_out,
-                          uint32_t *counts_out, uint64_t cap, int mem, bool sort, uint64_t *n_out) {
+static int select_entries(kmu_counter *c, uint32_t min_count, uint32_t maxc, uint32_t part, uint32_t n_parts,
+                          uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap, int mem, bool sort, uint64_t *n_out) {
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (c->empty) {
+        *n_out = 0;
+        return KMU_OK;
+    }
     const int w32 = kmer_val_bytes(c->p.kmer_type) == 4;
     uint64_t *d_k = nullptr;
     uint32_t *d_c = nullptr;
@@ -430,7 +808,7 @@ static int select_entries(kmu_counter *c, uint32_t min_count, uint32_t part, uin
     {
         KernelTimer tm(ctx, "k_count_select");
         hipLaunchKernelGGL(k_count_select, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), 0, ctx->stream, table_of(c),
-                           min_count, max_count(c), w32, part, n_parts, cap, d_k, d_c, c->scalars + 2);
+                           c->nslots, min_count, maxc, w32, part, n_parts, cap, d_k, d_c, c->scalars + 2);
     }
     KMU_HIP(ctx, hipGetLastError());
     uint64_t n = 0;
@@ -459,48 +837,14 @@ static int select_entries(kmu_counter *c, uint32_t min_count, uint32_t part, uin
 int kmu_count_dump(kmu_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,
                    uint64_t *n_out) {
     if (!c || !n_out || (kmers_out && !counts_out)) return KMU_E_BAD_ARG;
-    return select_entries(c, min_count, 0, 0, kmers_out, counts_out, cap, KMU_MEM_HOST, true, n_out);
+    return select_entries(c, min_count, max_count(c), 0, 0, kmers_out, counts_out, cap, KMU_MEM_HOST, true, n_out);
 }
 
 int kmu_count_export_part(kmu_counter *c, uint32_t part, uint32_t n_parts, uint64_t *kmers_out, uint32_t *counts_out,
                           uint64_t cap, int mem, uint64_t *n_out) {
     if (!c || !n_out || n_parts == 0 || part >= n_parts || (kmers_out && !counts_out)) return KMU_E_BAD_ARG;
     // raw (unclamped) counts are exported so that merged totals saturate only once, at query time
-    kmu_ctx *ctx = c->ctx;
-    KMU_HIP(ctx, hipSetDevice(ctx->device));
-    const int w32 = kmer_val_bytes(c->p.kmer_type) == 4;
-    uint64_t *d_k = nullptr;
-    uint32_t *d_c = nullptr;
-    if (kmers_out) {
-        if (mem == KMU_MEM_HOST) {
-            void *q;
-            KMU_TRY(dev_buf(ctx, "cnt.sel.k", cap * 8 + 8, &q));
-            d_k = (uint64_t *) q;
-            KMU_TRY(dev_buf(ctx, "cnt.sel.c", cap * 4 + 8, &q));
-            d_c = (uint32_t *) q;
-        } else {
-            d_k = kmers_out;
-            d_c = counts_out;
-        }
-    }
-    KMU_HIP(ctx, hipMemsetAsync(c->scalars, 0, 64, ctx->stream));
-    {
-        KernelTimer tm(ctx, "k_count_select");
-        hipLaunchKernelGGL(k_count_select, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), 0, ctx->stream, table_of(c),
-                           1u, 0xFFFFFFFFu, w32, part, n_parts, cap, d_k, d_c, c->scalars + 2);
-    }
-    KMU_HIP(ctx, hipGetLastError());
-    uint64_t n = 0;
-    KMU_HIP(ctx, hipMemcpyAsync(&n, c->scalars + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *n_out = n;
-    if (!kmers_out) return KMU_OK;
-    if (n > cap) return fail(ctx, KMU_E_BAD_ARG, "output capacity %llu < %llu records", (unsigned long long) cap, (unsigned long long) n);
-    if (mem == KMU_MEM_HOST) {
-        KMU_HIP(ctx, hipMemcpy(kmers_out, d_k, n * 8, hipMemcpyDeviceToHost));
-        KMU_HIP(ctx, hipMemcpy(counts_out, d_c, n * 4, hipMemcpyDeviceToHost));
-    }
-    return KMU_OK;
+    return select_entries(c, 1u, 0xFFFFFFFFu, part, n_parts, kmers_out, counts_out, cap, mem, false, n_out);
 }
 
 int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts) {

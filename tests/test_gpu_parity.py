@@ -228,6 +228,43 @@ def test_count_parity(ctx, oracle, kmer_type, k):
     assert gc.nb_distinct() == k1.size
 
 
+def test_count_partitioned_two_level_vs_direct_and_oracle(ctx, oracle):
+    """the radix-partitioned build (two levels: table >= 2^24 slots) against the direct-insert path and the oracle,
+    including a second batch merged into a non-empty table"""
+    import os
+    bases, off = synth.ont_reads(2500, 3_000_000, 0xC4)  # ~15 Mbases
+    extra, eoff = oracle.concat([b"A" * 5000, b"ACGT" * 100, b"AC", b"T" * 3000])
+    bases = np.concatenate([bases, extra])
+    off = np.concatenate([off, eoff[1:] + off[-1]])
+    k = 31
+    oc = oracle.Counter(A.KMER64BIT, k, 8, 1 << 20)
+    oc.add_reads(bases, off)
+    res = {}
+    for path in ("partitioned", "direct"):
+        os.environ["KMU_COUNT_PATH"] = path
+        try:
+            gc = ctx.counter(A.KMER64BIT, k, 8, 12_000_000)  # 2^25 slots -> 13 region bits -> two levels
+            gc.add_reads(bases, off)
+            assert gc.nb_distinct() == oc.nb_distinct() and gc.nb_unique() == oc.nb_unique()
+            res[path] = gc.dump(2)
+            if path == "partitioned":
+                gc.add_reads(bases, off)  # non-empty table: regions are loaded, updated, written back
+                kk, cc = gc.export_part(0, 1)
+                k1, c1 = oc.dump(1)
+                order = np.argsort(kk)
+                assert np.array_equal(kk[order], k1)
+                oc2 = oracle.Counter(A.KMER64BIT, k, 16, 1 << 20)
+                oc2.add_reads(bases, off)
+                oc2.add_reads(bases, off)
+                canon = oracle.kmer_hashes(bases, off, A.KMER64BIT, k, A.FHASH_CANON_VALUE)[:200000]
+                assert np.array_equal(np.minimum(oc2.query(canon), 255), gc.query(canon))
+        finally:
+            os.environ.pop("KMU_COUNT_PATH", None)
+    wk, wc = oc.dump(2)
+    for path in res:
+        assert np.array_equal(res[path][0], wk) and np.array_equal(res[path][1], wc), path
+
+
 def test_count_reference_kat(ctx, oracle):
     """kmercount.rs:1524-1559 / 1580-1617 through the GPU counter"""
     import json
