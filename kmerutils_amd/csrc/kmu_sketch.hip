@@ -3,11 +3,14 @@
 // Reference loop being replaced (src/sketching/seqsketchjaccard.rs:224-243, setsketchert.rs:121-157):
 //     for every read (rayon):  FnvHashMap<Val,u64> of fhash(kmer) over all k-mers  ->  ProbMinHash3a(m)
 // MI355X mapping: one persistent workgroup per CU pulls reads from an atomic queue.  The read's weighted
-// multiset lives in an LDS open-addressing table (8-byte key + 4-byte count per slot, ~13k slots in 160 KiB);
-// reads with more distinct k-mers than the table holds are processed in P hash-partitions (each pass rescans
-// the read and keeps the keys of its partition; counts stay exact because a key always lands in one partition).
-// The m slot minima (h as order-preserving f64 bits, arg-min key) stay in LDS across passes.
-// Integer / f64 ALU + LDS atomics only; HBM traffic = the read's bases in, m signatures out.
+// multiset is built in LDS by a counting sort on a 12-bit hash bucket: every k-mer takes a rank in its bucket with
+// one ds_add_rtn, an in-place scan turns the bucket counts into starts, the keys are placed densely (dk[], dw[] = 1)
+// and every key then looks for an earlier equal key inside its own (short) bucket segment -- a repeat zeroes its own
+// weight and adds one to the first occurrence.  No compare-and-swap probing: the divergent probe loop of a hash
+// table cost ~250 wave instructions per 64 k-mers on this VALU-bound kernel.  Reads with more k-mers than the dense
+// arrays hold (~10.6 k) are processed in P hash-partitions (a key always lands in one partition, so counts stay
+// exact).  The m slot minima (h as order-preserving f64 bits, arg-min key) stay in LDS across passes.
+// Integer / f64 ALU + LDS only; HBM traffic = the read's bases in, m signatures out.
 #include <algorithm>
 #include <cmath>
 
@@ -35,9 +38,10 @@ struct SketchArgs {
     int rand08;
     int sig_bytes;   // 4 or 8
     uint32_t block_size;
-    uint32_t table_slots; // S
-    uint32_t list_cap;    // dense list capacity = max distinct keys of one pass
-    uint32_t part_target; // k-mers aimed at per pass (list_cap minus a fluctuation margin)
+    uint32_t cap;         // dense key / weight capacity of one pass
+    uint32_t part_target; // k-mers aimed at per pass (cap minus a fluctuation margin)
+    uint64_t *scr_keys;   // per-workgroup overflow scratch (keys that found no register slot): [grid][cap]
+    uint32_t *scr_info;   //   (bucket << 16) | rank-or-position
     uint32_t tile_words;  // staged code words per tile (16 bases each)
     uint32_t idx_thresh;  // rand 0.9 Uniform<usize>(0, m): reject while lo < (2^32 - m) % m
     uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
@@ -57,25 +61,10 @@ __device__ __forceinline__ uint32_t mix32(uint64_t key) {
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t) (((uint64_t) a * b) >> 32); }
 
 // misc words in LDS
-enum { M_READ = 0, M_SENT = 1, M_LIST = 2, M_FLAGS = 3, M_QMAX = 4 /* 4,5: u64 */, M_WORDS = 8 };
-
-// LDS multiset insert: keys[] (u64, KEY_EMPTY = free) + cnt[] (u32).  Returns 0 = key was present, 1 = this lane
-// claimed a free slot (*slot), 2 = table full.
-__device__ __forceinline__ int table_insert(uint64_t *keys, uint32_t *cnt, uint32_t S, uint64_t key, uint32_t h,
-                                            uint32_t *slot) {
-    uint32_t s = mulhi32(h, S);
-    for (uint32_t probes = 0; probes < S; probes++) {
-        unsigned long long old = atomicCAS((unsigned long long *) &keys[s], (unsigned long long) KEY_EMPTY,
-                                           (unsigned long long) key);
-        if (old == KEY_EMPTY || old == key) {
-            atomicAdd(&cnt[s], 1u);
-            *slot = s;
-            return old == KEY_EMPTY ? 1 : 0;
-        }
-        s = s + 1 == S ? 0 : s + 1;
-    }
-    return 2;
-}
+enum { M_READ = 0, M_NSCR = 1, M_FLAGS = 2, M_QMAX = 4 /* 4,5: u64 */, M_WORDS = 8 };
+static constexpr int BUCKET_BITS = 12;               // counting-sort buckets
+static constexpr uint32_t NBUCKETS = 1u << BUCKET_BITS;
+static constexpr int KREG = 10;                      // keys a thread keeps in registers between the sort phases
 
 // slot update: keep (h, key) minimal per slot; exact ties go to the smaller key (order independence)
 __device__ __forceinline__ void slot_update(uint64_t *hmin, uint64_t *sig, uint32_t k, double h, uint64_t key) {
@@ -205,29 +194,64 @@ __device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t
     }
 }
 
+// in-place exclusive scan of bst[0..NBUCKETS) by the whole workgroup (NBUCKETS / nthreads entries per thread);
+// bst[NBUCKETS] = total.  wtot: one word per wave.
+__device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const uint32_t per = (NBUCKETS + nthreads - 1) / nthreads;
+    const uint32_t b0 = tid * per;
+    uint32_t c[8];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+        c[q] = (q < per && b0 + q < NBUCKETS) ? bst[b0 + q] : 0u;
+        sum += c[q];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t) __shfl_up((int) incl, d, 64);
+        if (lane_id() >= d) incl += o;
+    }
+    if (lane_id() == 63) wtot[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < (tid >> 6); w++) run += wtot[w];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++)
+        if (q < per && b0 + q < NBUCKETS) {
+            bst[b0 + q] = run;
+            run += c[q];
+        }
+    if (tid == nthreads - 1) bst[NBUCKETS] = run;
+    __syncthreads();
+}
+
 // One workgroup = one read at a time (all blocks of it in block mode).
 template <bool AA>
 __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t S = a.table_slots;
-    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    uint64_t *hmin = keys + S;
+    const uint32_t cap = a.cap;
+    uint64_t *dk = reinterpret_cast<uint64_t *>(smem); // dense keys of the current pass, grouped by bucket
+    uint64_t *hmin = dk + cap;
     uint64_t *sig = hmin + a.m;
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(sig + a.m);
-    uint32_t *misc = cnt + S;
-    uint32_t *words = misc + M_WORDS;
-    uint16_t *list = reinterpret_cast<uint16_t *>(words + a.tile_words + 4);
+    uint32_t *dw = reinterpret_cast<uint32_t *>(sig + a.m); // weights (0 = repeat of an earlier entry)
+    uint32_t *bst = dw + cap;                                // NBUCKETS + 1: counts, then starts
+    uint32_t *misc = bst + NBUCKETS + 1;
+    misc += (8 - ((NBUCKETS + 1) & 7)) & 7; // keep the u64 at misc[M_QMAX] 8-byte aligned
+    uint32_t *wtot = misc + M_WORDS;
+    uint32_t *words = wtot + 16;
     uint64_t *qmax_sh = reinterpret_cast<uint64_t *>(&misc[M_QMAX]);
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
     const int k = a.cfg.k;
     const uint32_t tile_pos = (a.tile_words - 2) * 16; // k-mer start positions covered by one staged tile
+    uint64_t *scr_keys = a.scr_keys + (uint64_t) blockIdx.x * cap;
+    uint32_t *scr_info = a.scr_info + (uint64_t) blockIdx.x * cap;
 
-    for (uint32_t s = tid; s < S; s += nthreads) { keys[s] = KEY_EMPTY; cnt[s] = 0; }
+    for (uint32_t s = tid; s <= NBUCKETS; s += nthreads) bst[s] = 0;
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
-    if (tid == 0) { misc[M_SENT] = 0; misc[M_LIST] = 0; misc[M_FLAGS] = 0; *qmax_sh = H_INIT; }
-    __syncthreads();
-
+    if (tid == 0) { misc[M_NSCR] = 0; misc[M_FLAGS] = 0; *qmax_sh = H_INIT; }
     if (tid == 0) misc[M_READ] = atomicAdd(a.queue, 1u);
     __syncthreads();
     for (;;) {
@@ -266,7 +290,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             uint32_t bad = 0;
             bool full = false;
             for (uint32_t part = 0; part < P; part++) {
-                // ---- pass A: multiset of the keys of this partition (seqsketchjaccard.rs:226-234) -----------
+                // ---- A1: bucket ranks of the keys of this partition (multiset of seqsketchjaccard.rs:226-234) --
+                uint64_t rk[KREG];  // keys held in registers (first KREG rounds of positions)
+                uint32_t rb[KREG];  // (bucket << 16) | rank, later (bucket << 16) | position; 0xFFFFFFFF = empty
+#pragma unroll
+                for (int q = 0; q < KREG; q++) { rk[q] = 0; rb[q] = 0xFFFFFFFFu; }
                 for (uint64_t tile = 0; tile < ntiles; tile++) {
                     const uint64_t tp0 = AA ? pb : pb + tile * tile_pos;
                     const uint64_t tp1 = AA ? pe : (tp0 + tile_pos < pe ? tp0 + tile_pos : pe);
@@ -285,83 +313,118 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             __syncthreads();
                         }
                     }
-                    for (uint64_t pw = tp0 + (uint64_t) wave * 64; pw < tp1; pw += nthreads) { // wave-uniform trip count
-                        const uint64_t p = pw + lane_id();
-                        bool claimed = false;
-                        uint32_t cslot = 0;
-                        if (p < tp1) {
-                            uint64_t val, rc = 0;
-                            if (AA) {
-                                val = 0;
-                                for (int j = 0; j < k; j++) {
-                                    uint32_t c = code_aa(sv.base[sv.begin + p + j]);
-                                    bad |= c == 0;
-                                    val = (val << 5) | c;
+                    // rounds of KREG positions per thread; only the first round of the first tile can use registers
+                    for (uint64_t pr = tp0; pr < tp1; pr += (uint64_t) KREG * nthreads) {
+                        const bool use_regs = tile == 0 && pr == tp0;
+#pragma unroll
+                        for (int q = 0; q < KREG; q++) {
+                            const uint64_t p = pr + (uint64_t) q * nthreads + tid;
+                            if (p < tp1) {
+                                uint64_t val, rc = 0;
+                                if (AA) {
+                                    val = 0;
+                                    for (int j = 0; j < k; j++) {
+                                        uint32_t c = code_aa(sv.base[sv.begin + p + j]);
+                                        bad |= c == 0;
+                                        val = (val << 5) | c;
+                                    }
+                                } else {
+                                    const uint32_t qq = (uint32_t) (p + lead - 16 * wfirst);
+                                    const uint32_t idx = qq >> 4, sh = (qq & 15u) * 2u;
+                                    const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
+                                    const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
+                                    val = v >> (64 - 2 * k);
+                                    rc = revcomp_val(val, k);
                                 }
-                            } else {
-                                const uint32_t q = (uint32_t) (p + lead - 16 * wfirst);
-                                const uint32_t idx = q >> 4, sh = (q & 15u) * 2u;
-                                const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
-                                const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
-                                val = v >> (64 - 2 * k);
-                                rc = revcomp_val(val, k);
-                            }
-                            bool go = !(a.ablate & 4u);
-                            uint64_t key = 0;
-                            uint32_t h = 0;
-                            if (go) {
-                                key = apply_fhash(a.cfg, val, rc);
-                                h = mix32(key);
-                                if (a.ablate & 2u) go = false;
-                                if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) go = false;
-                            } else if (val == 0x1234567ull) full = true;
-                            if (go) {
-                                if (key == KEY_EMPTY) atomicAdd(&misc[M_SENT], 1u);
-                                else {
-                                    int rcode = table_insert(keys, cnt, S, key, h, &cslot);
-                                    claimed = rcode == 1;
-                                    if (rcode == 2) full = true;
-                                }
-                            } else if (h == 0x12345u) full = true;
-                        }
-                        // one LDS atomic per wave appends all newly claimed slots to the dense list
-                        const uint64_t cmask = __ballot(claimed);
-                        if (cmask) {
-                            const int leader = __ffsll((unsigned long long) cmask) - 1;
-                            uint32_t basepos = 0;
-                            if (lane_id() == leader) basepos = atomicAdd(&misc[M_LIST], (uint32_t) __popcll(cmask));
-                            basepos = bcast_u32(basepos, leader);
-                            if (claimed) {
-                                uint32_t pos = basepos + (uint32_t) __popcll(cmask & ((1ull << lane_id()) - 1ull));
-                                if (pos < a.list_cap) list[pos] = (uint16_t) cslot;
-                                else full = true;
+                                bool go = !(a.ablate & 4u);
+                                uint64_t key = 0;
+                                uint32_t h = 0;
+                                if (go) {
+                                    key = apply_fhash(a.cfg, val, rc);
+                                    h = mix32(key);
+                                    if (a.ablate & 2u) go = false;
+                                    if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) go = false;
+                                } else if (val == 0x1234567ull) full = true;
+                                if (go) {
+                                    const uint32_t b = h >> (32 - BUCKET_BITS);
+                                    const uint32_t rank = atomicAdd(&bst[b], 1u);
+                                    if (rank >= 65536u) full = true;
+                                    else if (use_regs) { rk[q] = key; rb[q] = (b << 16) | rank; }
+                                    else {
+                                        const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
+                                        if (si < cap) { scr_keys[si] = key; scr_info[si] = (b << 16) | rank; }
+                                        else full = true;
+                                    }
+                                } else if (h == 0x12345u) full = true;
                             }
                         }
                     }
                 }
                 __syncthreads();
-                const uint32_t n_list = misc[M_LIST] < a.list_cap ? misc[M_LIST] : a.list_cap;
-                const uint32_t n_sent = misc[M_SENT];
+                // ---- A2: counts -> starts, dense placement ---------------------------------------------------
+                bucket_scan(bst, wtot);
+                const uint32_t n_keys = bst[NBUCKETS];
+                const uint32_t n_scr = misc[M_NSCR] < cap ? misc[M_NSCR] : cap;
+                const bool fits = n_keys <= cap;
+                if (!fits) full = true;
+                if (fits) {
+#pragma unroll
+                    for (int q = 0; q < KREG; q++)
+                        if (rb[q] != 0xFFFFFFFFu) {
+                            const uint32_t b = rb[q] >> 16, pos = bst[b] + (rb[q] & 0xFFFFu);
+                            dk[pos] = rk[q];
+                            dw[pos] = 1u;
+                            rb[q] = (b << 16) | pos;
+                        }
+                    for (uint32_t i = tid; i < n_scr; i += nthreads) { // keys written by this workgroup: L2 hits
+                        const uint32_t info = __hip_atomic_load(&scr_info[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t b = info >> 16, pos = bst[b] + (info & 0xFFFFu);
+                        dk[pos] = __hip_atomic_load(&scr_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        dw[pos] = 1u;
+                        scr_info[i] = (b << 16) | pos;
+                    }
+                }
                 __syncthreads();
-                if (tid == 0) { misc[M_LIST] = 0; misc[M_SENT] = 0; }
-                // ---- pass B: every distinct key generates its points; its table slot is freed -----------------
+                // ---- A3: a key that has an earlier equal key in its bucket segment hands its weight over ---------
+                if (fits) {
+#pragma unroll
+                    for (int q = 0; q < KREG; q++)
+                        if (rb[q] != 0xFFFFFFFFu) {
+                            const uint32_t b = rb[q] >> 16, pos = rb[q] & 0xFFFFu;
+                            for (uint32_t j = bst[b]; j < pos; j++)
+                                if (dk[j] == rk[q]) {
+                                    dw[pos] = 0u;
+                                    atomicAdd(&dw[j], 1u);
+                                    break;
+                                }
+                        }
+                    for (uint32_t i = tid; i < n_scr; i += nthreads) {
+                        const uint32_t info = scr_info[i];
+                        const uint32_t b = info >> 16, pos = info & 0xFFFFu;
+                        const uint64_t key = dk[pos];
+                        for (uint32_t j = bst[b]; j < pos; j++)
+                            if (dk[j] == key) {
+                                dw[pos] = 0u;
+                                atomicAdd(&dw[j], 1u);
+                                break;
+                            }
+                    }
+                }
+                __syncthreads();
+                // ---- B: every distinct key generates its points ----------------------------------------------
+                const uint32_t n_sweep = fits ? n_keys : 0u;
                 uint32_t chunk = 0;
-                for (uint32_t base = 0; base < n_list; base += nthreads, chunk++) {
+                for (uint32_t base = 0; base < n_sweep; base += nthreads, chunk++) {
                     const uint32_t i = base + tid;
-                    const bool have = i < n_list;
                     uint64_t key = 0;
-                    uint32_t w = 1;
-                    if (have) {
-                        const uint32_t s = list[i];
-                        key = keys[s];
-                        w = cnt[s];
-                        keys[s] = KEY_EMPTY;
-                        cnt[s] = 0;
-                    }
-                    if (__any(have) && !(a.ablate & 1u)) pmh3a_consume_wave(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
+                    uint32_t w = 0;
+                    if (i < n_sweep) { key = dk[i]; w = dw[i]; }
+                    const bool have = w != 0u;
+                    if (__any(have) && !(a.ablate & 1u))
+                        pmh3a_consume_wave(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
                 }
-                if (wave == 0 && n_sent != 0) // the key whose value equals the table sentinel
-                    pmh3a_consume_wave(a, hmin, sig, qmax_sh, true, lane_id() == 0, KEY_EMPTY, n_sent);
+                for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
+                if (tid == 0) misc[M_NSCR] = 0;
                 __syncthreads();
             }
             if (bad) atomicOr(a.err, AA ? DERR_BAD_AA : DERR_NON_ACGT);
@@ -462,29 +525,36 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         (void) hipGetLastError();
         lds_max = 64 * 1024;
     }
-    // LDS budget: slot minima 16 m | misc 32 B | staged code words 4 (tile_words + 4) | table 12 S | list 2 * 0.75 S
+    // LDS budget: dense keys 8 cap | weights 4 cap | slot minima 16 m | buckets 4 (NB+1) | misc | staged words
     a.tile_words = aa ? 4 : (lds_max > 64 * 1024 ? 4096 + 2 : 1024 + 2);
-    size_t fixed = (size_t) 16 * a.m + 4 * M_WORDS + 4 * ((size_t) a.tile_words + 4) + 64;
-    if (fixed + 13.5 * 256 > lds_max) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS", a.m);
-    uint32_t S = (uint32_t) ((double) (lds_max - fixed) / 13.5);
-    S &= ~63u;
-    if (S > 65536) S = 65536; // slot indices are stored as u16
+    size_t fixed = (size_t) 16 * a.m + 4 * ((size_t) NBUCKETS + 1 + 8) + 4 * (M_WORDS + 16) +
+                   4 * ((size_t) a.tile_words + 4) + 64;
+    if (fixed + 12 * 256 > lds_max) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS", a.m);
+    uint32_t cap = (uint32_t) ((lds_max - fixed) / 12);
+    cap &= ~63u;
+    if (cap > 65472) cap = 65472; // positions are stored in 16 bits
     const char *env = getenv("KMU_PMH_SLOTS");
-    if (env && atoi(env) >= 256) S = std::min<uint32_t>(S, (uint32_t) atoi(env) & ~63u);
-    a.table_slots = S;
-    a.list_cap = (S / 4) * 3;
-    a.part_target = a.list_cap - a.list_cap / 10;
-    size_t lds = (size_t) 12 * S + 2 * (size_t) a.list_cap + fixed;
+    if (env && atoi(env) >= 256) cap = std::min<uint32_t>(cap, (uint32_t) atoi(env) & ~63u);
+    a.cap = cap;
+    a.part_target = cap - cap / 10;
+    size_t lds = (size_t) 12 * cap + fixed;
     void *q;
     KMU_TRY(dev_buf(ctx, "queue", 64, &q));
     KMU_HIP(ctx, hipMemsetAsync(q, 0, 64, ctx->stream));
     a.queue = (uint32_t *) q;
     int threads = 1024;
     const char *tenv = getenv("KMU_PMH_THREADS");
-    if (tenv && atoi(tenv) >= 64) threads = std::min(1024, atoi(tenv) & ~63);
+    if (tenv && atoi(tenv) >= 512) threads = std::min(1024, atoi(tenv) & ~63); // bucket_scan: <= 8 buckets per thread
     int blocks_per_cu = std::max<int>(1, (int) (lds_max / lds));
     int grid = (int) std::min<uint64_t>((uint64_t) ds.n_seq, (uint64_t) ctx->num_cus * blocks_per_cu);
     if (grid < 1) grid = 1;
+    {
+        void *sk, *si;
+        KMU_TRY(dev_buf(ctx, "pmh.scr_keys", (size_t) grid * cap * 8, &sk));
+        KMU_TRY(dev_buf(ctx, "pmh.scr_info", (size_t) grid * cap * 4, &si));
+        a.scr_keys = (uint64_t *) sk;
+        a.scr_info = (uint32_t *) si;
+    }
     {
         KernelTimer t(ctx, "k_sketch_pmh3a");
         if (aa) hipLaunchKernelGGL(k_sketch_pmh3a<true>, dim3(grid), dim3(threads), lds, ctx->stream, a);
