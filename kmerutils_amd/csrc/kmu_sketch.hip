@@ -42,6 +42,13 @@ struct SketchArgs {
     uint32_t part_target; // k-mers aimed at per pass (cap minus a fluctuation margin)
     uint64_t *scr_keys;   // per-workgroup overflow scratch (keys that found no register slot): [grid][cap]
     uint32_t *scr_info;   //   (bucket << 16) | rank-or-position
+    uint32_t *scr_w;      //   weight carried in (bottom-k running list), 1 otherwise
+    // bottom-k (MinHashCount, src/sketching/minhash.rs:62-99)
+    int bk_shift;         // bucket = (key >> bk_shift) & 0xFFF: the 12 most significant *used* bits of the hash
+    uint32_t bk_mask;     // count wrap mask: 0xFFFF (u16 counts) or 0xFF (MinInvHashCountKmer)
+    uint64_t *bk_keys;    // per-workgroup running list between partition passes: [grid][m]
+    uint32_t *bk_cnt;
+    uint32_t *counts_out; // may be null
     uint32_t tile_words;  // staged code words per tile (16 bases each)
     uint32_t idx_thresh;  // rand 0.9 Uniform<usize>(0, m): reject while lo < (2^32 - m) % m
     uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
@@ -194,6 +201,16 @@ __device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t
     }
 }
 
+// The per-workgroup scratch lists live in global memory and are re-used read after read: a plain load can be served
+// by a stale line of this CU's vector L1 (stores write through to L2 without refreshing it), so every read of them
+// bypasses L1 (agent-scope load, `sc1`).
+template <typename T>
+__device__ __forceinline__ T ld_scr(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... and every write is a write-through store (`sc1`), completed (vmcnt(0)) by the workgroup barrier that precedes
+// the reads: the "sc1 stores and loads on both sides" hand-off form of the CDNA guide.
+template <typename T>
+__device__ __forceinline__ void st_scr(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // in-place exclusive scan of bst[0..NBUCKETS) by the whole workgroup (NBUCKETS / nthreads entries per thread);
 // bst[NBUCKETS] = total.  wtot: one word per wave.
 __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
@@ -228,7 +245,15 @@ __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
 }
 
 // One workgroup = one read at a time (all blocks of it in block mode).
-template <bool AA>
+// BOTTOMK = false: ProbMinHash3a on the multiset.  BOTTOMK = true: the multiset of hasher(fhash(kmer)) is sorted by
+// the top bits of the hash itself, so the `m` smallest distinct hashes sit in the leading buckets; their exact rank
+// (= output position) is "distinct keys in earlier buckets + smaller distinct keys in the own bucket".
+//
+// A partition pass normally sorts all its k-mer occurrences at once (SINGLE).  If the occurrences do not fit the dense
+// arrays -- repetitive reads: poly-A, tandem repeats -- the pass is redone in ROUNDS of cap/2 positions; after every
+// round the distinct (key, weight) pairs are compacted into a carry list that joins the next round's sort with its
+// weights.  If even the distinct keys do not fit, the block is restarted with twice as many partitions.
+template <bool AA, bool BOTTOMK>
 __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t cap = a.cap;
@@ -248,6 +273,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     const uint32_t tile_pos = (a.tile_words - 2) * 16; // k-mer start positions covered by one staged tile
     uint64_t *scr_keys = a.scr_keys + (uint64_t) blockIdx.x * cap;
     uint32_t *scr_info = a.scr_info + (uint64_t) blockIdx.x * cap;
+    uint32_t *scr_w = a.scr_w + (uint64_t) blockIdx.x * cap;
+    // bottom-k: the running list of the m smallest hashes re-uses the LDS of the (unused) slot minima
+    uint64_t *bk_keys = hmin;
+    uint32_t *bk_cnt = reinterpret_cast<uint32_t *>(sig);
+    uint32_t bk_n = 0; // entries of the bottom-k running list (uniform)
 
     for (uint32_t s = tid; s <= NBUCKETS; s += nthreads) bst[s] = 0;
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
@@ -285,152 +315,256 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             if (pb > nk_all) pb = nk_all;
             if (pe > nk_all) pe = nk_all;
             const uint64_t nk = pe - pb;
-            const uint32_t P = nk ? (uint32_t) ((nk + a.part_target - 1) / a.part_target) : 0;
-            const uint64_t ntiles = AA ? 1 : (nk + tile_pos - 1) / tile_pos;
+            uint32_t P = nk ? (uint32_t) ((nk + a.part_target - 1) / a.part_target) : 0;
             uint32_t bad = 0;
             bool full = false;
-            for (uint32_t part = 0; part < P; part++) {
-                // ---- A1: bucket ranks of the keys of this partition (multiset of seqsketchjaccard.rs:226-234) --
-                uint64_t rk[KREG];  // keys held in registers (first KREG rounds of positions)
-                uint32_t rb[KREG];  // (bucket << 16) | rank, later (bucket << 16) | position; 0xFFFFFFFF = empty
+            // k-mer occurrences of positions [q0, q1) that belong to partition `part` take a bucket rank; the first
+            // KREG * nthreads positions of a SINGLE pass keep their key in registers, the rest goes to the scratch.
+            for (bool block_done = (P == 0); !block_done;) {
+                bool restart_block = false; // uniform
+                for (uint32_t part = 0; part < P && !restart_block; part++) {
+                    bool rounds_mode = false; // uniform
+                    for (bool part_done = false; !part_done;) {
+                        uint64_t rk[KREG];
+                        uint32_t rb[KREG];
 #pragma unroll
-                for (int q = 0; q < KREG; q++) { rk[q] = 0; rb[q] = 0xFFFFFFFFu; }
-                for (uint64_t tile = 0; tile < ntiles; tile++) {
-                    const uint64_t tp0 = AA ? pb : pb + tile * tile_pos;
-                    const uint64_t tp1 = AA ? pe : (tp0 + tile_pos < pe ? tp0 + tile_pos : pe);
-                    uint64_t wfirst = 0;
-                    if (!AA) {
-                        wfirst = (tp0 + lead) >> 4;
-                        if (!(part > 0 && ntiles == 1)) { // a single-tile read stays staged across partitions
-                            if (tile > 0 || part > 0) __syncthreads(); // previous tile still being read
-                            const uint64_t wlast = (tp1 - 1 + lead + (uint64_t) k - 1) >> 4;
-                            const uint32_t nw = (uint32_t) (wlast - wfirst + 1) + 2;
-                            for (uint32_t t = tid; t < nw; t += nthreads) {
-                                uint32_t b;
-                                words[t] = load_code_word(sv, wfirst + t, b);
-                                bad |= b;
-                            }
+                        for (int q = 0; q < KREG; q++) { rk[q] = 0; rb[q] = 0xFFFFFFFFu; }
+                        const uint64_t round_len = rounds_mode ? (uint64_t) (cap / 2) : nk;
+                        uint32_t carry_n = 0; // distinct (key, weight) pairs carried from earlier rounds (in scr_*)
+                        if (BOTTOMK && part > 0) { // the running list of the earlier partitions travels as carry
+                            for (uint32_t i = tid; i < bk_n; i += nthreads) { st_scr(&scr_keys[i], bk_keys[i]); st_scr(&scr_w[i], bk_cnt[i]); }
+                            carry_n = bk_n;
                             __syncthreads();
                         }
-                    }
-                    // rounds of KREG positions per thread; only the first round of the first tile can use registers
-                    for (uint64_t pr = tp0; pr < tp1; pr += (uint64_t) KREG * nthreads) {
-                        const bool use_regs = tile == 0 && pr == tp0;
+                        bool overflow = false; // uniform
+                        for (uint64_t q0 = pb; q0 < pe && !overflow; q0 += round_len) {
+                            const uint64_t q1 = q0 + round_len < pe ? q0 + round_len : pe;
+                            const bool last_round = q1 == pe;
+                            if (tid == 0) misc[M_NSCR] = carry_n;
+                            // carried pairs take their ranks first
+                            for (uint32_t i = tid; i < carry_n; i += nthreads) {
+                                const uint64_t key = ld_scr(&scr_keys[i]);
+                                const uint32_t b = BOTTOMK ? (uint32_t) (key >> a.bk_shift) & (NBUCKETS - 1)
+                                                           : mix32(key) >> (32 - BUCKET_BITS);
+                                st_scr(&scr_info[i], (b << 16) | atomicAdd(&bst[b], 1u));
+                            }
+                            __syncthreads();
+                            // ---- A1: bucket ranks of the keys of this partition in [q0, q1) ------------------------
+                            const uint64_t ntiles = AA ? 1 : (q1 - q0 + tile_pos - 1) / tile_pos;
+                            for (uint64_t tile = 0; tile < ntiles; tile++) {
+                                const uint64_t tp0 = AA ? q0 : q0 + tile * tile_pos;
+                                const uint64_t tp1 = AA ? q1 : (tp0 + tile_pos < q1 ? tp0 + tile_pos : q1);
+                                uint64_t wfirst = 0;
+                                if (!AA) {
+                                    wfirst = (tp0 + lead) >> 4;
+                                    __syncthreads(); // the previous user of `words` is done
+                                    const uint64_t wlast = (tp1 - 1 + lead + (uint64_t) k - 1) >> 4;
+                                    const uint32_t nw = (uint32_t) (wlast - wfirst + 1) + 2;
+                                    for (uint32_t t = tid; t < nw; t += nthreads) {
+                                        uint32_t b;
+                                        words[t] = load_code_word(sv, wfirst + t, b);
+                                        bad |= b;
+                                    }
+                                    __syncthreads();
+                                }
+                                for (uint64_t pr = tp0; pr < tp1; pr += (uint64_t) KREG * nthreads) {
+                                    const bool use_regs = !rounds_mode && tile == 0 && pr == tp0;
 #pragma unroll
-                        for (int q = 0; q < KREG; q++) {
-                            const uint64_t p = pr + (uint64_t) q * nthreads + tid;
-                            if (p < tp1) {
-                                uint64_t val, rc = 0;
-                                if (AA) {
-                                    val = 0;
-                                    for (int j = 0; j < k; j++) {
-                                        uint32_t c = code_aa(sv.base[sv.begin + p + j]);
-                                        bad |= c == 0;
-                                        val = (val << 5) | c;
+                                    for (int q = 0; q < KREG; q++) {
+                                        const uint64_t p = pr + (uint64_t) q * nthreads + tid;
+                                        if (p < tp1) {
+                                            uint64_t val, rc = 0;
+                                            if (AA) {
+                                                val = 0;
+                                                for (int j = 0; j < k; j++) {
+                                                    uint32_t c = code_aa(sv.base[sv.begin + p + j]);
+                                                    bad |= c == 0;
+                                                    val = (val << 5) | c;
+                                                }
+                                            } else {
+                                                const uint32_t qq = (uint32_t) (p + lead - 16 * wfirst);
+                                                const uint32_t idx = qq >> 4, sh = (qq & 15u) * 2u;
+                                                const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
+                                                const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
+                                                val = v >> (64 - 2 * k);
+                                                rc = revcomp_val(val, k);
+                                            }
+                                            bool go = !(a.ablate & 4u);
+                                            uint64_t key = 0;
+                                            uint32_t h = 0;
+                                            if (go) {
+                                                key = apply_fhash(a.cfg, val, rc);
+                                                if (BOTTOMK) key = hasher_finish(a.hasher, key, a.sig_bytes == 4);
+                                                h = mix32(key);
+                                                if (a.ablate & 2u) go = false;
+                                                if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) go = false;
+                                            } else if (val == 0x1234567ull) full = true;
+                                            if (go) {
+                                                const uint32_t b = BOTTOMK ? (uint32_t) (key >> a.bk_shift) & (NBUCKETS - 1)
+                                                                           : h >> (32 - BUCKET_BITS);
+                                                const uint32_t rank = atomicAdd(&bst[b], 1u);
+                                                if (rank < 65536u) { // else: the pass overflows and is redone in rounds
+                                                    if (use_regs) { rk[q] = key; rb[q] = (b << 16) | rank; }
+                                                    else {
+                                                        const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
+                                                        if (si < cap) { st_scr(&scr_keys[si], key); st_scr(&scr_info[si], (b << 16) | rank); st_scr(&scr_w[si], 1u); }
+                                                    }
+                                                }
+                                            } else if (h == 0x12345u) full = true;
+                                        }
+                                    }
+                                }
+                            }
+                            __syncthreads();
+                            // ---- A2: counts -> starts, dense placement ---------------------------------------------
+                            bucket_scan(bst, wtot);
+                            const uint32_t n_keys = bst[NBUCKETS];
+                            const uint32_t n_scr = misc[M_NSCR];
+                            if (n_keys > cap || n_scr > cap) overflow = true;
+                            if (!overflow) {
+#pragma unroll
+                                for (int q = 0; q < KREG; q++)
+                                    if (rb[q] != 0xFFFFFFFFu) {
+                                        const uint32_t b = rb[q] >> 16, pos = bst[b] + (rb[q] & 0xFFFFu);
+                                        dk[pos] = rk[q];
+                                        dw[pos] = 1u;
+                                        rb[q] = (b << 16) | pos;
+                                    }
+                                for (uint32_t i = tid; i < n_scr; i += nthreads) { // written by this workgroup: L2 hits
+                                    const uint32_t info = ld_scr(&scr_info[i]);
+                                    const uint32_t b = info >> 16, pos = bst[b] + (info & 0xFFFFu);
+                                    dk[pos] = ld_scr(&scr_keys[i]);
+                                    dw[pos] = ld_scr(&scr_w[i]);
+                                }
+                            }
+                            __syncthreads();
+                            // ---- A3: a key with an earlier equal key in its bucket segment hands its weight over ------
+                            if (!overflow) {
+#pragma unroll
+                                for (int q = 0; q < KREG; q++)
+                                    if (rb[q] != 0xFFFFFFFFu) {
+                                        const uint32_t b = rb[q] >> 16, pos = rb[q] & 0xFFFFu;
+                                        for (uint32_t j = bst[b]; j < pos; j++)
+                                            if (dk[j] == rk[q]) {
+                                                dw[pos] = 0u;
+                                                atomicAdd(&dw[j], 1u);
+                                                break;
+                                            }
+                                    }
+                                for (uint32_t i = tid; i < n_scr; i += nthreads) {
+                                    const uint32_t info = ld_scr(&scr_info[i]);
+                                    const uint32_t b = info >> 16, pos = bst[b] + (info & 0xFFFFu);
+                                    const uint64_t key = dk[pos];
+                                    for (uint32_t j = bst[b]; j < pos; j++)
+                                        if (dk[j] == key) {
+                                            // the weight is only written here (by its owner) and read at the end
+                                            const uint32_t wpos = __hip_atomic_exchange(&dw[pos], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                            atomicAdd(&dw[j], wpos);
+                                            break;
+                                        }
+                                }
+                            }
+                            __syncthreads();
+                            if (!overflow && !last_round) {
+                                // ---- compact the distinct pairs into the carry list (scr_keys / scr_w) ------------------
+                                if (tid == 0) misc[M_NSCR] = 0;
+                                __syncthreads();
+                                for (uint32_t base = 0; base < n_keys; base += nthreads) { // uniform trip count (ballot)
+                                    const uint32_t i = base + tid;
+                                    const uint32_t w = i < n_keys ? dw[i] : 0u;
+                                    const uint64_t cm = __ballot(w != 0u);
+                                    if (cm) {
+                                        const int leader = __ffsll((unsigned long long) cm) - 1;
+                                        uint32_t basepos = 0;
+                                        if (lane_id() == leader) basepos = atomicAdd(&misc[M_NSCR], (uint32_t) __popcll(cm));
+                                        basepos = bcast_u32(basepos, leader);
+                                        if (w != 0u) {
+                                            const uint32_t pos = basepos + (uint32_t) __popcll(cm & ((1ull << lane_id()) - 1ull));
+                                            st_scr(&scr_keys[pos], dk[i]);
+                                            st_scr(&scr_w[pos], w);
+                                        }
+                                    }
+                                }
+                                __syncthreads();
+                                carry_n = misc[M_NSCR];
+                                if (carry_n > cap - cap / 2) overflow = true; // no room for another round of new k-mers
+                                for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
+                                __syncthreads();
+                            }
+                            if (!overflow && last_round) {
+                                if (!BOTTOMK) {
+                                    // ---- B: every distinct key generates its points ------------------------------------
+                                    uint32_t chunk = 0;
+                                    for (uint32_t base = 0; base < n_keys; base += nthreads, chunk++) {
+                                        const uint32_t i = base + tid;
+                                        uint64_t key = 0;
+                                        uint32_t w = 0;
+                                        if (i < n_keys) { key = dk[i]; w = dw[i]; }
+                                        const bool have = w != 0u;
+                                        if (__any(have) && !(a.ablate & 1u))
+                                            pmh3a_consume_wave(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
                                     }
                                 } else {
-                                    const uint32_t qq = (uint32_t) (p + lead - 16 * wfirst);
-                                    const uint32_t idx = qq >> 4, sh = (qq & 15u) * 2u;
-                                    const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
-                                    const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
-                                    val = v >> (64 - 2 * k);
-                                    rc = revcomp_val(val, k);
-                                }
-                                bool go = !(a.ablate & 4u);
-                                uint64_t key = 0;
-                                uint32_t h = 0;
-                                if (go) {
-                                    key = apply_fhash(a.cfg, val, rc);
-                                    h = mix32(key);
-                                    if (a.ablate & 2u) go = false;
-                                    if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) go = false;
-                                } else if (val == 0x1234567ull) full = true;
-                                if (go) {
-                                    const uint32_t b = h >> (32 - BUCKET_BITS);
-                                    const uint32_t rank = atomicAdd(&bst[b], 1u);
-                                    if (rank >= 65536u) full = true;
-                                    else if (use_regs) { rk[q] = key; rb[q] = (b << 16) | rank; }
-                                    else {
-                                        const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
-                                        if (si < cap) { scr_keys[si] = key; scr_info[si] = (b << 16) | rank; }
-                                        else full = true;
+                                    // ---- bottom-k selection: rank = distinct keys in earlier buckets + smaller ones in
+                                    //      the own bucket ----------------------------------------------------------------
+                                    uint32_t *dcnt = words; // the staged code words are no longer needed in this pass
+                                    for (uint32_t b = tid; b < NBUCKETS; b += nthreads) {
+                                        uint32_t d = 0;
+                                        for (uint32_t j = bst[b]; j < bst[b + 1]; j++) d += dw[j] != 0u;
+                                        dcnt[b] = d;
                                     }
-                                } else if (h == 0x12345u) full = true;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                // ---- A2: counts -> starts, dense placement ---------------------------------------------------
-                bucket_scan(bst, wtot);
-                const uint32_t n_keys = bst[NBUCKETS];
-                const uint32_t n_scr = misc[M_NSCR] < cap ? misc[M_NSCR] : cap;
-                const bool fits = n_keys <= cap;
-                if (!fits) full = true;
-                if (fits) {
-#pragma unroll
-                    for (int q = 0; q < KREG; q++)
-                        if (rb[q] != 0xFFFFFFFFu) {
-                            const uint32_t b = rb[q] >> 16, pos = bst[b] + (rb[q] & 0xFFFFu);
-                            dk[pos] = rk[q];
-                            dw[pos] = 1u;
-                            rb[q] = (b << 16) | pos;
-                        }
-                    for (uint32_t i = tid; i < n_scr; i += nthreads) { // keys written by this workgroup: L2 hits
-                        const uint32_t info = __hip_atomic_load(&scr_info[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t b = info >> 16, pos = bst[b] + (info & 0xFFFFu);
-                        dk[pos] = __hip_atomic_load(&scr_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        dw[pos] = 1u;
-                        scr_info[i] = (b << 16) | pos;
-                    }
-                }
-                __syncthreads();
-                // ---- A3: a key that has an earlier equal key in its bucket segment hands its weight over ---------
-                if (fits) {
-#pragma unroll
-                    for (int q = 0; q < KREG; q++)
-                        if (rb[q] != 0xFFFFFFFFu) {
-                            const uint32_t b = rb[q] >> 16, pos = rb[q] & 0xFFFFu;
-                            for (uint32_t j = bst[b]; j < pos; j++)
-                                if (dk[j] == rk[q]) {
-                                    dw[pos] = 0u;
-                                    atomicAdd(&dw[j], 1u);
-                                    break;
+                                    __syncthreads();
+                                    bucket_scan(dcnt, wtot);
+                                    const uint32_t n_distinct = dcnt[NBUCKETS];
+                                    for (uint32_t i = tid; i < n_keys; i += nthreads) {
+                                        if (dw[i] == 0u) continue;
+                                        const uint64_t key = dk[i];
+                                        const uint32_t b = (uint32_t) (key >> a.bk_shift) & (NBUCKETS - 1);
+                                        uint32_t rnk = dcnt[b];
+                                        if (rnk >= (uint32_t) a.m) continue;
+                                        for (uint32_t j = bst[b]; j < bst[b + 1]; j++) rnk += (dw[j] != 0u) && dk[j] < key;
+                                        if (rnk < (uint32_t) a.m) { bk_keys[rnk] = key; bk_cnt[rnk] = dw[i]; }
+                                    }
+                                    bk_n = n_distinct < (uint32_t) a.m ? n_distinct : (uint32_t) a.m;
+                                    __syncthreads(); // bst / dk / dw are still being read until every thread is done
                                 }
-                        }
-                    for (uint32_t i = tid; i < n_scr; i += nthreads) {
-                        const uint32_t info = scr_info[i];
-                        const uint32_t b = info >> 16, pos = info & 0xFFFFu;
-                        const uint64_t key = dk[pos];
-                        for (uint32_t j = bst[b]; j < pos; j++)
-                            if (dk[j] == key) {
-                                dw[pos] = 0u;
-                                atomicAdd(&dw[j], 1u);
-                                break;
                             }
+                            if (overflow || last_round) {
+                                for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
+                                if (tid == 0) misc[M_NSCR] = 0;
+                                __syncthreads();
+                            }
+                        }
+                        if (!overflow) part_done = true;
+                        else if (!rounds_mode) rounds_mode = true; // redo this partition round by round
+                        else { restart_block = true; part_done = true; }
                     }
                 }
-                __syncthreads();
-                // ---- B: every distinct key generates its points ----------------------------------------------
-                const uint32_t n_sweep = fits ? n_keys : 0u;
-                uint32_t chunk = 0;
-                for (uint32_t base = 0; base < n_sweep; base += nthreads, chunk++) {
-                    const uint32_t i = base + tid;
-                    uint64_t key = 0;
-                    uint32_t w = 0;
-                    if (i < n_sweep) { key = dk[i]; w = dw[i]; }
-                    const bool have = w != 0u;
-                    if (__any(have) && !(a.ablate & 1u))
-                        pmh3a_consume_wave(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
+                if (!restart_block) block_done = true;
+                else if (P >= 65536u) { full = true; block_done = true; }
+                else {
+                    // too many distinct keys per partition: start the block over with twice as many partitions
+                    P *= 2;
+                    for (int t = tid; t < a.m; t += nthreads) { hmin[t] = H_INIT; sig[t] = 0; }
+                    if (tid == 0) *qmax_sh = H_INIT;
+                    bk_n = 0;
+                    __syncthreads();
                 }
-                for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
-                if (tid == 0) misc[M_NSCR] = 0;
-                __syncthreads();
             }
             if (bad) atomicOr(a.err, AA ? DERR_BAD_AA : DERR_NON_ACGT);
             if (full) atomicOr(a.err, DERR_TABLE_FULL);
-            // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
-            {
+            if (BOTTOMK) {
+                // rows: the m smallest distinct hashes ascending, padded with u64::MAX; counts wrap like the
+                // reference's u16 / u8 (minhash.rs:87-96, :243-262)
+                __syncthreads();
+                for (int t = tid; t < a.m; t += nthreads) {
+                    const bool have = (uint32_t) t < bk_n;
+                    reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = have ? bk_keys[t] : 0xFFFFFFFFFFFFFFFFull;
+                    if (a.counts_out) a.counts_out[(uint64_t) r * a.m + t] = have ? (bk_cnt[t] & a.bk_mask) : 0u;
+                }
+                bk_n = 0;
+            } else {
+                // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
                 uint64_t row = a.block_rows ? a.block_rows[r] + blk : (uint64_t) r;
                 for (int t = tid; t < a.m; t += nthreads) {
                     uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
@@ -482,12 +616,11 @@ static int sketch_params_check(kmu_ctx *ctx, const kmu_sketch_params *p) {
 
 namespace kmu {
 int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err);
-int launch_bottomk(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_counts,
-                   uint32_t *d_err);
 }
 
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
-                        void *d_sig, uint32_t *d_err) {
+                        void *d_sig, uint32_t *d_counts, uint32_t *d_err) {
+    const bool bottomk = p->algo == KMU_ALGO_BOTTOMK;
     SketchArgs a;
     memset(&a, 0, sizeof a);
     a.bases = ds.bases;
@@ -510,7 +643,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         a.idx_zone = 0xFFFFFFFFFFFFFFFFull - (0xFFFFFFFFFFFFFFFFull - m64 + 1ull) % m64;
     }
     // ExpRestricted01::new(lambda), lambda = ln(m / (m-1)) -- same libm expressions as the crate / the oracle
-    double lambda = std::log((double) a.m / (double) (a.m - 1));
+    double lambda = a.m >= 2 ? std::log((double) a.m / (double) (a.m - 1)) : 1.0;
     a.e01.lambda = lambda;
     a.e01.c1 = (std::exp(lambda) - 1.0) / lambda;
     a.e01.c2 = std::log(2.0 / (1.0 + std::exp(-lambda))) / lambda;
@@ -519,7 +652,11 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.err = d_err;
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
     const bool aa = kmer_is_aa(p->kmer_type);
-    auto fn = aa ? (const void *) k_sketch_pmh3a<true> : (const void *) k_sketch_pmh3a<false>;
+    const void *fn = bottomk ? (aa ? (const void *) k_sketch_pmh3a<true, true> : (const void *) k_sketch_pmh3a<false, true>)
+                             : (aa ? (const void *) k_sketch_pmh3a<true, false> : (const void *) k_sketch_pmh3a<false, false>);
+    a.counts_out = d_counts;
+    a.bk_shift = (a.sig_bytes == 4 && p->hasher == KMU_HASHER_NOHASH) ? 20 : 52; // NoHashHasher of a u32 is < 2^32
+    a.bk_mask = p->hasher == KMU_HASHER_INT64HASH ? 0xFFu : 0xFFFFu;
     size_t lds_max = 160 * 1024;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) != hipSuccess) {
         (void) hipGetLastError();
@@ -549,16 +686,25 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     int grid = (int) std::min<uint64_t>((uint64_t) ds.n_seq, (uint64_t) ctx->num_cus * blocks_per_cu);
     if (grid < 1) grid = 1;
     {
-        void *sk, *si;
+        void *sk, *si, *sw, *bk = nullptr, *bc = nullptr;
         KMU_TRY(dev_buf(ctx, "pmh.scr_keys", (size_t) grid * cap * 8, &sk));
         KMU_TRY(dev_buf(ctx, "pmh.scr_info", (size_t) grid * cap * 4, &si));
+        KMU_TRY(dev_buf(ctx, "pmh.scr_w", (size_t) grid * cap * 4, &sw));
         a.scr_keys = (uint64_t *) sk;
         a.scr_info = (uint32_t *) si;
+        a.scr_w = (uint32_t *) sw;
+        a.bk_keys = (uint64_t *) bk;
+        a.bk_cnt = (uint32_t *) bc;
     }
     {
-        KernelTimer t(ctx, "k_sketch_pmh3a");
-        if (aa) hipLaunchKernelGGL(k_sketch_pmh3a<true>, dim3(grid), dim3(threads), lds, ctx->stream, a);
-        else hipLaunchKernelGGL(k_sketch_pmh3a<false>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+        KernelTimer t(ctx, bottomk ? "k_sketch_bottomk" : "k_sketch_pmh3a");
+        if (bottomk) {
+            if (aa) hipLaunchKernelGGL((k_sketch_pmh3a<true, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+            else hipLaunchKernelGGL((k_sketch_pmh3a<false, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+        } else {
+            if (aa) hipLaunchKernelGGL((k_sketch_pmh3a<true, false>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+            else hipLaunchKernelGGL((k_sketch_pmh3a<false, false>), dim3(grid), dim3(threads), lds, ctx->stream, a);
+        }
     }
     KMU_HIP(ctx, hipGetLastError());
     return KMU_OK;
@@ -606,10 +752,10 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_
     KMU_TRY(get_err_word(ctx, &d_err));
     if (n_seq) {
         switch (p->algo) {
-        case KMU_ALGO_PROB3A: KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, d_err)); break;
+        case KMU_ALGO_PROB3A: KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err)); break;
         case KMU_ALGO_SUPER:
         case KMU_ALGO_SUPER2: KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err)); break;
-        case KMU_ALGO_BOTTOMK: KMU_TRY(launch_bottomk(ctx, p, ds, d_sig, d_counts, d_err)); break;
+        case KMU_ALGO_BOTTOMK: KMU_TRY(launch_pmh3a(ctx, p, ds, nullptr, d_sig, d_counts, d_err)); break;
         }
     }
     if (p->mem == KMU_MEM_HOST) {

@@ -244,8 +244,4 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     return KMU_OK;
 }
 
-int launch_bottomk(kmu_ctx *ctx, const kmu_sketch_params *, const DevSeqs &, void *, uint32_t *, uint32_t *) {
-    return fail(ctx, KMU_E_UNSUPPORTED, "bottom-k sketch is not built yet");
-}
-
 } // namespace kmu

@@ -110,6 +110,9 @@ def test_probminhash3a_parity(ctx, oracle, kmer_type, k, m, fhash, lens):
     seqs = ragged_dna(1000 + k + m, lens)
     # a low-complexity read: heavy weights
     seqs.append(b"ACGT" * 700 + b"A" * 900 + bytes(synth.ACGT[np.random.default_rng(3).integers(0, 4, 400)]))
+    # repetitive reads whose k-mer occurrences exceed the dense LDS arrays: redone in rounds with a carry list
+    seqs.append(b"A" * 40000 + b"ACGT" * 6000 + bytes(synth.ACGT[np.random.default_rng(4).integers(0, 4, 9000)]) + b"T" * 30000)
+    seqs.append((bytes(synth.ACGT[np.random.default_rng(6).integers(0, 4, 7000)]) + b"GATTACA" * 300) * 6)
     bases, off = oracle.concat(seqs)
     sig_t = A.SIG_U32 if A.kmer_val_bytes(kmer_type) == 4 else A.SIG_U64
     for flags in (0, A.FLAG_RAND08):
@@ -175,6 +178,26 @@ def test_superminhash_parity(ctx, oracle, algo, kmer_type, k, m, sig, hasher, fh
         got = ctx.sketch(bases, off, p)
         assert got.dtype == want.dtype
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+@pytest.mark.parametrize("kmer_type,k,m,hasher,fhash", [
+    (A.KMER16B32BIT, 16, 50, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH),     # sketch_seqrange_minhash, seqminhash.rs:65-119
+    (A.KMER32BIT, 12, 200, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH),
+    (A.KMER16B32BIT, 16, 64, A.HASHER_INT64HASH, A.FHASH_CANON_VALUE),   # MinInvHashCountKmer, minhash.rs:219-265
+    (A.KMER64BIT, 31, 1000, A.HASHER_INT64HASH, A.FHASH_CANON_VALUE),
+    (A.KMER64BIT, 21, 300, A.HASHER_FNV1A, A.FHASH_IDENTITY_RAW),
+    (A.KMER32BIT, 6, 5000, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH),       # fewer distinct k-mers than the sketch size
+])
+def test_bottomk_parity(ctx, oracle, kmer_type, k, m, hasher, fhash):
+    seqs = ragged_dna(900 + m, [k - 1, k, k + 3, 100, 3000, 9000, 25000, 60000])
+    seqs.append(b"ACGT" * 2000 + b"A" * 70000 + bytes(synth.ACGT[np.random.default_rng(5).integers(0, 4, 3000)]))
+    bases, off = oracle.concat(seqs)
+    p = A.SketchParams(A.ALGO_BOTTOMK, kmer_type, k, m, A.SIG_U64, hasher, fhash, 0, 0, 0, 0, 0)
+    wsig, wcnt = oracle.sketch(bases, off, p, want_counts=True)
+    gsig, gcnt = ctx.sketch(bases, off, p, want_counts=True)
+    assert np.array_equal(gsig, wsig)
+    assert np.array_equal(gcnt, wcnt)
+    assert np.array_equal(ctx.sketch(bases, off, p), wsig)  # counts not requested
 
 
 def test_superminhash_aa(ctx, oracle):
