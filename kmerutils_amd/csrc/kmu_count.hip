@@ -497,69 +497,77 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     }
 }
 
-// level 2 unit (p1, c): its slice of partition p1
-__device__ __forceinline__ void unit2_range(const uint64_t *binstart1, PartPlan pl, uint32_t unit, uint64_t *i0, uint64_t *i1) {
-    const uint32_t p1 = unit / pl.chunks2, c = unit % pl.chunks2;
-    const uint64_t s = binstart1[p1], len = binstart1[p1 + 1] - s;
-    *i0 = s + len * c / pl.chunks2;
-    *i1 = s + len * (c + 1) / pl.chunks2;
+// ---- generic radix partition of a u64 array (level 2 of the read path; both levels of the array path) ------------
+// The input is a set of `nparts` consecutive partitions (bounds[nparts + 1]); every partition is cut into `chunks`
+// units; a unit scatters its slice by the digit (region >> shift) & (bins - 1) into bins sub-partitions.
+struct ArrPlan {
+    int region_bits;
+    int shift;
+    uint32_t bins;
+    uint32_t nparts;
+    uint32_t chunks;
+};
+
+__device__ __forceinline__ void arr_unit_range(const uint64_t *bounds, const ArrPlan &pl, uint32_t unit, uint64_t *i0,
+                                               uint64_t *i1) {
+    const uint32_t part = unit / pl.chunks, c = unit % pl.chunks;
+    const uint64_t s = bounds[part], len = bounds[part + 1] - s;
+    *i0 = s + len * c / pl.chunks;
+    *i1 = s + len * (c + 1) / pl.chunks;
 }
 
-__global__ void __launch_bounds__(256) k_part_hist2(const uint64_t *in, const uint64_t *binstart1, PartPlan pl,
-                                                    uint32_t *hist2) {
+__global__ void __launch_bounds__(256) k_arr_hist(const uint64_t *in, const uint64_t *bounds, ArrPlan pl, uint32_t *hist) {
     extern __shared__ uint32_t lh[];
-    const uint32_t bins2 = 1u << pl.b2;
-    for (uint32_t b = threadIdx.x; b < bins2; b += blockDim.x) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) lh[b] = 0;
     __syncthreads();
     uint64_t i0, i1;
-    unit2_range(binstart1, pl, blockIdx.x, &i0, &i1);
+    arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
     for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
-        atomicAdd(&lh[region_of(in[i], pl.region_bits) & (bins2 - 1)], 1u);
+        atomicAdd(&lh[(region_of(in[i], pl.region_bits) >> pl.shift) & (pl.bins - 1)], 1u);
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bins2; b += blockDim.x) hist2[(uint64_t) blockIdx.x * bins2 + b] = lh[b];
+    for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) hist[(uint64_t) blockIdx.x * pl.bins + b] = lh[b];
 }
 
-// level 2 scan: one workgroup per level-1 partition; order = (bin2 major, chunk minor)
-__global__ void __launch_bounds__(256) k_part_scan2(const uint32_t *hist2, const uint64_t *binstart1, PartPlan pl,
-                                                    uint64_t *offs2, uint64_t *leafstart) {
+// one workgroup per input partition; order = (bin major, chunk minor); outbounds[nparts * bins + 1]
+__global__ void __launch_bounds__(256) k_arr_scan(const uint32_t *hist, const uint64_t *bounds, ArrPlan pl, uint64_t *offs,
+                                                  uint64_t *outbounds) {
     __shared__ uint64_t part[256];
-    const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2, p1 = blockIdx.x, C = pl.chunks2;
-    const uint32_t per = (bins2 + 255) / 256;
-    const uint32_t b0 = threadIdx.x * per < bins2 ? threadIdx.x * per : bins2, b1 = b0 + per < bins2 ? b0 + per : bins2;
+    const uint32_t bins = pl.bins, p1 = blockIdx.x, C = pl.chunks;
+    const uint32_t per = (bins + 255) / 256;
+    const uint32_t b0 = threadIdx.x * per < bins ? threadIdx.x * per : bins, b1 = b0 + per < bins ? b0 + per : bins;
     uint64_t sum = 0;
     for (uint32_t b = b0; b < b1; b++)
-        for (uint32_t c = 0; c < C; c++) sum += hist2[((uint64_t) p1 * C + c) * bins2 + b];
+        for (uint32_t c = 0; c < C; c++) sum += hist[((uint64_t) p1 * C + c) * bins + b];
     part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint64_t run = binstart1[p1];
+        uint64_t run = bounds[p1];
         for (int i = 0; i < 256; i++) { uint64_t v = part[i]; part[i] = run; run += v; }
-        if (p1 == bins1 - 1) leafstart[(uint64_t) bins1 * bins2] = binstart1[bins1];
+        if (p1 == pl.nparts - 1) outbounds[(uint64_t) pl.nparts * bins] = bounds[pl.nparts];
     }
     __syncthreads();
     uint64_t run = part[threadIdx.x];
     for (uint32_t b = b0; b < b1; b++) {
-        leafstart[(uint64_t) p1 * bins2 + b] = run;
+        outbounds[(uint64_t) p1 * bins + b] = run;
         for (uint32_t c = 0; c < C; c++) {
-            offs2[((uint64_t) p1 * C + c) * bins2 + b] = run;
-            run += hist2[((uint64_t) p1 * C + c) * bins2 + b];
+            offs[((uint64_t) p1 * C + c) * bins + b] = run;
+            run += hist[((uint64_t) p1 * C + c) * bins + b];
         }
     }
 }
 
-__global__ void __launch_bounds__(1024) k_part_scatter2(const uint64_t *in, const uint64_t *binstart1, PartPlan pl,
-                                                        const uint64_t *offs2, uint64_t *out) {
+__global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
+                                                      const uint64_t *offs, uint64_t *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t bins2 = 1u << pl.b2;
-    ScatterLds l = scatter_lds(smem, bins2);
-    for (uint32_t b = threadIdx.x; b < bins2; b += blockDim.x) {
-        l.gbase[b] = offs2[(uint64_t) blockIdx.x * bins2 + b];
+    ScatterLds l = scatter_lds(smem, pl.bins);
+    for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) {
+        l.gbase[b] = offs[(uint64_t) blockIdx.x * pl.bins + b];
         l.lstart[b] = 0;
     }
-    if (threadIdx.x == 0) l.lstart[bins2] = 0;
+    if (threadIdx.x == 0) l.lstart[pl.bins] = 0;
     __syncthreads();
     uint64_t i0, i1;
-    unit2_range(binstart1, pl, blockIdx.x, &i0, &i1);
+    arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
     for (uint64_t t0 = i0; t0 < i1; t0 += TILE_ITEMS) {
         uint64_t it[16];
 #pragma unroll
@@ -567,7 +575,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter2(const uint64_t *in, cons
             const uint64_t i = t0 + (uint64_t) j * blockDim.x + threadIdx.x;
             it[j] = i < i1 ? in[i] : CKEY_EMPTY;
         }
-        tile_scatter(it, l, bins2, pl.region_bits, 0, bins2 - 1, out);
+        tile_scatter(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
 }
 
@@ -676,7 +684,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     static bool lds_attr_done = false;
     if (!lds_attr_done) {
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_done = true;
     }
     {
@@ -700,20 +708,21 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     const uint64_t *items = (const uint64_t *) A;
     const uint64_t *leaves = (const uint64_t *) binstart1;
     if (pl.b2) {
+        ArrPlan ap{pl.region_bits, 0, bins2, bins1, pl.chunks2};
         {
             KernelTimer tm(ctx, "k_part_hist2");
-            hipLaunchKernelGGL(k_part_hist2, dim3(units2), dim3(256), bins2 * 4, ctx->stream, (const uint64_t *) A,
-                               (const uint64_t *) binstart1, pl, (uint32_t *) hist2);
+            hipLaunchKernelGGL(k_arr_hist, dim3(units2), dim3(256), bins2 * 4, ctx->stream, (const uint64_t *) A,
+                               (const uint64_t *) binstart1, ap, (uint32_t *) hist2);
         }
         {
             KernelTimer tm(ctx, "k_part_scan2");
-            hipLaunchKernelGGL(k_part_scan2, dim3(bins1), dim3(256), 0, ctx->stream, (const uint32_t *) hist2,
-                               (const uint64_t *) binstart1, pl, (uint64_t *) offs2, (uint64_t *) leafstart);
+            hipLaunchKernelGGL(k_arr_scan, dim3(bins1), dim3(256), 0, ctx->stream, (const uint32_t *) hist2,
+                               (const uint64_t *) binstart1, ap, (uint64_t *) offs2, (uint64_t *) leafstart);
         }
         {
             KernelTimer tm(ctx, "k_part_scatter2");
-            hipLaunchKernelGGL(k_part_scatter2, dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
-                               (const uint64_t *) A, (const uint64_t *) binstart1, pl, (const uint64_t *) offs2,
+            hipLaunchKernelGGL(k_arr_scatter, dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
+                               (const uint64_t *) A, (const uint64_t *) binstart1, ap, (const uint64_t *) offs2,
                                (uint64_t *) B);
         }
         items = (const uint64_t *) B;
@@ -726,6 +735,88 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KernelTimer tm(ctx, "k_part_build");
         hipLaunchKernelGGL(k_part_build, dim3(grid), dim3(256), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
                            table_of(c), c->empty ? 1 : 0, d_err);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    c->empty = false;
+    return KMU_OK;
+}
+
+namespace kmu {
+
+// Partition a device array of u64 keys by the top `region_bits` bits of fmix64(key) into 2^region_bits leaves
+// (<= 22 bits: two 11-bit passes).  Returns the partitioned copy and the leaf bounds (both in context scratch
+// buffers, valid until the next partition call).
+int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits, const uint64_t **items_out,
+                  const uint64_t **bounds_out) {
+    if (region_bits > 22) return fail(ctx, KMU_E_UNSUPPORTED, "too many partitions (2^%d)", region_bits);
+    static bool lds_attr_done = false;
+    if (!lds_attr_done) {
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr_done = true;
+    }
+    const int b1 = region_bits <= 11 ? region_bits : (region_bits + 1) / 2;
+    const int b2 = region_bits - b1;
+    void *b0;
+    KMU_TRY(dev_buf(ctx, "arr.bounds0", 16, &b0));
+    uint64_t h0[2] = {0, n};
+    KMU_HIP(ctx, hipMemcpyAsync(b0, h0, 16, hipMemcpyHostToDevice, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // h0 lives on the stack
+    const uint64_t *bounds = (const uint64_t *) b0;
+    const uint64_t *items = in;
+    uint32_t nparts = 1;
+    for (int level = 0; level < 2; level++) {
+        const int bits = level == 0 ? b1 : b2;
+        if (bits == 0) continue;
+        const int shift = level == 0 ? b2 : 0;
+        const uint32_t bins = 1u << bits;
+        uint32_t chunks = level == 0 ? (uint32_t) std::min<uint64_t>(std::max<uint64_t>(1, n / 65536), 16384)
+                                     : std::max<uint32_t>(1u, 16384u / nparts);
+        ArrPlan ap{region_bits, shift, bins, nparts, chunks};
+        const uint32_t units = nparts * chunks;
+        void *hist, *offs, *outb, *outbuf;
+        KMU_TRY(dev_buf(ctx, level == 0 ? "arr.hist0" : "arr.hist1", (size_t) units * bins * 4, &hist));
+        KMU_TRY(dev_buf(ctx, level == 0 ? "arr.offs0" : "arr.offs1", (size_t) units * bins * 8, &offs));
+        KMU_TRY(dev_buf(ctx, level == 0 ? "arr.bounds1" : "arr.bounds2", ((size_t) nparts * bins + 1) * 8, &outb));
+        KMU_TRY(dev_buf(ctx, level == 0 ? "cnt.partA" : "cnt.partB", n * 8 + 64, &outbuf));
+        {
+            KernelTimer tm(ctx, "k_arr_hist");
+            hipLaunchKernelGGL(k_arr_hist, dim3(units), dim3(256), bins * 4, ctx->stream, items, bounds, ap, (uint32_t *) hist);
+        }
+        {
+            KernelTimer tm(ctx, "k_arr_scan");
+            hipLaunchKernelGGL(k_arr_scan, dim3(nparts), dim3(256), 0, ctx->stream, (const uint32_t *) hist, bounds, ap,
+                               (uint64_t *) offs, (uint64_t *) outb);
+        }
+        {
+            KernelTimer tm(ctx, "k_arr_scatter");
+            hipLaunchKernelGGL(k_arr_scatter, dim3(units), dim3(SCATTER_THREADS), scatter_lds_bytes(bins), ctx->stream, items,
+                               bounds, ap, (const uint64_t *) offs, (uint64_t *) outbuf);
+        }
+        KMU_HIP(ctx, hipGetLastError());
+        items = (const uint64_t *) outbuf;
+        bounds = (const uint64_t *) outb;
+        nparts *= bins;
+    }
+    *items_out = items;
+    *bounds_out = bounds;
+    return KMU_OK;
+}
+
+} // namespace kmu
+
+// big batches of explicit canonical k-mers (device arrays): partition by region, then the LDS build
+static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64_t n, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    const uint64_t *items, *bounds;
+    const int region_bits = c->lg - c->rbits;
+    KMU_TRY(partition_u64(ctx, d_kmers, n, region_bits, &items, &bounds));
+    const uint32_t R = 1u << c->rbits;
+    const uint64_t n_regions = 1ull << region_bits;
+    int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * 3 * 8);
+    {
+        KernelTimer tm(ctx, "k_part_build");
+        hipLaunchKernelGGL(k_part_build, dim3(grid), dim3(256), (size_t) R * 12, ctx->stream, items, bounds,
+                           (uint32_t) n_regions, table_of(c), c->empty ? 1 : 0, d_err);
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;
@@ -832,7 +923,6 @@ static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *co
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     if (n == 0) return KMU_OK;
-    KMU_TRY(materialize(c));
     const uint64_t *d_k = kmers;
     const uint32_t *d_c = counts;
     if (mem == KMU_MEM_HOST) {
@@ -848,6 +938,18 @@ static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *co
     }
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
+    {
+        const char *force = getenv("KMU_COUNT_PATH");
+        bool partitioned = !counts && n * 4 >= c->nslots && n >= (1u << 16) && c->lg - c->rbits <= 22;
+        if (force && !strcmp(force, "direct")) partitioned = false;
+        if (force && !strcmp(force, "partitioned")) partitioned = !counts;
+        if (partitioned) {
+            KMU_TRY(partitioned_add_kmers(c, d_k, n, d_err));
+            if (!(mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
+            return finish_call(ctx, mem);
+        }
+    }
+    KMU_TRY(materialize(c));
     {
         KernelTimer tm(ctx, "k_count_add_kmers");
         hipLaunchKernelGGL(k_count_add_kmers, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, d_k, d_c, n,

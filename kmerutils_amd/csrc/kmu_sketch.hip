@@ -49,6 +49,12 @@ struct SketchArgs {
     uint64_t *bk_keys;    // per-workgroup running list between partition passes: [grid][m]
     uint32_t *bk_cnt;
     uint32_t *counts_out; // may be null
+    // pre-hashed input (kmu_sketch_hashed, and the leaves of a sketch over all sequences): the "sequence" is an array
+    // of Kmer::Val values, offsets count values; runs on the AA instantiation (no code-word staging) with k = 1
+    const void *hashed;
+    int hashed_bytes;     // 0 = sequences of bases / residues, 4 / 8 = width of the pre-hashed values
+    uint64_t *part_h;     // non-null: write the slot minima (h bits, arg-min key) of every "sequence" here instead
+    uint64_t *part_k;     //   of a signature row: partial results of disjoint key sets, merged by k_pmh_reduce
     uint32_t tile_words;  // staged code words per tile (16 bases each)
     uint32_t idx_thresh;  // rand 0.9 Uniform<usize>(0, m): reject while lo < (2^32 - m) % m
     uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
@@ -304,8 +310,9 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         }
         const uint64_t L = sv.len;
         const uint64_t nk_all = L >= (uint64_t) k ? L - k + 1 : 0;
-        if (L == 0 && tid == 0) atomicOr(a.err, 8u);
-        if (nk_all == 0 && wave_validate_seq(sv, wave, nwaves, AA)) atomicOr(a.err, AA ? DERR_BAD_AA : DERR_NON_ACGT);
+        if (L == 0 && tid == 0 && !a.hashed_bytes) atomicOr(a.err, 8u); // an empty list of pre-hashed values is fine
+        if (nk_all == 0 && !a.hashed_bytes && wave_validate_seq(sv, wave, nwaves, AA))
+            atomicOr(a.err, AA ? DERR_BAD_AA : DERR_NON_ACGT);
         const uint32_t lead = AA ? 0u : seq_lead(sv);
         // blocks of the read (src/sketching/seqblocksketch.rs:108-146); whole read = one block
         const uint64_t B = a.block_size ? a.block_size : (nk_all ? nk_all : 1);
@@ -374,7 +381,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                         const uint64_t p = pr + (uint64_t) q * nthreads + tid;
                                         if (p < tp1) {
                                             uint64_t val, rc = 0;
-                                            if (AA) {
+                                            if (AA && a.hashed_bytes) {
+                                                val = a.hashed_bytes == 4
+                                                          ? (uint64_t) reinterpret_cast<const uint32_t *>(a.hashed)[sv.begin + p]
+                                                          : reinterpret_cast<const uint64_t *>(a.hashed)[sv.begin + p];
+                                            } else if (AA) {
                                                 val = 0;
                                                 for (int j = 0; j < k; j++) {
                                                     uint32_t c = code_aa(sv.base[sv.begin + p + j]);
@@ -393,7 +404,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                             uint64_t key = 0;
                                             uint32_t h = 0;
                                             if (go) {
-                                                key = apply_fhash(a.cfg, val, rc);
+                                                key = (AA && a.hashed_bytes) ? val : apply_fhash(a.cfg, val, rc);
                                                 if (BOTTOMK) key = hasher_finish(a.hasher, key, a.sig_bytes == 4);
                                                 h = mix32(key);
                                                 if (a.ablate & 2u) go = false;
@@ -567,9 +578,14 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                 // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
                 uint64_t row = a.block_rows ? a.block_rows[r] + blk : (uint64_t) r;
                 for (int t = tid; t < a.m; t += nthreads) {
-                    uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
-                    if (a.sig_bytes == 4) reinterpret_cast<uint32_t *>(a.sig_out)[row * a.m + t] = (uint32_t) v;
-                    else reinterpret_cast<uint64_t *>(a.sig_out)[row * a.m + t] = v;
+                    if (a.part_h) {
+                        a.part_h[row * a.m + t] = hmin[t];
+                        a.part_k[row * a.m + t] = sig[t];
+                    } else {
+                        uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
+                        if (a.sig_bytes == 4) reinterpret_cast<uint32_t *>(a.sig_out)[row * a.m + t] = (uint32_t) v;
+                        else reinterpret_cast<uint64_t *>(a.sig_out)[row * a.m + t] = v;
+                    }
                     hmin[t] = H_INIT;
                     sig[t] = 0;
                 }
@@ -580,6 +596,107 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         if (tid == 0) misc[M_READ] = r_next;
         __syncthreads();
     }
+}
+
+// merge the slot minima of disjoint key sets (leaves): per slot the smallest (h, key); one workgroup per slot
+__global__ void __launch_bounds__(256) k_pmh_reduce(const uint64_t *part_h, const uint64_t *part_k, uint64_t n_parts, int m,
+                                                    int sig_bytes, void *sig_out) {
+    __shared__ uint64_t sh[256], sk[256];
+    const int t = blockIdx.x;
+    uint64_t bh = H_INIT, bk = 0;
+    for (uint64_t i = threadIdx.x; i < n_parts; i += blockDim.x) {
+        const uint64_t h = part_h[i * m + t], key = part_k[i * m + t];
+        if (h < bh || (h == bh && h != H_INIT && key < bk)) { bh = h; bk = key; }
+    }
+    sh[threadIdx.x] = bh;
+    sk[threadIdx.x] = bk;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int) threadIdx.x < d) {
+            const uint64_t h = sh[threadIdx.x + d], key = sk[threadIdx.x + d];
+            if (h < sh[threadIdx.x] || (h == sh[threadIdx.x] && h != H_INIT && key < sk[threadIdx.x])) {
+                sh[threadIdx.x] = h;
+                sk[threadIdx.x] = key;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t v = sh[0] == H_INIT ? 0ull : sk[0];
+        if (sig_bytes == 4) reinterpret_cast<uint32_t *>(sig_out)[t] = (uint32_t) v;
+        else reinterpret_cast<uint64_t *>(sig_out)[t] = v;
+    }
+}
+
+// exclusive scan of the k-mer counts max(0, L_i - k + 1) of all sequences (single workgroup); koff[n] = total
+__global__ void __launch_bounds__(1024) k_nk_scan(const uint64_t *offsets, uint32_t n_seq, int k, uint64_t *koff,
+                                                  uint32_t *err) {
+    __shared__ uint64_t wtot[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_seq; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        uint64_t v = 0;
+        if (i < n_seq) {
+            const uint64_t L = offsets[i + 1] - offsets[i];
+            if (L == 0) atomicOr(err, 8u);
+            v = L >= (uint64_t) k ? L - k + 1 : 0;
+        }
+        uint64_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t o = ((uint64_t) (uint32_t) __shfl_up((int) (incl >> 32), d, 64) << 32) |
+                         (uint32_t) __shfl_up((int) (uint32_t) incl, d, 64);
+            if (lane_id() >= d) incl += o;
+        }
+        if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (int w = 0; w < (int) (threadIdx.x >> 6); w++) pre += wtot[w];
+        if (i < n_seq) koff[i] = pre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry = pre + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) koff[n_seq] = carry;
+}
+
+// fhash(kmer) of every k-mer of every sequence, compact: out[koff[i] + p]
+__global__ void __launch_bounds__(256) k_seq_hashes_compact(const uint8_t *bases, const uint64_t *offsets,
+                                                            const uint64_t *packed_offsets, uint32_t n_seq, int packed,
+                                                            uint64_t total, KmerCfg cfg, const uint64_t *koff, uint64_t *out,
+                                                            uint32_t *err) {
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const bool aa = cfg.kmer_type == KMU_KMERAA32BIT || cfg.kmer_type == KMU_KMERAA64BIT;
+    for (uint32_t i = blockIdx.x; i < n_seq; i += gridDim.x) {
+        SeqView s;
+        s.base = bases;
+        s.len = offsets[i + 1] - offsets[i];
+        s.packed = packed;
+        if (packed) {
+            s.begin = packed_offsets[i];
+            s.total = total ? total : (packed_offsets[n_seq - 1] + (offsets[n_seq] - offsets[n_seq - 1] + 3) / 4);
+        } else {
+            s.begin = offsets[i];
+            s.total = total ? total : offsets[n_seq];
+        }
+        const uint64_t nk = s.len >= (uint64_t) cfg.k ? s.len - cfg.k + 1 : 0;
+        uint64_t *o = out + koff[i];
+        uint32_t bad = 0;
+        if (nk == 0) bad |= wave_validate_seq(s, wave, nwaves, aa);
+        else if (aa) {
+            for (uint64_t st = wave; st < (s.len + 63) / 64; st += nwaves)
+                bad |= wave_step_kmers_aa(s, cfg.k, st, 0, nk, [&](uint64_t p, uint64_t val, uint64_t) { o[p] = apply_fhash(cfg, val, 0); });
+        } else {
+            for (uint64_t st = wave; st < (seq_num_words(s) + 63) / 64; st += nwaves)
+                bad |= wave_step_kmers(s, cfg.k, st, 0, nk, [&](uint64_t p, uint64_t val, uint64_t rc) { o[p] = apply_fhash(cfg, val, rc); });
+        }
+        if (bad) atomicOr(err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_widen_u32(const uint32_t *in, uint64_t n, uint64_t *out) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = in[i];
 }
 
 } // namespace kmu
@@ -615,14 +732,21 @@ static int sketch_params_check(kmu_ctx *ctx, const kmu_sketch_params *p) {
 }
 
 namespace kmu {
-int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err);
+int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err,
+                 const void *hashed, int hashed_bytes, uint64_t *part_rows);
+int launch_super_reduce(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *part_rows, uint64_t n_parts, void *d_sig);
 }
 
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
-                        void *d_sig, uint32_t *d_counts, uint32_t *d_err) {
+                        void *d_sig, uint32_t *d_counts, uint32_t *d_err, const void *hashed = nullptr,
+                        int hashed_bytes = 0, uint64_t *part_h = nullptr, uint64_t *part_k = nullptr) {
     const bool bottomk = p->algo == KMU_ALGO_BOTTOMK;
     SketchArgs a;
     memset(&a, 0, sizeof a);
+    a.hashed = hashed;
+    a.hashed_bytes = hashed_bytes;
+    a.part_h = part_h;
+    a.part_k = part_k;
     a.bases = ds.bases;
     a.offsets = ds.offsets;
     a.packed_offsets = ds.packed_offsets;
@@ -630,7 +754,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.n_seq = ds.n_seq;
     a.packed = ds.packed;
     a.total_bytes = ds.total_bytes;
-    a.cfg = KmerCfg{p->kmer_type, p->kmer_size, p->fhash};
+    a.cfg = KmerCfg{p->kmer_type, hashed_bytes ? 1 : p->kmer_size, p->fhash};
     a.m = p->sketch_size;
     a.hasher = p->hasher;
     a.rand08 = (p->flags & KMU_FLAG_RAND08) ? 1 : 0;
@@ -651,7 +775,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.sig_out = d_sig;
     a.err = d_err;
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
-    const bool aa = kmer_is_aa(p->kmer_type);
+    const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
     const void *fn = bottomk ? (aa ? (const void *) k_sketch_pmh3a<true, true> : (const void *) k_sketch_pmh3a<false, true>)
                              : (aa ? (const void *) k_sketch_pmh3a<true, false> : (const void *) k_sketch_pmh3a<false, false>);
     a.counts_out = d_counts;
@@ -663,7 +787,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         lds_max = 64 * 1024;
     }
     // LDS budget: dense keys 8 cap | weights 4 cap | slot minima 16 m | buckets 4 (NB+1) | misc | staged words
-    a.tile_words = aa ? 4 : (lds_max > 64 * 1024 ? 4096 + 2 : 1024 + 2);
+    // (bottom-k re-uses the staged-word area for its per-bucket distinct counts: NBUCKETS + 1 words)
+    a.tile_words = (aa && !bottomk) ? 4 : (lds_max > 64 * 1024 || bottomk ? 4096 + 2 : 1024 + 2);
     size_t fixed = (size_t) 16 * a.m + 4 * ((size_t) NBUCKETS + 1 + 8) + 4 * (M_WORDS + 16) +
                    4 * ((size_t) a.tile_words + 4) + 64;
     if (fixed + 12 * 256 > lds_max) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS", a.m);
@@ -710,6 +835,56 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     return KMU_OK;
 }
 
+// One sketch over a device array of n pre-hashed values (u64, zero-extended Kmer::Val).
+//  ProbMinHash3a: the keys are radix-partitioned by hash into leaves that fit the LDS multiset; every leaf is an
+//  independent weighted set (disjoint keys), sketched into partial slot minima, merged per slot by (h, key).
+//  SuperMinHash(2): items are independent; chunks are sketched separately and the slot values merged by min.
+static int sketch_all_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *d_vals, uint64_t n, void *d_sig,
+                             uint32_t *d_err) {
+    const int m = p->sketch_size;
+    if (p->algo == KMU_ALGO_PROB3A) {
+        // leaves of ~4k keys: comfortably inside one LDS pass even with a skewed hash
+        int region_bits = 0;
+        while (region_bits < 22 && (n >> region_bits) > 4096) region_bits++;
+        const uint64_t *items, *bounds;
+        KMU_TRY(partition_u64(ctx, d_vals, n, region_bits, &items, &bounds));
+        const uint64_t n_leaves = 1ull << region_bits;
+        void *ph, *pk;
+        KMU_TRY(dev_buf(ctx, "all.part_h", n_leaves * m * 8, &ph));
+        KMU_TRY(dev_buf(ctx, "all.part_k", n_leaves * m * 8, &pk));
+        DevSeqs leaves;
+        leaves.bases = reinterpret_cast<const uint8_t *>(items);
+        leaves.offsets = bounds;
+        leaves.n_seq = (uint32_t) n_leaves;
+        leaves.total_bytes = 1; // unused for pre-hashed input
+        KMU_TRY(launch_pmh3a(ctx, p, leaves, nullptr, nullptr, nullptr, d_err, items, 8, (uint64_t *) ph, (uint64_t *) pk));
+        {
+            KernelTimer t(ctx, "k_pmh_reduce");
+            hipLaunchKernelGGL(k_pmh_reduce, dim3(m), dim3(256), 0, ctx->stream, (const uint64_t *) ph, (const uint64_t *) pk,
+                               n_leaves, m, kmer_val_bytes(p->kmer_type), d_sig);
+        }
+        KMU_HIP(ctx, hipGetLastError());
+        return KMU_OK;
+    }
+    // SuperMinHash / SuperMinHash2
+    const uint64_t per = 16384;
+    const uint64_t n_chunks = std::max<uint64_t>(1, std::min<uint64_t>((n + per - 1) / per, 8192));
+    std::vector<uint64_t> h_off(n_chunks + 1);
+    for (uint64_t c = 0; c <= n_chunks; c++) h_off[c] = n * c / n_chunks;
+    void *d_off, *pr;
+    KMU_TRY(dev_buf(ctx, "all.chunk_off", (n_chunks + 1) * 8, &d_off));
+    KMU_HIP(ctx, hipMemcpyAsync(d_off, h_off.data(), (n_chunks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // h_off is a local
+    KMU_TRY(dev_buf(ctx, "all.part_rows", n_chunks * m * 8, &pr));
+    DevSeqs chunks;
+    chunks.bases = reinterpret_cast<const uint8_t *>(d_vals);
+    chunks.offsets = (const uint64_t *) d_off;
+    chunks.n_seq = (uint32_t) n_chunks;
+    chunks.total_bytes = 1;
+    KMU_TRY(launch_super(ctx, p, chunks, nullptr, d_err, d_vals, 8, (uint64_t *) pr));
+    return launch_super_reduce(ctx, p, (const uint64_t *) pr, n_chunks, d_sig);
+}
+
 extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_t *bases, const uint64_t *offsets,
                           const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *block_row_offsets,
                           void *sig_out, uint32_t *counts_out) {
@@ -719,8 +894,8 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_
     if (!fhash_valid(p->fhash, p->kmer_type)) return fail(ctx, KMU_E_BAD_ARG, "fhash %d not valid for kmer_type %d", p->fhash, p->kmer_type);
     if (p->input_kind == KMU_INPUT_PACKED2 && (kmer_is_aa(p->kmer_type) || p->fhash == KMU_FHASH_CANON_NTHASH_8B))
         return fail(ctx, KMU_E_BAD_ARG, "packed input not valid for this kmer_type / fhash");
-    if (p->mode == KMU_MODE_ALL_SEQS)
-        return fail(ctx, KMU_E_UNSUPPORTED, "sketch_compressedkmer_seqs (one sketch for all sequences) is not built yet");
+    if (p->mode == KMU_MODE_ALL_SEQS && p->algo == KMU_ALGO_BOTTOMK)
+        return fail(ctx, KMU_E_UNSUPPORTED, "the reference has no bottom-k sketch over a list of sequences");
     if (p->block_size > 0 && !block_row_offsets) return fail(ctx, KMU_E_BAD_ARG, "block mode needs block_row_offsets");
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     DevSeqs ds;
@@ -750,17 +925,43 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_
     }
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
-    if (n_seq) {
+    if (p->mode == KMU_MODE_ALL_SEQS) {
+        rows = 1;
+        if (p->mem == KMU_MEM_HOST) {
+            void *q;
+            KMU_TRY(dev_buf(ctx, "out.sig", (size_t) p->sketch_size * sigb + 64, &q));
+            d_sig = q;
+        }
+        // sketch_compressedkmer_seqs (setsketchert.rs:160-202, :299-335): one multiset / one stream over every
+        // sequence.  fhash values of all k-mers, compact; then the pre-hashed all-sequences path.
+        void *koff, *hk;
+        KMU_TRY(dev_buf(ctx, "all.koff", ((size_t) n_seq + 1) * 8, &koff));
+        hipLaunchKernelGGL(k_nk_scan, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, p->kmer_size, (uint64_t *) koff, d_err);
+        uint64_t n_items = 0;
+        KMU_HIP(ctx, hipMemcpyAsync(&n_items, (uint64_t *) koff + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &hk));
+        if (n_seq) {
+            KmerCfg cfg{p->kmer_type, p->kmer_size, p->fhash};
+            int grid = (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
+            KernelTimer t(ctx, "k_seq_hashes_compact");
+            hipLaunchKernelGGL(k_seq_hashes_compact, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets,
+                               ds.packed_offsets, n_seq, ds.packed, ds.total_bytes, cfg, (const uint64_t *) koff,
+                               (uint64_t *) hk, d_err);
+        }
+        KMU_HIP(ctx, hipGetLastError());
+        KMU_TRY(sketch_all_hashed(ctx, p, (const uint64_t *) hk, n_items, d_sig, d_err));
+    } else if (n_seq) {
         switch (p->algo) {
         case KMU_ALGO_PROB3A: KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err)); break;
         case KMU_ALGO_SUPER:
-        case KMU_ALGO_SUPER2: KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err)); break;
+        case KMU_ALGO_SUPER2: KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err, nullptr, 0, nullptr)); break;
         case KMU_ALGO_BOTTOMK: KMU_TRY(launch_pmh3a(ctx, p, ds, nullptr, d_sig, d_counts, d_err)); break;
         }
     }
     if (p->mem == KMU_MEM_HOST) {
         KMU_HIP(ctx, hipMemcpyAsync(sig_out, d_sig, rows * p->sketch_size * sigb, hipMemcpyDeviceToHost, ctx->stream));
-        if (counts_out)
+        if (counts_out && p->mode != KMU_MODE_ALL_SEQS)
             KMU_HIP(ctx, hipMemcpyAsync(counts_out, d_counts, rows * p->sketch_size * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
@@ -769,7 +970,66 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_
 
 extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const void *hashed, const uint64_t *offsets,
                                  uint32_t n_seq, void *sig_out, uint32_t *counts_out) {
-    (void) hashed; (void) offsets; (void) n_seq; (void) sig_out; (void) counts_out; (void) p;
-    if (!ctx) return KMU_E_BAD_ARG;
-    return fail(ctx, KMU_E_UNSUPPORTED, "kmu_sketch_hashed is not built yet");
+    if (!ctx || !p || !sig_out || !offsets || (!hashed && n_seq)) return KMU_E_BAD_ARG;
+    KMU_TRY(sketch_params_check(ctx, p));
+    if (p->block_size > 0) return fail(ctx, KMU_E_UNSUPPORTED, "block sketching needs the sequences (k-mer positions)");
+    if (p->mode == KMU_MODE_ALL_SEQS && p->algo == KMU_ALGO_BOTTOMK)
+        return fail(ctx, KMU_E_UNSUPPORTED, "the reference has no bottom-k sketch over a list of sequences");
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    const int w = kmer_val_bytes(p->kmer_type);
+    const size_t sigb = (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    const int m = p->sketch_size;
+    const uint64_t rows = p->mode == KMU_MODE_ALL_SEQS ? 1 : n_seq;
+    const void *d_vals = hashed;
+    const uint64_t *d_off = offsets;
+    void *d_sig = sig_out;
+    uint32_t *d_counts = counts_out;
+    uint64_t n_items = 0;
+    if (p->mem == KMU_MEM_HOST) {
+        n_items = offsets[n_seq];
+        void *q;
+        KMU_TRY(dev_buf(ctx, "in.bases", n_items * w + 64, &q));
+        KMU_HIP(ctx, hipMemcpyAsync(q, hashed, n_items * w, hipMemcpyHostToDevice, ctx->stream));
+        d_vals = q;
+        KMU_TRY(dev_buf(ctx, "in.offsets", ((size_t) n_seq + 1) * 8, &q));
+        KMU_HIP(ctx, hipMemcpyAsync(q, offsets, ((size_t) n_seq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_off = (const uint64_t *) q;
+        KMU_TRY(dev_buf(ctx, "out.sig", rows * m * sigb + 64, &q));
+        d_sig = q;
+        if (counts_out) {
+            KMU_TRY(dev_buf(ctx, "out.counts", rows * m * 4 + 64, &q));
+            d_counts = (uint32_t *) q;
+        }
+    } else {
+        KMU_HIP(ctx, hipMemcpyAsync(&n_items, offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint32_t *d_err;
+    KMU_TRY(get_err_word(ctx, &d_err));
+    if (p->mode == KMU_MODE_ALL_SEQS) {
+        const uint64_t *v64 = (const uint64_t *) d_vals;
+        if (w == 4) { // widen to u64 once (the all-sequences path partitions u64 keys)
+            void *q;
+            KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &q));
+            hipLaunchKernelGGL(k_widen_u32, dim3((unsigned) std::min<uint64_t>((n_items + 255) / 256 + 1, 65535)), dim3(256), 0,
+                               ctx->stream, (const uint32_t *) d_vals, n_items, (uint64_t *) q);
+            v64 = (const uint64_t *) q;
+        }
+        KMU_TRY(sketch_all_hashed(ctx, p, v64, n_items, d_sig, d_err));
+    } else if (n_seq) {
+        DevSeqs ds;
+        ds.bases = reinterpret_cast<const uint8_t *>(d_vals);
+        ds.offsets = d_off;
+        ds.n_seq = n_seq;
+        ds.total_bytes = 1;
+        if (p->algo == KMU_ALGO_SUPER || p->algo == KMU_ALGO_SUPER2) KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err, d_vals, w, nullptr));
+        else KMU_TRY(launch_pmh3a(ctx, p, ds, nullptr, d_sig, d_counts, d_err, d_vals, w));
+    }
+    if (p->mem == KMU_MEM_HOST) {
+        KMU_HIP(ctx, hipMemcpyAsync(sig_out, d_sig, rows * m * sigb, hipMemcpyDeviceToHost, ctx->stream));
+        if (counts_out && p->mode != KMU_MODE_ALL_SEQS)
+            KMU_HIP(ctx, hipMemcpyAsync(counts_out, d_counts, rows * m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
+    return finish_call(ctx, p->mem);
 }

@@ -31,6 +31,9 @@ struct SuperArgs {
     int mode;     // 0 f64, 1 f32, 2 u64 (SuperMinHash2), 3 u32 (SuperMinHash2)
     int val_w32;  // Kmer::Val is 32 bits
     uint32_t chunk; // items staged per chunk
+    const void *hashed;  // pre-hashed input: array of Kmer::Val values (offsets count values, k = 1), else null
+    int hashed_bytes;    // 4 / 8
+    uint64_t *part_rows; // non-null: raw slot bits per "sequence" (partial results merged by k_super_reduce)
     void *sig_out;
     uint32_t *queue;
     uint32_t *err;
@@ -94,8 +97,9 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
         }
         const uint64_t L = sv.len;
         const uint64_t nk = L >= (uint64_t) a.cfg.k ? L - a.cfg.k + 1 : 0;
-        if (L == 0 && tid == 0) atomicOr(a.err, 8u);
-        if (nk == 0 && wave_validate_seq(sv, wave, nwaves, aa)) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
+        if (L == 0 && tid == 0 && !a.hashed_bytes) atomicOr(a.err, 8u); // an empty list of pre-hashed values is fine
+        if (nk == 0 && !a.hashed_bytes && wave_validate_seq(sv, wave, nwaves, aa))
+            atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
         const uint32_t lead = aa ? 0 : seq_lead(sv);
         for (uint64_t c0 = 0; c0 < nk; c0 += a.chunk) {
             const uint64_t c1 = c0 + a.chunk < nk ? c0 + a.chunk : nk;
@@ -104,7 +108,13 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
             auto visit = [&](uint64_t p, uint64_t val, uint64_t rc) {
                 items[p - c0] = hasher_finish(a.hasher, apply_fhash(a.cfg, val, rc), a.val_w32 != 0);
             };
-            if (aa) {
+            if (a.hashed_bytes) {
+                for (uint64_t p = c0 + tid; p < c1; p += nthreads) {
+                    const uint64_t v = a.hashed_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(a.hashed)[sv.begin + p]
+                                                           : reinterpret_cast<const uint64_t *>(a.hashed)[sv.begin + p];
+                    items[p - c0] = hasher_finish(a.hasher, v, a.val_w32 != 0);
+                }
+            } else if (aa) {
                 for (uint64_t st = c0 / 64 + wave; st < (c1 + 63) / 64; st += nwaves)
                     bad |= wave_step_kmers_aa(sv, a.cfg.k, st, c0, c1, visit);
             } else {
@@ -176,6 +186,11 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
         // ---- signature -------------------------------------------------------------------------------------
         for (int t = tid; t < m; t += nthreads) {
             uint64_t v = hs[t];
+            if (a.part_rows) {
+                a.part_rows[(uint64_t) r * m + t] = v;
+                hs[t] = init_bits;
+                continue;
+            }
             switch (a.mode) {
             case 0: reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * m + t] = v; break;
             case 2: reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * m + t] = v; break;
@@ -188,16 +203,43 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
     }
 }
 
-int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err) {
+// element-wise minimum of the partial slot arrays (order-preserving bit patterns); one thread per slot
+__global__ void __launch_bounds__(256) k_super_reduce(const uint64_t *part_rows, uint64_t n_parts, int m, int mode,
+                                                      void *sig_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    uint64_t best = super_init_bits(mode);
+    for (uint64_t i = 0; i < n_parts; i++) {
+        const uint64_t v = part_rows[i * m + t];
+        best = v < best ? v : best;
+    }
+    if (mode == 0 || mode == 2) reinterpret_cast<uint64_t *>(sig_out)[t] = best;
+    else reinterpret_cast<uint32_t *>(sig_out)[t] = (uint32_t) best;
+}
+
+int launch_super_reduce(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *part_rows, uint64_t n_parts, void *d_sig) {
+    int mode = p->algo == KMU_ALGO_SUPER ? (p->sig_type == KMU_SIG_F32 ? 1 : 0) : (p->sig_type == KMU_SIG_U32 ? 3 : 2);
+    KernelTimer t(ctx, "k_super_reduce");
+    hipLaunchKernelGGL(k_super_reduce, dim3((p->sketch_size + 255) / 256), dim3(256), 0, ctx->stream, part_rows, n_parts,
+                       p->sketch_size, mode, d_sig);
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+
+int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err,
+                 const void *hashed, int hashed_bytes, uint64_t *part_rows) {
     SuperArgs a;
     memset(&a, 0, sizeof a);
+    a.hashed = hashed;
+    a.hashed_bytes = hashed_bytes;
+    a.part_rows = part_rows;
     a.bases = ds.bases;
     a.offsets = ds.offsets;
     a.packed_offsets = ds.packed_offsets;
     a.n_seq = ds.n_seq;
     a.packed = ds.packed;
     a.total_bytes = ds.total_bytes;
-    a.cfg = KmerCfg{p->kmer_type, p->kmer_size, p->fhash};
+    a.cfg = KmerCfg{p->kmer_type, hashed_bytes ? 1 : p->kmer_size, p->fhash};
     a.m = p->sketch_size;
     a.lg = 0;
     while ((1 << a.lg) < a.m) a.lg++;

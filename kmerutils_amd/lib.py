@@ -237,6 +237,32 @@ class Context:
             return out, counts_out[:rows]
         return out
 
+    def sketch_hashed(self, hashed, offsets, params, want_counts=False):
+        """kmu_sketch_hashed: the caller evaluated fhash; `hashed` holds Kmer::Val values (uint32 / uint64) of
+        sequence i in hashed[offsets[i]:offsets[i+1]]."""
+        n = len(offsets) - 1
+        mem = self._mem(hashed, offsets)
+        self._wait_producers(hashed)
+        p = A.SketchParams.from_buffer_copy(params)
+        p.mem = mem
+        m = p.sketch_size
+        rows = 1 if p.mode == A.MODE_ALL_SEQS else n
+        counts = None
+        if mem == A.MEM_DEVICE:
+            import torch
+            tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
+                   A.SIG_F64: torch.float64}[p.sig_type]
+            out = torch.zeros((max(rows, 1), m), dtype=tdt, device=hashed.device)
+            if want_counts:
+                counts = torch.zeros((max(rows, 1), m), dtype=torch.int32, device=hashed.device)
+        else:
+            out = np.zeros((max(rows, 1), m), dtype=A.SIG_NP[p.sig_type])
+            if want_counts:
+                counts = np.zeros((max(rows, 1), m), np.uint32)
+        self._check(self.L.kmu_sketch_hashed(self.h, C.byref(p), _ptr(hashed)[0], _ptr(offsets)[0], n, _ptr(out)[0],
+                                             _ptr(counts)[0]))
+        return (out[:rows], counts[:rows]) if want_counts else out[:rows]
+
     def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20):
         return Counter(self, kmer_type, k, counter_bits, capacity_hint)
 

@@ -200,6 +200,66 @@ def test_bottomk_parity(ctx, oracle, kmer_type, k, m, hasher, fhash):
     assert np.array_equal(ctx.sketch(bases, off, p), wsig)  # counts not requested
 
 
+@pytest.mark.parametrize("algo,kmer_type,k,m,sig,hasher", [
+    (A.ALGO_PROB3A, A.KMER32BIT, 8, 200, A.SIG_U32, A.HASHER_NOHASH),
+    (A.ALGO_PROB3A, A.KMER64BIT, 31, 128, A.SIG_U64, A.HASHER_NOHASH),
+    (A.ALGO_SUPER, A.KMER16B32BIT, 16, 64, A.SIG_F64, A.HASHER_NOHASH),
+    (A.ALGO_SUPER, A.KMER64BIT, 21, 100, A.SIG_F32, A.HASHER_FNV1A),
+    (A.ALGO_SUPER2, A.KMER64BIT, 21, 128, A.SIG_U64, A.HASHER_NOHASH),
+])
+def test_all_seqs_mode_parity(ctx, oracle, algo, kmer_type, k, m, sig, hasher):
+    """sketch_compressedkmer_seqs: ONE signature for a whole list of sequences (setsketchert.rs:160-202, :299-335);
+    ~600 k k-mers => many LDS-sized leaves / chunks merged on the device"""
+    bases, off = synth.ont_reads(120, 400_000, 0xA11)
+    extra, eoff = oracle.concat([b"A" * 3000, b"ACGT" * 500, b"AC"])
+    bases = np.concatenate([bases, extra])
+    off = np.concatenate([off, eoff[1:] + off[-1]])
+    p = A.SketchParams(algo, kmer_type, k, m, sig, hasher, A.FHASH_CANON_INVHASH, 0, A.MODE_ALL_SEQS, 0, 0, 0)
+    want = oracle.sketch(bases, off, p)
+    got = ctx.sketch(bases, off, p)
+    assert got.shape == want.shape == (1, m)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    small, soff = oracle.concat([b"ACGTTGCA" * 40, b"GATTACAGATTACA" * 9])
+    assert np.array_equal(ctx.sketch(small, soff, p).view(np.uint8), oracle.sketch(small, soff, p).view(np.uint8))
+
+
+def test_sketch_hashed_parity(ctx, oracle):
+    """kmu_sketch_hashed: the host evaluates an arbitrary fhash closure, the device does multiset + sketch"""
+    rng = np.random.default_rng(21)
+    lens = [0, 1, 50, 4000, 30000, 9000]
+    off = np.zeros(len(lens) + 1, np.uint64)
+    off[1:] = np.cumsum(lens)
+    for dt, kt in ((np.uint32, A.KMER16B32BIT), (np.uint64, A.KMER64BIT)):
+        vals = rng.integers(0, 5000 if dt == np.uint32 else 2**62, int(off[-1]), dtype=np.uint64).astype(dt)
+        vals[100:3000] = vals[100]  # heavy repeats
+        sigt = A.SIG_U32 if dt == np.uint32 else A.SIG_U64
+        cases = [(A.ALGO_PROB3A, sigt, A.HASHER_NOHASH, A.MODE_PER_SEQ), (A.ALGO_SUPER, A.SIG_F64, A.HASHER_FNV1A, A.MODE_PER_SEQ),
+                 (A.ALGO_BOTTOMK, A.SIG_U64, A.HASHER_INT64HASH, A.MODE_PER_SEQ), (A.ALGO_PROB3A, sigt, A.HASHER_NOHASH, A.MODE_ALL_SEQS),
+                 (A.ALGO_SUPER, A.SIG_F32, A.HASHER_NOHASH, A.MODE_ALL_SEQS)]
+        for algo, sig, hasher, mode in cases:
+            p = A.SketchParams(algo, kt, 16 if dt == np.uint32 else 31, 100, sig, hasher, 0, 0, mode, 0, 0, 0)
+            want = oracle.sketch_hashed(vals, off, p)
+            got = ctx.sketch_hashed(vals, off, p)
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (algo, mode, dt)
+
+
+def test_count_add_kmers_partitioned(ctx, oracle):
+    """explicit canonical k-mers in one big batch go through the radix-partitioned build as well"""
+    bases, off = synth.illumina_reads(20000, 200_000, 0xC4)
+    canon = oracle.kmer_hashes(bases, off, A.KMER64BIT, 31, A.FHASH_CANON_VALUE)
+    L = np.diff(off.astype(np.int64))
+    keep = np.concatenate([np.arange(int(off[i]), int(off[i]) + max(0, int(L[i]) - 30)) for i in range(len(L))])
+    kmers = np.ascontiguousarray(canon[keep])
+    oc = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 20)
+    oc.add_kmers(kmers)
+    gc = ctx.counter(A.KMER64BIT, 31, 8, kmers.size)  # batch >= table / 4 -> partitioned
+    gc.add_kmers(kmers)
+    assert gc.nb_distinct() == oc.nb_distinct() and gc.nb_unique() == oc.nb_unique()
+    gk, gcn = gc.dump(2)
+    wk, wc = oc.dump(2)
+    assert np.array_equal(gk, wk) and np.array_equal(gcn, wc)
+
+
 def test_superminhash_aa(ctx, oracle):
     res, off = synth.protein_seqs(300, 0xC5, median=250)
     for kt, k, m in ((A.KMERAA64BIT, 12, 128), (A.KMERAA32BIT, 5, 400)):
