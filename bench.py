@@ -115,10 +115,10 @@ def main():
             ctx.sketch(bases, offsets, p, out=sig)
         if cfg["count"]:
             counter.reset()
-            counter.add_reads(bases, offsets)
-            if world > 1:
-                ctx.synchronize()
-                kdist.merge_counters(counter, device=dev)
+            if world > 1:  # group the k-mers by owner rank, one all-to-all over RCCL, build the owned table
+                kdist.count_reads_exchange(counter, bases, offsets)
+            else:
+                counter.add_reads(bases, offsets)
 
     def barrier():
         ctx.synchronize()

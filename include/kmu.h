@@ -227,6 +227,13 @@ int kmu_count_dump(kmu_counter *c, uint32_t min_count, uint64_t *kmers_out, uint
 int kmu_count_export_part(kmu_counter *c, uint32_t part, uint32_t n_parts, uint64_t *kmers_out, uint32_t *counts_out,
                           uint64_t cap, int mem, uint64_t *n_out);
 int kmu_count_merge_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *counts, uint64_t n, int mem);
+/* multi-GPU counting, the throughput path: the canonical k-mers of the reads grouped by owner rank
+ * (`int64_hash(kmer) % n_parts`, the reference's own key-space dispatch, kmercount.rs:412-420,942).
+ * *dev_kmers_out points to a device buffer owned by the counter's context (valid until its next call);
+ * part_bounds_out[n_parts + 1] (host) delimits the group of every owner.  The caller exchanges the groups
+ * (all-to-all over RCCL) and feeds what it receives to kmu_count_add_kmers. */
+int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
+                                uint32_t n_parts, uint64_t **dev_kmers_out, uint64_t *part_bounds_out);
 /* drop every entry not owned by `part` (after the exchange each rank keeps only its key range) */
 int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts);
 

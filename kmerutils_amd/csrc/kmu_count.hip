@@ -46,6 +46,11 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
     return x;
 }
 
+// owner of a k-mer in an n-way key partition: DispatchableT, kmercount.rs:382-420
+__device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_parts) {
+    return w32 ? (uint32_t) (int32_hash((uint32_t) v) % n_parts) : (uint32_t) (int64_hash(v) % (uint64_t) n_parts);
+}
+
 struct CountTable {
     uint64_t *keys;
     uint32_t *counts;
@@ -224,11 +229,6 @@ __global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslo
     }
 }
 
-// owner of a k-mer in an n-way key partition: DispatchableT, kmercount.rs:382-420
-__device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_parts) {
-    return w32 ? (uint32_t) (int32_hash((uint32_t) v) % n_parts) : (uint32_t) (int64_hash(v) % (uint64_t) n_parts);
-}
-
 // compact (kmer, count) with count >= min_count (and owner == part when n_parts > 0); cap-limited
 __global__ void __launch_bounds__(256) k_count_select(CountTable t, uint64_t nslots, uint32_t min_count, uint32_t maxc,
                                                       int w32, uint32_t part, uint32_t n_parts, uint64_t cap,
@@ -274,6 +274,8 @@ struct PartPlan {
     uint32_t units1; // level-1 units (workgroups), each a contiguous range of wave steps
     uint32_t steps_per_unit;
     uint32_t chunks2; // level-2 units per level-1 partition
+    uint32_t owner_parts; // != 0: level 1 groups the k-mers by owner rank instead (multi-GPU exchange), bins1 = owner_parts
+    int owner_w32;
 };
 
 __device__ __forceinline__ uint32_t region_of(uint64_t canon, int region_bits) {
@@ -284,7 +286,7 @@ __device__ __forceinline__ uint32_t region_of(uint64_t canon, int region_bits) {
 __global__ void __launch_bounds__(256) k_part_hist1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
                                                     PartPlan pl, uint32_t *hist1, uint32_t *err) {
     extern __shared__ uint32_t lh[];
-    const uint32_t bins1 = 1u << pl.b1;
+    const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1;
     for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) lh[b] = 0;
     __syncthreads();
     const uint64_t total = offsets[n_seq];
@@ -295,7 +297,8 @@ __global__ void __launch_bounds__(256) k_part_hist1(const uint8_t *bases, const 
     uint32_t bad = 0;
     for (uint64_t st = s0 + wave; st < s1; st += nwaves)
         bad |= flat_step_canon(bases, offsets, n_seq, total, k, st, [&](uint64_t canon) {
-            atomicAdd(&lh[region_of(canon, pl.region_bits) >> pl.b2], 1u);
+            atomicAdd(&lh[pl.owner_parts ? kmer_owner(canon, pl.owner_w32, pl.owner_parts)
+                                         : region_of(canon, pl.region_bits) >> pl.b2], 1u);
         });
     if (bad) atomicOr(err, DERR_NON_ACGT);
     __syncthreads();
@@ -305,7 +308,7 @@ __global__ void __launch_bounds__(256) k_part_hist1(const uint8_t *bases, const 
 // level 1 scan, step a: one workgroup per bin -> exclusive prefix over the units + bin total
 __global__ void __launch_bounds__(256) k_part_scan1a(const uint32_t *hist1, PartPlan pl, uint64_t *offs1, uint64_t *tot1) {
     __shared__ uint64_t part[256];
-    const uint32_t bins1 = 1u << pl.b1, b = blockIdx.x, U = pl.units1;
+    const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1, b = blockIdx.x, U = pl.units1;
     const uint32_t per = (U + 255) / 256;
     const uint32_t u0 = threadIdx.x * per < U ? threadIdx.x * per : U, u1 = u0 + per < U ? u0 + per : U;
     uint64_t sum = 0;
@@ -328,7 +331,7 @@ __global__ void __launch_bounds__(256) k_part_scan1a(const uint32_t *hist1, Part
 // level 1 scan, step b: exclusive scan of the bin totals (single workgroup); binstart1[bins1] = number of k-mers
 __global__ void __launch_bounds__(256) k_part_scan1b(const uint64_t *tot1, PartPlan pl, uint64_t *binstart1) {
     __shared__ uint64_t part[256];
-    const uint32_t bins1 = 1u << pl.b1;
+    const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1;
     const uint32_t per = (bins1 + 255) / 256;
     const uint32_t b0 = threadIdx.x * per < bins1 ? threadIdx.x * per : bins1, b1 = b0 + per < bins1 ? b0 + per : bins1;
     uint64_t sum = 0;
@@ -369,7 +372,10 @@ __device__ __forceinline__ ScatterLds scatter_lds(uint8_t *smem, uint32_t nbins)
 }
 static size_t scatter_lds_bytes(uint32_t nbins) { return (size_t) TILE_ITEMS * 8 + (size_t) nbins * 8 + ((size_t) nbins + 1 + 16) * 4 + 16; }
 
+// region_bits >= 0: digit = (region >> shift) & mask.  region_bits < 0: digit = owner of the k-mer in a `shift`-way key
+// partition (DispatchableT, kmercount.rs:382-420); `mask` != 0 marks 32-bit k-mer values.
 __device__ __forceinline__ uint32_t digit_of(uint64_t canon, int region_bits, int shift, uint32_t mask) {
+    if (region_bits < 0) return kmer_owner(canon, mask != 0u, (uint32_t) shift);
     return (region_of(canon, region_bits) >> shift) & mask;
 }
 
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
                                                         int k, PartPlan pl, const uint64_t *offs1,
                                                         const uint64_t *binstart1, uint64_t *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t bins1 = 1u << pl.b1;
+    const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1;
     ScatterLds l = scatter_lds(smem, bins1);
     for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) {
         l.gbase[b] = binstart1[b] + offs1[(uint64_t) blockIdx.x * bins1 + b];
@@ -493,7 +499,8 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     for (uint64_t t0 = s0; t0 < s1; t0 += nwaves) {
         uint64_t it[16];
         flat_step_items(bases, offsets, n_seq, total, k, t0 + wave, t0 + wave < s1, it);
-        tile_scatter(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
+        if (pl.owner_parts) tile_scatter(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
+        else tile_scatter(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
     }
 }
 
@@ -653,6 +660,8 @@ static int materialize(kmu_counter *c) {
 static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err) {
     kmu_ctx *ctx = c->ctx;
     PartPlan pl;
+    pl.owner_parts = 0;
+    pl.owner_w32 = 0;
     pl.region_bits = c->lg - c->rbits;
     if (pl.region_bits <= 11) { pl.b1 = pl.region_bits; pl.b2 = 0; }
     else { pl.b1 = (pl.region_bits + 1) / 2; pl.b2 = pl.region_bits - pl.b1; }
@@ -820,6 +829,57 @@ static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;
+    return KMU_OK;
+}
+
+// canonical k-mers of the reads, grouped by owner rank (one level of the partition machinery with digit = owner)
+static int extract_by_owner(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t n_parts, uint64_t **dev_out,
+                            uint64_t *bounds_host, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    if (n_parts == 0 || n_parts > 2048) return fail(ctx, KMU_E_BAD_ARG, "n_parts must be in 1..2048");
+    PartPlan pl;
+    memset(&pl, 0, sizeof pl);
+    pl.owner_parts = n_parts;
+    pl.owner_w32 = kmer_val_bytes(c->p.kmer_type) == 4;
+    const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
+    uint32_t units1 = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(nsteps, 1), (uint64_t) ctx->num_cus * 8);
+    pl.steps_per_unit = (uint32_t) ((std::max<uint64_t>(nsteps, 1) + units1 - 1) / units1);
+    units1 = (uint32_t) ((std::max<uint64_t>(nsteps, 1) + pl.steps_per_unit - 1) / pl.steps_per_unit);
+    pl.units1 = units1;
+    void *out, *hist1, *offs1, *tot1, *binstart1;
+    KMU_TRY(dev_buf(ctx, "cnt.partB", total_bases * 8 + 64, &out));
+    KMU_TRY(dev_buf(ctx, "cnt.hist1", (size_t) units1 * n_parts * 4, &hist1));
+    KMU_TRY(dev_buf(ctx, "cnt.offs1", (size_t) units1 * n_parts * 8, &offs1));
+    KMU_TRY(dev_buf(ctx, "cnt.tot1", (size_t) n_parts * 8, &tot1));
+    KMU_TRY(dev_buf(ctx, "cnt.binstart1", (size_t) (n_parts + 1) * 8, &binstart1));
+    static bool lds_attr_done = false;
+    if (!lds_attr_done) {
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr_done = true;
+    }
+    const int k = c->p.kmer_size;
+    {
+        KernelTimer tm(ctx, "k_part_hist1");
+        hipLaunchKernelGGL(k_part_hist1, dim3(units1), dim3(256), n_parts * 4, ctx->stream, ds.bases, ds.offsets, ds.n_seq, k,
+                           pl, (uint32_t *) hist1, d_err);
+    }
+    {
+        KernelTimer tm(ctx, "k_part_scan1");
+        hipLaunchKernelGGL(k_part_scan1a, dim3(n_parts), dim3(256), 0, ctx->stream, (const uint32_t *) hist1, pl,
+                           (uint64_t *) offs1, (uint64_t *) tot1);
+        hipLaunchKernelGGL(k_part_scan1b, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *) tot1, pl,
+                           (uint64_t *) binstart1);
+    }
+    {
+        KernelTimer tm(ctx, "k_part_scatter1");
+        hipLaunchKernelGGL(k_part_scatter1, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(n_parts), ctx->stream,
+                           ds.bases, ds.offsets, ds.n_seq, k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1,
+                           (uint64_t *) out);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    KMU_HIP(ctx, hipMemcpyAsync(bounds_host, binstart1, (size_t) (n_parts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *dev_out = (uint64_t *) out;
     return KMU_OK;
 }
 
@@ -1110,6 +1170,27 @@ int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts) {
     int rc = add_entries(c, (const uint64_t *) k, (const uint32_t *) cc, n2, KMU_MEM_DEVICE);
     if (rc) return rc;
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMU_OK;
+}
+
+int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
+                                uint32_t n_parts, uint64_t **dev_kmers_out, uint64_t *part_bounds_out) {
+    if (!c || !dev_kmers_out || !part_bounds_out) return KMU_E_BAD_ARG;
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    DevSeqs ds;
+    KMU_TRY(stage_sequences(ctx, bases, offsets, nullptr, n_seq, KMU_INPUT_ASCII, mem, &ds));
+    uint64_t total_bases = 0;
+    if (mem == KMU_MEM_HOST) total_bases = offsets[n_seq];
+    else {
+        KMU_HIP(ctx, hipMemcpyAsync(&total_bases, ds.offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint32_t *d_err;
+    KMU_TRY(get_err_word(ctx, &d_err));
+    KMU_TRY(extract_by_owner(c, ds, total_bases, n_parts, dev_kmers_out, part_bounds_out, d_err));
+    KMU_TRY(check_err_word(ctx, d_err));
+    if (ctx->profiling) profile_collect(ctx);
     return KMU_OK;
 }
 

@@ -6,9 +6,10 @@ read range and the rows are concatenated in read order (the rank re-ordering of 
 
 Counting has one real exchange step.  The reference partitions the *key space* over threads
 (`int64_hash(kmer) % n`, src/base/kmercount.rs:412-420, :942) and ships every k-mer occurrence to its owner
-through channels.  Here every rank first counts its own read shard locally (duplicates collapse on the GPU), then
-ONE all-to-all moves each distinct (k-mer, count) entry to its owner rank, which adds it into its table.  After the
-merge rank r holds the exact counts of the keys with owner == r, i.e. the KmerCounterPool layout
+through channels.  `count_reads_exchange` does the same across GPUs: group the local k-mers by owner on the device,
+ONE all-to-all over RCCL, the owner builds its table from what it receives.  `merge_counters` is the alternative
+for already-built tables: every rank counts locally, then the distinct (k-mer, count) entries travel to their
+owners.  Either way rank r ends with the exact counts of the keys with owner == r, i.e. the KmerCounterPool layout
 (kmercount.rs:424-565) with one counter per GPU.
 
 PyTorch is plumbing here: process group, all_to_all; the compute is in libkmu.
@@ -62,6 +63,43 @@ def _all_to_all_var(send_list, recv_sizes, dtype, device, group=None):
     for r in reqs:
         r.wait()
     return recv
+
+
+def count_reads_exchange(counter, bases, offsets, group=None):
+    """Distributed counting of this rank's read shard -- the throughput path.
+
+    The reference's one-to-many driver dispatches every canonical k-mer to the thread that owns it,
+    `int64_hash(kmer) % n` (src/base/kmercount.rs:933-949, :412-420).  Same dispatch here, across GPUs: the k-mers of
+    the local reads are grouped by owner rank on the device (`kmu_count_extract_by_owner`), ONE all-to-all over
+    RCCL/xGMI moves every group to its owner, and the owner builds its table from what it receives with the
+    radix-partitioned build (`kmu_count_add_kmers`).  Afterwards rank r holds the exact global counts of the keys it
+    owns: the KmerCounterPool layout with one counter per GPU.  Returns the number of k-mers received."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        counter.add_reads(bases, offsets)
+        return 0
+    rank = dist.get_rank(group)
+    kmers, bounds = counter.extract_by_owner(bases, offsets, world)
+    kmers = torch.as_tensor(kmers)
+    dev = kmers.device
+    send_n = torch.as_tensor(np.diff(bounds.astype(np.int64)), dtype=torch.int64).to(dev)
+    all_n = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_n, send_n, group=group)
+    recv_n = [int(all_n[p][rank].item()) for p in range(world)]
+    send_sizes = [int(bounds[p + 1]) - int(bounds[p]) for p in range(world)]
+    if dist.get_backend(group) == "nccl":
+        # the groups are already contiguous in owner order: send straight from the library's buffer
+        flat = torch.empty(int(sum(recv_n)), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(flat, kmers, recv_n, send_sizes, group=group)
+    else:
+        send_list = [kmers[int(bounds[p]):int(bounds[p + 1])] for p in range(world)]
+        recv = _all_to_all_var(send_list, recv_n, torch.int64, dev, group)
+        flat = torch.cat(recv) if recv else torch.empty(0, dtype=torch.int64, device=dev)
+    if flat.numel():
+        counter.add_kmers(flat if dev.type != "cpu" else flat.numpy().view(np.uint64))
+    return int(flat.numel())
 
 
 def merge_counters(counter, device=None, group=None, chunk_entries=1 << 27):

@@ -21,7 +21,7 @@ SYMBOLS = [
     "kmu_kmer_hashes", "kmu_sketch", "kmu_block_layout", "kmu_sketch_hashed", "kmu_count_create", "kmu_count_destroy",
     "kmu_count_reset", "kmu_count_add_reads", "kmu_count_add_kmers", "kmu_count_query", "kmu_count_nb_distinct",
     "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
-    "kmu_count_retain_part",
+    "kmu_count_retain_part", "kmu_count_extract_by_owner",
 ]
 
 
@@ -73,6 +73,7 @@ def load():
     L.kmu_count_export_part.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, u64p]
     L.kmu_count_merge_entries.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     L.kmu_count_retain_part.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.kmu_count_extract_by_owner.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(vp), vp]
     _lib = L
     return L
 
@@ -351,6 +352,26 @@ class Counter:
         self.ctx._check(self.L.kmu_count_export_part(self.h, part, n_parts, _ptr(k)[0], _ptr(c)[0], n.value, mem,
                                                      C.byref(n)))
         return k[:n.value], c[:n.value]
+
+    def extract_by_owner(self, bases, offsets, n_parts):
+        """canonical k-mers of the reads grouped by owner rank.  Returns (kmers, bounds): `kmers` is a zero-copy view
+        (torch int64 cuda tensor via __cuda_array_interface__) of a buffer owned by the context, valid until the next
+        counter call; bounds[n_parts + 1] (numpy) delimits the groups."""
+        import torch
+        mem = Context._mem(bases, offsets)
+        self.ctx._wait_producers(bases)
+        ptr = C.c_void_p()
+        bounds = np.zeros(n_parts + 1, np.uint64)
+        self.ctx._check(self.L.kmu_count_extract_by_owner(self.h, _ptr(bases)[0], _ptr(offsets)[0], len(offsets) - 1, mem,
+                                                          n_parts, C.byref(ptr), _ptr(bounds)[0]))
+        n = int(bounds[-1])
+
+        class _Dev:  # CUDA array interface v2 over the library-owned buffer
+            __cuda_array_interface__ = {"shape": (max(n, 1),), "typestr": "<i8", "data": (ptr.value, False), "version": 2}
+
+        dev = bases.device if _is_torch(bases) else torch.device("cuda", self.ctx.device_id)
+        t = torch.as_tensor(_Dev(), device=dev)
+        return t[:n], bounds
 
     def merge_entries(self, kmers, counts):
         mem = Context._mem(kmers, counts)

@@ -46,6 +46,23 @@ class OracleCounterDouble:
     def merge_entries(self, k, c):
         self.c.add_kmers(np.repeat(k, c.astype(np.int64)))
 
+    def add_kmers(self, k):
+        self.c.add_kmers(np.ascontiguousarray(k, np.uint64))
+
+    def extract_by_owner(self, bases, offsets, n_parts):
+        import torch
+        canon = self.O.kmer_hashes(bases, offsets, self.kt, self.k, A.FHASH_CANON_VALUE)
+        L = np.diff(offsets.astype(np.int64))
+        keep = np.concatenate([np.arange(int(offsets[i]), int(offsets[i]) + max(0, int(L[i]) - self.k + 1))
+                               for i in range(len(L))]) if len(L) else np.zeros(0, np.int64)
+        km = canon[keep]
+        lib = self.O.lib()
+        own = np.array([lib.kmo_int64_hash(int(x)) % n_parts for x in km], dtype=np.int64)
+        order = np.argsort(own, kind="stable")
+        bounds = np.zeros(n_parts + 1, np.uint64)
+        bounds[1:] = np.cumsum(np.bincount(own, minlength=n_parts))
+        return torch.from_numpy(km[order].view(np.int64).copy()), bounds
+
 
 def _worker(rank, world, port, ret):
     import torch.distributed as dist
@@ -75,6 +92,11 @@ def _worker(rank, world, port, ret):
         rows = torch.arange((r1 - r0) * 4, dtype=torch.int64).reshape(r1 - r0, 4) + 1000 * rank
         allrows = kdist.gather_rows(rows)
         ok = ok and allrows.shape[0] == len(lens) and int(allrows[0, 0]) == 0
+        # the throughput path: k-mers grouped by owner, one all-to-all, owner builds its table
+        cd2 = OracleCounterDouble(O, A.KMER64BIT, 21)
+        nrecv = kdist.count_reads_exchange(cd2, sb, so)
+        k2, c2 = cd2.c.dump(1)
+        ok = ok and nrecv > 0 and np.array_equal(k2, gk[own]) and np.array_equal(c2, gc[own])
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

@@ -260,6 +260,36 @@ def test_count_add_kmers_partitioned(ctx, oracle):
     assert np.array_equal(gk, wk) and np.array_equal(gcn, wc)
 
 
+def test_extract_by_owner_single_gpu(ctx, oracle):
+    """the multi-GPU exchange front end on one GPU: k-mers grouped by owner rank, every group complete and pure"""
+    bases, off = synth.illumina_reads(4000, 100_000, 0xC4)
+    c = ctx.counter(A.KMER64BIT, 31, 8, 1 << 20)
+    world = 5
+    kmers, bounds = c.extract_by_owner(bases, off, world)
+    km = kmers.cpu().numpy().view(np.uint64)
+    L = oracle.lib()
+    canon = oracle.kmer_hashes(bases, off, A.KMER64BIT, 31, A.FHASH_CANON_VALUE)
+    lens = np.diff(off.astype(np.int64))
+    keep = np.concatenate([np.arange(int(off[i]), int(off[i]) + max(0, int(lens[i]) - 30)) for i in range(len(lens))])
+    want = canon[keep]
+    assert km.size == want.size == int(bounds[-1])
+    for p in range(world):
+        grp = km[int(bounds[p]):int(bounds[p + 1])]
+        own = np.array([L.kmo_int64_hash(int(x)) % world for x in grp[:500]])
+        assert (own == p).all()
+    assert np.array_equal(np.sort(km), np.sort(want))
+    # each owner building from its group reproduces the global counts restricted to its keys
+    oc = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 20)
+    oc.add_kmers(want)
+    gk, gc = oc.dump(1)
+    for p in (0, world - 1):
+        cp = ctx.counter(A.KMER64BIT, 31, 8, 1 << 20)
+        cp.add_kmers(np.ascontiguousarray(km[int(bounds[p]):int(bounds[p + 1])]))
+        kk, cc = cp.dump(1)
+        own = np.array([L.kmo_int64_hash(int(x)) % world for x in gk]) == p
+        assert np.array_equal(kk, gk[own]) and np.array_equal(cc, gc[own])
+
+
 def test_superminhash_aa(ctx, oracle):
     res, off = synth.protein_seqs(300, 0xC5, median=250)
     for kt, k, m in ((A.KMERAA64BIT, 12, 128), (A.KMERAA32BIT, 5, 400)):
