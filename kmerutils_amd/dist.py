@@ -84,8 +84,9 @@ def count_reads_exchange(counter, bases, offsets, group=None):
     kmers, bounds = counter.extract_by_owner(bases, offsets, world)
     kmers = torch.as_tensor(kmers)
     dev = kmers.device
-    send_n = torch.as_tensor(np.diff(bounds.astype(np.int64)), dtype=torch.int64).to(dev)
-    all_n = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    cdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    send_n = torch.as_tensor(np.diff(bounds.astype(np.int64)), dtype=torch.int64).to(cdev)
+    all_n = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(all_n, send_n, group=group)
     recv_n = [int(all_n[p][rank].item()) for p in range(world)]
     send_sizes = [int(bounds[p + 1]) - int(bounds[p]) for p in range(world)]
@@ -94,9 +95,10 @@ def count_reads_exchange(counter, bases, offsets, group=None):
         flat = torch.empty(int(sum(recv_n)), dtype=torch.int64, device=dev)
         dist.all_to_all_single(flat, kmers, recv_n, send_sizes, group=group)
     else:
-        send_list = [kmers[int(bounds[p]):int(bounds[p + 1])] for p in range(world)]
-        recv = _all_to_all_var(send_list, recv_n, torch.int64, dev, group)
-        flat = torch.cat(recv) if recv else torch.empty(0, dtype=torch.int64, device=dev)
+        # gloo (CPU tests, single-GPU rehearsals): point-to-point pairs, staged through host memory
+        send_list = [kmers[int(bounds[p]):int(bounds[p + 1])].cpu() for p in range(world)]
+        recv = _all_to_all_var(send_list, recv_n, torch.int64, torch.device("cpu"), group)
+        flat = (torch.cat(recv) if recv else torch.empty(0, dtype=torch.int64)).to(dev)
     if flat.numel():
         counter.add_kmers(flat if dev.type != "cpu" else flat.numpy().view(np.uint64))
     return int(flat.numel())
