@@ -164,10 +164,21 @@ def main():
     if rank == 0:
         value = job_bases * args.steps / elapsed / 1e9
         # ---- roofline of the dominant kernel (HBM-bound integer path) -------------------------------------
+        sigw = 8 if cfg["sig"] in (A.SIG_U64, A.SIG_F64) else 4
+        nslots = 1 << max(10, int(np.ceil(np.log2(max(1.5 * nk, 1024)))))
+        # algorithmic bytes per launch: sketch = bases in + signatures out; the partitioned count is a
+        # pipeline of streaming kernels: bases (+ 8 B per k-mer per scatter level), then the 12-byte-per-slot table image
         alg_bytes = {
-            "k_sketch_pmh3a": total_bases + n_reads * cfg["m"] * (8 if cfg["sig"] in (A.SIG_U64, A.SIG_F64) else 4),
-            "k_sketch_super": total_bases + n_reads * cfg["m"] * (8 if cfg["sig"] in (A.SIG_U64, A.SIG_F64) else 4),
+            "k_sketch_pmh3a": total_bases + n_reads * cfg["m"] * sigw,
+            "k_sketch_super": total_bases + n_reads * cfg["m"] * sigw,
             "k_count_add_flat": total_bases + nk * 16,
+            "k_part_hist1": total_bases,
+            "k_part_scatter1": total_bases + nk * 8,
+            "k_part_hist2": nk * 8,
+            "k_part_scatter2": nk * 16,
+            "k_arr_hist": nk * 8,
+            "k_arr_scatter": nk * 16,
+            "k_part_build": nk * 8 + nslots * 12,
         }
         kern = {}
         for name, (launches, ms) in stats.items():
