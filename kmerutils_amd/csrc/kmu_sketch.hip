@@ -144,14 +144,15 @@ __device__ __forceinline__ double exp01_rest(const Exp01 &e, Xoshiro &rng) {
     }
 }
 
-// ProbMinHash3a for one key of weight w per lane: every generated point (h, slot) is offered to the slot minima.
-// `qmax` is any upper bound of the current q_max (shared word, refreshed by whoever still has live lanes); pruning
-// with a stale bound never changes the arg-min.  RNG draw order per key = the crate's: round 1 draws the slot only
-// when h < q_max (otherwise the key is dropped), later rounds always draw it.
+// ProbMinHash3a, pass B1: the FIRST point of every key (h1 = winv * Exp01, slot k1).  Like the crate's first loop over
+// the map, a key that may need further points (winv < q_max) is only remembered (return value) -- the crate pushes it
+// to `to_be_processed` and comes back to it after every key had its first point, when q_max is small and most of
+// those keys are dropped without drawing anything.  `qmax` is any upper bound of the current q_max (shared word,
+// refreshed now and then); pruning with a stale bound never changes the arg-min.
 // The first xoshiro256++ output needs only state words s0 and s3 (= SplitMix64 outputs 1 and 4 of the seed): the
-// other two are computed only for the minority of keys whose first point survives the q_max test.
-__device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t *hmin, uint64_t *sig, uint64_t *qmax_sh,
-                                                   bool refresh, bool have, uint64_t key, uint32_t w) {
+// other two are computed only for the keys whose first point survives the q_max test.
+__device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, uint64_t *hmin, uint64_t *sig, uint64_t *qmax_sh,
+                                                  bool refresh, bool have, uint64_t key, uint32_t w) {
     uint64_t qb;
     if (refresh) {
         qb = wave_qmax(hmin, a.m);
@@ -159,13 +160,11 @@ __device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t
     } else {
         qb = __hip_atomic_load(qmax_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    Xoshiro rng;
-    double winv = 0.0;
-    bool alive = false;
-    uint32_t i = 1;
+    bool deferred = false;
     if (have) {
         const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, a.sig_bytes == 4);
-        winv = 1.0 / (double) w;
+        const double winv = 1.0 / (double) w;
+        Xoshiro rng;
         rng.s0 = splitmix_at(seed, 1);
         rng.s3 = splitmix_at(seed, 4);
         const uint64_t r1 = rotl64(rng.s0 + rng.s3, 23) + rng.s0;
@@ -182,14 +181,26 @@ __device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t
             if (h < qmax) {
                 uint32_t k = draw_slot(a, rng);
                 slot_update(hmin, sig, k, h, key);
-                alive = winv < qmax; // keep iff winv * 1 < q_max
+                deferred = winv < qmax; // the crate: `if winv < qmax { to_be_processed.push(..) }`
             }
-            i = 2;
         }
     }
+    return deferred;
+}
+
+// pass B2: further points (rounds i >= 2) of the remembered keys, against the q_max reached after all first points.
+// The RNG stream of a key is replayed from its seed: round 1 consumed the Exp01 draws and one slot draw.
+// `qb` (bits of a q_max upper bound) is carried by the wave across calls and refreshed after every round.
+__device__ __forceinline__ void pmh3a_more_points(const SketchArgs &a, uint64_t *hmin, uint64_t *sig, uint64_t &qb,
+                                                  bool alive, uint64_t key, double winv) {
+    Xoshiro rng;
+    uint32_t i = 2;
+    if (alive) {
+        rng.seed(hasher_finish(KMU_HASHER_NOHASH, key, a.sig_bytes == 4));
+        (void) exp01_sample(a.e01, rng);
+        (void) draw_slot(a, rng);
+    }
     while (__any(alive)) {
-        qb = wave_qmax(hmin, a.m);
-        if (lane_id() == 0) atomicMin((unsigned long long *) qmax_sh, (unsigned long long) qb);
         if (alive) {
             double qmax = __longlong_as_double((long long) qb);
             double hbase = winv * (double) (i - 1);
@@ -204,6 +215,7 @@ __device__ __forceinline__ void pmh3a_consume_wave(const SketchArgs &a, uint64_t
                 i++;
             }
         }
+        qb = wave_qmax(hmin, a.m);
     }
 }
 
@@ -504,16 +516,41 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                             if (!overflow && last_round) {
                                 if (!BOTTOMK) {
-                                    // ---- B: every distinct key generates its points ------------------------------------
+                                    // ---- B1: the first point of every distinct key -------------------------------------
                                     uint32_t chunk = 0;
+                                    bool any_deferred = false;
                                     for (uint32_t base = 0; base < n_keys; base += nthreads, chunk++) {
                                         const uint32_t i = base + tid;
                                         uint64_t key = 0;
                                         uint32_t w = 0;
                                         if (i < n_keys) { key = dk[i]; w = dw[i]; }
                                         const bool have = w != 0u;
-                                        if (__any(have) && !(a.ablate & 1u))
-                                            pmh3a_consume_wave(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
+                                        if (__any(have) && !(a.ablate & 1u)) {
+                                            const bool deferred = pmh3a_first_point(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
+                                            if (deferred && !(a.ablate & 16u)) { dw[i] = w | 0x80000000u; any_deferred = true; }
+                                        }
+                                    }
+                                    // ---- B2: more points for the remembered keys that still lie below q_max -----------
+                                    // (a flag word in LDS, not __syncthreads_or: its library reduction brings static LDS,
+                                    // which would cost the kernel its 160 KiB dynamic allocation)
+                                    if (__any(any_deferred) && lane_id() == 0) misc[M_FLAGS] = 1u;
+                                    __syncthreads();
+                                    const bool run_b2 = misc[M_FLAGS] != 0u;
+                                    __syncthreads();
+                                    if (tid == 0) misc[M_FLAGS] = 0u;
+                                    if (run_b2 && !(a.ablate & 8u)) {
+                                        uint64_t qb = wave_qmax(hmin, a.m);
+                                        for (uint32_t base = 0; base < n_keys; base += nthreads) {
+                                            const uint32_t i = base + tid;
+                                            const uint32_t w = i < n_keys ? dw[i] : 0u;
+                                            double winv = 0.0;
+                                            bool alive = false;
+                                            if (w & 0x80000000u) { // round 2 starts at h = winv * 1
+                                                winv = 1.0 / (double) (w & 0x7FFFFFFFu);
+                                                alive = winv < __longlong_as_double((long long) qb);
+                                            }
+                                            if (__any(alive)) pmh3a_more_points(a, hmin, sig, qb, alive, alive ? dk[i] : 0ull, winv);
+                                        }
                                     }
                                 } else {
                                     // ---- bottom-k selection: rank = distinct keys in earlier buckets + smaller ones in
@@ -782,6 +819,11 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.bk_shift = (a.sig_bytes == 4 && p->hasher == KMU_HASHER_NOHASH) ? 20 : 52; // NoHashHasher of a u32 is < 2^32
     a.bk_mask = p->hasher == KMU_HASHER_INT64HASH ? 0xFFu : 0xFFFFu;
     size_t lds_max = 160 * 1024;
+    {
+        hipFuncAttributes fa;
+        KMU_HIP(ctx, hipFuncGetAttributes(&fa, fn));
+        lds_max -= fa.sharedSizeBytes; // static LDS (none today) comes out of the same 160 KiB
+    }
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) != hipSuccess) {
         (void) hipGetLastError();
         lds_max = 64 * 1024;

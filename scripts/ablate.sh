@@ -1,9 +1,6 @@
 #!/bin/bash
 # diagnostics: phase ablation of k_sketch_pmh3a on the bench read set (not part of the product)
 cd $GRAFT_REPO_ROOT
-for ab in 0 1 3 7; do
+for ab in ${ABLATE_LIST:-0 1 3 7}; do
   KMU_PMH_ABLATE=$ab timeout -k 10 120 python bench.py --workload ont_k31_sketch --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('ablate',$ab, d['kernels']['k_sketch_pmh3a']['avg_ms'])"
-done
-for th in 512 256; do
-  KMU_PMH_THREADS=$th timeout -k 10 120 python bench.py --workload ont_k31_sketch --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('threads',$th, d['kernels']['k_sketch_pmh3a']['avg_ms'])"
 done
