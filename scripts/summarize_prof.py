@@ -22,7 +22,7 @@ def main():
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         others = 0
         for r in rows:
-            ours = r["Name"].startswith("kmu::")
+            ours = "kmu::" in r["Name"].split("(")[0]
             if ours or others < 5:
                 others += 0 if ours else 1
                 f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (r["Name"][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
@@ -33,8 +33,9 @@ def main():
             acc = collections.defaultdict(float)
             cnt = collections.Counter()
             for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
-                if r["Counter_Name"] == name and r["Kernel_Name"].startswith("kmu::"):
-                    k = r["Kernel_Name"].split("(")[0].replace("kmu::", "")
+                if r["Counter_Name"] == name and "kmu::" in r["Kernel_Name"].split("(")[0]:
+                    # "void kmu::k_sketch_pmh3a<false, false>(kmu::SketchArgs)" -> "k_sketch_pmh3a"
+                    k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kmu::", "").strip()
                     acc[k] += float(r["Counter_Value"])
                     cnt[k] += 1
             for k in acc:
