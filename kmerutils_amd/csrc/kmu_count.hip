@@ -4,7 +4,7 @@
 // the counts >= 2; both are randomised per process, so the observable contract is "exact multiplicity of the
 // canonical k-mer, reported saturated at 2^bits - 1" (plus ~3 % false positives the reference itself treats as
 // noise).  Here: one exact table in HBM -- keys[2^q] (canonical value, all-ones = free) + counts[2^q] (u32) --
-// cut into REGIONS of 4096 slots; a key lives in the region named by the top bits of fmix64(key) and is probed
+// cut into REGIONS of 4096 slots; a key lives in the region named by the top bits of khash(key) and is probed
 // linearly inside it (wrapping at the region end), so a region is an independent little hash table that fits LDS.
 //
 // Two ways to add k-mers:
@@ -46,6 +46,21 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
     return x;
 }
 
+// Table hash: a bijection of the 64-bit key space.  The complemented form maps the impossible key (all ones) to all
+// ones, so CKEY_EMPTY marks "nothing" in the key domain AND in the hash domain.  The partition passes of the build
+// carry khash(key) instead of the key: every later digit is a bit field of the item (no second or third evaluation),
+// and the key comes back with khash_inv when the region is built.
+__device__ __forceinline__ uint64_t khash(uint64_t key) { return ~fmix64(~key); }
+__device__ __forceinline__ uint64_t khash_inv(uint64_t h) {
+    uint64_t x = ~h;
+    x ^= x >> 33;
+    x *= 0x9cb4b2f8129337dbull; // inverse of 0xc4ceb9fe1a85ec53 mod 2^64
+    x ^= x >> 33;
+    x *= 0x4f74430c22a54005ull; // inverse of 0xff51afd7ed558ccd mod 2^64
+    x ^= x >> 33;
+    return ~x;
+}
+
 // owner of a k-mer in an n-way key partition: DispatchableT, kmercount.rs:382-420
 __device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_parts) {
     return w32 ? (uint32_t) (int32_hash((uint32_t) v) % n_parts) : (uint32_t) (int64_hash(v) % (uint64_t) n_parts);
@@ -60,7 +75,7 @@ struct CountTable {
 
 // KmerCounter::insert_kmer (kmercount.rs:241-267), exact form: count[v] += add
 __device__ __forceinline__ bool count_insert(const CountTable &t, uint64_t v, uint32_t add) {
-    const uint64_t idx0 = fmix64(v) >> t.shift;
+    const uint64_t idx0 = khash(v) >> t.shift;
     const uint64_t base = idx0 & ~(uint64_t) t.rmask;
     uint32_t off = (uint32_t) idx0 & t.rmask;
     for (uint32_t probes = 0; probes <= t.rmask; probes++) {
@@ -80,7 +95,7 @@ __device__ __forceinline__ bool count_insert(const CountTable &t, uint64_t v, ui
 }
 
 __device__ __forceinline__ uint32_t count_lookup(const CountTable &t, uint64_t v) {
-    const uint64_t idx0 = fmix64(v) >> t.shift;
+    const uint64_t idx0 = khash(v) >> t.shift;
     const uint64_t base = idx0 & ~(uint64_t) t.rmask;
     uint32_t off = (uint32_t) idx0 & t.rmask;
     for (uint32_t probes = 0; probes <= t.rmask; probes++) {
@@ -109,11 +124,21 @@ __device__ __forceinline__ uint32_t wave_find_read(const uint64_t *offsets, uint
     return lo;
 }
 
+// the same with a hint: a wave walks the flat stream forwards, so the read is usually one of the next 64
+__device__ __forceinline__ uint32_t wave_find_read_from(const uint64_t *offsets, uint32_t n, uint64_t g, uint32_t hint) {
+    if (hint >= n || offsets[hint] > g) return wave_find_read(offsets, n, g);
+    const uint64_t idx = (uint64_t) hint + 1 + (uint32_t) lane_id();
+    const bool le = idx < n && offsets[idx] <= g;
+    const uint32_t c = (uint32_t) __popcll(__ballot(le));
+    if (c < 64u) return hint + c;
+    return wave_find_read(offsets, n, g);
+}
+
 // One wave step (64 words = 1024 bases) of the flat base stream: f(canon) for every k-mer that lies inside one read.
 // Returns a non-zero mask if this lane saw a non-ACGT byte.
 template <typename F>
 __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
-                                                    uint64_t total, int k, uint64_t st, F &&f) {
+                                                    uint64_t total, int k, uint64_t st, uint32_t &r_hint, F &&f) {
     SeqView s;
     s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
     const int lane = lane_id();
@@ -125,7 +150,8 @@ __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const 
     uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
     if (lane == 63) { w1 = e0; w2 = e1; }
     if (lane == 62) { w2 = e0; }
-    uint32_t r = wave_find_read(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1);
+    uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
+    r_hint = r;
     const uint64_t g0 = widx * 16;
     if (g0 < total) {
         uint64_t rend = offsets[r + 1];
@@ -155,9 +181,9 @@ __global__ void __launch_bounds__(256) k_count_add_flat(const uint8_t *bases, co
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
     const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
-    uint32_t anybad = 0, full = 0;
+    uint32_t anybad = 0, full = 0, r_hint = 0xFFFFFFFFu;
     for (uint64_t st = wave_global; st < nsteps; st += nwaves_global)
-        anybad |= flat_step_canon(bases, offsets, n_seq, total, k, st, [&](uint64_t canon) {
+        anybad |= flat_step_canon(bases, offsets, n_seq, total, k, st, r_hint, [&](uint64_t canon) {
             if (!count_insert(t, canon, 1u)) full = 1;
         });
     if (anybad) atomicOr(err, DERR_NON_ACGT);
@@ -278,8 +304,11 @@ struct PartPlan {
     int owner_w32;
 };
 
+__device__ __forceinline__ uint32_t region_of_hash(uint64_t h, int region_bits) {
+    return region_bits ? (uint32_t) (h >> (64 - region_bits)) : 0u;
+}
 __device__ __forceinline__ uint32_t region_of(uint64_t canon, int region_bits) {
-    return region_bits ? (uint32_t) (fmix64(canon) >> (64 - region_bits)) : 0u;
+    return region_of_hash(khash(canon), region_bits);
 }
 
 // level 1, pass 1: per-unit histogram of the level-1 digit (also validates the bases)
@@ -294,9 +323,9 @@ __global__ void __launch_bounds__(256) k_part_hist1(const uint8_t *bases, const 
     const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    uint32_t bad = 0;
+    uint32_t bad = 0, r_hint = 0xFFFFFFFFu;
     for (uint64_t st = s0 + wave; st < s1; st += nwaves)
-        bad |= flat_step_canon(bases, offsets, n_seq, total, k, st, [&](uint64_t canon) {
+        bad |= flat_step_canon(bases, offsets, n_seq, total, k, st, r_hint, [&](uint64_t canon) {
             atomicAdd(&lh[pl.owner_parts ? kmer_owner(canon, pl.owner_w32, pl.owner_parts)
                                          : region_of(canon, pl.region_bits) >> pl.b2], 1u);
         });
@@ -372,14 +401,18 @@ __device__ __forceinline__ ScatterLds scatter_lds(uint8_t *smem, uint32_t nbins)
 }
 static size_t scatter_lds_bytes(uint32_t nbins) { return (size_t) TILE_ITEMS * 8 + (size_t) nbins * 8 + ((size_t) nbins + 1 + 16) * 4 + 16; }
 
-// region_bits >= 0: digit = (region >> shift) & mask.  region_bits < 0: digit = owner of the k-mer in a `shift`-way key
-// partition (DispatchableT, kmercount.rs:382-420); `mask` != 0 marks 32-bit k-mer values.
-__device__ __forceinline__ uint32_t digit_of(uint64_t canon, int region_bits, int shift, uint32_t mask) {
-    if (region_bits < 0) return kmer_owner(canon, mask != 0u, (uint32_t) shift);
-    return (region_of(canon, region_bits) >> shift) & mask;
+// What a partition item is: IT_HASH = khash(key) (digit = a bit field of the item), IT_KEY = the key itself (digit from
+// khash(key)), IT_OWNER = the key, digit = its owner in a `shift`-way key partition (DispatchableT,
+// kmercount.rs:382-420; `mask` != 0 marks 32-bit k-mer values).
+enum { IT_HASH = 0, IT_KEY = 1, IT_OWNER = 2 };
+template <int IT>
+__device__ __forceinline__ uint32_t digit_of(uint64_t item, int region_bits, int shift, uint32_t mask) {
+    if (IT == IT_OWNER) return kmer_owner(item, mask != 0u, (uint32_t) shift);
+    return (region_of_hash(IT == IT_HASH ? item : khash(item), region_bits) >> shift) & mask;
 }
 
 // it[j] == CKEY_EMPTY marks "no k-mer".  All 1024 threads call this together.
+template <int IT>
 __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLds &l, uint32_t nbins, int region_bits,
                                              int shift, uint32_t mask, uint64_t *out) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -388,7 +421,7 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
     for (int j = 0; j < 16; j++) {
         br[j] = 0;
         if (it[j] != CKEY_EMPTY) {
-            uint32_t bin = digit_of(it[j], region_bits, shift, mask);
+            uint32_t bin = digit_of<IT>(it[j], region_bits, shift, mask);
             uint32_t rank = atomicAdd(&l.lstart[bin], 1u);
             br[j] = (bin << 16) | rank;
         }
@@ -421,7 +454,7 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
     const uint32_t total = l.lstart[nbins];
     for (uint32_t p = tid; p < total; p += nthreads) {
         const uint64_t v = l.stage[p];
-        const uint32_t bin = digit_of(v, region_bits, shift, mask);
+        const uint32_t bin = digit_of<IT>(v, region_bits, shift, mask);
         out[l.gbase[bin] + (uint64_t) (p - l.lstart[bin])] = v;
     }
     __syncthreads();
@@ -441,24 +474,34 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
     __syncthreads();
 }
 
-// up to 16 canonical k-mers of this lane for wave step `st` (CKEY_EMPTY where a k-mer would straddle a read end)
-__device__ __forceinline__ void flat_step_items(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
-                                                uint64_t total, int k, uint64_t st, bool active, uint64_t (&it)[16]) {
-#pragma unroll
-    for (int j = 0; j < 16; j++) it[j] = CKEY_EMPTY;
+// the code words of wave step `st`: this lane's word and (lanes 0/1) the two words after the wave's last
+__device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t total, uint64_t st, bool active, uint32_t &w0,
+                                               uint32_t &ex) {
+    w0 = 0;
+    ex = 0;
     if (!active) return; // wave-uniform
     SeqView s;
     s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
+    uint32_t bad, bad2;
+    w0 = load_code_word(s, st * 64 + (uint64_t) lane_id(), bad);
+    ex = load_code_word(s, st * 64 + 64 + (uint64_t) (lane_id() & 1), bad2);
+}
+
+// up to 16 canonical k-mers of this lane for wave step `st` (CKEY_EMPTY where a k-mer would straddle a read end)
+__device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_t n_seq, uint64_t total, int k, uint64_t st,
+                                                bool active, uint32_t w0, uint32_t ex, uint32_t &r_hint,
+                                                uint64_t (&it)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) it[j] = CKEY_EMPTY;
+    if (!active) return; // wave-uniform
     const int lane = lane_id();
     const uint64_t widx = st * 64 + lane;
-    uint32_t bad, bad2;
-    uint32_t w0 = load_code_word(s, widx, bad);
-    uint32_t ex = load_code_word(s, st * 64 + 64 + (uint64_t) (lane & 1), bad2);
     uint32_t e0 = bcast_u32(ex, 0), e1 = bcast_u32(ex, 1);
     uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
     if (lane == 63) { w1 = e0; w2 = e1; }
     if (lane == 62) { w2 = e0; }
-    uint32_t r = wave_find_read(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1);
+    uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
+    r_hint = r;
     const uint64_t g0 = widx * 16;
     if (g0 < total) {
         uint64_t rend = offsets[r + 1];
@@ -496,11 +539,20 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint32_t r_hint = 0xFFFFFFFFu, w0, ex;
+    flat_step_load(bases, total, s0 + wave, s0 + wave < s1, w0, ex);
     for (uint64_t t0 = s0; t0 < s1; t0 += nwaves) {
         uint64_t it[16];
-        flat_step_items(bases, offsets, n_seq, total, k, t0 + wave, t0 + wave < s1, it);
-        if (pl.owner_parts) tile_scatter(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
-        else tile_scatter(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
+        flat_step_items(offsets, n_seq, total, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
+        // the next step's words are requested now; their latency hides under the tile sort
+        flat_step_load(bases, total, t0 + nwaves + wave, t0 + nwaves + wave < s1, w0, ex);
+        if (pl.owner_parts) tile_scatter<IT_OWNER>(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
+        else { // from here on the k-mers travel as their table hash
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
+            tile_scatter<IT_HASH>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
+        }
     }
 }
 
@@ -523,6 +575,7 @@ __device__ __forceinline__ void arr_unit_range(const uint64_t *bounds, const Arr
     *i1 = s + len * (c + 1) / pl.chunks;
 }
 
+template <int IT>
 __global__ void __launch_bounds__(256) k_arr_hist(const uint64_t *in, const uint64_t *bounds, ArrPlan pl, uint32_t *hist) {
     extern __shared__ uint32_t lh[];
     for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) lh[b] = 0;
@@ -530,7 +583,7 @@ __global__ void __launch_bounds__(256) k_arr_hist(const uint64_t *in, const uint
     uint64_t i0, i1;
     arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
     for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x)
-        atomicAdd(&lh[(region_of(in[i], pl.region_bits) >> pl.shift) & (pl.bins - 1)], 1u);
+        atomicAdd(&lh[digit_of<IT>(in[i], pl.region_bits, pl.shift, pl.bins - 1)], 1u);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) hist[(uint64_t) blockIdx.x * pl.bins + b] = lh[b];
 }
@@ -563,6 +616,7 @@ __global__ void __launch_bounds__(256) k_arr_scan(const uint32_t *hist, const ui
     }
 }
 
+template <int IT>
 __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
                                                       const uint64_t *offs, uint64_t *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -575,38 +629,65 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     __syncthreads();
     uint64_t i0, i1;
     arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
+    uint64_t nxt[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint64_t i = i0 + (uint64_t) j * blockDim.x + threadIdx.x;
+        nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
+    }
     for (uint64_t t0 = i0; t0 < i1; t0 += TILE_ITEMS) {
         uint64_t it[16];
 #pragma unroll
+        for (int j = 0; j < 16; j++) it[j] = nxt[j];
+        // the next tile is requested before this one is sorted: its HBM latency hides under the LDS work
+#pragma unroll
         for (int j = 0; j < 16; j++) {
-            const uint64_t i = t0 + (uint64_t) j * blockDim.x + threadIdx.x;
-            it[j] = i < i1 ? in[i] : CKEY_EMPTY;
+            const uint64_t i = t0 + TILE_ITEMS + (uint64_t) j * blockDim.x + threadIdx.x;
+            nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
         }
-        tile_scatter(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
+        tile_scatter<IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
 }
 
 // build: one workgroup per region.  The region (keys + counts) lives in LDS while its k-mers are inserted, then it
-// is streamed out.  `fresh` = the table holds nothing yet (every region is written, no region is read).
-__global__ void __launch_bounds__(256) k_part_build(const uint64_t *items, const uint64_t *leafstart, uint32_t n_regions,
-                                                    CountTable t, int fresh, uint32_t *err) {
+// is streamed out with 16-byte stores.  `fresh` = the table holds nothing yet (every region is written, no region is
+// read).  The first BUILD_PRE items of every thread are requested before the region is initialised, so their HBM
+// latency hides under the LDS fill; three workgroups share a CU and overlap each other's phases.
+static constexpr int BUILD_THREADS = 512;
+static constexpr int BUILD_PRE = 6;
+
+template <int IT>
+__global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *items, const uint64_t *leafstart,
+                                                              uint32_t n_regions, CountTable t, int fresh, uint32_t *err) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t R = t.rmask + 1;
+    const uint32_t R = t.rmask + 1; // >= 1024
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
     uint32_t *lc = reinterpret_cast<uint32_t *>(lk + R);
+    uint4 *lk4 = reinterpret_cast<uint4 *>(lk), *lc4 = reinterpret_cast<uint4 *>(lc);
+    const uint32_t tid = threadIdx.x;
     uint32_t full = 0;
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
         const uint64_t gbase = (uint64_t) r * R;
+        const uint64_t i0 = leafstart[r], i1 = leafstart[r + 1];
+        uint64_t pre[BUILD_PRE];
+#pragma unroll
+        for (int q = 0; q < BUILD_PRE; q++) {
+            const uint64_t i = i0 + (uint64_t) q * BUILD_THREADS + tid;
+            pre[q] = i < i1 ? items[i] : CKEY_EMPTY;
+        }
+        uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + gbase), *gc4 = reinterpret_cast<uint4 *>(t.counts + gbase);
         if (fresh) {
-            for (uint32_t s = threadIdx.x; s < R; s += blockDim.x) { lk[s] = CKEY_EMPTY; lc[s] = 0; }
+            for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (uint32_t s = tid; s < R / 4; s += BUILD_THREADS) lc4[s] = make_uint4(0u, 0u, 0u, 0u);
         } else {
-            for (uint32_t s = threadIdx.x; s < R; s += blockDim.x) { lk[s] = t.keys[gbase + s]; lc[s] = t.counts[gbase + s]; }
+            for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = gk4[s];
+            for (uint32_t s = tid; s < R / 4; s += BUILD_THREADS) lc4[s] = gc4[s];
         }
         __syncthreads();
-        const uint64_t i0 = leafstart[r], i1 = leafstart[r + 1];
-        for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-            const uint64_t v = items[i];
-            uint32_t off = (uint32_t) (fmix64(v) >> t.shift) & t.rmask;
+        auto insert = [&](uint64_t item) {
+            const uint64_t h = IT == IT_HASH ? item : khash(item);
+            const uint64_t v = IT == IT_HASH ? khash_inv(item) : item;
+            uint32_t off = (uint32_t) (h >> t.shift) & t.rmask;
             bool done = false;
             for (uint32_t probes = 0; probes < R; probes++) {
                 unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY,
@@ -619,9 +700,14 @@ __global__ void __launch_bounds__(256) k_part_build(const uint64_t *items, const
                 off = (off + 1) & t.rmask;
             }
             if (!done) full = 1;
-        }
+        };
+#pragma unroll
+        for (int q = 0; q < BUILD_PRE; q++)
+            if (pre[q] != CKEY_EMPTY) insert(pre[q]);
+        for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) insert(items[i]);
         __syncthreads();
-        for (uint32_t s = threadIdx.x; s < R; s += blockDim.x) { t.keys[gbase + s] = lk[s]; t.counts[gbase + s] = lc[s]; }
+        for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
+        for (uint32_t s = tid; s < R / 4; s += BUILD_THREADS) gc4[s] = lc4[s];
         __syncthreads();
     }
     if (full) atomicOr(err, DERR_TABLE_FULL);
@@ -693,7 +779,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     static bool lds_attr_done = false;
     if (!lds_attr_done) {
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_done = true;
     }
     {
@@ -720,7 +806,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         ArrPlan ap{pl.region_bits, 0, bins2, bins1, pl.chunks2};
         {
             KernelTimer tm(ctx, "k_part_hist2");
-            hipLaunchKernelGGL(k_arr_hist, dim3(units2), dim3(256), bins2 * 4, ctx->stream, (const uint64_t *) A,
+            hipLaunchKernelGGL(k_arr_hist<IT_HASH>, dim3(units2), dim3(256), bins2 * 4, ctx->stream, (const uint64_t *) A,
                                (const uint64_t *) binstart1, ap, (uint32_t *) hist2);
         }
         {
@@ -730,7 +816,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         }
         {
             KernelTimer tm(ctx, "k_part_scatter2");
-            hipLaunchKernelGGL(k_arr_scatter, dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
+            hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
                                (const uint64_t *) A, (const uint64_t *) binstart1, ap, (const uint64_t *) offs2,
                                (uint64_t *) B);
         }
@@ -742,8 +828,8 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         const size_t lds = (size_t) R * 12;
         int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * 3 * 8);
         KernelTimer tm(ctx, "k_part_build");
-        hipLaunchKernelGGL(k_part_build, dim3(grid), dim3(256), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
-                           table_of(c), c->empty ? 1 : 0, d_err);
+        hipLaunchKernelGGL(k_part_build<IT_HASH>, dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves,
+                           (uint32_t) n_regions, table_of(c), c->empty ? 1 : 0, d_err);
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;
@@ -752,7 +838,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
 
 namespace kmu {
 
-// Partition a device array of u64 keys by the top `region_bits` bits of fmix64(key) into 2^region_bits leaves
+// Partition a device array of u64 keys by the top `region_bits` bits of khash(key) into 2^region_bits leaves
 // (<= 22 bits: two 11-bit passes).  Returns the partitioned copy and the leaf bounds (both in context scratch
 // buffers, valid until the next partition call).
 int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits, const uint64_t **items_out,
@@ -760,7 +846,7 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
     if (region_bits > 22) return fail(ctx, KMU_E_UNSUPPORTED, "too many partitions (2^%d)", region_bits);
     static bool lds_attr_done = false;
     if (!lds_attr_done) {
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_done = true;
     }
     const int b1 = region_bits <= 11 ? region_bits : (region_bits + 1) / 2;
@@ -789,7 +875,7 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
         KMU_TRY(dev_buf(ctx, level == 0 ? "cnt.partA" : "cnt.partB", n * 8 + 64, &outbuf));
         {
             KernelTimer tm(ctx, "k_arr_hist");
-            hipLaunchKernelGGL(k_arr_hist, dim3(units), dim3(256), bins * 4, ctx->stream, items, bounds, ap, (uint32_t *) hist);
+            hipLaunchKernelGGL(k_arr_hist<IT_KEY>, dim3(units), dim3(256), bins * 4, ctx->stream, items, bounds, ap, (uint32_t *) hist);
         }
         {
             KernelTimer tm(ctx, "k_arr_scan");
@@ -798,7 +884,7 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
         }
         {
             KernelTimer tm(ctx, "k_arr_scatter");
-            hipLaunchKernelGGL(k_arr_scatter, dim3(units), dim3(SCATTER_THREADS), scatter_lds_bytes(bins), ctx->stream, items,
+            hipLaunchKernelGGL(k_arr_scatter<IT_KEY>, dim3(units), dim3(SCATTER_THREADS), scatter_lds_bytes(bins), ctx->stream, items,
                                bounds, ap, (const uint64_t *) offs, (uint64_t *) outbuf);
         }
         KMU_HIP(ctx, hipGetLastError());
@@ -824,7 +910,7 @@ static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64
     int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * 3 * 8);
     {
         KernelTimer tm(ctx, "k_part_build");
-        hipLaunchKernelGGL(k_part_build, dim3(grid), dim3(256), (size_t) R * 12, ctx->stream, items, bounds,
+        hipLaunchKernelGGL(k_part_build<IT_KEY>, dim3(grid), dim3(BUILD_THREADS), (size_t) R * 12, ctx->stream, items, bounds,
                            (uint32_t) n_regions, table_of(c), c->empty ? 1 : 0, d_err);
     }
     KMU_HIP(ctx, hipGetLastError());
