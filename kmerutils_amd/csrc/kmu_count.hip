@@ -426,7 +426,7 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
             br[j] = (bin << 16) | rank;
         }
     }
-    __syncthreads();
+    lds_barrier();
     // in-place exclusive scan of lstart[0..nbins) (two bins per thread); lstart[nbins] = tile total
     {
         const uint32_t b0 = 2u * tid, b1 = b0 + 1;
@@ -438,40 +438,44 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
             if (lane_id() >= d) incl += o;
         }
         if (lane_id() == 63) l.wtot[tid >> 6] = incl;
-        __syncthreads();
+        lds_barrier();
         uint32_t wpre = 0;
-        for (int w = 0; w < (tid >> 6); w++) wpre += l.wtot[w];
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t v = l.wtot[w];
+            wpre += w < (tid >> 6) ? v : 0u;
+        }
         const uint32_t excl = wpre + incl - (c0 + c1);
         if (b0 < nbins) l.lstart[b0] = excl;
         if (b1 < nbins) l.lstart[b1] = excl + c0;
         if (tid == nthreads - 1) l.lstart[nbins] = wpre + incl;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < 16; j++)
         if (it[j] != CKEY_EMPTY) l.stage[l.lstart[br[j] >> 16] + (br[j] & 0xFFFFu)] = it[j];
-    __syncthreads();
+    lds_barrier();
     const uint32_t total = l.lstart[nbins];
     for (uint32_t p = tid; p < total; p += nthreads) {
         const uint64_t v = l.stage[p];
         const uint32_t bin = digit_of<IT>(v, region_bits, shift, mask);
         out[l.gbase[bin] + (uint64_t) (p - l.lstart[bin])] = v;
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t cnt[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const uint32_t b = 2u * tid + q;
         cnt[q] = b < nbins ? l.lstart[b + 1] - l.lstart[b] : 0u;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const uint32_t b = 2u * tid + q;
         if (b < nbins) { l.gbase[b] += cnt[q]; l.lstart[b] = 0; }
     }
     if (tid == 0) l.lstart[nbins] = 0;
-    __syncthreads();
+    lds_barrier();
 }
 
 // the code words of wave step `st`: this lane's word and (lanes 0/1) the two words after the wave's last
@@ -533,7 +537,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
         l.lstart[b] = 0;
     }
     if (threadIdx.x == 0) l.lstart[bins1] = 0;
-    __syncthreads();
+    lds_barrier();
     const uint64_t total = offsets[n_seq];
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
     const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
@@ -626,7 +630,7 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
         l.lstart[b] = 0;
     }
     if (threadIdx.x == 0) l.lstart[pl.bins] = 0;
-    __syncthreads();
+    lds_barrier();
     uint64_t i0, i1;
     arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
     uint64_t nxt[16];
@@ -683,7 +687,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *it
             for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = gk4[s];
             for (uint32_t s = tid; s < R / 4; s += BUILD_THREADS) lc4[s] = gc4[s];
         }
-        __syncthreads();
+        lds_barrier();
         auto insert = [&](uint64_t item) {
             const uint64_t h = IT == IT_HASH ? item : khash(item);
             const uint64_t v = IT == IT_HASH ? khash_inv(item) : item;
@@ -705,10 +709,10 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *it
         for (int q = 0; q < BUILD_PRE; q++)
             if (pre[q] != CKEY_EMPTY) insert(pre[q]);
         for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) insert(items[i]);
-        __syncthreads();
+        lds_barrier();
         for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
         for (uint32_t s = tid; s < R / 4; s += BUILD_THREADS) gc4[s] = lc4[s];
-        __syncthreads();
+        lds_barrier();
     }
     if (full) atomicOr(err, DERR_TABLE_FULL);
 }
@@ -752,6 +756,11 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     if (pl.region_bits <= 11) { pl.b1 = pl.region_bits; pl.b2 = 0; }
     else { pl.b1 = (pl.region_bits + 1) / 2; pl.b2 = pl.region_bits - pl.b1; }
     if (pl.b1 > 11 || pl.b2 > 11) return fail(ctx, KMU_E_UNSUPPORTED, "table too large for the two-level partitioned build");
+    bool dbg_split = false;
+    if (const char *e = getenv("KMU_DBG_SPLIT")) { // timing experiments only: incomplete partition, no build
+        int x = 0, y = 0;
+        if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && x <= 11 && y >= 1 && y <= 11 && x + y <= pl.region_bits) { pl.b1 = x; pl.b2 = y; pl.region_bits = x + y; dbg_split = true; }
+    }
     const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
     const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
     uint32_t units1 = (uint32_t) std::min<uint64_t>(nsteps, (uint64_t) ctx->num_cus * 8);
@@ -760,6 +769,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     units1 = (uint32_t) ((nsteps + pl.steps_per_unit - 1) / pl.steps_per_unit);
     pl.units1 = units1;
     pl.chunks2 = pl.b2 ? std::max<uint32_t>(1u, 16384u / bins1) : 1u;
+    if (const char *e = getenv("KMU_DBG_CHUNKS2")) pl.chunks2 = (uint32_t) std::max(1, atoi(e));
     const uint32_t units2 = bins1 * pl.chunks2;
     const uint64_t n_regions = 1ull << pl.region_bits;
 
@@ -828,6 +838,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         const size_t lds = (size_t) R * 12;
         int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * 3 * 8);
         KernelTimer tm(ctx, "k_part_build");
+        if (!dbg_split)
         hipLaunchKernelGGL(k_part_build<IT_HASH>, dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves,
                            (uint32_t) n_regions, table_of(c), c->empty ? 1 : 0, d_err);
     }

@@ -268,6 +268,10 @@ __device__ __forceinline__ double exp01_sample(const Exp01 &e, Xoshiro &rng) {
 // wave helpers
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)), which serialises HBM streaming against the LDS phases of a kernel; use this
+// one where the waves of a workgroup hand data to each other through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t shfl_down_u32(uint32_t v, int d) { return (uint32_t) __shfl_down((int) v, d, 64); }
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, 64); }
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {

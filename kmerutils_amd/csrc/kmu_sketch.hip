@@ -74,9 +74,10 @@ __device__ __forceinline__ uint32_t mix32(uint64_t key) {
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t) (((uint64_t) a * b) >> 32); }
 
 // misc words in LDS
-enum { M_READ = 0, M_NSCR = 1, M_FLAGS = 2, M_QMAX = 4 /* 4,5: u64 */, M_WORDS = 8 };
+enum { M_READ = 0, M_NSCR = 1, M_NEXT = 2, M_QMAX = 4 /* 4,5: u64 */, M_FLAGS = 6 /* 6,7 */, M_WORDS = 8 };
 static constexpr int BUCKET_BITS = 12;               // counting-sort buckets
 static constexpr uint32_t NBUCKETS = 1u << BUCKET_BITS;
+static constexpr int QCHUNK = 4;                     // reads taken from the queue per atomic
 static constexpr int KREG = 10;                      // keys a thread keeps in registers between the sort phases
 
 // slot update: keep (h, key) minimal per slot; exact ties go to the smaller key (order independence)
@@ -251,7 +252,11 @@ __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
     if (lane_id() == 63) wtot[tid >> 6] = incl;
     __syncthreads();
     uint32_t run = incl - sum;
-    for (int w = 0; w < (tid >> 6); w++) run += wtot[w];
+#pragma unroll
+    for (int w = 0; w < 16; w++) { // all 16 words are requested at once (a loop up to the own wave would be a chain)
+        const uint32_t v = wtot[w];
+        run += w < (tid >> 6) ? v : 0u;
+    }
 #pragma unroll
     for (uint32_t q = 0; q < 8; q++)
         if (q < per && b0 + q < NBUCKETS) {
@@ -299,27 +304,47 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
 
     for (uint32_t s = tid; s <= NBUCKETS; s += nthreads) bst[s] = 0;
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
-    if (tid == 0) { misc[M_NSCR] = 0; misc[M_FLAGS] = 0; *qmax_sh = H_INIT; }
-    if (tid == 0) misc[M_READ] = atomicAdd(a.queue, 1u);
+    if (tid == 0) { misc[M_NSCR] = 0; misc[M_FLAGS] = 0; misc[M_FLAGS + 1] = 0; *qmax_sh = H_INIT; }
+    uint32_t flag_sel = 0; // uniform
+    // reads are taken from the global queue QCHUNK at a time (thread 0 keeps the cursor): one same-address atomic per
+    // read would cap the whole grid at the L2's rate for a single address
+    uint32_t q_next = 0, q_end = 0;
+    if (tid == 0) {
+        q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
+        q_end = q_next + QCHUNK;
+        misc[M_READ] = q_next++;
+    }
     __syncthreads();
-    for (;;) {
-        const uint32_t r = misc[M_READ];
-        __syncthreads(); // everyone holds r before thread 0 posts the next one
-        if (r >= a.n_seq) break;
-        uint32_t r_next = 0;
-        if (tid == 0) r_next = atomicAdd(a.queue, 1u); // its latency hides under this read's work
-        SeqView sv;
-        sv.base = a.bases;
-        sv.len = a.offsets[r + 1] - a.offsets[r];
-        sv.packed = a.packed;
+    auto view_of = [&](uint32_t r) {
+        SeqView v;
+        v.base = a.bases;
+        v.len = a.offsets[r + 1] - a.offsets[r];
+        v.packed = a.packed;
         if (a.packed) {
-            sv.begin = a.packed_offsets[r];
-            sv.total = a.total_bytes ? a.total_bytes
-                                     : (a.packed_offsets[a.n_seq - 1] + (a.offsets[a.n_seq] - a.offsets[a.n_seq - 1] + 3) / 4);
+            v.begin = a.packed_offsets[r];
+            v.total = a.total_bytes ? a.total_bytes
+                                    : (a.packed_offsets[a.n_seq - 1] + (a.offsets[a.n_seq] - a.offsets[a.n_seq - 1] + 3) / 4);
         } else {
-            sv.begin = a.offsets[r];
-            sv.total = a.total_bytes ? a.total_bytes : a.offsets[a.n_seq];
+            v.begin = a.offsets[r];
+            v.total = a.total_bytes ? a.total_bytes : a.offsets[a.n_seq];
         }
+        return v;
+    };
+    lds_barrier();
+    uint32_t r = misc[M_READ];
+    while (r < a.n_seq) {
+        // Thread 0 takes the next read now (the atomic's latency hides under this read's work), posts it in
+        // misc[M_NEXT] before the first barrier after the ranks are taken, and everybody picks it up behind that barrier.
+        uint32_t r_next = 0, r_follow = 0xFFFFFFFFu;
+        bool next_posted = false;
+        if (tid == 0) {
+            if (q_next == q_end) { // its latency hides under this read's work
+                q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
+                q_end = q_next + QCHUNK;
+            }
+            r_next = q_next++;
+        }
+        const SeqView sv = view_of(r);
         const uint64_t L = sv.len;
         const uint64_t nk_all = L >= (uint64_t) k ? L - k + 1 : 0;
         if (L == 0 && tid == 0 && !a.hashed_bytes) atomicOr(a.err, 8u); // an empty list of pre-hashed values is fine
@@ -335,6 +360,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             if (pe > nk_all) pe = nk_all;
             const uint64_t nk = pe - pb;
             uint32_t P = nk ? (uint32_t) ((nk + a.part_target - 1) / a.part_target) : 0;
+            if (a.ablate & 64u) P = 0;
             uint32_t bad = 0;
             bool full = false;
             // k-mer occurrences of positions [q0, q1) that belong to partition `part` take a bucket rank; the first
@@ -359,15 +385,16 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                         for (uint64_t q0 = pb; q0 < pe && !overflow; q0 += round_len) {
                             const uint64_t q1 = q0 + round_len < pe ? q0 + round_len : pe;
                             const bool last_round = q1 == pe;
-                            if (tid == 0) misc[M_NSCR] = carry_n;
-                            // carried pairs take their ranks first
-                            for (uint32_t i = tid; i < carry_n; i += nthreads) {
-                                const uint64_t key = ld_scr(&scr_keys[i]);
-                                const uint32_t b = BOTTOMK ? (uint32_t) (key >> a.bk_shift) & (NBUCKETS - 1)
-                                                           : mix32(key) >> (32 - BUCKET_BITS);
-                                st_scr(&scr_info[i], (b << 16) | atomicAdd(&bst[b], 1u));
+                            if (carry_n) { // carried pairs take their ranks first (misc[M_NSCR] is 0 between passes)
+                                if (tid == 0) misc[M_NSCR] = carry_n;
+                                for (uint32_t i = tid; i < carry_n; i += nthreads) {
+                                    const uint64_t key = ld_scr(&scr_keys[i]);
+                                    const uint32_t b = BOTTOMK ? (uint32_t) (key >> a.bk_shift) & (NBUCKETS - 1)
+                                                               : mix32(key) >> (32 - BUCKET_BITS);
+                                    st_scr(&scr_info[i], (b << 16) | atomicAdd(&bst[b], 1u));
+                                }
+                                __syncthreads(); // orders the scratch stores above
                             }
-                            __syncthreads();
                             // ---- A1: bucket ranks of the keys of this partition in [q0, q1) ------------------------
                             const uint64_t ntiles = AA ? 1 : (q1 - q0 + tile_pos - 1) / tile_pos;
                             for (uint64_t tile = 0; tile < ntiles; tile++) {
@@ -376,7 +403,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 uint64_t wfirst = 0;
                                 if (!AA) {
                                     wfirst = (tp0 + lead) >> 4;
-                                    __syncthreads(); // the previous user of `words` is done
+                                    lds_barrier(); // the previous user of `words` is done
                                     const uint64_t wlast = (tp1 - 1 + lead + (uint64_t) k - 1) >> 4;
                                     const uint32_t nw = (uint32_t) (wlast - wfirst + 1) + 2;
                                     for (uint32_t t = tid; t < nw; t += nthreads) {
@@ -384,14 +411,14 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                         words[t] = load_code_word(sv, wfirst + t, b);
                                         bad |= b;
                                     }
-                                    __syncthreads();
+                                    lds_barrier();
                                 }
                                 for (uint64_t pr = tp0; pr < tp1; pr += (uint64_t) KREG * nthreads) {
                                     const bool use_regs = !rounds_mode && tile == 0 && pr == tp0;
 #pragma unroll
                                     for (int q = 0; q < KREG; q++) {
                                         const uint64_t p = pr + (uint64_t) q * nthreads + tid;
-                                        if (p < tp1) {
+                                        if (p < tp1 && !(a.ablate & 32u)) {
                                             uint64_t val, rc = 0;
                                             if (AA && a.hashed_bytes) {
                                                 val = a.hashed_bytes == 4
@@ -438,9 +465,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     }
                                 }
                             }
+                            if (tid == 0 && !next_posted) { misc[M_NEXT] = r_next; next_posted = true; }
                             __syncthreads();
                             // ---- A2: counts -> starts, dense placement ---------------------------------------------
-                            bucket_scan(bst, wtot);
+                            r_follow = misc[M_NEXT];
+                            if (!(a.ablate & 128u)) bucket_scan(bst, wtot);
                             const uint32_t n_keys = bst[NBUCKETS];
                             const uint32_t n_scr = misc[M_NSCR];
                             if (n_keys > cap || n_scr > cap) overflow = true;
@@ -532,12 +561,13 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     }
                                     // ---- B2: more points for the remembered keys that still lie below q_max -----------
                                     // (a flag word in LDS, not __syncthreads_or: its library reduction brings static LDS,
-                                    // which would cost the kernel its 160 KiB dynamic allocation)
-                                    if (__any(any_deferred) && lane_id() == 0) misc[M_FLAGS] = 1u;
-                                    __syncthreads();
-                                    const bool run_b2 = misc[M_FLAGS] != 0u;
-                                    __syncthreads();
-                                    if (tid == 0) misc[M_FLAGS] = 0u;
+                                    // which would cost the kernel its 160 KiB dynamic allocation; the word
+                                    // alternates with every pass: it is cleared one pass after it was read)
+                                    if (__any(any_deferred) && lane_id() == 0) misc[M_FLAGS + flag_sel] = 1u;
+                                    lds_barrier();
+                                    const bool run_b2 = misc[M_FLAGS + flag_sel] != 0u;
+                                    flag_sel ^= 1u;
+                                    if (tid == 0) misc[M_FLAGS + flag_sel] = 0u;
                                     if (run_b2 && !(a.ablate & 8u)) {
                                         uint64_t qb = wave_qmax(hmin, a.m);
                                         for (uint32_t base = 0; base < n_keys; base += nthreads) {
@@ -580,7 +610,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             if (overflow || last_round) {
                                 for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
                                 if (tid == 0) misc[M_NSCR] = 0;
-                                __syncthreads();
+                                lds_barrier(); // the points are final (-> signature row); bst is clean for the next pass
                             }
                         }
                         if (!overflow) part_done = true;
@@ -628,10 +658,15 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                 }
                 if (tid == 0) *qmax_sh = H_INIT;
             }
-            __syncthreads();
+            // (no barrier: the row and the slots are touched again only behind the barriers of the next pass)
         }
-        if (tid == 0) misc[M_READ] = r_next;
-        __syncthreads();
+        if (r_follow == 0xFFFFFFFFu) { // a read without a single pass (no k-mer)
+            if (tid == 0) misc[M_NEXT] = r_next;
+            lds_barrier();
+            r_follow = misc[M_NEXT];
+            lds_barrier();
+        }
+        r = r_follow;
     }
 }
 
