@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc()] + FLAGS + os.environ.get("KMU_BUILD_DEFS", "").split() + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

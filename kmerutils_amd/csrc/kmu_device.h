@@ -341,6 +341,29 @@ __device__ __forceinline__ uint32_t load_code_word(const SeqView &s, uint64_t wi
     bad = b & m;
     return w;
 }
+// ---- split form for prefetching (ASCII input): an aligned 16-byte chunk goes from HBM straight into LDS
+// (global_load_lds_dwordx4: no VGPR is held while the request is in flight; lane l of the wave lands at lds_wave_base +
+// 16 l), and is turned into a code word when the sequence's turn comes.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void chunk16_to_lds(const uint8_t *src, uint8_t *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+                                     (__attribute__((address_space(3))) void *) lds_wave_base, 16, 0, 0);
+}
+// true if word `widx` of the sequence's aligned stream is a whole chunk inside the array (chunk16_to_lds may fetch it)
+__device__ __forceinline__ bool chunk_is_plain(const SeqView &s, uint64_t widx) {
+    return !s.packed && (s.begin & ~15ull) + 16 * widx + 16 <= s.total;
+}
+__device__ __forceinline__ uint32_t code_word_from_chunk(const SeqView &s, uint64_t widx, u32x4 c, uint32_t &bad) {
+    const uint64_t a0 = (s.begin & ~15ull) + 16 * widx;
+    uint32_t b;
+    const uint32_t w = pack16_ascii(make_uint4(c.x, c.y, c.z, c.w), b);
+    const uint64_t lo = s.begin > a0 ? s.begin - a0 : 0;
+    const uint64_t end = s.begin + s.len;
+    const uint64_t hi = end > a0 ? (end - a0 > 16 ? 16 : end - a0) : 0;
+    const uint32_t m = (hi > lo) ? (uint32_t) (((1ull << hi) - 1ull) & ~((1ull << lo) - 1ull)) : 0u;
+    bad = b & m;
+    return w;
+}
 // number of leading code slots of the aligned stream that precede the first base of the sequence
 __device__ __forceinline__ uint32_t seq_lead(const SeqView &s) {
     return s.packed ? (uint32_t) (s.begin & 3ull) * 4u : (uint32_t) (s.begin & 15ull);

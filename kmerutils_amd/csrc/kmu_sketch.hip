@@ -75,6 +75,11 @@ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (ui
 
 // misc words in LDS
 enum { M_READ = 0, M_NSCR = 1, M_NEXT = 2, M_QMAX = 4 /* 4,5: u64 */, M_FLAGS = 6 /* 6,7 */, M_WORDS = 8 };
+#ifndef KMU_DIAG
+#define KMU_DIAG 0 // build with KMU_BUILD_DEFS=-DKMU_DIAG=1 for the KMU_PMH_ABLATE phase ablations / phase clocks
+#endif
+#define ABL(bits) (KMU_DIAG && (a.ablate & (bits)))
+
 static constexpr int BUCKET_BITS = 12;               // counting-sort buckets
 static constexpr uint32_t NBUCKETS = 1u << BUCKET_BITS;
 static constexpr int QCHUNK = 4;                     // reads taken from the queue per atomic
@@ -152,8 +157,8 @@ __device__ __forceinline__ double exp01_rest(const Exp01 &e, Xoshiro &rng) {
 // refreshed now and then); pruning with a stale bound never changes the arg-min.
 // The first xoshiro256++ output needs only state words s0 and s3 (= SplitMix64 outputs 1 and 4 of the seed): the
 // other two are computed only for the keys whose first point survives the q_max test.
-__device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, uint64_t *hmin, uint64_t *sig, uint64_t *qmax_sh,
-                                                  bool refresh, bool have, uint64_t key, uint32_t w) {
+__device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, bool sig32, uint64_t *hmin, uint64_t *sig,
+                                                  uint64_t *qmax_sh, bool refresh, bool have, uint64_t key, uint32_t w) {
     uint64_t qb;
     if (refresh) {
         qb = wave_qmax(hmin, a.m);
@@ -163,7 +168,7 @@ __device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, uint64_t 
     }
     bool deferred = false;
     if (have) {
-        const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, a.sig_bytes == 4);
+        const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, sig32);
         const double winv = 1.0 / (double) w;
         Xoshiro rng;
         rng.s0 = splitmix_at(seed, 1);
@@ -192,12 +197,12 @@ __device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, uint64_t 
 // pass B2: further points (rounds i >= 2) of the remembered keys, against the q_max reached after all first points.
 // The RNG stream of a key is replayed from its seed: round 1 consumed the Exp01 draws and one slot draw.
 // `qb` (bits of a q_max upper bound) is carried by the wave across calls and refreshed after every round.
-__device__ __forceinline__ void pmh3a_more_points(const SketchArgs &a, uint64_t *hmin, uint64_t *sig, uint64_t &qb,
-                                                  bool alive, uint64_t key, double winv) {
+__device__ __forceinline__ void pmh3a_more_points(const SketchArgs &a, bool sig32, uint64_t *hmin, uint64_t *sig,
+                                                  uint64_t &qb, bool alive, uint64_t key, double winv) {
     Xoshiro rng;
     uint32_t i = 2;
     if (alive) {
-        rng.seed(hasher_finish(KMU_HASHER_NOHASH, key, a.sig_bytes == 4));
+        rng.seed(hasher_finish(KMU_HASHER_NOHASH, key, sig32));
         (void) exp01_sample(a.e01, rng);
         (void) draw_slot(a, rng);
     }
@@ -276,8 +281,12 @@ __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
 // arrays -- repetitive reads: poly-A, tandem repeats -- the pass is redone in ROUNDS of cap/2 positions; after every
 // round the distinct (key, weight) pairs are compacted into a carry list that joins the next round's sort with its
 // weights.  If even the distinct keys do not fit, the block is restarted with twice as many partitions.
+// (A variant with the closure and k-mer type as template constants was tried: the hashing loop gets 18 % shorter, but
+// the allocator then spills loop-carried state around the read header and the kernel as a whole is slower.)
 template <bool AA, bool BOTTOMK>
 __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
+    const KmerCfg cfg = a.cfg;
+    const bool sig32 = a.sig_bytes == 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t cap = a.cap;
     uint64_t *dk = reinterpret_cast<uint64_t *>(smem); // dense keys of the current pass, grouped by bucket
@@ -289,10 +298,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     misc += (8 - ((NBUCKETS + 1) & 7)) & 7; // keep the u64 at misc[M_QMAX] 8-byte aligned
     uint32_t *wtot = misc + M_WORDS;
     uint32_t *words = wtot + 16;
+    words += (4 - ((uintptr_t) words >> 2 & 3)) & 3; // 16-byte aligned: raw chunks are parked here as uint4
     uint64_t *qmax_sh = reinterpret_cast<uint64_t *>(&misc[M_QMAX]);
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
-    const int k = a.cfg.k;
+    const int k = cfg.k;
     const uint32_t tile_pos = (a.tile_words - 2) * 16; // k-mer start positions covered by one staged tile
     uint64_t *scr_keys = a.scr_keys + (uint64_t) blockIdx.x * cap;
     uint32_t *scr_info = a.scr_info + (uint64_t) blockIdx.x * cap;
@@ -308,7 +318,10 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     uint32_t flag_sel = 0; // uniform
     // reads are taken from the global queue QCHUNK at a time (thread 0 keeps the cursor): one same-address atomic per
     // read would cap the whole grid at the L2's rate for a single address
-    uint32_t q_next = 0, q_end = 0;
+    // The next chunk is requested while the last read of the current one is still to be handed out, so its latency is
+    // never waited for.
+    uint32_t q_next = 0, q_end = 0, q_pend = 0;
+    bool q_pending = false;
     if (tid == 0) {
         q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
         q_end = q_next + QCHUNK;
@@ -330,21 +343,56 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         }
         return v;
     };
+    // number of staged code words of a read's very first tile (block 0, positions from 0)
+    auto first_tile_words = [&](const SeqView &v) -> uint32_t {
+        const uint64_t nka = v.len >= (uint64_t) k ? v.len - k + 1 : 0;
+        uint64_t pe0 = a.block_size ? (uint64_t) a.block_size : nka;
+        if (pe0 > nka) pe0 = nka;
+        if (pe0 == 0) return 0u;
+        const uint64_t t1 = pe0 < (uint64_t) tile_pos ? pe0 : (uint64_t) tile_pos;
+        const uint32_t ld = seq_lead(v);
+        return (uint32_t) (((t1 - 1 + ld + (uint64_t) k - 1) >> 4) - (uint64_t) (ld >> 4) + 1) + 2;
+    };
+    // The NEXT read's header is fetched as soon as its index is known, and the first 16 chunks x 64 lanes x 16 waves of its
+    // bases are requested while this read's duplicates are merged (A3): HBM -> LDS directly, raw, into the `words` area
+    // (free from there on).  A fresh read starts without waiting for HBM.  pf_r = the read whose head sits there.
+    SeqView nv;
+    nv.base = a.bases; nv.begin = 0; nv.len = 0; nv.total = 0; nv.packed = a.packed;
+    uint32_t nv_r = 0xFFFFFFFFu, pf_r = 0xFFFFFFFFu, pf_nw = 0;
+    // diagnostics (KMU_PMH_ABLATE & 256): thread 0 accumulates the clock spent in every phase of the read loop
+    uint64_t ph_acc[10], ph_t = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) ph_acc[i] = 0;
+    const bool ph_on = KMU_DIAG && ABL(256u) && tid == 0;
+    auto phase = [&](int i) {
+        if (ph_on) {
+            const uint64_t t = __builtin_readcyclecounter();
+            ph_acc[i] += t - ph_t;
+            ph_t = t;
+        }
+    };
     lds_barrier();
     uint32_t r = misc[M_READ];
+    if (ph_on) ph_t = __builtin_readcyclecounter();
     while (r < a.n_seq) {
         // Thread 0 takes the next read now (the atomic's latency hides under this read's work), posts it in
         // misc[M_NEXT] before the first barrier after the ranks are taken, and everybody picks it up behind that barrier.
         uint32_t r_next = 0, r_follow = 0xFFFFFFFFu;
         bool next_posted = false;
         if (tid == 0) {
-            if (q_next == q_end) { // its latency hides under this read's work
-                q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
-                q_end = q_next + QCHUNK;
+            if (q_next == q_end) {
+                if (!q_pending) q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
+                q_next = q_pend;
+                q_end = q_pend + QCHUNK;
+                q_pending = false;
             }
             r_next = q_next++;
+            if (q_next == q_end && !q_pending) { // used one read from now
+                q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
+                q_pending = true;
+            }
         }
-        const SeqView sv = view_of(r);
+        const SeqView sv = nv_r == r ? nv : view_of(r);
         const uint64_t L = sv.len;
         const uint64_t nk_all = L >= (uint64_t) k ? L - k + 1 : 0;
         if (L == 0 && tid == 0 && !a.hashed_bytes) atomicOr(a.err, 8u); // an empty list of pre-hashed values is fine
@@ -354,13 +402,14 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         // blocks of the read (src/sketching/seqblocksketch.rs:108-146); whole read = one block
         const uint64_t B = a.block_size ? a.block_size : (nk_all ? nk_all : 1);
         const uint64_t nblocks = a.block_size ? (L + B - 1) / B : 1;
+        phase(0); // read header
         for (uint64_t blk = 0; blk < nblocks; blk++) {
             uint64_t pb = blk * B, pe = pb + B;
             if (pb > nk_all) pb = nk_all;
             if (pe > nk_all) pe = nk_all;
             const uint64_t nk = pe - pb;
             uint32_t P = nk ? (uint32_t) ((nk + a.part_target - 1) / a.part_target) : 0;
-            if (a.ablate & 64u) P = 0;
+            if (ABL(64u)) P = 0;
             uint32_t bad = 0;
             bool full = false;
             // k-mer occurrences of positions [q0, q1) that belong to partition `part` take a bucket rank; the first
@@ -403,22 +452,30 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 uint64_t wfirst = 0;
                                 if (!AA) {
                                     wfirst = (tp0 + lead) >> 4;
-                                    lds_barrier(); // the previous user of `words` is done
                                     const uint64_t wlast = (tp1 - 1 + lead + (uint64_t) k - 1) >> 4;
                                     const uint32_t nw = (uint32_t) (wlast - wfirst + 1) + 2;
+                                    // the raw chunks of words [0, pf_nw) may have been parked here by the previous read
+                                    const bool parked = pf_r == r && tp0 == 0 && (uint32_t) tid < pf_nw;
+                                    pf_r = 0xFFFFFFFFu;
+                                    u32x4 raw = (u32x4) (0u);
+                                    if (parked) raw = reinterpret_cast<const u32x4 *>(words)[tid];
+                                    lds_barrier(); // the previous user of `words` is done
                                     for (uint32_t t = tid; t < nw; t += nthreads) {
                                         uint32_t b;
-                                        words[t] = load_code_word(sv, wfirst + t, b);
+                                        words[t] = (parked && t == (uint32_t) tid && chunk_is_plain(sv, wfirst + t))
+                                                       ? code_word_from_chunk(sv, wfirst + t, raw, b)
+                                                       : load_code_word(sv, wfirst + t, b);
                                         bad |= b;
                                     }
                                     lds_barrier();
                                 }
+                                phase(1); // read header + code words staged
                                 for (uint64_t pr = tp0; pr < tp1; pr += (uint64_t) KREG * nthreads) {
                                     const bool use_regs = !rounds_mode && tile == 0 && pr == tp0;
 #pragma unroll
                                     for (int q = 0; q < KREG; q++) {
                                         const uint64_t p = pr + (uint64_t) q * nthreads + tid;
-                                        if (p < tp1 && !(a.ablate & 32u)) {
+                                        if (p < tp1 && !ABL(32u)) {
                                             uint64_t val, rc = 0;
                                             if (AA && a.hashed_bytes) {
                                                 val = a.hashed_bytes == 4
@@ -439,14 +496,14 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                                 val = v >> (64 - 2 * k);
                                                 rc = revcomp_val(val, k);
                                             }
-                                            bool go = !(a.ablate & 4u);
+                                            bool go = !ABL(4u);
                                             uint64_t key = 0;
                                             uint32_t h = 0;
                                             if (go) {
-                                                key = (AA && a.hashed_bytes) ? val : apply_fhash(a.cfg, val, rc);
-                                                if (BOTTOMK) key = hasher_finish(a.hasher, key, a.sig_bytes == 4);
+                                                key = (AA && a.hashed_bytes) ? val : apply_fhash(cfg, val, rc);
+                                                if (BOTTOMK) key = hasher_finish(a.hasher, key, sig32);
                                                 h = mix32(key);
-                                                if (a.ablate & 2u) go = false;
+                                                if (ABL(2u)) go = false;
                                                 if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) go = false;
                                             } else if (val == 0x1234567ull) full = true;
                                             if (go) {
@@ -468,8 +525,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             if (tid == 0 && !next_posted) { misc[M_NEXT] = r_next; next_posted = true; }
                             __syncthreads();
                             // ---- A2: counts -> starts, dense placement ---------------------------------------------
+                            phase(2); // A1
                             r_follow = misc[M_NEXT];
-                            if (!(a.ablate & 128u)) bucket_scan(bst, wtot);
+                            if (nv_r != r_follow && r_follow < a.n_seq) { nv = view_of(r_follow); nv_r = r_follow; }
+                            if (!ABL(128u)) bucket_scan(bst, wtot);
+                            phase(3); // scan
                             const uint32_t n_keys = bst[NBUCKETS];
                             const uint32_t n_scr = misc[M_NSCR];
                             if (n_keys > cap || n_scr > cap) overflow = true;
@@ -490,7 +550,21 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 }
                             }
                             __syncthreads();
+                            phase(4); // placement
                             // ---- A3: a key with an earlier equal key in its bucket segment hands its weight over ------
+                            const bool do_pf = !AA && !BOTTOMK && !a.packed && !overflow && last_round && blk + 1 == nblocks &&
+                                               part + 1 == P && nv_r == r_follow && r_follow < a.n_seq && !ABL(512u) &&
+                                               (size_t) a.tile_words * 4 >= (size_t) nthreads * 16;
+                            if (do_pf) {
+                                uint32_t n = first_tile_words(nv);
+                                if (n > (uint32_t) nthreads) n = (uint32_t) nthreads; // the head only
+                                const uint64_t wf = seq_lead(nv) >> 4;
+                                if ((uint32_t) tid < n && chunk_is_plain(nv, wf + tid))
+                                    chunk16_to_lds(nv.base + (nv.begin & ~15ull) + 16 * (wf + tid),
+                                                   reinterpret_cast<uint8_t *>(words) + (size_t) wave * 1024);
+                                pf_r = r_follow;
+                                pf_nw = n;
+                            }
                             if (!overflow) {
 #pragma unroll
                                 for (int q = 0; q < KREG; q++)
@@ -517,6 +591,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 }
                             }
                             __syncthreads();
+                            phase(5); // A3
                             if (!overflow && !last_round) {
                                 // ---- compact the distinct pairs into the carry list (scr_keys / scr_w) ------------------
                                 if (tid == 0) misc[M_NSCR] = 0;
@@ -554,9 +629,9 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                         uint32_t w = 0;
                                         if (i < n_keys) { key = dk[i]; w = dw[i]; }
                                         const bool have = w != 0u;
-                                        if (__any(have) && !(a.ablate & 1u)) {
-                                            const bool deferred = pmh3a_first_point(a, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
-                                            if (deferred && !(a.ablate & 16u)) { dw[i] = w | 0x80000000u; any_deferred = true; }
+                                        if (__any(have) && !ABL(1u)) {
+                                            const bool deferred = pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
+                                            if (deferred && !ABL(16u)) { dw[i] = w | 0x80000000u; any_deferred = true; }
                                         }
                                     }
                                     // ---- B2: more points for the remembered keys that still lie below q_max -----------
@@ -565,10 +640,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     // alternates with every pass: it is cleared one pass after it was read)
                                     if (__any(any_deferred) && lane_id() == 0) misc[M_FLAGS + flag_sel] = 1u;
                                     lds_barrier();
+                                    phase(6); // B1
                                     const bool run_b2 = misc[M_FLAGS + flag_sel] != 0u;
                                     flag_sel ^= 1u;
                                     if (tid == 0) misc[M_FLAGS + flag_sel] = 0u;
-                                    if (run_b2 && !(a.ablate & 8u)) {
+                                    if (run_b2 && !ABL(8u)) {
                                         uint64_t qb = wave_qmax(hmin, a.m);
                                         for (uint32_t base = 0; base < n_keys; base += nthreads) {
                                             const uint32_t i = base + tid;
@@ -579,7 +655,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                                 winv = 1.0 / (double) (w & 0x7FFFFFFFu);
                                                 alive = winv < __longlong_as_double((long long) qb);
                                             }
-                                            if (__any(alive)) pmh3a_more_points(a, hmin, sig, qb, alive, alive ? dk[i] : 0ull, winv);
+                                            if (__any(alive)) pmh3a_more_points(a, sig32, hmin, sig, qb, alive, alive ? dk[i] : 0ull, winv);
                                         }
                                     }
                                 } else {
@@ -611,6 +687,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
                                 if (tid == 0) misc[M_NSCR] = 0;
                                 lds_barrier(); // the points are final (-> signature row); bst is clean for the next pass
+                                phase(7); // B2 + clear
                             }
                         }
                         if (!overflow) part_done = true;
@@ -650,7 +727,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                         a.part_k[row * a.m + t] = sig[t];
                     } else {
                         uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
-                        if (a.sig_bytes == 4) reinterpret_cast<uint32_t *>(a.sig_out)[row * a.m + t] = (uint32_t) v;
+                        if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[row * a.m + t] = (uint32_t) v;
                         else reinterpret_cast<uint64_t *>(a.sig_out)[row * a.m + t] = v;
                     }
                     hmin[t] = H_INIT;
@@ -667,7 +744,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             lds_barrier();
         }
         r = r_follow;
+        phase(8); // row out
     }
+    if (ph_on)
+        for (int i = 0; i < 10; i++)
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.queue) + 8 + i, (unsigned long long) ph_acc[i]);
 }
 
 // merge the slot minima of disjoint key sets (leaves): per slot the smallest (h, key); one workgroup per slot
@@ -848,8 +929,10 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.err = d_err;
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
     const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
-    const void *fn = bottomk ? (aa ? (const void *) k_sketch_pmh3a<true, true> : (const void *) k_sketch_pmh3a<false, true>)
-                             : (aa ? (const void *) k_sketch_pmh3a<true, false> : (const void *) k_sketch_pmh3a<false, false>);
+    typedef void (*sketch_kernel_t)(SketchArgs);
+    const sketch_kernel_t kern = bottomk ? (aa ? k_sketch_pmh3a<true, true> : k_sketch_pmh3a<false, true>)
+                                         : (aa ? k_sketch_pmh3a<true, false> : k_sketch_pmh3a<false, false>);
+    const void *fn = (const void *) kern;
     a.counts_out = d_counts;
     a.bk_shift = (a.sig_bytes == 4 && p->hasher == KMU_HASHER_NOHASH) ? 20 : 52; // NoHashHasher of a u32 is < 2^32
     a.bk_mask = p->hasher == KMU_HASHER_INT64HASH ? 0xFFu : 0xFFFFu;
@@ -878,8 +961,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.part_target = cap - cap / 10;
     size_t lds = (size_t) 12 * cap + fixed;
     void *q;
-    KMU_TRY(dev_buf(ctx, "queue", 64, &q));
-    KMU_HIP(ctx, hipMemsetAsync(q, 0, 64, ctx->stream));
+    KMU_TRY(dev_buf(ctx, "queue", 256, &q)); // [0] read cursor; u64 words 8..23: phase clocks (diagnostics)
+    KMU_HIP(ctx, hipMemsetAsync(q, 0, 256, ctx->stream));
     a.queue = (uint32_t *) q;
     int threads = 1024;
     const char *tenv = getenv("KMU_PMH_THREADS");
@@ -900,15 +983,20 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     }
     {
         KernelTimer t(ctx, bottomk ? "k_sketch_bottomk" : "k_sketch_pmh3a");
-        if (bottomk) {
-            if (aa) hipLaunchKernelGGL((k_sketch_pmh3a<true, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
-            else hipLaunchKernelGGL((k_sketch_pmh3a<false, true>), dim3(grid), dim3(threads), lds, ctx->stream, a);
-        } else {
-            if (aa) hipLaunchKernelGGL((k_sketch_pmh3a<true, false>), dim3(grid), dim3(threads), lds, ctx->stream, a);
-            else hipLaunchKernelGGL((k_sketch_pmh3a<false, false>), dim3(grid), dim3(threads), lds, ctx->stream, a);
-        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
     KMU_HIP(ctx, hipGetLastError());
+    if (ABL(256u)) { // diagnostics: mean clocks per workgroup and phase
+        unsigned long long ph[10];
+        KMU_HIP(ctx, hipMemcpyAsync(ph, (const uint64_t *) a.queue + 8, sizeof ph, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        static const char *nm[10] = {"header", "stage", "A1", "scan", "place", "A3", "B1", "B2+clear", "row", "-"};
+        double tot = 0;
+        for (int i = 0; i < 10; i++) tot += (double) ph[i];
+        fprintf(stderr, "[kmu phases] grid %d:", grid);
+        for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double) ph[i] / (tot > 0 ? tot : 1));
+        fprintf(stderr, "  (clocks/wg %.3g)\n", tot / grid);
+    }
     return KMU_OK;
 }
 
