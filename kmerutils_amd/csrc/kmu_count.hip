@@ -431,12 +431,7 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
     {
         const uint32_t b0 = 2u * tid, b1 = b0 + 1;
         const uint32_t c0 = b0 < nbins ? l.lstart[b0] : 0u, c1 = b1 < nbins ? l.lstart[b1] : 0u;
-        uint32_t incl = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = (uint32_t) __shfl_up((int) incl, d, 64);
-            if (lane_id() >= d) incl += o;
-        }
+        const uint32_t incl = wave_incl_scan_u32(c0 + c1);
         if (lane_id() == 63) l.wtot[tid >> 6] = incl;
         lds_barrier();
         uint32_t wpre = 0;

@@ -272,6 +272,17 @@ __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
 // store of the wave (s_waitcnt vmcnt(0)), which serialises HBM streaming against the LDS phases of a kernel; use this
 // one where the waves of a workgroup hand data to each other through LDS alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside the rows of 16, then row_bcast15 /
+// row_bcast31 across rows): six VALU instructions, no LDS crossbar round trips.  All lanes must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);
+    return v;
+}
 __device__ __forceinline__ uint32_t shfl_down_u32(uint32_t v, int d) { return (uint32_t) __shfl_down((int) v, d, 64); }
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, 64); }
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {

@@ -248,12 +248,7 @@ __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
         c[q] = (q < per && b0 + q < NBUCKETS) ? bst[b0 + q] : 0u;
         sum += c[q];
     }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = (uint32_t) __shfl_up((int) incl, d, 64);
-        if (lane_id() >= d) incl += o;
-    }
+    const uint32_t incl = wave_incl_scan_u32(sum);
     if (lane_id() == 63) wtot[tid >> 6] = incl;
     __syncthreads();
     uint32_t run = incl - sum;
@@ -534,13 +529,20 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             const uint32_t n_scr = misc[M_NSCR];
                             if (n_keys > cap || n_scr > cap) overflow = true;
                             if (!overflow) {
+                                // (all bucket starts are requested before the first store: a load behind a store to LDS
+                                // cannot be moved up by the compiler, and ten dependent round trips are the phase)
 #pragma unroll
                                 for (int q = 0; q < KREG; q++)
                                     if (rb[q] != 0xFFFFFFFFu) {
-                                        const uint32_t b = rb[q] >> 16, pos = bst[b] + (rb[q] & 0xFFFFu);
+                                        const uint32_t b = rb[q] >> 16;
+                                        rb[q] = (b << 16) | (bst[b] + (rb[q] & 0xFFFFu));
+                                    }
+#pragma unroll
+                                for (int q = 0; q < KREG; q++)
+                                    if (rb[q] != 0xFFFFFFFFu) {
+                                        const uint32_t pos = rb[q] & 0xFFFFu;
                                         dk[pos] = rk[q];
                                         dw[pos] = 1u;
-                                        rb[q] = (b << 16) | pos;
                                     }
                                 for (uint32_t i = tid; i < n_scr; i += nthreads) { // written by this workgroup: L2 hits
                                     const uint32_t info = ld_scr(&scr_info[i]);
@@ -566,17 +568,41 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 pf_nw = n;
                             }
                             if (!overflow) {
+                                // rb[q] becomes (own position << 16) | cursor; the walks of a thread's keys advance together,
+                                // five LDS reads in flight at a time, instead of one key after the other
 #pragma unroll
-                                for (int q = 0; q < KREG; q++)
-                                    if (rb[q] != 0xFFFFFFFFu) {
-                                        const uint32_t b = rb[q] >> 16, pos = rb[q] & 0xFFFFu;
-                                        for (uint32_t j = bst[b]; j < pos; j++)
-                                            if (dk[j] == rk[q]) {
-                                                dw[pos] = 0u;
-                                                atomicAdd(&dw[j], 1u);
-                                                break;
+                                for (int q = 0; q < KREG; q++) {
+                                    uint32_t v = 0u; // invalid: cursor == position == 0
+                                    if (rb[q] != 0xFFFFFFFFu) v = ((rb[q] & 0xFFFFu) << 16) | bst[rb[q] >> 16];
+                                    rb[q] = v;
+                                }
+                                static_assert(KREG % 5 == 0, "the duplicate walk advances five keys at a time");
+#pragma unroll
+                                for (int q0 = 0; q0 < KREG; q0 += 5) {
+                                    for (;;) {
+                                        bool act[5];
+                                        uint64_t kq[5];
+                                        bool any_act = false;
+#pragma unroll
+                                        for (int u = 0; u < 5; u++) {
+                                            act[u] = (rb[q0 + u] & 0xFFFFu) < (rb[q0 + u] >> 16);
+                                            kq[u] = act[u] ? dk[rb[q0 + u] & 0xFFFFu] : 0ull;
+                                            any_act |= act[u];
+                                        }
+                                        if (!__any(any_act)) break;
+#pragma unroll
+                                        for (int u = 0; u < 5; u++)
+                                            if (act[u]) {
+                                                if (kq[u] == rk[q0 + u]) {
+                                                    dw[rb[q0 + u] >> 16] = 0u;
+                                                    atomicAdd(&dw[rb[q0 + u] & 0xFFFFu], 1u);
+                                                    rb[q0 + u] = 0u; // done
+                                                } else rb[q0 + u]++;
                                             }
                                     }
+                                }
+#pragma unroll
+                                for (int q = 0; q < KREG; q++) rb[q] = 0xFFFFFFFFu; // consumed (a later round must not see them)
                                 for (uint32_t i = tid; i < n_scr; i += nthreads) {
                                     const uint32_t info = ld_scr(&scr_info[i]);
                                     const uint32_t b = info >> 16, pos = bst[b] + (info & 0xFFFFu);
