@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--bases", type=float, default=0, help="override total bases per GPU")
     ap.add_argument("--genome", type=int, default=100_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads timed on the host oracle (0 = auto)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the oracle baseline (0 = min(16, cores))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sketch-size", type=int, default=0)
     return ap.parse_args()
@@ -199,7 +200,7 @@ def main():
                         "avg_launch_ms": kern[dom]["avg_ms"], "alg_bytes_per_launch": kern[dom]["alg_bytes"]}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(cfg, bases, offsets, lens, args.cpu_sample_reads)
+            cpu = cpu_baseline(cfg, bases, offsets, lens, args.cpu_sample_reads, args.cpu_threads)
         out = {
             "metric": "Gbases/sec k-mer+sketch throughput, k=31, 200 sketches/read",
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -251,35 +252,66 @@ def _describe(cfg, n_reads, total_bases):
     return "%s: %s, %.3g bases, k=%d, %s" % (cfg["name"], shape, total_bases, cfg["k"], " + ".join(ops))
 
 
-def cpu_baseline(cfg, bases, offsets, lens, sample_reads):
-    """The oracle (a C restatement of the reference algorithm, single thread = `kind: port`) timed on this box's host
-    cores over a bounded sample of the same workload."""
+def cpu_baseline(cfg, bases, offsets, lens, sample_reads, threads=0):
+    """The oracle (a C restatement of the reference algorithm = `kind: port`) timed on this box's host cores over a
+    bounded sample of the same workload.  Like the reference's rayon map (seqsketchjaccard.rs:245-248) the reads are
+    sharded over T threads for sketching; counting uses one independent counter per thread over its shard
+    (count_kmer_thread_independant, kmercount.rs:797).  ctypes releases the GIL, so the threads run in parallel."""
+    from concurrent.futures import ThreadPoolExecutor
     from kmerutils_amd import _abi as A
     from oracle import oracle as O
     O.lib()
+    T = threads or max(1, min(16, os.cpu_count() or 1))
     if not sample_reads:
-        # aim at roughly 10-20 s of single-thread work
-        target_bases = 6e7 if (cfg["sketch"] and cfg["count"]) else 1e8
+        # roughly 10-20 s of wall time: ~3e7 bases per thread when both legs run
+        target_bases = T * (3e7 if (cfg["sketch"] and cfg["count"]) else 6e7)
         csum = np.cumsum(lens)
         sample_reads = int(min(len(lens), max(16, np.searchsorted(csum, target_bases) + 1)))
+    T = max(1, min(T, sample_reads))
     nb = int(offsets[sample_reads].item())
     hb = bases[:nb].cpu().numpy()
     ho = offsets[:sample_reads + 1].cpu().numpy().astype(np.uint64)
     p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0, 0,
                        0, 0, 0)
-    t0 = time.perf_counter()
-    if cfg["sketch"]:
-        O.sketch(hb, ho, p)
-    t_sk = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    if cfg["count"]:
-        c = O.Counter(cfg["kmer_type"], cfg["k"], 8, max(1024, nb))
-        c.add_reads(hb, ho)
-    t_ct = time.perf_counter() - t0
+    from kmerutils_amd.dist import shard_reads_by_bases
+    shards = shard_reads_by_bases(np.diff(ho.astype(np.int64)), T)
+
+    def shard_arrays(r0, r1):
+        b0, b1 = int(ho[r0]), int(ho[r1])
+        return np.ascontiguousarray(hb[b0:b1]), np.ascontiguousarray(ho[r0:r1 + 1] - ho[r0])
+
+    parts = [shard_arrays(r0, r1) for r0, r1 in shards if r1 > r0]
+
+    def run_sketch(part):
+        t = time.perf_counter()
+        O.sketch(part[0], part[1], p)
+        return time.perf_counter() - t
+
+    def run_count(part):
+        t = time.perf_counter()
+        c = O.Counter(cfg["kmer_type"], cfg["k"], 8, max(1024, part[0].size))
+        c.add_reads(part[0], part[1])
+        del c
+        return time.perf_counter() - t
+
+    t_sk = t_ct = 0.0
+    one = []
+    with ThreadPoolExecutor(max_workers=len(parts)) as ex:
+        if cfg["sketch"]:
+            t0 = time.perf_counter()
+            one.append(list(ex.map(run_sketch, parts)))
+            t_sk = time.perf_counter() - t0
+        if cfg["count"]:
+            t0 = time.perf_counter()
+            one.append(list(ex.map(run_count, parts)))
+            t_ct = time.perf_counter() - t0
     tot = t_sk + t_ct
-    return {"value": nb / tot / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads (%d bases) of the same read set; sketch %.2f s + count %.2f s, oracle C "
-                      "restatement, gcc -O2, 1 thread" % (sample_reads, nb, t_sk, t_ct),
+    per_thread = sum(np.array(x) for x in one)  # seconds each thread spent on its shard
+    rate1 = float(np.mean([parts[i][0].size / per_thread[i] for i in range(len(parts))])) / 1e9
+    return {"value": nb / tot / 1e9, "unit": "Gbases/s", "cores": len(parts), "kind": "port",
+            "sample": "first %d reads (%d bases) of the same read set, sharded over %d threads; sketch %.2f s + count "
+                      "%.2f s wall; oracle C restatement, gcc -O2; one thread alone: %.4f Gbases/s"
+                      % (sample_reads, nb, len(parts), t_sk, t_ct, rate1),
             "host_cpus": os.cpu_count()}
 
 
