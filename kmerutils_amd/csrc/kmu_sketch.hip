@@ -235,6 +235,10 @@ __device__ __forceinline__ T ld_scr(const T *p) { return __hip_atomic_load(p, __
 template <typename T>
 __device__ __forceinline__ void st_scr(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// A word every thread reads from the same LDS address is the same in all lanes, but the compiler cannot know: taking it
+// through readfirstlane puts it (and every loop bound, address and branch derived from it) on the scalar unit.
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+
 // in-place exclusive scan of bst[0..NBUCKETS) by the whole workgroup (NBUCKETS / nthreads entries per thread);
 // bst[NBUCKETS] = total.  wtot: one word per wave.
 __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         }
     };
     lds_barrier();
-    uint32_t r = misc[M_READ];
+    uint32_t r = uniform_u32(misc[M_READ]);
     if (ph_on) ph_t = __builtin_readcyclecounter();
     while (r < a.n_seq) {
         // Thread 0 takes the next read now (the atomic's latency hides under this read's work), posts it in
@@ -418,6 +422,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                         uint32_t rb[KREG];
 #pragma unroll
                         for (int q = 0; q < KREG; q++) { rk[q] = 0; rb[q] = 0xFFFFFFFFu; }
+
                         const uint64_t round_len = rounds_mode ? (uint64_t) (cap / 2) : nk;
                         uint32_t carry_n = 0; // distinct (key, weight) pairs carried from earlier rounds (in scr_*)
                         if (BOTTOMK && part > 0) { // the running list of the earlier partitions travels as carry
@@ -466,7 +471,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 }
                                 phase(1); // read header + code words staged
                                 for (uint64_t pr = tp0; pr < tp1; pr += (uint64_t) KREG * nthreads) {
-                                    const bool use_regs = !rounds_mode && tile == 0 && pr == tp0;
+                                    // Where a key waits for the scan: in registers (one pass over a read that fits: its first
+                                    // KREG * nthreads positions), parked unsorted in the still unused dense arrays (a pass of
+                                    // a partitioned read keeps 1/P of the positions it scans), else in the global scratch.
+                                    const bool use_park = !rounds_mode && P > 1 && carry_n == 0;
+                                    const bool use_regs = !rounds_mode && !use_park && tile == 0 && pr == tp0;
 #pragma unroll
                                     for (int q = 0; q < KREG; q++) {
                                         const uint64_t p = pr + (uint64_t) q * nthreads + tid;
@@ -509,7 +518,9 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                                     if (use_regs) { rk[q] = key; rb[q] = (b << 16) | rank; }
                                                     else {
                                                         const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
-                                                        if (si < cap) { st_scr(&scr_keys[si], key); st_scr(&scr_info[si], (b << 16) | rank); st_scr(&scr_w[si], 1u); }
+                                                        if (use_park) {
+                                                            if (si < (uint32_t) KREG * nthreads && si < cap) { dk[si] = key; dw[si] = (b << 16) | rank; }
+                                                        } else if (si < cap) { st_scr(&scr_keys[si], key); st_scr(&scr_info[si], (b << 16) | rank); st_scr(&scr_w[si], 1u); }
                                                     }
                                                 }
                                             } else if (h == 0x12345u) full = true;
@@ -521,13 +532,24 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             __syncthreads();
                             // ---- A2: counts -> starts, dense placement ---------------------------------------------
                             phase(2); // A1
-                            r_follow = misc[M_NEXT];
+                            r_follow = uniform_u32(misc[M_NEXT]);
                             if (nv_r != r_follow && r_follow < a.n_seq) { nv = view_of(r_follow); nv_r = r_follow; }
+                            // parked keys move to the registers (the barriers of the scan separate this from the placement)
+                            const bool parked_pass = !rounds_mode && P > 1 && carry_n == 0;
+                            const uint32_t n_park = parked_pass ? uniform_u32(misc[M_NSCR]) : 0u;
+                            if (parked_pass && n_park <= (uint32_t) KREG * nthreads && n_park <= cap) {
+#pragma unroll
+                                for (int q = 0; q < KREG; q++) {
+                                    const uint32_t idx = (uint32_t) q * nthreads + tid;
+                                    if (idx < n_park) { rk[q] = dk[idx]; rb[q] = dw[idx]; }
+                                }
+
+                            }
                             if (!ABL(128u)) bucket_scan(bst, wtot);
                             phase(3); // scan
-                            const uint32_t n_keys = bst[NBUCKETS];
-                            const uint32_t n_scr = misc[M_NSCR];
-                            if (n_keys > cap || n_scr > cap) overflow = true;
+                            const uint32_t n_keys = uniform_u32(bst[NBUCKETS]);
+                            const uint32_t n_scr = parked_pass ? 0u : uniform_u32(misc[M_NSCR]);
+                            if (n_keys > cap || n_scr > cap || n_park > (uint32_t) KREG * nthreads || n_park > cap) overflow = true;
                             if (!overflow) {
                                 // (all bucket starts are requested before the first store: a load behind a store to LDS
                                 // cannot be moved up by the compiler, and ten dependent round trips are the phase)
@@ -639,7 +661,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     }
                                 }
                                 __syncthreads();
-                                carry_n = misc[M_NSCR];
+                                carry_n = uniform_u32(misc[M_NSCR]);
                                 if (carry_n > cap - cap / 2) overflow = true; // no room for another round of new k-mers
                                 for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
                                 __syncthreads();
@@ -667,7 +689,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     if (__any(any_deferred) && lane_id() == 0) misc[M_FLAGS + flag_sel] = 1u;
                                     lds_barrier();
                                     phase(6); // B1
-                                    const bool run_b2 = misc[M_FLAGS + flag_sel] != 0u;
+                                    const bool run_b2 = uniform_u32(misc[M_FLAGS + flag_sel]) != 0u;
                                     flag_sel ^= 1u;
                                     if (tid == 0) misc[M_FLAGS + flag_sel] = 0u;
                                     if (run_b2 && !ABL(8u)) {
@@ -695,7 +717,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     }
                                     __syncthreads();
                                     bucket_scan(dcnt, wtot);
-                                    const uint32_t n_distinct = dcnt[NBUCKETS];
+                                    const uint32_t n_distinct = uniform_u32(dcnt[NBUCKETS]);
                                     for (uint32_t i = tid; i < n_keys; i += nthreads) {
                                         if (dw[i] == 0u) continue;
                                         const uint64_t key = dk[i];
@@ -766,7 +788,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         if (r_follow == 0xFFFFFFFFu) { // a read without a single pass (no k-mer)
             if (tid == 0) misc[M_NEXT] = r_next;
             lds_barrier();
-            r_follow = misc[M_NEXT];
+            r_follow = uniform_u32(misc[M_NEXT]);
             lds_barrier();
         }
         r = r_follow;
