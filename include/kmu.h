@@ -237,6 +237,25 @@ int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint6
 /* drop every entry not owned by `part` (after the exchange each rank keeps only its key range) */
 int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts);
 
+/* ---- L4 signature comparison: what the callers do with the signatures next --------------------
+ * Rows are compared as raw words (4 bytes for KMU_SIG_U32 / F32, 8 for U64 / F64).
+ * out[p] = number of slots t with A[ia[p]][t] == B[ib[p]][t]:
+ *   probminhash_get_jaccard_objects (src/sketching/seqsketchjaccard.rs:86-108): jaccard = out / m
+ *   DistBlockSketched::eval / distance_jaccard_serial (src/sketching/seqblocksketch.rs:419-440): (m - out) / m, and 1.0
+ *   when both blocks belong to the same sequence (the caller's rule); DistHamming of datasketcher.rs:156-185 likewise.
+ * sig_a has na rows of m words, sig_b nb rows (they may be the same array). */
+int kmu_sig_equal_pairs(kmu_ctx *ctx, const void *sig_a, uint32_t na, const void *sig_b, uint32_t nb, uint32_t m,
+                        int sig_type, const uint32_t *ia, const uint32_t *ib, uint64_t n_pairs, int mem, uint32_t *out);
+/* all pairs: out[i * nb + j] (m <= 65535) */
+int kmu_sig_equal_matrix(kmu_ctx *ctx, const void *sig_a, uint32_t na, const void *sig_b, uint32_t nb, uint32_t m,
+                         int sig_type, int mem, uint16_t *out);
+/* minhash_distance / mininvhash_distance (src/sketching/minhash.rs:134-190, :295-340) on KMU_ALGO_BOTTOMK rows
+ * (ascending hashes, u64::MAX padding).  out[3p..3p+2] = common, total, i: jaccard = common / total,
+ * containment = common / i (MinHashDist). */
+int kmu_minhash_distance_pairs(kmu_ctx *ctx, const uint64_t *hashes_a, uint32_t na, const uint64_t *hashes_b, uint32_t nb,
+                               uint32_t m, const uint32_t *ia, const uint32_t *ib, uint64_t n_pairs, int mem,
+                               uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

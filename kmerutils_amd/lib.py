@@ -21,7 +21,8 @@ SYMBOLS = [
     "kmu_kmer_hashes", "kmu_sketch", "kmu_block_layout", "kmu_sketch_hashed", "kmu_count_create", "kmu_count_destroy",
     "kmu_count_reset", "kmu_count_add_reads", "kmu_count_add_kmers", "kmu_count_query", "kmu_count_nb_distinct",
     "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
-    "kmu_count_retain_part", "kmu_count_extract_by_owner",
+    "kmu_count_retain_part", "kmu_count_extract_by_owner", "kmu_sig_equal_pairs", "kmu_sig_equal_matrix",
+    "kmu_minhash_distance_pairs",
 ]
 
 
@@ -74,6 +75,9 @@ def load():
     L.kmu_count_merge_entries.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     L.kmu_count_retain_part.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.kmu_count_extract_by_owner.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(vp), vp]
+    L.kmu_sig_equal_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
+    L.kmu_sig_equal_matrix.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
+    L.kmu_minhash_distance_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, vp]
     _lib = L
     return L
 
@@ -263,6 +267,50 @@ class Context:
         self._check(self.L.kmu_sketch_hashed(self.h, C.byref(p), _ptr(hashed)[0], _ptr(offsets)[0], n, _ptr(out)[0],
                                              _ptr(counts)[0]))
         return (out[:rows], counts[:rows]) if want_counts else out[:rows]
+
+    # ---- signature comparison (kmu_compare.hip) ----
+    def _new_like(self, ref, shape, np_dtype, torch_dtype_name):
+        if _is_torch(ref) and ref.is_cuda:
+            import torch
+            return torch.zeros(shape, dtype=getattr(torch, torch_dtype_name), device=ref.device)
+        return np.zeros(shape, np_dtype)
+
+    @staticmethod
+    def _sig_type_of(sig):
+        name = str(sig.dtype).replace("torch.", "")
+        return {"uint32": A.SIG_U32, "int32": A.SIG_U32, "uint64": A.SIG_U64, "int64": A.SIG_U64, "float32": A.SIG_F32,
+                "float64": A.SIG_F64}[name]
+
+    def sig_equal_pairs(self, sig_a, sig_b, ia, ib):
+        """kmu_sig_equal_pairs: number of equal slots of rows sig_a[ia[p]] and sig_b[ib[p]]."""
+        mem = self._mem(sig_a, sig_b, ia, ib)
+        self._wait_producers(sig_a, sig_b)
+        n = int(ia.shape[0])
+        out = self._new_like(sig_a, max(n, 1), np.uint32, "int32")
+        self._check(self.L.kmu_sig_equal_pairs(self.h, _ptr(sig_a)[0], sig_a.shape[0], _ptr(sig_b)[0], sig_b.shape[0],
+                                               sig_a.shape[1], self._sig_type_of(sig_a), _ptr(ia)[0], _ptr(ib)[0], n, mem,
+                                               _ptr(out)[0]))
+        return out[:n]
+
+    def sig_equal_matrix(self, sig_a, sig_b):
+        """kmu_sig_equal_matrix: equal-slot counts of every row of sig_a against every row of sig_b."""
+        mem = self._mem(sig_a, sig_b)
+        self._wait_producers(sig_a, sig_b)
+        out = self._new_like(sig_a, (max(sig_a.shape[0], 1), max(sig_b.shape[0], 1)), np.uint16, "int16")
+        self._check(self.L.kmu_sig_equal_matrix(self.h, _ptr(sig_a)[0], sig_a.shape[0], _ptr(sig_b)[0], sig_b.shape[0],
+                                                sig_a.shape[1], self._sig_type_of(sig_a), mem, _ptr(out)[0]))
+        return out[:sig_a.shape[0], :sig_b.shape[0]]
+
+    def minhash_distance_pairs(self, hashes_a, hashes_b, ia, ib):
+        """kmu_minhash_distance_pairs on bottom-k rows: (common, total, i) per pair."""
+        mem = self._mem(hashes_a, hashes_b, ia, ib)
+        self._wait_producers(hashes_a, hashes_b)
+        n = int(ia.shape[0])
+        out = self._new_like(hashes_a, (max(n, 1), 3), np.uint32, "int32")
+        self._check(self.L.kmu_minhash_distance_pairs(self.h, _ptr(hashes_a)[0], hashes_a.shape[0], _ptr(hashes_b)[0],
+                                                      hashes_b.shape[0], hashes_a.shape[1], _ptr(ia)[0], _ptr(ib)[0], n,
+                                                      mem, _ptr(out)[0]))
+        return out[:n]
 
     def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20):
         return Counter(self, kmer_type, k, counter_bits, capacity_hint)

@@ -191,8 +191,58 @@ class BlockSeqSketcher:
         return rows, numseq, numblock
 
 
-def jaccard_from_signatures(siga, sigb):
-    """probminhash::jaccard::compute_probminhash_jaccard (called at seqsketchjaccard.rs:95-101): fraction of equal
-    slots"""
-    siga, sigb = np.asarray(siga), np.asarray(sigb)
-    return float((siga == sigb).mean())
+# ---- what the callers do with the signatures next: all on the device through libkmu -----------
+def probminhash_get_jaccard_objects(siga, sigb, ctx=None):
+    """probminhash_get_jaccard_objects(siga, sigb) -> (jp, Some(common objects) | None), src/sketching/
+    seqsketchjaccard.rs:86-108.  The count of equal slots comes from kmu_sig_equal_pairs."""
+    ctx = ctx or default_context()
+    a = np.ascontiguousarray(siga).reshape(1, -1)
+    b = np.ascontiguousarray(sigb).reshape(1, -1)
+    assert a.shape == b.shape
+    z = np.zeros(1, np.uint32)
+    inter = int(ctx.sig_equal_pairs(a, b, z, z)[0])
+    jp = inter / a.shape[1]
+    if jp > 0.0:
+        return jp, a[0][a[0] == b[0]].tolist()
+    return 0.0, None
+
+
+def jaccard_matrix(sig_a, sig_b=None, ctx=None):
+    """all-pairs slot-equality Jaccard of signature rows (numpy or device tensors): kmu_sig_equal_matrix / m"""
+    ctx = ctx or default_context()
+    sig_b = sig_a if sig_b is None else sig_b
+    eq = ctx.sig_equal_matrix(sig_a, sig_b)
+    m = sig_a.shape[1]
+    return (eq.astype(np.float64) if isinstance(eq, np.ndarray) else eq.double()) / m
+
+
+class DistBlockSketched:
+    """Distance<BlockSketched>, src/sketching/seqblocksketch.rs:419-431: 1.0 inside one sequence, else the fraction of
+    differing slots.  `eval_pairs` takes block rows + their numseq (BlockSeqSketcher.blocksketch_sequences) and index
+    pairs."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def eval_pairs(self, rows, numseq, ia, ib):
+        ia = np.ascontiguousarray(ia, np.uint32)
+        ib = np.ascontiguousarray(ib, np.uint32)
+        rows = np.ascontiguousarray(rows)
+        eq = self.ctx.sig_equal_pairs(rows, rows, ia, ib).astype(np.float32)
+        m = rows.shape[1]
+        d = (m - eq) / np.float32(m)
+        numseq = np.asarray(numseq)
+        d[numseq[ia] == numseq[ib]] = 1.0
+        return d
+
+
+def minhash_distance(hashes_a, hashes_b, ia, ib, ctx=None):
+    """minhash_distance / mininvhash_distance (src/sketching/minhash.rs:134-190, :295-340) for pairs of bottom-k rows:
+    returns (containment, jaccard, common, total) arrays -- the fields of MinHashDist."""
+    ctx = ctx or default_context()
+    ia = np.ascontiguousarray(ia, np.uint32)
+    ib = np.ascontiguousarray(ib, np.uint32)
+    r = np.asarray(ctx.minhash_distance_pairs(np.ascontiguousarray(hashes_a, np.uint64),
+                                              np.ascontiguousarray(hashes_b, np.uint64), ia, ib)).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return r[:, 0] / r[:, 2], r[:, 0] / r[:, 1], r[:, 0].astype(np.uint64), r[:, 1].astype(np.uint64)

@@ -1117,3 +1117,36 @@ int kmo_count_dump(kmo_counter *c, uint32_t min_count, uint64_t *kmers_out, uint
     free(v);
     return 0;
 }
+
+/* ---- signature comparison ------------------------------------------------------------------ */
+/* probminhash_get_jaccard_objects, src/sketching/seqsketchjaccard.rs:86-108 (`inter`); distance_jaccard_serial,
+ * src/sketching/seqblocksketch.rs:435-439 (m - inter).  Rows are compared word by word. */
+uint32_t kmo_sig_equal_count(const void *a, const void *b, uint32_t m, int word_bytes) {
+    uint32_t inter = 0;
+    for (uint32_t i = 0; i < m; i++) {
+        if (word_bytes == 4) inter += ((const uint32_t *) a)[i] == ((const uint32_t *) b)[i];
+        else inter += ((const uint64_t *) a)[i] == ((const uint64_t *) b)[i];
+    }
+    return inter;
+}
+/* minhash_distance / mininvhash_distance, src/sketching/minhash.rs:134-190, :295-340, on ascending hash lists.
+ * out = {common, total, i}; MinHashDist(containment = common / i, jaccard = common / total, common, total). */
+void kmo_minhash_distance(const uint64_t *s1, uint32_t n1, const uint64_t *s2, uint32_t n2, uint32_t out[3]) {
+    uint32_t i = 0, j = 0, common = 0, total = 0;
+    const uint32_t sketch_size = n1;
+    while (i < n1 && j < n2) {
+        if (s1[i] < s2[j]) i++;
+        else if (s2[j] < s1[i]) j++;
+        else { i++; j++; common++; }
+        total++;
+        if (total >= n1) break;
+    }
+    if (total < n1) { /* both top-ups use the first sketch's length (minhash.rs:171-176) */
+        if (i < n1) total += n1 - i;
+        if (j < n1) total += n1 - j;
+        if (total > sketch_size) total = sketch_size;
+    }
+    out[0] = common;
+    out[1] = total;
+    out[2] = i;
+}

@@ -205,3 +205,27 @@ class Counter:
         c = np.zeros(max(n.value, 1), np.uint32)
         lib().kmo_count_dump(self.h, min_count, _p(k), _p(c), n.value, C.byref(n))
         return k[:n.value], c[:n.value]
+
+
+# ---- signature comparison ----
+def sig_equal_count(a, b):
+    """number of equal slots of two signature rows (raw 4- or 8-byte words)"""
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.dtype.itemsize == b.dtype.itemsize and a.size == b.size
+    f = lib().kmo_sig_equal_count
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    f.restype = C.c_uint32
+    return int(f(_p(a), _p(b), a.size, a.dtype.itemsize))
+
+
+def minhash_distance(s1, s2):
+    """(common, total, i) of two ascending hash lists (valid entries only)"""
+    s1 = np.ascontiguousarray(s1, np.uint64)
+    s2 = np.ascontiguousarray(s2, np.uint64)
+    out = np.zeros(3, np.uint32)
+    f = lib().kmo_minhash_distance
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    f.restype = None
+    f(_p(s1), s1.size, _p(s2), s2.size, _p(out))
+    return tuple(int(x) for x in out)

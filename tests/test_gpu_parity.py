@@ -427,3 +427,80 @@ def test_full_size_properties(ctx):
     k_all, c_all = c.export_part(0, 1)
     assert int(c_all.astype(np.int64).sum()) == nk
     assert k_all.size == c.nb_distinct()
+
+
+# ---- signature comparison ------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,m", [(np.uint32, 200), (np.uint64, 200), (np.float64, 64), (np.float32, 37)])
+def test_sig_equal_pairs_and_matrix(ctx, oracle, dtype, m):
+    rng = np.random.default_rng(11)
+    na, nb = 150, 97
+    # few distinct values per slot so that equal slots are common
+    a = rng.integers(0, 3, size=(na, m)).astype(dtype)
+    b = rng.integers(0, 3, size=(nb, m)).astype(dtype)
+    ia = rng.integers(0, na, size=500).astype(np.uint32)
+    ib = rng.integers(0, nb, size=500).astype(np.uint32)
+    want = np.array([oracle.sig_equal_count(a[i], b[j]) for i, j in zip(ia, ib)], np.uint32)
+    got = ctx.sig_equal_pairs(a, b, ia, ib)
+    assert np.array_equal(got, want)
+    mat = ctx.sig_equal_matrix(a, b)
+    assert mat.shape == (na, nb)
+    want_m = (a[:, None, :] == b[None, :, :]).sum(-1).astype(np.uint16)
+    assert np.array_equal(mat, want_m)
+    # device-resident rows give the same answer
+    import torch
+    ta, tb = torch.from_numpy(a.view(np.int32 if a.itemsize == 4 else np.int64)).cuda(), \
+        torch.from_numpy(b.view(np.int32 if b.itemsize == 4 else np.int64)).cuda()
+    g2 = ctx.sig_equal_pairs(ta, tb, torch.from_numpy(ia.view(np.int32)).cuda(), torch.from_numpy(ib.view(np.int32)).cuda())
+    ctx.synchronize()
+    assert np.array_equal(g2.cpu().numpy().view(np.uint32), want)
+    m2 = ctx.sig_equal_matrix(ta, tb)
+    ctx.synchronize()
+    assert np.array_equal(m2.cpu().numpy().view(np.uint16), want_m)
+
+
+@pytest.mark.gpu
+def test_sig_equal_on_real_signatures(ctx):
+    """J(read, revcomp(read)) == 1 with the canonical closure (the reference's own check, seqsketchjaccard.rs:785,903)
+    and the block distance rule of DistBlockSketched (1.0 inside a sequence)."""
+    from kmerutils_amd import sketching as S
+    rng = np.random.default_rng(5)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n)) for n in (3000, 4000, 2500)]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rc = [r.translate(comp)[::-1] for r in reads]
+    sk = S.ProbHash3aSketch(S.SeqSketcherParams(16, 200), kmer_type=A.KMER16B32BIT, ctx=ctx)
+    sa = np.asarray(sk.sketch_compressedkmer(reads, A.FHASH_CANON_INVHASH))
+    sb = np.asarray(sk.sketch_compressedkmer(rc, A.FHASH_CANON_INVHASH))
+    jm = S.jaccard_matrix(sa, sb, ctx=ctx)
+    assert np.allclose(np.diag(jm), 1.0)
+    assert jm[0, 1] < 0.1
+    jp, common = S.probminhash_get_jaccard_objects(sa[0], sb[0], ctx=ctx)
+    assert jp == 1.0 and len(common) == 200
+    bs = S.BlockSeqSketcher(1000, 12, 64, ctx=ctx)
+    rows, numseq, _ = bs.blocksketch_sequences(reads, A.FHASH_CANON_INVHASH)
+    rows = np.asarray(rows)
+    ia = np.array([0, 0, 1], np.uint32)
+    ib = np.array([1, len(rows) - 1, 1], np.uint32)
+    d = S.DistBlockSketched(ctx).eval_pairs(rows, numseq, ia, ib)
+    assert d[0] == 1.0 and d[2] == 1.0           # same sequence
+    want = (rows[0] != rows[-1]).sum() / np.float32(64)
+    assert abs(d[1] - want) < 1e-6
+
+
+@pytest.mark.gpu
+def test_minhash_distance_pairs(ctx, oracle):
+    rng = np.random.default_rng(3)
+    m, n = 50, 40
+    rows = np.full((n, m), np.uint64(0xFFFFFFFFFFFFFFFF))
+    lens = rng.integers(0, m + 1, size=n)
+    lens[0], lens[1] = m, 0
+    pool = rng.integers(1, 400, size=4000).astype(np.uint64)
+    for i in range(n):
+        rows[i, :lens[i]] = np.sort(rng.choice(np.unique(pool), size=lens[i], replace=False))
+    ia = rng.integers(0, n, size=300).astype(np.uint32)
+    ib = rng.integers(0, n, size=300).astype(np.uint32)
+    ia[:3], ib[:3] = [0, 1, 0], [0, 0, 1]
+    got = np.asarray(ctx.minhash_distance_pairs(rows, rows, ia, ib))
+    want = np.array([oracle.minhash_distance(rows[i, :lens[i]], rows[j, :lens[j]]) for i, j in zip(ia, ib)], np.uint32)
+    assert np.array_equal(got, want)
+    assert tuple(got[0]) == (m, m, m)  # a sketch against itself

@@ -242,3 +242,21 @@ def test_canonical_fhash_modes(oracle):
     for byte in (0x04, 0x03, 0x02, 0x01):
         h = ((h ^ byte) * 0x100000001b3) & (2**64 - 1)
     assert L.kmo_fnv1a(0x01020304, 4) == h
+
+
+def test_signature_comparison_oracle():
+    """probminhash_get_jaccard_objects (seqsketchjaccard.rs:86-108) and minhash_distance (minhash.rs:134-190) on hand
+    cases worked out from the reference's source."""
+    from oracle import oracle as O
+    a = np.array([1, 2, 3, 4, 5, 6], np.uint32)
+    b = np.array([1, 9, 3, 9, 5, 9], np.uint32)
+    assert O.sig_equal_count(a, b) == 3          # jp = 3 / 6
+    assert O.sig_equal_count(a.astype(np.uint64), a.astype(np.uint64)) == 6
+    # identical sketches: every step is a match, total stops at the sketch size
+    s = np.array([2, 5, 7, 11], np.uint64)
+    assert O.minhash_distance(s, s) == (4, 4, 4)
+    # disjoint: the walk stops when `total` reaches len(sketch1); nothing in common
+    assert O.minhash_distance(np.array([1, 2, 3, 4], np.uint64), np.array([10, 11, 12, 13], np.uint64)) == (0, 4, 4)
+    # second sketch exhausted early: total is topped up from the unwalked part of sketch1, capped at its size
+    assert O.minhash_distance(np.array([1, 2, 3, 4], np.uint64), np.array([1], np.uint64)) == (1, 4, 1)
+    assert O.minhash_distance(np.array([], np.uint64), s) == (0, 0, 0)
