@@ -237,6 +237,25 @@ int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint6
 /* drop every entry not owned by `part` (after the exchange each rank keeps only its key range) */
 int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts);
 
+/* ---- L-1 ingest: the step before the path ----------------------------------------------------
+ * FASTQ text (4-line records, "\n" or "\r\n") -> the accepted reads as (bases, offsets), in file order.
+ * Rule of the reference's readers: a record with any byte outside ACGTacgt is dropped and counted
+ * (readblockseq, src/bin/datasketcher.rs:358-388; parse_with_needletail, src/io.rs:37-57).
+ * Call with bases_out == offsets_out == NULL to get the sizes in *info, then with buffers of at least
+ * info->kept_bases bytes and info->n_kept + 1 offsets.  record_index_out (optional, n_kept entries) = position of every
+ * kept read among the records of the text.  `text` must be 16-byte aligned in KMU_MEM_DEVICE mode.
+ * Errors: KMU_E_BAD_ARG for a malformed or truncated record (the reference: `record.expect("invalid record")`). */
+typedef struct kmu_ingest_info {
+    uint64_t n_records;    /* records in the text */
+    uint64_t n_kept;       /* records made of ACGTacgt only */
+    uint64_t kept_bases;   /* sum of their lengths */
+    uint64_t n_bases;      /* bases of all records        (io.rs:40) */
+    uint64_t nb_bad_bases; /* non-ACGT bytes in sequences (io.rs:42) */
+    uint64_t nb_bad_reads; /* dropped records             (io.rs:47, datasketcher.rs:368) */
+} kmu_ingest_info;
+int kmu_ingest_fastq(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out, uint64_t bases_cap,
+                     uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out, kmu_ingest_info *info);
+
 /* ---- L4 signature comparison: what the callers do with the signatures next --------------------
  * Rows are compared as raw words (4 bytes for KMU_SIG_U32 / F32, 8 for U64 / F64).
  * out[p] = number of slots t with A[ia[p]][t] == B[ib[p]][t]:

@@ -58,6 +58,11 @@ class CountParams(C.Structure):
                 ("reserved", C.c_int32), ("capacity_hint", C.c_uint64)]
 
 
+class IngestInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_kept", C.c_uint64), ("kept_bases", C.c_uint64), ("n_bases", C.c_uint64),
+                ("nb_bad_bases", C.c_uint64), ("nb_bad_reads", C.c_uint64)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 

@@ -1150,3 +1150,41 @@ void kmo_minhash_distance(const uint64_t *s1, uint32_t n1, const uint64_t *s2, u
     out[1] = total;
     out[2] = i;
 }
+
+/* ---- ingest: readblockseq, src/bin/datasketcher.rs:358-388; parse_with_needletail, src/io.rs:37-57.
+ * Sequential 4-line FASTQ reader with the reference's rule: a record with any non-ACGT byte is dropped and counted.
+ * info = {n_records, n_kept, kept_bases, n_bases, nb_bad_bases, nb_bad_reads}.  Outputs may be NULL (sizes only).
+ * Returns KMU_E_BAD_ARG for a malformed / truncated record. */
+int kmo_ingest_fastq(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
+                     uint64_t info[6]) {
+    memset(info, 0, 6 * sizeof(uint64_t));
+    uint64_t pos = 0, rec = 0, out = 0, kept = 0;
+    if (offsets_out) offsets_out[0] = 0;
+    while (pos < n) {
+        uint64_t ls[4], le[4]; /* start / end (newline and a preceding '\r' stripped) of the record's 4 lines */
+        for (int l = 0; l < 4; l++) {
+            if (pos >= n) return KMU_E_BAD_ARG; /* the text stops inside a record */
+            ls[l] = pos;
+            uint64_t e = pos;
+            while (e < n && text[e] != '\n') e++;
+            le[l] = (e > ls[l] && text[e - 1] == '\r') ? e - 1 : e;
+            pos = e < n ? e + 1 : n;
+        }
+        if (text[ls[0]] != '@' || text[ls[2]] != '+') return KMU_E_BAD_ARG;
+        const uint64_t len = le[1] - ls[1], nb_bad = kmo_count_non_acgt(text + ls[1], len);
+        info[3] += len;
+        if (nb_bad) { info[4] += nb_bad; info[5]++; }
+        else {
+            if (bases_out) memcpy(bases_out + out, text + ls[1], len);
+            out += len;
+            if (offsets_out) offsets_out[kept + 1] = out;
+            if (record_index_out) record_index_out[kept] = (uint32_t) rec;
+            kept++;
+        }
+        rec++;
+    }
+    info[0] = rec;
+    info[1] = kept;
+    info[2] = out;
+    return 0;
+}

@@ -83,6 +83,9 @@ uint64_t kmo_count_nb_unique(kmo_counter *c);
 int kmo_count_dump(kmo_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,
                    uint64_t *n_out);
 
+/* ingest */
+int kmo_ingest_fastq(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
+                     uint64_t info[6]);
 /* signature comparison */
 uint32_t kmo_sig_equal_count(const void *a, const void *b, uint32_t m, int word_bytes);
 void kmo_minhash_distance(const uint64_t *s1, uint32_t n1, const uint64_t *s2, uint32_t n2, uint32_t out[3]);

@@ -229,3 +229,24 @@ def minhash_distance(s1, s2):
     f.restype = None
     f(_p(s1), s1.size, _p(s2), s2.size, _p(out))
     return tuple(int(x) for x in out)
+
+
+# ---- ingest ----
+def ingest_fastq(text):
+    """(bases, offsets, info dict, record_index) of the ACGT-only reads of a 4-line FASTQ text, in file order"""
+    text = np.frombuffer(bytes(text), np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+    f = lib().kmo_ingest_fastq
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = C.c_int
+    info = np.zeros(6, np.uint64)
+    rc = f(_p(text) if text.size else None, text.size, None, None, None, _p(info))
+    if rc:
+        raise OracleError(rc)
+    bases = np.zeros(max(int(info[2]), 1), np.uint8)
+    offs = np.zeros(int(info[1]) + 1, np.uint64)
+    idx = np.zeros(max(int(info[1]), 1), np.uint32)
+    rc = f(_p(text) if text.size else None, text.size, _p(bases), _p(offs), _p(idx), _p(info))
+    if rc:
+        raise OracleError(rc)
+    names = ("n_records", "n_kept", "kept_bases", "n_bases", "nb_bad_bases", "nb_bad_reads")
+    return bases[:int(info[2])], offs, dict(zip(names, (int(x) for x in info))), idx[:int(info[1])]

@@ -260,3 +260,23 @@ def test_signature_comparison_oracle():
     # second sketch exhausted early: total is topped up from the unwalked part of sketch1, capped at its size
     assert O.minhash_distance(np.array([1, 2, 3, 4], np.uint64), np.array([1], np.uint64)) == (1, 4, 1)
     assert O.minhash_distance(np.array([], np.uint64), s) == (0, 0, 0)
+
+
+def test_ingest_oracle_hand_cases():
+    """readblockseq / parse_with_needletail rule (datasketcher.rs:364-371, io.rs:37-48): records with a non-ACGT byte are
+    dropped and counted; the others keep their file order."""
+    from oracle import oracle as O
+    fq = (b"@r0\nACGTAC\n+\nIIIIII\n"
+          b"@r1 has an N\nACNTAC\n+r1\nIIIIII\n"
+          b"@r2 lower case is fine\nacgtTTGA\n+\n@@@@@@@@\n"      # quality line starting with '@'
+          b"@r3\r\nGGGCCC\r\n+\r\nIIIIII\r\n"                      # CRLF
+          b"@r4\nAC-T\n+\nIIII")                                   # no newline at the end; '-' is not ACGT
+    bases, offs, info, idx = O.ingest_fastq(fq)
+    assert info == dict(n_records=5, n_kept=3, kept_bases=20, n_bases=30, nb_bad_bases=2, nb_bad_reads=2)
+    assert bytes(bases) == b"ACGTAC" + b"acgtTTGA" + b"GGGCCC"
+    assert offs.tolist() == [0, 6, 14, 20] and idx.tolist() == [0, 2, 3]
+    assert O.ingest_fastq(b"")[2]["n_records"] == 0
+    for broken in (b"@r0\nACGT\n+\n", b"@r0\nACGT\n", b"r0\nACGT\n+\nIIII\n", b"@r0\nACGT\n-\nIIII\n",
+                   b"@r0\nACGT\n+\nIIII\n\n"):
+        with pytest.raises(O.OracleError):
+            O.ingest_fastq(broken)
