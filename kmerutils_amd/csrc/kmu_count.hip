@@ -63,7 +63,10 @@ __device__ __forceinline__ uint64_t khash_inv(uint64_t h) {
 
 // owner of a k-mer in an n-way key partition: DispatchableT, kmercount.rs:382-420
 __device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_parts) {
-    return w32 ? (uint32_t) (int32_hash((uint32_t) v) % n_parts) : (uint32_t) (int64_hash(v) % (uint64_t) n_parts);
+    const uint64_t h = w32 ? (uint64_t) int32_hash((uint32_t) v) : int64_hash(v);
+    // 2 / 4 / 8 GPUs: the remainder is a mask (a 64-bit division per k-mer would dominate the grouping kernels)
+    if ((n_parts & (n_parts - 1u)) == 0u) return (uint32_t) h & (n_parts - 1u);
+    return w32 ? (uint32_t) h % n_parts : (uint32_t) (h % (uint64_t) n_parts);
 }
 
 struct CountTable {
@@ -451,10 +454,26 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
         if (it[j] != CKEY_EMPTY) l.stage[l.lstart[br[j] >> 16] + (br[j] & 0xFFFFu)] = it[j];
     lds_barrier();
     const uint32_t total = l.lstart[nbins];
-    for (uint32_t p = tid; p < total; p += nthreads) {
-        const uint64_t v = l.stage[p];
-        const uint32_t bin = digit_of<IT>(v, region_bits, shift, mask);
-        out[l.gbase[bin] + (uint64_t) (p - l.lstart[bin])] = v;
+    // eight positions at a time: the staged items, then their bins' bases, are requested together (one LDS round trip
+    // per batch instead of two per position)
+    for (uint32_t p0 = 0; p0 < total; p0 += 8u * nthreads) {
+        uint64_t v[8], dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
+            v[u] = p < total ? l.stage[p] : CKEY_EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
+            const uint32_t bin = p < total ? digit_of<IT>(v[u], region_bits, shift, mask) : 0u;
+            dst[u] = l.gbase[bin] + (uint64_t) (p - l.lstart[bin]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
+            if (p < total) out[dst[u]] = v[u];
+        }
     }
     lds_barrier();
     uint32_t cnt[2];
@@ -555,6 +574,13 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     }
 }
 
+// launch the two scan steps (host side)
+static inline uint32_t scan_threads_per_bin(uint32_t chunks) {
+    uint32_t T = 1;
+    while (T * 2 <= chunks && T < 256) T *= 2;
+    return T;
+}
+
 // ---- generic radix partition of a u64 array (level 2 of the read path; both levels of the array path) ------------
 // The input is a set of `nparts` consecutive partitions (bounds[nparts + 1]); every partition is cut into `chunks`
 // units; a unit scatters its slice by the digit (region >> shift) & (bins - 1) into bins sub-partitions.
@@ -587,16 +613,46 @@ __global__ void __launch_bounds__(256) k_arr_hist(const uint64_t *in, const uint
     for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) hist[(uint64_t) blockIdx.x * pl.bins + b] = lh[b];
 }
 
-// one workgroup per input partition; order = (bin major, chunk minor); outbounds[nparts * bins + 1]
-__global__ void __launch_bounds__(256) k_arr_scan(const uint32_t *hist, const uint64_t *bounds, ArrPlan pl, uint64_t *offs,
-                                                  uint64_t *outbounds) {
+// Offsets of the units' private output ranges; order inside a partition = (bin major, chunk minor).
+// Step a: T threads share one (partition, bin): exclusive prefix of the bin's counts over the partition's chunks
+// (relative offsets) and the bin total.  T = min(256, chunks) rounded down to a power of two, 256 / T bins per workgroup.
+__global__ void __launch_bounds__(256) k_arr_scan_a(const uint32_t *hist, ArrPlan pl, uint32_t T, uint64_t *offs_rel,
+                                                    uint64_t *tot) {
     __shared__ uint64_t part[256];
-    const uint32_t bins = pl.bins, p1 = blockIdx.x, C = pl.chunks;
+    const uint32_t bins = pl.bins, C = pl.chunks, per_wg = 256u / T;
+    const uint32_t groups = (bins + per_wg - 1) / per_wg; // workgroups per partition
+    const uint32_t p1 = blockIdx.x / groups, b = (blockIdx.x % groups) * per_wg + threadIdx.x / T, tc = threadIdx.x % T;
+    const uint32_t per = (C + T - 1) / T;
+    const uint32_t c0 = tc * per < C ? tc * per : C, c1 = c0 + per < C ? c0 + per : C;
+    uint64_t sum = 0;
+    if (b < bins)
+        for (uint32_t c = c0; c < c1; c++) sum += hist[((uint64_t) p1 * C + c) * bins + b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (tc == 0) { // exclusive scan of this bin's T partial sums
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < T; i++) { const uint64_t v = part[threadIdx.x + i]; part[threadIdx.x + i] = run; run += v; }
+        if (b < bins) tot[(uint64_t) p1 * bins + b] = run;
+    }
+    __syncthreads();
+    if (b < bins) {
+        uint64_t run = part[threadIdx.x];
+        for (uint32_t c = c0; c < c1; c++) {
+            offs_rel[((uint64_t) p1 * C + c) * bins + b] = run;
+            run += hist[((uint64_t) p1 * C + c) * bins + b];
+        }
+    }
+}
+
+// Step b: one workgroup per partition: exclusive scan of the bin totals, shifted by the partition's start ->
+// outbounds[p1 * bins + b]; outbounds[nparts * bins] = end of the last partition.
+__global__ void __launch_bounds__(256) k_arr_scan_b(const uint64_t *tot, const uint64_t *bounds, ArrPlan pl, uint64_t *outbounds) {
+    __shared__ uint64_t part[256];
+    const uint32_t bins = pl.bins, p1 = blockIdx.x;
     const uint32_t per = (bins + 255) / 256;
     const uint32_t b0 = threadIdx.x * per < bins ? threadIdx.x * per : bins, b1 = b0 + per < bins ? b0 + per : bins;
     uint64_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++)
-        for (uint32_t c = 0; c < C; c++) sum += hist[((uint64_t) p1 * C + c) * bins + b];
+    for (uint32_t b = b0; b < b1; b++) sum += tot[(uint64_t) p1 * bins + b];
     part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -608,20 +664,17 @@ __global__ void __launch_bounds__(256) k_arr_scan(const uint32_t *hist, const ui
     uint64_t run = part[threadIdx.x];
     for (uint32_t b = b0; b < b1; b++) {
         outbounds[(uint64_t) p1 * bins + b] = run;
-        for (uint32_t c = 0; c < C; c++) {
-            offs[((uint64_t) p1 * C + c) * bins + b] = run;
-            run += hist[((uint64_t) p1 * C + c) * bins + b];
-        }
+        run += tot[(uint64_t) p1 * bins + b];
     }
 }
 
 template <int IT>
 __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
-                                                      const uint64_t *offs, uint64_t *out) {
+                                                      const uint64_t *offs_rel, const uint64_t *outbounds, uint64_t *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds l = scatter_lds(smem, pl.bins);
     for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) {
-        l.gbase[b] = offs[(uint64_t) blockIdx.x * pl.bins + b];
+        l.gbase[b] = outbounds[(uint64_t) (blockIdx.x / pl.chunks) * pl.bins + b] + offs_rel[(uint64_t) blockIdx.x * pl.bins + b];
         l.lstart[b] = 0;
     }
     if (threadIdx.x == 0) l.lstart[pl.bins] = 0;
@@ -768,7 +821,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     const uint32_t units2 = bins1 * pl.chunks2;
     const uint64_t n_regions = 1ull << pl.region_bits;
 
-    void *A, *B = nullptr, *hist1, *offs1, *tot1, *binstart1, *hist2 = nullptr, *offs2 = nullptr, *leafstart = nullptr;
+    void *A, *B = nullptr, *hist1, *offs1, *tot1, *binstart1, *hist2 = nullptr, *offs2 = nullptr, *leafstart = nullptr, *tot2 = nullptr;
     KMU_TRY(dev_buf(ctx, "cnt.partA", total_bases * 8 + 64, &A));
     KMU_TRY(dev_buf(ctx, "cnt.hist1", (size_t) units1 * bins1 * 4, &hist1));
     KMU_TRY(dev_buf(ctx, "cnt.offs1", (size_t) units1 * bins1 * 8, &offs1));
@@ -779,6 +832,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KMU_TRY(dev_buf(ctx, "cnt.hist2", (size_t) units2 * bins2 * 4, &hist2));
         KMU_TRY(dev_buf(ctx, "cnt.offs2", (size_t) units2 * bins2 * 8, &offs2));
         KMU_TRY(dev_buf(ctx, "cnt.leafstart", (size_t) (n_regions + 1) * 8, &leafstart));
+        KMU_TRY(dev_buf(ctx, "cnt.tot2", (size_t) n_regions * 8, &tot2));
     }
     const int k = c->p.kmer_size;
     static bool lds_attr_done = false;
@@ -816,13 +870,17 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         }
         {
             KernelTimer tm(ctx, "k_part_scan2");
-            hipLaunchKernelGGL(k_arr_scan, dim3(bins1), dim3(256), 0, ctx->stream, (const uint32_t *) hist2,
-                               (const uint64_t *) binstart1, ap, (uint64_t *) offs2, (uint64_t *) leafstart);
+            const uint32_t T = scan_threads_per_bin(ap.chunks), per_wg = 256u / T;
+            hipLaunchKernelGGL(k_arr_scan_a, dim3(bins1 * ((bins2 + per_wg - 1) / per_wg)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *) hist2, ap, T, (uint64_t *) offs2, (uint64_t *) tot2);
+            hipLaunchKernelGGL(k_arr_scan_b, dim3(bins1), dim3(256), 0, ctx->stream, (const uint64_t *) tot2,
+                               (const uint64_t *) binstart1, ap, (uint64_t *) leafstart);
         }
         {
             KernelTimer tm(ctx, "k_part_scatter2");
             hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
                                (const uint64_t *) A, (const uint64_t *) binstart1, ap, (const uint64_t *) offs2,
+                               (const uint64_t *) leafstart,
                                (uint64_t *) B);
         }
         items = (const uint64_t *) B;
@@ -874,7 +932,8 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
                                      : std::max<uint32_t>(1u, 16384u / nparts);
         ArrPlan ap{region_bits, shift, bins, nparts, chunks};
         const uint32_t units = nparts * chunks;
-        void *hist, *offs, *outb, *outbuf;
+        void *hist, *offs, *outb, *outbuf, *tot;
+        KMU_TRY(dev_buf(ctx, level == 0 ? "arr.tot0" : "arr.tot1", (size_t) nparts * bins * 8, &tot));
         KMU_TRY(dev_buf(ctx, level == 0 ? "arr.hist0" : "arr.hist1", (size_t) units * bins * 4, &hist));
         KMU_TRY(dev_buf(ctx, level == 0 ? "arr.offs0" : "arr.offs1", (size_t) units * bins * 8, &offs));
         KMU_TRY(dev_buf(ctx, level == 0 ? "arr.bounds1" : "arr.bounds2", ((size_t) nparts * bins + 1) * 8, &outb));
@@ -885,13 +944,16 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
         }
         {
             KernelTimer tm(ctx, "k_arr_scan");
-            hipLaunchKernelGGL(k_arr_scan, dim3(nparts), dim3(256), 0, ctx->stream, (const uint32_t *) hist, bounds, ap,
-                               (uint64_t *) offs, (uint64_t *) outb);
+            const uint32_t T = scan_threads_per_bin(chunks), per_wg = 256u / T;
+            hipLaunchKernelGGL(k_arr_scan_a, dim3(nparts * ((bins + per_wg - 1) / per_wg)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *) hist, ap, T, (uint64_t *) offs, (uint64_t *) tot);
+            hipLaunchKernelGGL(k_arr_scan_b, dim3(nparts), dim3(256), 0, ctx->stream, (const uint64_t *) tot, bounds, ap,
+                               (uint64_t *) outb);
         }
         {
             KernelTimer tm(ctx, "k_arr_scatter");
             hipLaunchKernelGGL(k_arr_scatter<IT_KEY>, dim3(units), dim3(SCATTER_THREADS), scatter_lds_bytes(bins), ctx->stream, items,
-                               bounds, ap, (const uint64_t *) offs, (uint64_t *) outbuf);
+                               bounds, ap, (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
         }
         KMU_HIP(ctx, hipGetLastError());
         items = (const uint64_t *) outbuf;
