@@ -88,6 +88,8 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world > 1:  # leave a few CUs to the RCCL kernels that run under the (persistent, one-workgroup-per-CU) sketch kernel
+        os.environ.setdefault("KMU_PMH_RESERVE_CUS", "16")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cfg = workload_cfg(args)
@@ -111,15 +113,21 @@ def main():
     sig = torch.zeros((n_reads, cfg["m"]), dtype=sig_dtype, device=dev) if cfg["sketch"] else None
     counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024)) if cfg["count"] else None
 
+    def sketch_step():
+        ctx.sketch(bases, offsets, p, out=sig)
+
     def step():
+        if cfg["count"] and world > 1:
+            # group the k-mers by owner rank, ONE all-to-all over RCCL, build the owned table; the reads are sketched
+            # while the exchange is on the links (ALU work under xGMI traffic)
+            counter.reset()
+            kdist.count_reads_exchange(counter, bases, offsets, overlap=sketch_step if cfg["sketch"] else None)
+            return
         if cfg["sketch"]:
-            ctx.sketch(bases, offsets, p, out=sig)
+            sketch_step()
         if cfg["count"]:
             counter.reset()
-            if world > 1:  # group the k-mers by owner rank, one all-to-all over RCCL, build the owned table
-                kdist.count_reads_exchange(counter, bases, offsets)
-            else:
-                counter.add_reads(bases, offsets)
+            counter.add_reads(bases, offsets)
 
     def barrier():
         ctx.synchronize()

@@ -1016,7 +1016,10 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     const char *tenv = getenv("KMU_PMH_THREADS");
     if (tenv && atoi(tenv) >= 512) threads = std::min(1024, atoi(tenv) & ~63); // bucket_scan: <= 8 buckets per thread
     int blocks_per_cu = std::max<int>(1, (int) (lds_max / lds));
-    int grid = (int) std::min<uint64_t>((uint64_t) ds.n_seq, (uint64_t) ctx->num_cus * blocks_per_cu);
+    int cus = ctx->num_cus;
+    if (const char *rs = getenv("KMU_PMH_RESERVE_CUS")) // CUs left to concurrent work (RCCL kernels of an exchange in flight)
+        cus = std::max(cus / 2, cus - std::max(0, atoi(rs)));
+    int grid = (int) std::min<uint64_t>((uint64_t) ds.n_seq, (uint64_t) cus * blocks_per_cu);
     if (grid < 1) grid = 1;
     {
         void *sk, *si, *sw, *bk = nullptr, *bc = nullptr;

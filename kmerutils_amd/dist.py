@@ -65,7 +65,7 @@ def _all_to_all_var(send_list, recv_sizes, dtype, device, group=None):
     return recv
 
 
-def count_reads_exchange(counter, bases, offsets, group=None):
+def count_reads_exchange(counter, bases, offsets, group=None, overlap=None):
     """Distributed counting of this rank's read shard -- the throughput path.
 
     The reference's one-to-many driver dispatches every canonical k-mer to the thread that owns it,
@@ -73,31 +73,53 @@ def count_reads_exchange(counter, bases, offsets, group=None):
     the local reads are grouped by owner rank on the device (`kmu_count_extract_by_owner`), ONE all-to-all over
     RCCL/xGMI moves every group to its owner, and the owner builds its table from what it receives with the
     radix-partitioned build (`kmu_count_add_kmers`).  Afterwards rank r holds the exact global counts of the keys it
-    owns: the KmerCounterPool layout with one counter per GPU.  Returns the number of k-mers received."""
+    owns: the KmerCounterPool layout with one counter per GPU.  Returns the number of k-mers received.
+
+    `overlap`: optional callable run while the all-to-all is in flight (the exchange is xGMI traffic, the sketch
+    kernel is ALU work: bench.py sketches the same reads under it).  It must not touch the counter."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
+        if overlap is not None:
+            overlap()
         counter.add_reads(bases, offsets)
         return 0
     rank = dist.get_rank(group)
     kmers, bounds = counter.extract_by_owner(bases, offsets, world)
     kmers = torch.as_tensor(kmers)
     dev = kmers.device
-    cdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    nccl = dist.get_backend(group) == "nccl"
+    cdev = dev if nccl else torch.device("cpu")
     send_n = torch.as_tensor(np.diff(bounds.astype(np.int64)), dtype=torch.int64).to(cdev)
     all_n = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(all_n, send_n, group=group)
     recv_n = [int(all_n[p][rank].item()) for p in range(world)]
     send_sizes = [int(bounds[p + 1]) - int(bounds[p]) for p in range(world)]
-    if dist.get_backend(group) == "nccl":
+    if nccl:
         # the groups are already contiguous in owner order: send straight from the library's buffer
         flat = torch.empty(int(sum(recv_n)), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(flat, kmers, recv_n, send_sizes, group=group)
+        work = dist.all_to_all_single(flat, kmers, recv_n, send_sizes, group=group, async_op=True)
+        if overlap is not None:
+            overlap()
+        work.wait()
     else:
         # gloo (CPU tests, single-GPU rehearsals): point-to-point pairs, staged through host memory
         send_list = [kmers[int(bounds[p]):int(bounds[p + 1])].cpu() for p in range(world)]
-        recv = _all_to_all_var(send_list, recv_n, torch.int64, torch.device("cpu"), group)
+        recv = [torch.empty(int(n), dtype=torch.int64) for n in recv_n]
+        reqs = []
+        for peer in range(world):
+            if peer == rank:
+                recv[peer].copy_(send_list[peer])
+                continue
+            if send_list[peer].numel():
+                reqs.append(dist.isend(send_list[peer].contiguous(), peer, group=group))
+            if recv[peer].numel():
+                reqs.append(dist.irecv(recv[peer], peer, group=group))
+        if overlap is not None:
+            overlap()
+        for r in reqs:
+            r.wait()
         flat = (torch.cat(recv) if recv else torch.empty(0, dtype=torch.int64)).to(dev)
     if flat.numel():
         counter.add_kmers(flat if dev.type != "cpu" else flat.numpy().view(np.uint64))

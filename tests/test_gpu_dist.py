@@ -29,7 +29,11 @@ def _worker(rank, world, port, ret):
         so = torch.from_numpy((off[r0:r1 + 1] - off[r0]).astype(np.int64)).cuda()
         ctx = lib.Context(0)
         c = ctx.counter(A.KMER64BIT, 31, 8, int(off[-1]))
-        nrecv = kdist.count_reads_exchange(c, sb, so)
+        # the shard is sketched while the exchange is in flight (what bench.py does at N > 1), with CUs held back for it
+        os.environ["KMU_PMH_RESERVE_CUS"] = "16"
+        p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        box = {}
+        nrecv = kdist.count_reads_exchange(c, sb, so, overlap=lambda: box.update(sig=ctx.sketch(sb, so, p)))
         g = O.Counter(A.KMER64BIT, 31, 8, 1 << 20)
         g.add_reads(bases, off)
         gk, gc = g.dump(1)
@@ -39,8 +43,7 @@ def _worker(rank, world, port, ret):
         order = np.argsort(kk)
         ok = nrecv > 0 and np.array_equal(kk[order], gk[own]) and np.array_equal(np.minimum(cc[order], 255), gc[own])
         # sketch shards: rows of this rank == rows r0..r1 of the single-process result
-        p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
-        mine = ctx.sketch(sb, so, p).cpu().numpy().view(np.uint64)
+        mine = box["sig"].cpu().numpy().view(np.uint64)
         want = O.sketch(bases, off, p)[r0:r1]
         ok = ok and np.array_equal(mine, want)
         ret[rank] = bool(ok)
