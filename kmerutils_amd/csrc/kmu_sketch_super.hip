@@ -31,6 +31,7 @@ struct SuperArgs {
     int mode;     // 0 f64, 1 f32, 2 u64 (SuperMinHash2), 3 u32 (SuperMinHash2)
     int val_w32;  // Kmer::Val is 32 bits
     uint32_t chunk; // items staged per chunk
+    int ncol;       // item lanes that own a permutation column (<= workgroup size)
     const void *hashed;  // pre-hashed input: array of Kmer::Val values (offsets count values, k = 1), else null
     int hashed_bytes;    // 4 / 8
     uint64_t *part_rows; // non-null: raw slot bits per "sequence" (partial results merged by k_super_reduce)
@@ -68,12 +69,16 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
     uint64_t *hs = reinterpret_cast<uint64_t *>(smem);          // m slot minima
     uint64_t *items = hs + m;                                     // a.chunk staged RNG seeds
     uint32_t *misc = reinterpret_cast<uint32_t *>(items + a.chunk); // [0] read, [1] a_upper
-    PT *perm = reinterpret_cast<PT *>(misc + 4);                  // [m][nthreads]
-    PT *slog = perm + (size_t) m * nthreads;                      // [m][nthreads]
+    // one permutation column + swap log per item lane; ncol = nthreads unless the sketch is so large that only some
+    // lanes of a single wave get a column
+    const int ncol = a.ncol;
+    PT *perm = reinterpret_cast<PT *>(misc + 4);                  // [m][ncol]
+    PT *slog = perm + (size_t) m * ncol;                          // [m][ncol]
     const bool aa = a.cfg.kmer_type == KMU_KMERAA32BIT || a.cfg.kmer_type == KMU_KMERAA64BIT;
     const uint64_t init_bits = super_init_bits(a.mode);
 
-    for (int e = 0; e < m; e++) perm[(size_t) e * nthreads + tid] = (PT) e;
+    if (tid < ncol)
+        for (int e = 0; e < m; e++) perm[(size_t) e * ncol + tid] = (PT) e;
     for (int s = tid; s < m; s += nthreads) hs[s] = init_bits;
     if (tid == 0) misc[1] = (uint32_t) (m - 1);
     __syncthreads();
@@ -127,8 +132,8 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
             __syncthreads();
             // ---- every lane sketches one staged item per batch; j advances in lock step ----------------------
             const uint32_t n_items = (uint32_t) (c1 - c0);
-            for (uint32_t b0 = 0; b0 < n_items; b0 += nthreads) {
-                const bool have = b0 + tid < n_items;
+            for (uint32_t b0 = 0; b0 < n_items; b0 += (uint32_t) ncol) {
+                const bool have = tid < ncol && b0 + tid < n_items;
                 Xoshiro rng;
                 if (have) rng.seed(items[b0 + tid]);
                 uint32_t j = 0, round = 0;
@@ -148,11 +153,11 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         default: ri = rng.next_u32(); break;
                         }
                         uint32_t k = rng.unif_index(j, (uint32_t) m, a.rand08 != 0);
-                        PT pj = perm[(size_t) j * nthreads + tid];
-                        PT pk = perm[(size_t) k * nthreads + tid];
-                        perm[(size_t) j * nthreads + tid] = pk;
-                        perm[(size_t) k * nthreads + tid] = pj;
-                        slog[(size_t) j * nthreads + tid] = (PT) k;
+                        PT pj = perm[(size_t) j * ncol + tid];
+                        PT pk = perm[(size_t) k * ncol + tid];
+                        perm[(size_t) j * ncol + tid] = pk;
+                        perm[(size_t) k * ncol + tid] = pj;
+                        slog[(size_t) j * ncol + tid] = (PT) k;
                         uint64_t bits;
                         switch (a.mode) {
                         case 0: bits = (uint64_t) __double_as_longlong(rd + (double) j); break;
@@ -176,9 +181,9 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                 }
                 // restore this lane's permutation column to the identity
                 for (uint32_t jj = 0; jj < j; jj++) {
-                    PT k = slog[(size_t) jj * nthreads + tid];
-                    perm[(size_t) jj * nthreads + tid] = (PT) jj;
-                    perm[(size_t) k * nthreads + tid] = k;
+                    PT k = slog[(size_t) jj * ncol + tid];
+                    perm[(size_t) jj * ncol + tid] = (PT) jj;
+                    perm[(size_t) k * ncol + tid] = k;
                 }
             }
             __syncthreads();
@@ -262,12 +267,20 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     // per-lane permutation + swap-log columns dominate the LDS footprint: shrink the workgroup for large m
     int threads = 256;
     size_t lds = 0;
+    int ncol = 0;
     for (; threads >= 64; threads -= 64) {
         lds = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + 2 * pt * a.m * threads;
         lds = (lds + 15) & ~(size_t) 15;
-        if (lds <= lds_max) break;
+        if (lds <= lds_max) { ncol = threads; break; }
     }
-    if (threads < 64) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS (%zu B)", a.m, lds);
+    if (!ncol) { // very large sketches: one wave, as many item lanes as columns fit
+        threads = 64;
+        const size_t fixed = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + 16;
+        if (fixed < lds_max) ncol = (int) std::min<size_t>(64, (lds_max - fixed) / (2 * pt * (size_t) a.m));
+        lds = (fixed + 2 * pt * (size_t) a.m * ncol + 15) & ~(size_t) 15;
+    }
+    a.ncol = ncol;
+    if (ncol < 1) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS (%zu B)", a.m, lds);
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) != hipSuccess) {
             (void) hipGetLastError();
