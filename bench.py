@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ont_k31", choices=["ont_k31", "ont_k31_sketch", "ont_k31_count", "c3_k8",
-                                                                "c2_count", "c1_super"])
+                                                                "c2_count", "c1_super", "c5_aa"])
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU")
     ap.add_argument("--bases", type=float, default=0, help="override total bases per GPU")
     ap.add_argument("--genome", type=int, default=100_000_000)
@@ -61,6 +61,9 @@ def workload_cfg(args):
     elif w == "c1_super":
         cfg.update(n_reads=10_000, total_bases=1e7, fixed_len=1000, errors=(0, 0, 0), k=16, kmer_type=A.KMER16B32BIT,
                    m=64, algo=A.ALGO_SUPER, sig=A.SIG_F64, count=False, seed=0xC1, genome=20_000_000)
+    elif w == "c5_aa":  # config 5, one GPU's share of the 5 M proteins
+        cfg.update(n_reads=625_000, total_bases=2.1e8, k=12, kmer_type=A.KMERAA64BIT, m=128, algo=A.ALGO_SUPER,
+                   sig=A.SIG_F64, fhash=A.FHASH_VALUE_MASKED, count=False, seed=0xC5, protein=True)
     if args.reads:
         cfg["total_bases"] = cfg["total_bases"] * args.reads / cfg["n_reads"]
         cfg["n_reads"] = args.reads
@@ -242,6 +245,9 @@ def pmc_traffic(cfg, total_bases, kernel):
 
 def _gen(synth, cfg, dev, rank):
     import torch
+    if cfg.get("protein"):  # log-normal lengths (median 300), residues iid with UniProt-like frequencies
+        res, off = synth.protein_seqs(cfg["n_reads"], cfg["seed"] * 1000 + rank)
+        return torch.from_numpy(res.copy()).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev), np.diff(off.astype(np.int64))
     # same genome on every rank (genome seed), rank-specific read sampling
     bases, offsets, lens = synth.ont_reads_device(cfg["n_reads"], cfg["total_bases"], cfg["genome"],
                                                   cfg["seed"], dev, errors=cfg["errors"], fixed_len=cfg["fixed_len"],
@@ -255,7 +261,8 @@ def _describe(cfg, n_reads, total_bases):
         ops.append("%s m=%d" % ("ProbMinHash3a" if cfg["algo"] == 0 else "SuperMinHash", cfg["m"]))
     if cfg["count"]:
         ops.append("kmercount 8-bit")
-    shape = "%d x %d bp reads" % (n_reads, cfg["fixed_len"]) if cfg["fixed_len"] else \
+    shape = "%d protein sequences" % n_reads if cfg.get("protein") else \
+        "%d x %d bp reads" % (n_reads, cfg["fixed_len"]) if cfg["fixed_len"] else \
         "%d ONT-shaped reads (log-normal lengths, 8%% errors)" % n_reads
     return "%s: %s, %.3g bases, k=%d, %s" % (cfg["name"], shape, total_bases, cfg["k"], " + ".join(ops))
 

@@ -83,11 +83,14 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
     if (tid == 0) misc[1] = (uint32_t) (m - 1);
     __syncthreads();
 
+    if (tid == 0) misc[0] = atomicAdd(a.queue, 1u);
+    __syncthreads();
     for (;;) {
-        if (tid == 0) misc[0] = atomicAdd(a.queue, 1u);
-        __syncthreads();
         const uint32_t r = misc[0];
+        __syncthreads(); // everyone holds r before thread 0 posts the next one
         if (r >= a.n_seq) break;
+        uint32_t r_next = 0;
+        if (tid == 0) r_next = atomicAdd(a.queue, 1u); // its latency hides under this read's work
         SeqView sv;
         sv.base = a.bases;
         sv.len = a.offsets[r + 1] - a.offsets[r];
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
             }
             hs[t] = init_bits;
         }
-        if (tid == 0) misc[1] = (uint32_t) (m - 1);
+        if (tid == 0) { misc[1] = (uint32_t) (m - 1); misc[0] = r_next; }
         __syncthreads();
     }
 }
@@ -259,13 +262,17 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     KMU_TRY(dev_buf(ctx, "queue", 64, &q));
     KMU_HIP(ctx, hipMemsetAsync(q, 0, 64, ctx->stream));
     a.queue = (uint32_t *) q;
-    a.chunk = 2048;
+    // One wave per workgroup and a small staging chunk: the kernel is latency-bound (LDS atomics, queue, row output),
+    // so many small workgroups per CU beat one large one (config 5: 27.6 -> 12.8 ms; scripts/dbg_super.sh).
+    a.chunk = 256;
+    if (const char *e = getenv("KMU_SUPER_CHUNK")) a.chunk = (uint32_t) std::max(64, atoi(e));
     const bool wide = a.m > 256;
     const size_t pt = wide ? 2 : 1;
     const size_t lds_max = 160 * 1024;
     auto fn = wide ? (const void *) k_sketch_super<uint16_t> : (const void *) k_sketch_super<uint8_t>;
     // per-lane permutation + swap-log columns dominate the LDS footprint: shrink the workgroup for large m
-    int threads = 256;
+    int threads = 64;
+    if (const char *e = getenv("KMU_SUPER_THREADS")) threads = std::max(64, std::min(256, atoi(e) & ~63));
     size_t lds = 0;
     int ncol = 0;
     for (; threads >= 64; threads -= 64) {
@@ -287,7 +294,7 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
             return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d needs %zu B of LDS", a.m, lds);
         }
     }
-    int blocks_per_cu = std::max<int>(1, std::min<int>(8, (int) (lds_max / lds)));
+    int blocks_per_cu = std::max<int>(1, std::min<int>(2048 / threads, (int) (lds_max / lds)));
     int grid = (int) std::min<uint64_t>((uint64_t) ds.n_seq, (uint64_t) ctx->num_cus * blocks_per_cu);
     if (grid < 1) grid = 1;
     {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the non-headline BASELINE.json configurations that fit one GPU (parity-test cases; measured for DESIGN.md only)
 cd $GRAFT_REPO_ROOT
-for w in c3_k8 c2_count c1_super; do
+for w in ${WORKLOADS:-c3_k8 c2_count c1_super c5_aa}; do
   timeout -k 10 300 python bench.py --workload $w --steps 3 --warmup 1 > gpurun_out/wl_$w.json 2> gpurun_out/wl_$w.err || echo "FAILED $w"
   python3 -c "
 import json
