@@ -84,7 +84,9 @@ typedef enum kmu_algo {
     KMU_ALGO_PROB3A = 0, /* ProbMinHash3a  (probminhash crate), src/sketching/seqsketchjaccard.rs:211-260 */
     KMU_ALGO_SUPER = 1,  /* SuperMinHash   (probminhash crate), src/sketching/setsketchert.rs:255-297 */
     KMU_ALGO_SUPER2 = 2, /* SuperMinHash2  (integer sketch),   src/sketching/setsketchert.rs:963-1004 */
-    KMU_ALGO_BOTTOMK = 3 /* MinHashCount / MinInvHashCountKmer, src/sketching/minhash.rs:62-99,219-265 */
+    KMU_ALGO_BOTTOMK = 3, /* MinHashCount / MinInvHashCountKmer, src/sketching/minhash.rs:62-99,219-265 */
+    KMU_ALGO_PROB3 = 4    /* ProbMinHash3 (SeqSketcher::sketch_probminhash3, seqsketchjaccard.rs:272-319): the same point
+                           * process as ProbMinHash3a handled key by key; the signature is the same per-slot arg-min */
 } kmu_algo;
 
 typedef enum kmu_sig_type { KMU_SIG_U32 = 0, KMU_SIG_U64 = 1, KMU_SIG_F32 = 2, KMU_SIG_F64 = 3 } kmu_sig_type;

@@ -1101,10 +1101,24 @@ static int sketch_all_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const uin
     return launch_super_reduce(ctx, p, (const uint64_t *) pr, n_chunks, d_sig);
 }
 
-extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_t *bases, const uint64_t *offsets,
+// ProbMinHash3 (sketch_probminhash3, seqsketchjaccard.rs:272-319) generates the same points per key as ProbMinHash3a
+// and keeps the same per-slot minimum: it runs on the ProbMinHash3a kernel (whole sequences only, like upstream).
+static int resolve_algo(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu_sketch_params *p) {
+    *p = *p_in;
+    if (p->algo == KMU_ALGO_PROB3) {
+        if (p->block_size > 0) return fail(ctx, KMU_E_UNSUPPORTED, "block sketching is ProbMinHash3a per sequence (seqblocksketch.rs:97)");
+        p->algo = KMU_ALGO_PROB3A;
+    }
+    return KMU_OK;
+}
+
+extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uint8_t *bases, const uint64_t *offsets,
                           const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *block_row_offsets,
                           void *sig_out, uint32_t *counts_out) {
-    if (!ctx || !p || !sig_out) return KMU_E_BAD_ARG;
+    if (!ctx || !p_in || !sig_out) return KMU_E_BAD_ARG;
+    kmu_sketch_params p_res;
+    KMU_TRY(resolve_algo(ctx, p_in, &p_res));
+    const kmu_sketch_params *p = &p_res;
     KMU_TRY(check_kmer(ctx, p->kmer_type, p->kmer_size));
     KMU_TRY(sketch_params_check(ctx, p));
     if (!fhash_valid(p->fhash, p->kmer_type)) return fail(ctx, KMU_E_BAD_ARG, "fhash %d not valid for kmer_type %d", p->fhash, p->kmer_type);
@@ -1184,9 +1198,12 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_
     return finish_call(ctx, p->mem);
 }
 
-extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const void *hashed, const uint64_t *offsets,
+extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, const void *hashed, const uint64_t *offsets,
                                  uint32_t n_seq, void *sig_out, uint32_t *counts_out) {
-    if (!ctx || !p || !sig_out || !offsets || (!hashed && n_seq)) return KMU_E_BAD_ARG;
+    if (!ctx || !p_in || !sig_out || !offsets || (!hashed && n_seq)) return KMU_E_BAD_ARG;
+    kmu_sketch_params p_res;
+    KMU_TRY(resolve_algo(ctx, p_in, &p_res));
+    const kmu_sketch_params *p = &p_res;
     KMU_TRY(sketch_params_check(ctx, p));
     if (p->block_size > 0) return fail(ctx, KMU_E_UNSUPPORTED, "block sketching needs the sequences (k-mer positions)");
     if (p->mode == KMU_MODE_ALL_SEQS && p->algo == KMU_ALGO_BOTTOMK)

@@ -19,7 +19,7 @@ from . import lib
 
 
 class SketchAlgo:
-    PROB3A, SUPER, SUPER2, BOTTOMK = A.ALGO_PROB3A, A.ALGO_SUPER, A.ALGO_SUPER2, A.ALGO_BOTTOMK
+    PROB3A, SUPER, SUPER2, BOTTOMK, PROB3 = A.ALGO_PROB3A, A.ALGO_SUPER, A.ALGO_SUPER2, A.ALGO_BOTTOMK, A.ALGO_PROB3
 
 
 class DataType:
@@ -155,6 +155,15 @@ class SeqSketcher:
         kt = kmer_type if kmer_type is not None else A.kmer_type_for_k(self.kmer_size)
         sig = A.SIG_U32 if A.kmer_val_bytes(kt) == 4 else A.SIG_U64
         p = A.SketchParams(A.ALGO_PROB3A, kt, self.kmer_size, self.sketch_size, sig, A.HASHER_NOHASH, fhash, 0,
+                           A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_HOST, flags)
+        bases, offsets = _as_arrays(vseq)
+        return self.ctx.sketch(bases, offsets, p)
+
+    def sketch_probminhash3(self, vseq, fhash, kmer_type=None, flags=0):
+        """seqsketchjaccard.rs:272-319: ProbMinHash3<Kmer::Val, NoHashHasher> over the same k-mer multiset"""
+        kt = kmer_type if kmer_type is not None else A.kmer_type_for_k(self.kmer_size)
+        sig = A.SIG_U32 if A.kmer_val_bytes(kt) == 4 else A.SIG_U64
+        p = A.SketchParams(A.ALGO_PROB3, kt, self.kmer_size, self.sketch_size, sig, A.HASHER_NOHASH, fhash, 0,
                            A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_HOST, flags)
         bases, offsets = _as_arrays(vseq)
         return self.ctx.sketch(bases, offsets, p)

@@ -716,6 +716,41 @@ int kmo_probminhash3a(const uint64_t *keys, const double *weights, uint64_t n, i
     return 0;
 }
 
+/* ProbMinHash3 (UNPINNED third-party: probminhash::probminhasher::ProbMinHash3; Ertl arXiv 1911.00675, Alg. 4), used by
+ * SeqSketcher::sketch_probminhash3 (src/sketching/seqsketchjaccard.rs:272-319).  Same point process as ProbMinHash3a --
+ * per key h_i = winv (i - 1 + Exp01), slot uniform, stop at q_max -- handled key by key (depth first) instead of round
+ * by round.  Pruning never changes a per-slot minimum, so the signature equals ProbMinHash3a's; this independent
+ * formulation is what the device result for KMU_ALGO_PROB3 is checked against. */
+int kmo_probminhash3(const uint64_t *keys, const double *weights, uint64_t n, int key_bytes, int m, uint32_t flags,
+                     uint64_t *sig_out) {
+    if (m < 2) return KMU_E_BAD_ARG;
+    exp01_t e;
+    exp01_init(&e, log((double) m / (double) (m - 1)));
+    mvt_t trk;
+    mvt_init(&trk, m);
+    for (int i = 0; i < m; i++) sig_out[i] = 0;
+    for (uint64_t it = 0; it < n; it++) {
+        const double winv = 1.0 / weights[it];
+        uint64_t s[4];
+        kmo_xoshiro_seed(kmo_nohash_finish(keys[it], key_bytes), s);
+        double h = winv * exp01_sample(&e, s);
+        uint64_t i = 1;
+        while (h < mvt_max(&trk)) {
+            uint64_t k = unif_usize(s, 0, (uint64_t) m, flags);
+            if (h < trk.v[k] || (h == trk.v[k] && keys[it] < sig_out[k])) {
+                sig_out[k] = keys[it];
+                mvt_update(&trk, (int) k, h);
+            }
+            h = winv * (double) i;
+            i++;
+            if (!(h < mvt_max(&trk))) break;
+            h = h + winv * exp01_sample(&e, s);
+        }
+    }
+    free(trk.v);
+    return 0;
+}
+
 /* ====================================================================================================
  * SuperMinHash (UNPINNED third-party: probminhash::superminhasher::SuperMinHash; Ertl arXiv 1706.05698 Alg. 3)
  * call sites: seqsketchjaccard.rs:346-360 (FnvHasher), setsketchert.rs:267-284 (NoHashHasher)
@@ -836,6 +871,7 @@ static int sketch_params_check(const kmu_sketch_params *p) {
     int w = kmer_val_bytes(p->kmer_type);
     switch (p->algo) {
     case KMU_ALGO_PROB3A:
+    case KMU_ALGO_PROB3:
         if (p->sig_type != (w == 4 ? KMU_SIG_U32 : KMU_SIG_U64)) return KMU_E_BAD_ARG;
         if (p->hasher != KMU_HASHER_NOHASH) return KMU_E_BAD_ARG; /* every call site uses NoHashHasher */
         break;
@@ -868,7 +904,7 @@ typedef struct {
 static void sk_begin(sk_state_t *st, const kmu_sketch_params *p, uint64_t expected) {
     st->p = p;
     st->w = kmer_val_bytes(p->kmer_type);
-    if (p->algo == KMU_ALGO_PROB3A) mset_init(&st->ms, expected);
+    if (p->algo == KMU_ALGO_PROB3A || p->algo == KMU_ALGO_PROB3) mset_init(&st->ms, expected);
     else if (p->algo == KMU_ALGO_SUPER) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_F32 ? 1 : 0);
     else if (p->algo == KMU_ALGO_SUPER2) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_U32 ? 3 : 2);
     else botk_init(&st->bk, p->sketch_size);
@@ -876,7 +912,7 @@ static void sk_begin(sk_state_t *st, const kmu_sketch_params *p, uint64_t expect
 }
 static void sk_feed(sk_state_t *st, const uint64_t *hashed, uint64_t n) {
     const kmu_sketch_params *p = st->p;
-    if (p->algo == KMU_ALGO_PROB3A) {
+    if (p->algo == KMU_ALGO_PROB3A || p->algo == KMU_ALGO_PROB3) {
         for (uint64_t i = 0; i < n; i++) mset_add(&st->ms, hashed[i], 1.0);
     } else if (p->algo == KMU_ALGO_SUPER || p->algo == KMU_ALGO_SUPER2) {
         for (uint64_t i = 0; i < n; i++) smh_sketch(&st->smh, hasher_finish(p->hasher, hashed[i], st->w), p->flags);
@@ -889,9 +925,10 @@ static void sk_feed(sk_state_t *st, const uint64_t *hashed, uint64_t n) {
 static int sk_end(sk_state_t *st, void *sig_row, uint32_t *count_row) {
     const kmu_sketch_params *p = st->p;
     int m = p->sketch_size, rc = 0;
-    if (p->algo == KMU_ALGO_PROB3A) {
+    if (p->algo == KMU_ALGO_PROB3A || p->algo == KMU_ALGO_PROB3) {
         uint64_t *sig = (uint64_t *) malloc((size_t) m * 8);
         if (st->ms.n == 0) { for (int i = 0; i < m; i++) sig[i] = 0; } /* empty map: signature = [initobj; m] */
+        else if (p->algo == KMU_ALGO_PROB3) rc = kmo_probminhash3(st->ms.keys, st->ms.w, st->ms.n, st->w, m, p->flags, sig);
         else rc = kmo_probminhash3a(st->ms.keys, st->ms.w, st->ms.n, st->w, m, p->flags, sig, 0);
         if (st->w == 4) for (int i = 0; i < m; i++) ((uint32_t *) sig_row)[i] = (uint32_t) sig[i];
         else memcpy(sig_row, sig, (size_t) m * 8);

@@ -568,3 +568,23 @@ def test_ingest_then_sketch_equals_direct(ctx, oracle):
     got = ctx.sketch(bases, offs, p)
     ctx.synchronize()
     assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.gpu
+def test_probminhash3_depth_first_oracle(ctx, oracle):
+    """KMU_ALGO_PROB3 (sketch_probminhash3, seqsketchjaccard.rs:272-319): the device runs the ProbMinHash3a kernel; the
+    oracle's key-by-key (depth-first) formulation is an independent check that both keep the same per-slot minimum."""
+    rng = np.random.default_rng(9)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in (40, 900, 5000, 23000)]
+    seqs.append(b"ACGTTGCA" * 400)  # heavy multiplicities
+    bases, off = oracle.concat(seqs)
+    for kmer_type, k, sig in ((A.KMER32BIT, 7, A.SIG_U32), (A.KMER64BIT, 25, A.SIG_U64)):
+        p3 = A.SketchParams(A.ALGO_PROB3, kmer_type, k, 150, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        p3a = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, 150, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        want3 = oracle.sketch(bases, off, p3)
+        assert np.array_equal(want3, oracle.sketch(bases, off, p3a))  # the two oracle formulations agree
+        assert np.array_equal(np.asarray(ctx.sketch(bases, off, p3)), want3)
+    from kmerutils_amd import sketching as S
+    sk = S.SeqSketcher(25, 150, ctx=ctx)
+    a = np.asarray(sk.sketch_probminhash3(seqs, A.FHASH_CANON_INVHASH))
+    assert np.array_equal(a, want3)

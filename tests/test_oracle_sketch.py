@@ -148,3 +148,18 @@ def test_bottomk_is_the_k_smallest_with_total_multiplicities(oracle):
         assert (sig[0] == u[:50]).all()
         mask = 0xFF if hasher == A.HASHER_INT64HASH else 0xFFFF
         assert (cnt[0] == (c[:50] & mask)).all()
+
+
+def test_probminhash3_equals_3a_in_the_oracle():
+    """ProbMinHash3 (key by key) and ProbMinHash3a (round by round) generate the same points per key and keep the same
+    per-slot minimum: the two independent oracle formulations must return the same signature."""
+    from oracle import oracle as O
+    from kmerutils_amd import _abi as A
+    rng = np.random.default_rng(4)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n).tobytes() for n in (33, 700, 12000)] + [b"AC" * 900]
+    b, o = O.concat(seqs)
+    for kt, k, sig in ((A.KMER32BIT, 9, A.SIG_U32), (A.KMER16B32BIT, 16, A.SIG_U32), (A.KMER64BIT, 31, A.SIG_U64)):
+        for m in (2, 64, 500):
+            p3 = A.SketchParams(A.ALGO_PROB3, kt, k, m, sig, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+            p3a = A.SketchParams(A.ALGO_PROB3A, kt, k, m, sig, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+            assert np.array_equal(O.sketch(b, o, p3), O.sketch(b, o, p3a))
