@@ -132,6 +132,13 @@ def main():
             counter.reset()
             counter.add_reads(bases, offsets)
 
+    if world > 1:  # bring up the RCCL peer-to-peer connections outside the timed region, whatever --warmup is
+        with torch.cuda.stream(stream):
+            t_in = torch.arange(world, dtype=torch.int64, device=dev)
+            t_out = torch.empty_like(t_in)
+            dist.all_to_all_single(t_out, t_in)
+        stream.synchronize()
+
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
