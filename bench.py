@@ -85,10 +85,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # KMU_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (the ranks
+    # then share devices and the exchange is staged through the host); the measured configuration is RCCL ("nccl")
+    backend = os.environ.get("KMU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if world > 1:  # leave a few CUs to the RCCL kernels that run under the (persistent, one-workgroup-per-CU) sketch kernel
@@ -132,7 +139,7 @@ def main():
             counter.reset()
             counter.add_reads(bases, offsets)
 
-    if world > 1:  # bring up the RCCL peer-to-peer connections outside the timed region, whatever --warmup is
+    if world > 1 and backend == "nccl":  # bring up the RCCL peer-to-peer connections outside the timed region
         with torch.cuda.stream(stream):
             t_in = torch.arange(world, dtype=torch.int64, device=dev)
             t_out = torch.empty_like(t_in)
@@ -163,10 +170,11 @@ def main():
     elapsed = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tb = torch.tensor([total_bases], dtype=torch.float64, device=dev)
+        tb = torch.tensor([total_bases], dtype=torch.float64, device=cdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         job_bases = float(tb.item())
     else:
