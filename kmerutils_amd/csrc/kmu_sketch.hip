@@ -40,6 +40,8 @@ struct SketchArgs {
     uint32_t block_size;
     uint32_t cap;         // dense key / weight capacity of one pass
     uint32_t part_target; // k-mers aimed at per pass (cap minus a fluctuation margin)
+    double inv_part_target;
+    uint32_t tile_shift;  // log2 of the k-mer positions covered by one staged tile
     uint64_t *scr_keys;   // per-workgroup overflow scratch (keys that found no register slot): [grid][cap]
     uint32_t *scr_info;   //   (bucket << 16) | rank-or-position
     uint32_t *scr_w;      //   weight carried in (bottom-k running list), 1 otherwise
@@ -55,6 +57,12 @@ struct SketchArgs {
     int hashed_bytes;     // 0 = sequences of bases / residues, 4 / 8 = width of the pre-hashed values
     uint64_t *part_h;     // non-null: write the slot minima (h bits, arg-min key) of every "sequence" here instead
     uint64_t *part_k;     //   of a signature row: partial results of disjoint key sets, merged by k_pmh_reduce
+    // two-kernel ProbMinHash3a (whole sequences): the multiset kernel leaves the distinct (key, weight) pairs of read r
+    // in lst_keys / lst_w [offsets[r] .. offsets[r] + lst_n[r]); k_pmh_points turns them into the signature row
+    uint64_t *lst_keys;
+    uint32_t *lst_w;
+    uint32_t *lst_n;
+    uint32_t *queue2;     // read counter of k_pmh_points
     uint32_t tile_words;  // staged code words per tile (16 bases each)
     uint32_t idx_thresh;  // rand 0.9 Uniform<usize>(0, m): reject while lo < (2^32 - m) % m
     uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
@@ -150,6 +158,14 @@ __device__ __forceinline__ double exp01_rest(const Exp01 &e, Xoshiro &rng) {
     }
 }
 
+// 1 / w.  Most weights are tiny: with a table of the exact quotients (filled once per workgroup with the same IEEE
+// division) the 25-instruction f64 division only runs for the rare wave that holds a weight beyond the table.
+static constexpr uint32_t WINV_LUT = 256;
+__device__ __forceinline__ double winv_of(const double *lut, uint32_t w) {
+    if (lut && w < WINV_LUT) return lut[w];
+    return 1.0 / (double) w;
+}
+
 // ProbMinHash3a, pass B1: the FIRST point of every key (h1 = winv * Exp01, slot k1).  Like the crate's first loop over
 // the map, a key that may need further points (winv < q_max) is only remembered (return value) -- the crate pushes it
 // to `to_be_processed` and comes back to it after every key had its first point, when q_max is small and most of
@@ -158,7 +174,8 @@ __device__ __forceinline__ double exp01_rest(const Exp01 &e, Xoshiro &rng) {
 // The first xoshiro256++ output needs only state words s0 and s3 (= SplitMix64 outputs 1 and 4 of the seed): the
 // other two are computed only for the keys whose first point survives the q_max test.
 __device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, bool sig32, uint64_t *hmin, uint64_t *sig,
-                                                  uint64_t *qmax_sh, bool refresh, bool have, uint64_t key, uint32_t w) {
+                                                  uint64_t *qmax_sh, bool refresh, bool have, uint64_t key, uint32_t w,
+                                                  const double *winv_lut = nullptr) {
     uint64_t qb;
     if (refresh) {
         qb = wave_qmax(hmin, a.m);
@@ -169,7 +186,7 @@ __device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, bool sig3
     bool deferred = false;
     if (have) {
         const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, sig32);
-        const double winv = 1.0 / (double) w;
+        const double winv = winv_of(winv_lut, w);
         Xoshiro rng;
         rng.s0 = splitmix_at(seed, 1);
         rng.s3 = splitmix_at(seed, 4);
@@ -243,7 +260,7 @@ __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t) 
 // bst[NBUCKETS] = total.  wtot: one word per wave.
 __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const uint32_t per = (NBUCKETS + nthreads - 1) / nthreads;
+    const uint32_t per = nthreads >= 1024 ? 4u : nthreads >= 768 ? 6u : 8u; // ceil(NBUCKETS / nthreads) without a division
     const uint32_t b0 = tid * per;
     uint32_t c[8];
     uint32_t sum = 0;
@@ -282,7 +299,9 @@ __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
 // weights.  If even the distinct keys do not fit, the block is restarted with twice as many partitions.
 // (A variant with the closure and k-mer type as template constants was tried: the hashing loop gets 18 % shorter, but
 // the allocator then spills loop-carried state around the read header and the kernel as a whole is slower.)
-template <bool AA, bool BOTTOMK>
+// EMIT: stop after the multiset and write the distinct (key, weight) pairs of the read to global lists (k_pmh_points
+// generates the points from there, one wave per read at full occupancy) instead of running pass B here.
+template <bool AA, bool BOTTOMK, bool EMIT = false>
 __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     const KmerCfg cfg = a.cfg;
     const bool sig32 = a.sig_bytes == 4;
@@ -407,7 +426,9 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             if (pb > nk_all) pb = nk_all;
             if (pe > nk_all) pe = nk_all;
             const uint64_t nk = pe - pb;
-            uint32_t P = nk ? (uint32_t) ((nk + a.part_target - 1) / a.part_target) : 0;
+            // number of hash partitions: any P with nk / P comfortably below the dense capacity will do (the multiset is
+            // exact for every P), so no 64-bit division: a product with the reciprocal, rounded up
+            uint32_t P = nk == 0 ? 0u : nk <= (uint64_t) a.part_target ? 1u : (uint32_t) ((double) nk * a.inv_part_target) + 1u;
             if (ABL(64u)) P = 0;
             uint32_t bad = 0;
             bool full = false;
@@ -445,7 +466,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 __syncthreads(); // orders the scratch stores above
                             }
                             // ---- A1: bucket ranks of the keys of this partition in [q0, q1) ------------------------
-                            const uint64_t ntiles = AA ? 1 : (q1 - q0 + tile_pos - 1) / tile_pos;
+                            const uint64_t ntiles = AA ? 1 : (q1 - q0 + tile_pos - 1) >> a.tile_shift; // tile_pos is a power of two
                             for (uint64_t tile = 0; tile < ntiles; tile++) {
                                 const uint64_t tp0 = AA ? q0 : q0 + tile * tile_pos;
                                 const uint64_t tp1 = AA ? q1 : (tp0 + tile_pos < q1 ? tp0 + tile_pos : q1);
@@ -667,7 +688,27 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 __syncthreads();
                             }
                             if (!overflow && last_round) {
-                                if (!BOTTOMK) {
+                                if (EMIT) {
+                                    // ---- the distinct pairs of this pass leave for the points kernel ---------------------
+                                    // misc[M_FLAGS] = pairs of this read written so far (all passes; reset with the row)
+                                    const uint64_t lbase = a.offsets[r];
+                                    for (uint32_t base = 0; base < n_keys; base += nthreads) { // uniform trip count (ballot)
+                                        const uint32_t i = base + tid;
+                                        const uint32_t w = i < n_keys ? dw[i] : 0u;
+                                        const uint64_t cm = __ballot(w != 0u);
+                                        if (cm) {
+                                            const int leader = __ffsll((unsigned long long) cm) - 1;
+                                            uint32_t basepos = 0;
+                                            if (lane_id() == leader) basepos = atomicAdd(&misc[M_FLAGS], (uint32_t) __popcll(cm));
+                                            basepos = bcast_u32(basepos, leader);
+                                            if (w != 0u) {
+                                                const uint64_t pos = lbase + basepos + (uint32_t) __popcll(cm & ((1ull << lane_id()) - 1ull));
+                                                a.lst_keys[pos] = dk[i];
+                                                a.lst_w[pos] = w;
+                                            }
+                                        }
+                                    }
+                                } else if (!BOTTOMK) {
                                     // ---- B1: the first point of every distinct key -------------------------------------
                                     uint32_t chunk = 0;
                                     bool any_deferred = false;
@@ -750,6 +791,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                     P *= 2;
                     for (int t = tid; t < a.m; t += nthreads) { hmin[t] = H_INIT; sig[t] = 0; }
                     if (tid == 0) *qmax_sh = H_INIT;
+                    if (EMIT && tid == 0) misc[M_FLAGS] = 0u; // the list of this read starts over
                     bk_n = 0;
                     __syncthreads();
                 }
@@ -766,6 +808,8 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                     if (a.counts_out) a.counts_out[(uint64_t) r * a.m + t] = have ? (bk_cnt[t] & a.bk_mask) : 0u;
                 }
                 bk_n = 0;
+            } else if (EMIT) {
+                if (tid == 0) { a.lst_n[r] = misc[M_FLAGS]; misc[M_FLAGS] = 0u; } // the row is written by k_pmh_points
             } else {
                 // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
                 uint64_t row = a.block_rows ? a.block_rows[r] + blk : (uint64_t) r;
@@ -797,6 +841,111 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     if (ph_on)
         for (int i = 0; i < 10; i++)
             atomicAdd(reinterpret_cast<unsigned long long *>(a.queue) + 8 + i, (unsigned long long) ph_acc[i]);
+}
+
+// the cheap half of pmh3a_first_point: can the first point of this key lie below q_max (bits `qb`)?  Needs two of the four
+// SplitMix64 words and one f64 product; the rare keys whose first Exp01 draw falls in the sampler's rejection branch pass.
+__device__ __forceinline__ bool pmh3a_first_point_may_matter(const SketchArgs &a, bool sig32, uint64_t qb, uint64_t key,
+                                                             uint32_t w, const double *winv_lut) {
+    const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, sig32);
+    const uint64_t s0 = splitmix_at(seed, 1), s3 = splitmix_at(seed, 4);
+    const uint64_t r1 = rotl64(s0 + s3, 23) + s0;
+    const double u1 = __longlong_as_double((long long) ((r1 >> 12) | 0x3FF0000000000000ull)) - 1.0;
+    const double x = a.e01.c1 * u1;
+    return !(x < 1.0) || winv_of(winv_lut, w) * x < __longlong_as_double((long long) qb);
+}
+
+// ProbMinHash3a points from the (key, weight) lists of k_sketch_pmh3a<.., EMIT>: one WAVE per read, so there is no
+// workgroup barrier anywhere and a CU holds as many reads in flight as its registers allow.  LDS per wave: the slot
+// minima (16 m bytes) + the shared q_max word.  Pass 1 = first point of every key; pass 2 = further rounds for the keys
+// with winv < q_max (a key is deferred in pass 1 exactly when winv < q_max then, and q_max only falls: re-testing
+// against the settled q_max selects a subset of the deferred keys, those that can still produce a point below it).
+__global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const bool sig32 = a.sig_bytes == 4;
+    // per wave: slot minima, arg-min keys, q_max word, and a queue of 128 (key, weight) pairs that passed the cheap test:
+    // they are worked off 64 at a time, so the expensive half of a first point always runs with all lanes busy
+    uint64_t *hmin = reinterpret_cast<uint64_t *>(smem) + (size_t) wave * (2 * (size_t) a.m + 2 + 128 + 64);
+    uint64_t *sig = hmin + a.m;
+    uint64_t *qmax_sh = sig + a.m;
+    uint64_t *qk = qmax_sh + 2;
+    uint32_t *qw = reinterpret_cast<uint32_t *>(qk + 128);
+    double *winv_lut = reinterpret_cast<double *>(reinterpret_cast<uint64_t *>(smem) + (size_t) 4 * (2 * (size_t) a.m + 2 + 128 + 64));
+    for (uint32_t t = threadIdx.x; t < WINV_LUT; t += blockDim.x) winv_lut[t] = t ? 1.0 / (double) t : 0.0;
+    __syncthreads();
+    uint32_t q_next = 0, q_end = 0; // lane 0: reads are taken QCHUNK at a time
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) {
+            if (q_next == q_end) {
+                q_next = atomicAdd(a.queue2, (uint32_t) QCHUNK);
+                q_end = q_next + QCHUNK;
+            }
+            r = q_next++;
+        }
+        r = uniform_u32(r);
+        if (r >= a.n_seq) break;
+        const uint64_t base = a.offsets[r];
+        const uint32_t n = a.lst_n[r];
+        for (int t = lane; t < a.m; t += 64) { hmin[t] = H_INIT; sig[t] = 0; }
+        if (lane == 0) *qmax_sh = H_INIT;
+        // ---- pass 1 ----
+        uint32_t chunk = 0, qn = 0; // qn: queued pairs (uniform)
+        uint64_t qb = H_INIT;
+        uint64_t key_nx = 0; // the next chunk's pair is requested one iteration ahead
+        uint32_t w_nx = 1;
+        if ((uint32_t) lane < n) { key_nx = a.lst_keys[base + lane]; w_nx = a.lst_w[base + lane]; }
+        for (uint32_t c = 0; c < n; c += 64, chunk++) { // uniform trip count
+            const uint32_t i = c + (uint32_t) lane;
+            const bool have = i < n;
+            const uint64_t key = key_nx;
+            const uint32_t w = w_nx;
+            if (i + 64u < n) { key_nx = a.lst_keys[base + i + 64u]; w_nx = a.lst_w[base + i + 64u]; }
+            if ((chunk & 3u) == 0u) {
+                qb = wave_qmax(hmin, a.m);
+                if (lane == 0) *qmax_sh = qb;
+            }
+            const bool pass = have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut);
+            const uint64_t pm = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));
+                qk[pos] = key;
+                qw[pos] = w;
+            }
+            qn += (uint32_t) __popcll(pm);
+            if (qn >= 64u) { // the newest 64
+                qn -= 64u;
+                (void) pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, false, true, qk[qn + lane], qw[qn + lane], winv_lut);
+            }
+        }
+        if (qn) {
+            const bool have = (uint32_t) lane < qn;
+            (void) pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, false, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u,
+                                     winv_lut);
+        }
+        // ---- pass 2 ----
+        qb = wave_qmax(hmin, a.m);
+        if (n && __longlong_as_double((long long) qb) > 0.0) {
+            for (uint32_t c = 0; c < n; c += 64) {
+                const uint32_t i = c + (uint32_t) lane;
+                double winv = 0.0;
+                bool alive = false;
+                if (i < n) {
+                    const uint32_t w = a.lst_w[base + i];
+                    winv = winv_of(winv_lut, w);
+                    alive = winv < __longlong_as_double((long long) qb);
+                }
+                if (__any(alive)) pmh3a_more_points(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
+            }
+        }
+        // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
+        for (int t = lane; t < a.m; t += 64) {
+            const uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
+            if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * a.m + t] = (uint32_t) v;
+            else reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = v;
+        }
+    }
 }
 
 // merge the slot minima of disjoint key sets (leaves): per slot the smallest (h, key); one workgroup per slot
@@ -978,8 +1127,15 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
     const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
     typedef void (*sketch_kernel_t)(SketchArgs);
+    // whole DNA sequences -> signature rows: multiset kernel + points kernel (KMU_PMH_SPLIT=0: the single kernel)
+    const char *split_env = getenv("KMU_PMH_SPLIT");
+    const bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 &&
+                       (size_t) 4 * (2 * (size_t) p->sketch_size + 200) * 8 <= 146 * 1024 && // four waves' slot arrays fit one workgroup
+                       !(split_env && atoi(split_env) == 0);
     const sketch_kernel_t kern = bottomk ? (aa ? k_sketch_pmh3a<true, true> : k_sketch_pmh3a<false, true>)
-                                         : (aa ? k_sketch_pmh3a<true, false> : k_sketch_pmh3a<false, false>);
+                                 : aa    ? k_sketch_pmh3a<true, false>
+                                 : split ? k_sketch_pmh3a<false, false, true>
+                                         : k_sketch_pmh3a<false, false>;
     const void *fn = (const void *) kern;
     a.counts_out = d_counts;
     a.bk_shift = (a.sig_bytes == 4 && p->hasher == KMU_HASHER_NOHASH) ? 20 : 52; // NoHashHasher of a u32 is < 2^32
@@ -1007,6 +1163,13 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     if (env && atoi(env) >= 256) cap = std::min<uint32_t>(cap, (uint32_t) atoi(env) & ~63u);
     a.cap = cap;
     a.part_target = cap - cap / 10;
+    a.inv_part_target = 1.0 / (double) a.part_target;
+    {
+        const uint32_t tp = (a.tile_words - 2) * 16; // 4096 or 1024 words of 16 bases
+        a.tile_shift = 0;
+        while ((1u << a.tile_shift) < tp) a.tile_shift++;
+        if ((1u << a.tile_shift) != tp) return fail(ctx, KMU_E_HIP, "internal: tile size %u is not a power of two", tp);
+    }
     size_t lds = (size_t) 12 * cap + fixed;
     void *q;
     KMU_TRY(dev_buf(ctx, "queue", 256, &q)); // [0] read cursor; u64 words 8..23: phase clocks (diagnostics)
@@ -1032,11 +1195,37 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         a.bk_keys = (uint64_t *) bk;
         a.bk_cnt = (uint32_t *) bc;
     }
+    if (split) {
+        uint64_t total = 0; // number of bases = capacity of the (key, weight) lists
+        if (!ds.h_offsets.empty()) total = ds.h_offsets[ds.n_seq];
+        else {
+            KMU_HIP(ctx, hipMemcpyAsync(&total, ds.offsets + ds.n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        void *lk, *lw, *ln;
+        KMU_TRY(dev_buf(ctx, "pmh.lst_keys", total * 8 + 64, &lk));
+        KMU_TRY(dev_buf(ctx, "pmh.lst_w", total * 4 + 64, &lw));
+        KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 4 + 64, &ln));
+        a.lst_keys = (uint64_t *) lk;
+        a.lst_w = (uint32_t *) lw;
+        a.lst_n = (uint32_t *) ln;
+        a.queue2 = a.queue + 48;
+    }
     {
         KernelTimer t(ctx, bottomk ? "k_sketch_bottomk" : "k_sketch_pmh3a");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
     KMU_HIP(ctx, hipGetLastError());
+    if (split) {
+        const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + 2 + 128 + 64) * 8 + WINV_LUT * 8;
+        if (lds2 > 64 * 1024)
+            KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_pmh_points, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
+        const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) ctx->num_cus * per_cu));
+        KernelTimer t(ctx, "k_pmh_points");
+        hipLaunchKernelGGL(k_pmh_points, dim3(grid2), dim3(256), lds2, ctx->stream, a);
+        KMU_HIP(ctx, hipGetLastError());
+    }
     if (ABL(256u)) { // diagnostics: mean clocks per workgroup and phase
         unsigned long long ph[10];
         KMU_HIP(ctx, hipMemcpyAsync(ph, (const uint64_t *) a.queue + 8, sizeof ph, hipMemcpyDeviceToHost, ctx->stream));
