@@ -196,7 +196,8 @@ def main():
         # algorithmic bytes per launch: sketch = bases in + signatures out; the partitioned count is a
         # pipeline of streaming kernels: bases (+ 8 B per k-mer per scatter level), then the 12-byte-per-slot table image
         alg_bytes = {
-            "k_sketch_pmh3a": total_bases + n_reads * cfg["m"] * sigw,
+            "k_sketch_pmh3a": total_bases + n_reads * cfg["m"] * sigw,   # the sketch path's bytes
+            "k_pmh_points": nk * 12 + n_reads * cfg["m"] * sigw,        # (key, weight) lists in, rows out
             "k_sketch_super": total_bases + n_reads * cfg["m"] * sigw,
             "k_count_add_flat": total_bases + nk * 16,
             "k_part_hist1": total_bases,

@@ -1203,7 +1203,10 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         void *lk, *lw, *ln;
-        KMU_TRY(dev_buf(ctx, "pmh.lst_keys", total * 8 + 64, &lk));
+        // 8 bytes per base: the same scratch the count build uses for its first partition level ("cnt.partA"); a
+        // context never runs the two at the same time, and at 4.4 Gbases per GPU a second copy would not fit next to
+        // the count table and the exchange buffers
+        KMU_TRY(dev_buf(ctx, "cnt.partA", total * 8 + 64, &lk));
         KMU_TRY(dev_buf(ctx, "pmh.lst_w", total * 4 + 64, &lw));
         KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 4 + 64, &ln));
         a.lst_keys = (uint64_t *) lk;
