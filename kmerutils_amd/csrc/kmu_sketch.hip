@@ -255,6 +255,9 @@ __device__ __forceinline__ void st_scr(T *p, T v) { __hip_atomic_store(p, v, __A
 // A word every thread reads from the same LDS address is the same in all lanes, but the compiler cannot know: taking it
 // through readfirstlane puts it (and every loop bound, address and branch derived from it) on the scalar unit.
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    return ((uint64_t) uniform_u32((uint32_t) (v >> 32)) << 32) | uniform_u32((uint32_t) v);
+}
 
 // in-place exclusive scan of bst[0..NBUCKETS) by the whole workgroup (NBUCKETS / nthreads entries per thread);
 // bst[NBUCKETS] = total.  wtot: one word per wave.
@@ -347,17 +350,19 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     }
     __syncthreads();
     auto view_of = [&](uint32_t r) {
+        // (the header words come back in vector registers although `r` is uniform: handing them to the scalar unit
+        // keeps every length, bound and address derived from them off the vector ALU)
         SeqView v;
         v.base = a.bases;
-        v.len = a.offsets[r + 1] - a.offsets[r];
+        v.len = uniform_u64(a.offsets[r + 1] - a.offsets[r]);
         v.packed = a.packed;
         if (a.packed) {
-            v.begin = a.packed_offsets[r];
+            v.begin = uniform_u64(a.packed_offsets[r]);
             v.total = a.total_bytes ? a.total_bytes
-                                    : (a.packed_offsets[a.n_seq - 1] + (a.offsets[a.n_seq] - a.offsets[a.n_seq - 1] + 3) / 4);
+                                    : uniform_u64(a.packed_offsets[a.n_seq - 1] + (a.offsets[a.n_seq] - a.offsets[a.n_seq - 1] + 3) / 4);
         } else {
-            v.begin = a.offsets[r];
-            v.total = a.total_bytes ? a.total_bytes : a.offsets[a.n_seq];
+            v.begin = uniform_u64(a.offsets[r]);
+            v.total = a.total_bytes ? a.total_bytes : uniform_u64(a.offsets[a.n_seq]);
         }
         return v;
     };
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     lds_barrier();
                                 }
                                 phase(1); // read header + code words staged
-                                for (uint64_t pr = tp0; pr < tp1; pr += (uint64_t) KREG * nthreads) {
+                                for (uint64_t pr = tp0; pr < tp1 && !ABL(4096u); pr += (uint64_t) KREG * nthreads) {
                                     // Where a key waits for the scan: in registers (one pass over a read that fits: its first
                                     // KREG * nthreads positions), parked unsorted in the still unused dense arrays (a pass of
                                     // a partitioned read keeps 1/P of the positions it scans), else in the global scratch.
@@ -571,7 +576,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             const uint32_t n_keys = uniform_u32(bst[NBUCKETS]);
                             const uint32_t n_scr = parked_pass ? 0u : uniform_u32(misc[M_NSCR]);
                             if (n_keys > cap || n_scr > cap || n_park > (uint32_t) KREG * nthreads || n_park > cap) overflow = true;
-                            if (!overflow) {
+                            if (!overflow && !ABL(1024u)) {
                                 // (all bucket starts are requested before the first store: a load behind a store to LDS
                                 // cannot be moved up by the compiler, and ten dependent round trips are the phase)
 #pragma unroll
@@ -610,7 +615,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 pf_r = r_follow;
                                 pf_nw = n;
                             }
-                            if (!overflow) {
+                            if (!overflow && !ABL(2048u)) {
                                 // rb[q] becomes (own position << 16) | cursor; the walks of a thread's keys advance together,
                                 // five LDS reads in flight at a time, instead of one key after the other
 #pragma unroll
