@@ -1132,11 +1132,13 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
     const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
     typedef void (*sketch_kernel_t)(SketchArgs);
-    // whole DNA sequences -> signature rows: multiset kernel + points kernel (KMU_PMH_SPLIT=0: the single kernel)
+    // KMU_PMH_SPLIT=1: whole DNA sequences go through two kernels -- the multiset kernel leaves (key, weight) lists in
+    // HBM, k_pmh_points (one wave per read, full occupancy) generates the points.  3 % faster on the ONT workload
+    // (100.4 vs 103.1 ms) for ~100 GB of extra HBM traffic and 12 bytes of scratch per base, so it is not the default.
     const char *split_env = getenv("KMU_PMH_SPLIT");
     const bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 &&
                        (size_t) 4 * (2 * (size_t) p->sketch_size + 200) * 8 <= 146 * 1024 && // four waves' slot arrays fit one workgroup
-                       !(split_env && atoi(split_env) == 0);
+                       split_env && atoi(split_env) == 1;
     const sketch_kernel_t kern = bottomk ? (aa ? k_sketch_pmh3a<true, true> : k_sketch_pmh3a<false, true>)
                                  : aa    ? k_sketch_pmh3a<true, false>
                                  : split ? k_sketch_pmh3a<false, false, true>

@@ -588,3 +588,22 @@ def test_probminhash3_depth_first_oracle(ctx, oracle):
     sk = S.SeqSketcher(25, 150, ctx=ctx)
     a = np.asarray(sk.sketch_probminhash3(seqs, A.FHASH_CANON_INVHASH))
     assert np.array_equal(a, want3)
+
+
+@pytest.mark.gpu
+def test_two_kernel_probminhash_path(ctx, oracle, monkeypatch):
+    """KMU_PMH_SPLIT=1: multiset kernel -> (key, weight) lists -> k_pmh_points; same rows as the oracle, including
+    reads that need several partition passes, tandem repeats and a read shorter than k."""
+    monkeypatch.setenv("KMU_PMH_SPLIT", "1")
+    rng = np.random.default_rng(21)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in (12, 300, 7000, 45000, 9000)]
+    seqs.append(b"ACGGT" * 3000)
+    bases, off = oracle.concat(seqs)
+    for kmer_type, k, sig, m in ((A.KMER64BIT, 31, A.SIG_U64, 200), (A.KMER32BIT, 8, A.SIG_U32, 64)):
+        p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, m, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        got = np.asarray(ctx.sketch(bases, off, p))
+        ctx.profile_enable(False)
+        assert "k_pmh_points" in ctx.profile_get()
+        assert np.array_equal(got, oracle.sketch(bases, off, p))
