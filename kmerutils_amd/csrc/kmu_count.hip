@@ -407,7 +407,7 @@ static size_t scatter_lds_bytes(uint32_t nbins) { return (size_t) TILE_ITEMS * 8
 // What a partition item is: IT_HASH = khash(key) (digit = a bit field of the item), IT_KEY = the key itself (digit from
 // khash(key)), IT_OWNER = the key, digit = its owner in a `shift`-way key partition (DispatchableT,
 // kmercount.rs:382-420; `mask` != 0 marks 32-bit k-mer values).
-enum { IT_HASH = 0, IT_KEY = 1, IT_OWNER = 2 };
+enum { IT_HASH = 0, IT_KEY = 1, IT_OWNER = 2, IT_KEY_TO_HASH = 3 /* k_arr_scatter: keys in, khash(key) out */ };
 template <int IT>
 __device__ __forceinline__ uint32_t digit_of(uint64_t item, int region_bits, int shift, uint32_t mask) {
     if (IT == IT_OWNER) return kmer_owner(item, mask != 0u, (uint32_t) shift);
@@ -697,7 +697,14 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
             const uint64_t i = t0 + TILE_ITEMS + (uint64_t) j * blockDim.x + threadIdx.x;
             nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
         }
-        tile_scatter<IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
+        if (IT == IT_KEY_TO_HASH) { // from here on the k-mers travel as their table hash (no further evaluations)
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
+            tile_scatter<IT_HASH>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
+        } else {
+            tile_scatter<IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
+        }
     }
 }
 
@@ -905,12 +912,15 @@ namespace kmu {
 // Partition a device array of u64 keys by the top `region_bits` bits of khash(key) into 2^region_bits leaves
 // (<= 22 bits: two 11-bit passes).  Returns the partitioned copy and the leaf bounds (both in context scratch
 // buffers, valid until the next partition call).
+// hashed_out: the output items are khash(key) instead of the keys (what k_part_build<IT_HASH> takes).
 int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits, const uint64_t **items_out,
-                  const uint64_t **bounds_out) {
+                  const uint64_t **bounds_out, bool hashed_out) {
     if (region_bits > 22) return fail(ctx, KMU_E_UNSUPPORTED, "too many partitions (2^%d)", region_bits);
     static bool lds_attr_done = false;
     if (!lds_attr_done) {
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY_TO_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_done = true;
     }
     const int b1 = region_bits <= 11 ? region_bits : (region_bits + 1) / 2;
@@ -923,6 +933,7 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
     const uint64_t *bounds = (const uint64_t *) b0;
     const uint64_t *items = in;
     uint32_t nparts = 1;
+    bool first_done = false;
     for (int level = 0; level < 2; level++) {
         const int bits = level == 0 ? b1 : b2;
         if (bits == 0) continue;
@@ -940,7 +951,9 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
         KMU_TRY(dev_buf(ctx, level == 0 ? "cnt.partA" : "cnt.partB", n * 8 + 64, &outbuf));
         {
             KernelTimer tm(ctx, "k_arr_hist");
-            hipLaunchKernelGGL(k_arr_hist<IT_KEY>, dim3(units), dim3(256), bins * 4, ctx->stream, items, bounds, ap, (uint32_t *) hist);
+            const bool in_hash = hashed_out && first_done; // the first executed level still reads keys
+            if (in_hash) hipLaunchKernelGGL(k_arr_hist<IT_HASH>, dim3(units), dim3(256), bins * 4, ctx->stream, items, bounds, ap, (uint32_t *) hist);
+            else hipLaunchKernelGGL(k_arr_hist<IT_KEY>, dim3(units), dim3(256), bins * 4, ctx->stream, items, bounds, ap, (uint32_t *) hist);
         }
         {
             KernelTimer tm(ctx, "k_arr_scan");
@@ -952,8 +965,17 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
         }
         {
             KernelTimer tm(ctx, "k_arr_scatter");
-            hipLaunchKernelGGL(k_arr_scatter<IT_KEY>, dim3(units), dim3(SCATTER_THREADS), scatter_lds_bytes(bins), ctx->stream, items,
-                               bounds, ap, (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
+            const size_t slds = scatter_lds_bytes(bins);
+            if (!hashed_out)
+                hipLaunchKernelGGL(k_arr_scatter<IT_KEY>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
+                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
+            else if (!first_done)
+                hipLaunchKernelGGL(k_arr_scatter<IT_KEY_TO_HASH>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds,
+                                   ap, (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
+            else
+                hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
+                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
+            first_done = true;
         }
         KMU_HIP(ctx, hipGetLastError());
         items = (const uint64_t *) outbuf;
@@ -972,14 +994,20 @@ static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64
     kmu_ctx *ctx = c->ctx;
     const uint64_t *items, *bounds;
     const int region_bits = c->lg - c->rbits;
-    KMU_TRY(partition_u64(ctx, d_kmers, n, region_bits, &items, &bounds));
+    // (a table of a single region is not partitioned at all: the items stay keys)
+    const bool hashed = region_bits > 0;
+    KMU_TRY(partition_u64(ctx, d_kmers, n, region_bits, &items, &bounds, hashed));
     const uint32_t R = 1u << c->rbits;
     const uint64_t n_regions = 1ull << region_bits;
     int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * 3 * 8);
     {
         KernelTimer tm(ctx, "k_part_build");
-        hipLaunchKernelGGL(k_part_build<IT_KEY>, dim3(grid), dim3(BUILD_THREADS), (size_t) R * 12, ctx->stream, items, bounds,
-                           (uint32_t) n_regions, table_of(c), c->empty ? 1 : 0, d_err);
+        if (hashed)
+            hipLaunchKernelGGL(k_part_build<IT_HASH>, dim3(grid), dim3(BUILD_THREADS), (size_t) R * 12, ctx->stream, items, bounds,
+                               (uint32_t) n_regions, table_of(c), c->empty ? 1 : 0, d_err);
+        else
+            hipLaunchKernelGGL(k_part_build<IT_KEY>, dim3(grid), dim3(BUILD_THREADS), (size_t) R * 12, ctx->stream, items, bounds,
+                               (uint32_t) n_regions, table_of(c), c->empty ? 1 : 0, d_err);
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;

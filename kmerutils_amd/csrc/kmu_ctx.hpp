@@ -180,6 +180,6 @@ bool fhash_valid(int fhash, int kmer_type);
 
 // radix partition of a device u64 array by the top bits of fmix64(key) (kmu_count.hip)
 int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits, const uint64_t **items_out,
-                  const uint64_t **bounds_out);
+                  const uint64_t **bounds_out, bool hashed_out = false);
 
 } // namespace kmu
