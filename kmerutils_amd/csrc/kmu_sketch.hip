@@ -259,36 +259,57 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t) uniform_u32((uint32_t) (v >> 32)) << 32) | uniform_u32((uint32_t) v);
 }
 
-// in-place exclusive scan of bst[0..NBUCKETS) by the whole workgroup (NBUCKETS / nthreads entries per thread);
-// bst[NBUCKETS] = total.  wtot: one word per wave.
+// in-place exclusive scan of bst[0..NBUCKETS); bst[NBUCKETS] = total.  wtot: one word per wave.
+// Four waves do it, sixteen counters per thread moved as 16-byte LDS words: the scan is pure bookkeeping that every
+// pass pays, and with all sixteen waves on it the instruction count is four times higher for the same LDS traffic
+// (the other waves simply wait at the barrier).  bst must be 16-byte aligned.
 __device__ __forceinline__ void bucket_scan(uint32_t *bst, uint32_t *wtot) {
-    const int tid = threadIdx.x, nthreads = blockDim.x;
-    const uint32_t per = nthreads >= 1024 ? 4u : nthreads >= 768 ? 6u : 8u; // ceil(NBUCKETS / nthreads) without a division
-    const uint32_t b0 = tid * per;
-    uint32_t c[8];
-    uint32_t sum = 0;
+    static_assert(NBUCKETS == 4096, "256 threads x 16 counters");
+    const int tid = threadIdx.x;
+    uint4 c[4];
+    uint32_t sum = 0, incl = 0;
+    if (tid < 256) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bst) + 4 * tid;
 #pragma unroll
-    for (uint32_t q = 0; q < 8; q++) {
-        c[q] = (q < per && b0 + q < NBUCKETS) ? bst[b0 + q] : 0u;
-        sum += c[q];
-    }
-    const uint32_t incl = wave_incl_scan_u32(sum);
-    if (lane_id() == 63) wtot[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { // all 16 words are requested at once (a loop up to the own wave would be a chain)
-        const uint32_t v = wtot[w];
-        run += w < (tid >> 6) ? v : 0u;
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < 8; q++)
-        if (q < per && b0 + q < NBUCKETS) {
-            bst[b0 + q] = run;
-            run += c[q];
+        for (int q = 0; q < 4; q++) {
+            c[q] = src[q];
+            sum += c[q].x + c[q].y + c[q].z + c[q].w;
         }
-    if (tid == nthreads - 1) bst[NBUCKETS] = run;
+        incl = wave_incl_scan_u32(sum);
+        if (lane_id() == 63) wtot[tid >> 6] = incl;
+    }
     __syncthreads();
+    if (tid < 256) {
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t v = wtot[w];
+            run += w < (tid >> 6) ? v : 0u;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(bst) + 4 * tid;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 o;
+            o.x = run; run += c[q].x;
+            o.y = run; run += c[q].y;
+            o.z = run; run += c[q].z;
+            o.w = run; run += c[q].w;
+            dst[q] = o;
+        }
+        if (tid == 255) bst[NBUCKETS] = run;
+    }
+    __syncthreads();
+}
+
+// the same economy for wiping the counters: four waves, 16-byte stores
+__device__ __forceinline__ void bucket_clear(uint32_t *bst) {
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        uint4 *dst = reinterpret_cast<uint4 *>(bst) + 4 * tid;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dst[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) bst[NBUCKETS] = 0u;
+    }
 }
 
 // One workgroup = one read at a time (all blocks of it in block mode).
@@ -333,7 +354,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     uint32_t *bk_cnt = reinterpret_cast<uint32_t *>(sig);
     uint32_t bk_n = 0; // entries of the bottom-k running list (uniform)
 
-    for (uint32_t s = tid; s <= NBUCKETS; s += nthreads) bst[s] = 0;
+    bucket_clear(bst);
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
     if (tid == 0) { misc[M_NSCR] = 0; misc[M_FLAGS] = 0; misc[M_FLAGS + 1] = 0; *qmax_sh = H_INIT; }
     uint32_t flag_sel = 0; // uniform
@@ -447,7 +468,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                         uint64_t rk[KREG];
                         uint32_t rb[KREG];
 #pragma unroll
-                        for (int q = 0; q < KREG; q++) { rk[q] = 0; rb[q] = 0xFFFFFFFFu; }
+                        for (int q = 0; q < KREG; q++) rb[q] = 0xFFFFFFFFu; // (rk[q] is read only where rb[q] names a key)
 
                         const uint64_t round_len = rounds_mode ? (uint64_t) (cap / 2) : nk;
                         uint32_t carry_n = 0; // distinct (key, weight) pairs carried from earlier rounds (in scr_*)
@@ -689,7 +710,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 __syncthreads();
                                 carry_n = uniform_u32(misc[M_NSCR]);
                                 if (carry_n > cap - cap / 2) overflow = true; // no room for another round of new k-mers
-                                for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
+                                bucket_clear(bst);
                                 __syncthreads();
                             }
                             if (!overflow && last_round) {
@@ -778,7 +799,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 }
                             }
                             if (overflow || last_round) {
-                                for (uint32_t s2 = tid; s2 <= NBUCKETS; s2 += nthreads) bst[s2] = 0;
+                                bucket_clear(bst);
                                 if (tid == 0) misc[M_NSCR] = 0;
                                 lds_barrier(); // the points are final (-> signature row); bst is clean for the next pass
                                 phase(7); // B2 + clear
