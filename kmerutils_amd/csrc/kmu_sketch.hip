@@ -437,24 +437,26 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             }
         }
         const SeqView sv = nv_r == r ? nv : view_of(r);
-        const uint64_t L = sv.len;
-        const uint64_t nk_all = L >= (uint64_t) k ? L - k + 1 : 0;
+        // positions inside a read are 32-bit from here on (half the scalar registers, half the vector instructions per
+        // index computation); a single sequence of 2^31 bases or more is refused
+        if (sv.len >= 0x80000000ull && tid == 0) atomicOr(a.err, DERR_TABLE_FULL);
+        const uint32_t L = sv.len >= 0x80000000ull ? 0u : (uint32_t) sv.len;
+        const uint32_t nk_all = L >= (uint32_t) k ? L - (uint32_t) k + 1u : 0u;
         if (L == 0 && tid == 0 && !a.hashed_bytes) atomicOr(a.err, 8u); // an empty list of pre-hashed values is fine
         if (nk_all == 0 && !a.hashed_bytes && wave_validate_seq(sv, wave, nwaves, AA))
             atomicOr(a.err, AA ? DERR_BAD_AA : DERR_NON_ACGT);
         const uint32_t lead = AA ? 0u : seq_lead(sv);
         // blocks of the read (src/sketching/seqblocksketch.rs:108-146); whole read = one block
-        const uint64_t B = a.block_size ? a.block_size : (nk_all ? nk_all : 1);
-        const uint64_t nblocks = a.block_size ? (L + B - 1) / B : 1;
+        const uint32_t B = a.block_size ? a.block_size : (nk_all ? nk_all : 1u);
+        const uint32_t nblocks = a.block_size ? (uint32_t) (((uint64_t) L + B - 1) / B) : 1u;
         phase(0); // read header
-        for (uint64_t blk = 0; blk < nblocks; blk++) {
-            uint64_t pb = blk * B, pe = pb + B;
-            if (pb > nk_all) pb = nk_all;
-            if (pe > nk_all) pe = nk_all;
-            const uint64_t nk = pe - pb;
+        for (uint32_t blk = 0; blk < nblocks; blk++) {
+            const uint64_t pb64 = (uint64_t) blk * B, pe64 = pb64 + B;
+            const uint32_t pb = pb64 > nk_all ? nk_all : (uint32_t) pb64, pe = pe64 > nk_all ? nk_all : (uint32_t) pe64;
+            const uint32_t nk = pe - pb;
             // number of hash partitions: any P with nk / P comfortably below the dense capacity will do (the multiset is
             // exact for every P), so no 64-bit division: a product with the reciprocal, rounded up
-            uint32_t P = nk == 0 ? 0u : nk <= (uint64_t) a.part_target ? 1u : (uint32_t) ((double) nk * a.inv_part_target) + 1u;
+            uint32_t P = nk == 0 ? 0u : nk <= a.part_target ? 1u : (uint32_t) ((double) nk * a.inv_part_target) + 1u;
             if (ABL(64u)) P = 0;
             uint32_t bad = 0;
             bool full = false;
@@ -470,7 +472,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
 #pragma unroll
                         for (int q = 0; q < KREG; q++) rb[q] = 0xFFFFFFFFu; // (rk[q] is read only where rb[q] names a key)
 
-                        const uint64_t round_len = rounds_mode ? (uint64_t) (cap / 2) : nk;
+                        const uint32_t round_len = rounds_mode ? cap / 2 : nk;
                         uint32_t carry_n = 0; // distinct (key, weight) pairs carried from earlier rounds (in scr_*)
                         if (BOTTOMK && part > 0) { // the running list of the earlier partitions travels as carry
                             for (uint32_t i = tid; i < bk_n; i += nthreads) { st_scr(&scr_keys[i], bk_keys[i]); st_scr(&scr_w[i], bk_cnt[i]); }
@@ -478,8 +480,8 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             __syncthreads();
                         }
                         bool overflow = false; // uniform
-                        for (uint64_t q0 = pb; q0 < pe && !overflow; q0 += round_len) {
-                            const uint64_t q1 = q0 + round_len < pe ? q0 + round_len : pe;
+                        for (uint32_t q0 = pb; q0 < pe && !overflow; q0 += round_len) {
+                            const uint32_t q1 = pe - q0 > round_len ? q0 + round_len : pe;
                             const bool last_round = q1 == pe;
                             if (carry_n) { // carried pairs take their ranks first (misc[M_NSCR] is 0 between passes)
                                 if (tid == 0) misc[M_NSCR] = carry_n;
@@ -492,15 +494,15 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 __syncthreads(); // orders the scratch stores above
                             }
                             // ---- A1: bucket ranks of the keys of this partition in [q0, q1) ------------------------
-                            const uint64_t ntiles = AA ? 1 : (q1 - q0 + tile_pos - 1) >> a.tile_shift; // tile_pos is a power of two
-                            for (uint64_t tile = 0; tile < ntiles; tile++) {
-                                const uint64_t tp0 = AA ? q0 : q0 + tile * tile_pos;
-                                const uint64_t tp1 = AA ? q1 : (tp0 + tile_pos < q1 ? tp0 + tile_pos : q1);
-                                uint64_t wfirst = 0;
+                            const uint32_t ntiles = AA ? 1u : (uint32_t) (((uint64_t) (q1 - q0) + tile_pos - 1) >> a.tile_shift); // tile_pos is a power of two
+                            for (uint32_t tile = 0; tile < ntiles; tile++) {
+                                const uint32_t tp0 = AA ? q0 : q0 + tile * tile_pos;
+                                const uint32_t tp1 = AA ? q1 : (q1 - tp0 > tile_pos ? tp0 + tile_pos : q1);
+                                uint32_t wfirst = 0;
                                 if (!AA) {
                                     wfirst = (tp0 + lead) >> 4;
-                                    const uint64_t wlast = (tp1 - 1 + lead + (uint64_t) k - 1) >> 4;
-                                    const uint32_t nw = (uint32_t) (wlast - wfirst + 1) + 2;
+                                    const uint32_t wlast = (uint32_t) (((uint64_t) tp1 - 1 + lead + (uint64_t) k - 1) >> 4);
+                                    const uint32_t nw = (wlast - wfirst + 1) + 2;
                                     // the raw chunks of words [0, pf_nw) may have been parked here by the previous read
                                     const bool parked = pf_r == r && tp0 == 0 && (uint32_t) tid < pf_nw;
                                     pf_r = 0xFFFFFFFFu;
@@ -517,7 +519,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     lds_barrier();
                                 }
                                 phase(1); // read header + code words staged
-                                for (uint64_t pr = tp0; pr < tp1 && !ABL(4096u); pr += (uint64_t) KREG * nthreads) {
+                                for (uint32_t pr = tp0; pr < tp1 && !ABL(4096u); pr += (uint32_t) KREG * nthreads) {
                                     // Where a key waits for the scan: in registers (one pass over a read that fits: its first
                                     // KREG * nthreads positions), parked unsorted in the still unused dense arrays (a pass of
                                     // a partitioned read keeps 1/P of the positions it scans), else in the global scratch.
@@ -525,7 +527,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     const bool use_regs = !rounds_mode && !use_park && tile == 0 && pr == tp0;
 #pragma unroll
                                     for (int q = 0; q < KREG; q++) {
-                                        const uint64_t p = pr + (uint64_t) q * nthreads + tid;
+                                        const uint32_t p = pr + (uint32_t) q * nthreads + tid;
                                         if (p < tp1 && !ABL(32u)) {
                                             uint64_t val, rc = 0;
                                             if (AA && a.hashed_bytes) {
@@ -540,7 +542,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                                     val = (val << 5) | c;
                                                 }
                                             } else {
-                                                const uint32_t qq = (uint32_t) (p + lead - 16 * wfirst);
+                                                const uint32_t qq = p + lead - 16u * wfirst;
                                                 const uint32_t idx = qq >> 4, sh = (qq & 15u) * 2u;
                                                 const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
                                                 const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
