@@ -607,3 +607,26 @@ def test_two_kernel_probminhash_path(ctx, oracle, monkeypatch):
         ctx.profile_enable(False)
         assert "k_pmh_points" in ctx.profile_get()
         assert np.array_equal(got, oracle.sketch(bases, off, p))
+
+
+@pytest.mark.gpu
+def test_io_mirror_parse_and_blocks(ctx, oracle, tmp_path):
+    """kmerutils_amd.io: parse_with_needletail (src/io.rs:12-72) on a file, readblockseq batching
+    (datasketcher.rs:358-388) over the accepted reads"""
+    from kmerutils_amd import io as kio
+    rng = np.random.default_rng(12)
+    fq = _make_fastq(rng, 90, allow_empty=False)
+    fn = tmp_path / "reads.fastq"
+    fn.write_bytes(fq)
+    bases, offs, stats = kio.parse_with_needletail(str(fn), ctx=ctx)
+    wb, wo, winfo, _ = oracle.ingest_fastq(fq)
+    assert bytes(bases) == bytes(wb) and np.array_equal(offs, wo)
+    assert stats == dict(nb_rec_loaded=winfo["n_kept"], nb_bases=winfo["n_bases"], nb_bad_bases=winfo["nb_bad_bases"],
+                         nb_bad_read=winfo["nb_bad_reads"], nb_records=winfo["n_records"])
+    got = []
+    first = 0
+    while first < len(offs) - 1:   # blocks of 25 reads, like the pack-of-10 000 loop of datasketcher
+        b, o = kio.readblockseq(bases, offs, first, 25)
+        got += [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)]
+        first += len(o) - 1
+    assert got == [bytes(wb[int(wo[i]):int(wo[i + 1])]) for i in range(len(wo) - 1)]
