@@ -192,6 +192,7 @@ extern "C" int kmu_ingest_fastq(kmu_ctx *ctx, const uint8_t *text, uint64_t n_by
         return KMU_OK;
     }
     const uint8_t *d_text = text;
+    if (mem == KMU_MEM_DEVICE && ((uintptr_t) text & 15u) != 0) return fail(ctx, KMU_E_BAD_ARG, "device `text` must be 16-byte aligned");
     if (mem == KMU_MEM_HOST) {
         void *q;
         KMU_TRY(dev_buf(ctx, "ing.text", n_bytes + 64, &q));
