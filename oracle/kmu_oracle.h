@@ -10,7 +10,10 @@
  *   pinned   : alphabet / packing / k-mer values / reverse complement / iteration / ntHash / multiset /
  *              counting semantics / AA k-mers -- restated from source in the reference tree and checked against
  *              every known-answer test the reference holds for them (tests/test_oracle_kat.py).
- *   UNPINNED : Wang invertible hashes, xoshiro seeding, ProbMinHash3a, SuperMinHash, SuperMinHash2 internals.
+ *              Restated from source in the tree, without a reference KAT of their own (hand cases in
+ *              tests/test_oracle_kat.py): the FASTQ reader rule (io.rs / datasketcher.rs), the signature comparison
+ *              functions (seqsketchjaccard.rs, seqblocksketch.rs, minhash.rs).
+ *   UNPINNED : Wang invertible hashes, xoshiro seeding, ProbMinHash3a / ProbMinHash3, SuperMinHash, SuperMinHash2 internals.
  *              They live in the un-vendored crate `probminhash = "0.1"` (reference Cargo.toml:89), which is
  *              not in /root/reference and cannot be built here (no Rust toolchain).  They are restated from
  *              Ertl's papers (arXiv 1706.05698, 1911.00675) and the crate's structure as recalled; the
