@@ -630,3 +630,36 @@ def test_io_mirror_parse_and_blocks(ctx, oracle, tmp_path):
         got += [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)]
         first += len(o) - 1
     assert got == [bytes(wb[int(wo[i]):int(wo[i + 1])]) for i in range(len(wo) - 1)]
+
+
+@pytest.mark.gpu
+def test_datasketcher_tool_end_to_end(oracle, tmp_path):
+    """the datasketcher mirror: FASTQ file -> device ingest -> ProbMinHash3a -> the reference's dump format"""
+    from kmerutils_amd import datasketcher, formats
+    rng = np.random.default_rng(31)
+    fq = _make_fastq(rng, 60, allow_empty=False)
+    fn, dump = tmp_path / "r.fastq", tmp_path / "r.sig"
+    fn.write_bytes(fq)
+    assert datasketcher.main(["-f", str(fn), "-k", "8", "-s", "64", "-d", str(dump)]) == 0
+    wb, wo, _, _ = oracle.ingest_fastq(fq)
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, 8, 64, A.SIG_U32, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    want = oracle.sketch(wb, wo, p)
+    r = formats.SigSketchFileReader(str(dump))
+    assert (r.get_kmer_size(), r.get_signature_length()) == (8, 64)
+    assert np.array_equal(r.read_all(), want)
+    # by blocks of 1000 bases
+    bdump = tmp_path / "r.blk"
+    assert datasketcher.main(["-f", str(fn), "-k", "8", "-s", "32", "-d", str(bdump), "-b", "1000"]) == 0
+    pb = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, 8, 32, A.SIG_U32, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 1000, 0, 0, 0, 0)
+    wantb = oracle.sketch(wb, wo, pb)
+    rb = formats.SigBlockSketchFileReader(str(bdump))
+    rows = []
+    seq = 0
+    while True:
+        nxt = rb.next()
+        if nxt is None:
+            break
+        assert nxt[0] == seq
+        rows += [b[1] for b in nxt[1]]
+        seq += 1
+    assert seq == len(wo) - 1 and np.array_equal(np.array(rows), wantb)
