@@ -663,3 +663,29 @@ def test_datasketcher_tool_end_to_end(oracle, tmp_path):
         rows += [b[1] for b in nxt[1]]
         seq += 1
     assert seq == len(wo) - 1 and np.array_equal(np.array(rows), wantb)
+
+
+@pytest.mark.gpu
+def test_parsefastq_tool_end_to_end(oracle, tmp_path):
+    """the parsefastq mirror (counting branch): FASTQ file -> device ingest -> counts -> COUNTER_MULTIPLE dump"""
+    from kmerutils_amd import formats, parsefastq
+    rng = np.random.default_rng(41)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=3000).tobytes()
+    recs = []
+    for i in range(80):  # overlapping reads from one genome: many k-mers seen more than once
+        s = int(rng.integers(0, 2500))
+        seq = genome[s:s + int(rng.integers(100, 500))]
+        if i % 10 == 3:
+            seq = seq[:5] + b"N" + seq[6:]
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * len(seq))
+    fn = tmp_path / "g.fastq"
+    fn.write_bytes(b"\n".join(recs) + b"\n")
+    for k, kmer_type, vb in ((21, A.KMER64BIT, 8), (16, A.KMER16B32BIT, 4), (11, A.KMER32BIT, 4)):
+        assert parsefastq.main(["-f", str(fn), "-s", str(k), "--outdir", str(tmp_path)]) == 0
+        wb, wo, _, _ = oracle.ingest_fastq(fn.read_bytes())
+        oc = oracle.Counter(kmer_type, k, 8, 1 << 20)
+        oc.add_reads(wb, wo)
+        wk, wc = oc.dump(2)
+        ks, vals, cnts = formats.load_kmer_counter(str(tmp_path / "g.fastq.multi_kmer.bin"), vb)
+        order = np.argsort(vals)
+        assert ks == k and np.array_equal(vals[order], wk) and np.array_equal(cnts[order].astype(np.uint32), np.minimum(wc, 255))
