@@ -156,10 +156,26 @@ __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const 
     uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
     r_hint = r;
     const uint64_t g0 = widx * 16;
-    if (g0 < total) {
-        uint64_t rend = offsets[r + 1];
-        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
-        const int sh = 64 - 2 * k;
+    const bool in = g0 < total;
+    uint64_t rend = 0;
+    if (in) {
+        rend = offsets[r + 1];
+        while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
+    }
+    const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+    const int sh = 64 - 2 * k;
+    // A wave whose lanes all sit well inside a read (long reads: most waves) skips the per-k-mer boundary tests.
+    if (__all(!in || rend - g0 >= (uint64_t) (15 + k))) {
+        if (in) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
+                uint64_t val = v >> sh;
+                uint64_t rc = revcomp_val(val, k);
+                f(rc < val ? rc : val); // kmer.reverse_complement().min(kmer), kmercount.rs:938
+            }
+        }
+    } else if (in) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint64_t g = g0 + j;
@@ -168,7 +184,7 @@ __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const 
                 uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
                 uint64_t val = v >> sh;
                 uint64_t rc = revcomp_val(val, k);
-                f(rc < val ? rc : val); // kmer.reverse_complement().min(kmer), kmercount.rs:938
+                f(rc < val ? rc : val);
             }
         }
     }
@@ -521,10 +537,25 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
     uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
     r_hint = r;
     const uint64_t g0 = widx * 16;
-    if (g0 < total) {
-        uint64_t rend = offsets[r + 1];
-        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
-        const int sh = 64 - 2 * k;
+    const bool in = g0 < total;
+    uint64_t rend = 0;
+    if (in) {
+        rend = offsets[r + 1];
+        while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
+    }
+    const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+    const int sh = 64 - 2 * k;
+    if (__all(!in || rend - g0 >= (uint64_t) (15 + k))) { // every lane well inside a read: no per-k-mer boundary tests
+        if (in) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
+                uint64_t val = v >> sh;
+                uint64_t rc = revcomp_val(val, k);
+                it[j] = rc < val ? rc : val;
+            }
+        }
+    } else if (in) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint64_t g = g0 + j;
