@@ -45,6 +45,7 @@ struct SketchArgs {
     uint64_t *scr_keys;   // per-workgroup overflow scratch (keys that found no register slot): [grid][cap]
     uint32_t *scr_info;   //   (bucket << 16) | rank-or-position
     uint32_t *scr_w;      //   weight carried in (bottom-k running list), 1 otherwise
+    uint64_t *def_keys;   // per-workgroup list of the keys that belong to later partition passes: [grid][DEF_CAP]
     // bottom-k (MinHashCount, src/sketching/minhash.rs:62-99)
     int bk_shift;         // bucket = (key >> bk_shift) & 0xFFF: the 12 most significant *used* bits of the hash
     uint32_t bk_mask;     // count wrap mask: 0xFFFF (u16 counts) or 0xFF (MinInvHashCountKmer)
@@ -82,7 +83,8 @@ __device__ __forceinline__ uint32_t mix32(uint64_t key) {
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t) (((uint64_t) a * b) >> 32); }
 
 // misc words in LDS
-enum { M_READ = 0, M_NSCR = 1, M_NEXT = 2, M_QMAX = 4 /* 4,5: u64 */, M_FLAGS = 6 /* 6,7 */, M_WORDS = 8 };
+enum { M_READ = 0, M_NSCR = 1, M_NEXT = 2, M_DEF = 3, M_QMAX = 4 /* 4,5: u64 */, M_FLAGS = 6 /* 6,7 */, M_WORDS = 8 };
+static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions a workgroup can set aside per block
 #ifndef KMU_DIAG
 #define KMU_DIAG 0 // build with KMU_BUILD_DEFS=-DKMU_DIAG=1 for the KMU_PMH_ABLATE phase ablations / phase clocks
 #endif
@@ -349,6 +351,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     uint64_t *scr_keys = a.scr_keys + (uint64_t) blockIdx.x * cap;
     uint32_t *scr_info = a.scr_info + (uint64_t) blockIdx.x * cap;
     uint32_t *scr_w = a.scr_w + (uint64_t) blockIdx.x * cap;
+    uint64_t *def_keys = a.def_keys + (uint64_t) blockIdx.x * DEF_CAP;
     // bottom-k: the running list of the m smallest hashes re-uses the LDS of the (unused) slot minima
     uint64_t *bk_keys = hmin;
     uint32_t *bk_cnt = reinterpret_cast<uint32_t *>(sig);
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
 
     bucket_clear(bst);
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
-    if (tid == 0) { misc[M_NSCR] = 0; misc[M_FLAGS] = 0; misc[M_FLAGS + 1] = 0; *qmax_sh = H_INIT; }
+    if (tid == 0) { misc[M_NSCR] = 0; misc[M_DEF] = 0; misc[M_FLAGS] = 0; misc[M_FLAGS + 1] = 0; *qmax_sh = H_INIT; }
     uint32_t flag_sel = 0; // uniform
     // reads are taken from the global queue QCHUNK at a time (thread 0 keeps the cursor): one same-address atomic per
     // read would cap the whole grid at the L2's rate for a single address
@@ -462,8 +465,13 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             bool full = false;
             // k-mer occurrences of positions [q0, q1) that belong to partition `part` take a bucket rank; the first
             // KREG * nthreads positions of a SINGLE pass keep their key in registers, the rest goes to the scratch.
+            // A block that needs several partition passes is scanned (extracted, hashed) ONCE: pass 0 sets the keys of the
+            // later partitions aside in a global list, the later passes read their keys from there.
+            bool def_valid = false; // uniform
+            uint32_t def_n = 0;
             for (bool block_done = (P == 0); !block_done;) {
                 bool restart_block = false; // uniform
+                def_valid = false;
                 for (uint32_t part = 0; part < P && !restart_block; part++) {
                     bool rounds_mode = false; // uniform
                     for (bool part_done = false; !part_done;) {
@@ -494,7 +502,23 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 __syncthreads(); // orders the scratch stores above
                             }
                             // ---- A1: bucket ranks of the keys of this partition in [q0, q1) ------------------------
-                            const uint32_t ntiles = AA ? 1u : (uint32_t) (((uint64_t) (q1 - q0) + tile_pos - 1) >> a.tile_shift); // tile_pos is a power of two
+                            const bool defer_on = !BOTTOMK && P > 1 && part == 0 && !rounds_mode; // this pass fills the list
+                            const bool from_list = !BOTTOMK && part > 0 && !rounds_mode && def_valid;
+                            if (from_list) {
+                                for (uint32_t i = tid; i < def_n; i += nthreads) {
+                                    const uint64_t key = ld_scr(&def_keys[i]);
+                                    const uint32_t h = mix32(key);
+                                    if (mulhi32(h * 0x85EBCA6Bu, P) == part) {
+                                        const uint32_t b = h >> (32 - BUCKET_BITS);
+                                        const uint32_t rank = atomicAdd(&bst[b], 1u);
+                                        if (rank < 65536u) { // (a pass of a partitioned block parks its keys: use_park)
+                                            const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
+                                            if (si < (uint32_t) KREG * nthreads && si < cap) { dk[si] = key; dw[si] = (b << 16) | rank; }
+                                        }
+                                    }
+                                }
+                            }
+                            const uint32_t ntiles = from_list ? 0u : AA ? 1u : (uint32_t) (((uint64_t) (q1 - q0) + tile_pos - 1) >> a.tile_shift); // tile_pos is a power of two
                             for (uint32_t tile = 0; tile < ntiles; tile++) {
                                 const uint32_t tp0 = AA ? q0 : q0 + tile * tile_pos;
                                 const uint32_t tp1 = AA ? q1 : (q1 - tp0 > tile_pos ? tp0 + tile_pos : q1);
@@ -557,7 +581,13 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                                 if (BOTTOMK) key = hasher_finish(a.hasher, key, sig32);
                                                 h = mix32(key);
                                                 if (ABL(2u)) go = false;
-                                                if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) go = false;
+                                                if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) {
+                                                    go = false;
+                                                    if (defer_on) { // a later pass will pick it up without re-hashing
+                                                        const uint32_t di = atomicAdd(&misc[M_DEF], 1u);
+                                                        if (di < DEF_CAP) st_scr(&def_keys[di], key);
+                                                    }
+                                                }
                                             } else if (val == 0x1234567ull) full = true;
                                             if (go) {
                                                 const uint32_t b = BOTTOMK ? (uint32_t) (key >> a.bk_shift) & (NBUCKETS - 1)
@@ -579,6 +609,10 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                             if (tid == 0 && !next_posted) { misc[M_NEXT] = r_next; next_posted = true; }
                             __syncthreads();
+                            if (defer_on) { // the list is complete (every position was scanned), provided it fitted
+                                def_n = uniform_u32(misc[M_DEF]);
+                                def_valid = def_n <= DEF_CAP;
+                            }
                             // ---- A2: counts -> starts, dense placement ---------------------------------------------
                             phase(2); // A1
                             r_follow = uniform_u32(misc[M_NEXT]);
@@ -802,7 +836,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                             if (overflow || last_round) {
                                 bucket_clear(bst);
-                                if (tid == 0) misc[M_NSCR] = 0;
+                                if (tid == 0) { misc[M_NSCR] = 0; misc[M_DEF] = 0; }
                                 lds_barrier(); // the points are final (-> signature row); bst is clean for the next pass
                                 phase(7); // B2 + clear
                             }
@@ -1222,6 +1256,9 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         a.scr_keys = (uint64_t *) sk;
         a.scr_info = (uint32_t *) si;
         a.scr_w = (uint32_t *) sw;
+        void *dkq;
+        KMU_TRY(dev_buf(ctx, "pmh.def_keys", (size_t) grid * DEF_CAP * 8, &dkq));
+        a.def_keys = (uint64_t *) dkq;
         a.bk_keys = (uint64_t *) bk;
         a.bk_cnt = (uint32_t *) bc;
     }
