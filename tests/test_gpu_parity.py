@@ -689,3 +689,15 @@ def test_parsefastq_tool_end_to_end(oracle, tmp_path):
         ks, vals, cnts = formats.load_kmer_counter(str(tmp_path / "g.fastq.multi_kmer.bin"), vb)
         order = np.argsort(vals)
         assert ks == k and np.array_equal(vals[order], wk) and np.array_equal(cnts[order].astype(np.uint32), np.minimum(wc, 255))
+
+
+@pytest.mark.gpu
+def test_probminhash_megabase_read(ctx, oracle):
+    """a 1.3 Mbase sequence: > 100 partition passes, more keys set aside for later passes than the per-workgroup list
+    holds (the later passes then rescan the read), several staged tiles"""
+    rng = np.random.default_rng(55)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=1_300_000).tobytes(),
+            rng.choice(np.frombuffer(b"ACGT", np.uint8), size=25_000).tobytes()]
+    bases, off = oracle.concat(seqs)
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    assert np.array_equal(np.asarray(ctx.sketch(bases, off, p)), oracle.sketch(bases, off, p))
