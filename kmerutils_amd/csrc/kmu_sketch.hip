@@ -45,6 +45,7 @@ struct SketchArgs {
     uint64_t *scr_keys;   // per-workgroup overflow scratch (keys that found no register slot): [grid][cap]
     uint32_t *scr_info;   //   (bucket << 16) | rank-or-position
     uint32_t *scr_w;      //   weight carried in (bottom-k running list), 1 otherwise
+    uint32_t skip_longer; // != 0: sequences with more k-mers than this are left to the global (partitioned) path
     uint64_t *def_keys;   // per-workgroup list of the keys that belong to later partition passes: [grid][DEF_CAP]
     // bottom-k (MinHashCount, src/sketching/minhash.rs:62-99)
     int bk_shift;         // bucket = (key >> bk_shift) & 0xFFF: the 12 most significant *used* bits of the hash
@@ -90,6 +91,7 @@ static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions 
 #endif
 #define ABL(bits) (KMU_DIAG && (a.ablate & (bits)))
 
+static constexpr uint32_t LONG_SEQ_KMERS = 1u << 18; // longer sequences take the global partitioned route (kmu_sketch)
 static constexpr int BUCKET_BITS = 12;               // counting-sort buckets
 static constexpr uint32_t NBUCKETS = 1u << BUCKET_BITS;
 static constexpr int QCHUNK = 4;                     // reads taken from the queue per atomic
@@ -451,7 +453,8 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         const uint32_t lead = AA ? 0u : seq_lead(sv);
         // blocks of the read (src/sketching/seqblocksketch.rs:108-146); whole read = one block
         const uint32_t B = a.block_size ? a.block_size : (nk_all ? nk_all : 1u);
-        const uint32_t nblocks = a.block_size ? (uint32_t) (((uint64_t) L + B - 1) / B) : 1u;
+        uint32_t nblocks = a.block_size ? (uint32_t) (((uint64_t) L + B - 1) / B) : 1u;
+        if (a.skip_longer && nk_all > a.skip_longer) nblocks = 0; // its row comes from the global path
         phase(0); // read header
         for (uint32_t blk = 0; blk < nblocks; blk++) {
             const uint64_t pb64 = (uint64_t) blk * B, pe64 = pb64 + B;
@@ -1040,6 +1043,23 @@ __global__ void __launch_bounds__(256) k_pmh_reduce(const uint64_t *part_h, cons
     }
 }
 
+// longest sequence (single workgroup): out[0] = max_i (offsets[i + 1] - offsets[i])
+__global__ void __launch_bounds__(1024) k_max_len(const uint64_t *offsets, uint32_t n_seq, uint64_t *out) {
+    __shared__ uint64_t wmax[16];
+    uint64_t mx = 0;
+    for (uint32_t i = threadIdx.x; i < n_seq; i += blockDim.x) {
+        const uint64_t L = offsets[i + 1] - offsets[i];
+        mx = L > mx ? L : mx;
+    }
+    mx = wave_max_u64(mx);
+    if (lane_id() == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int) (blockDim.x >> 6); w++) mx = wmax[w] > mx ? wmax[w] : mx;
+        out[0] = mx;
+    }
+}
+
 // exclusive scan of the k-mer counts max(0, L_i - k + 1) of all sequences (single workgroup); koff[n] = total
 __global__ void __launch_bounds__(1024) k_nk_scan(const uint64_t *offsets, uint32_t n_seq, int k, uint64_t *koff,
                                                   uint32_t *err) {
@@ -1077,10 +1097,13 @@ __global__ void __launch_bounds__(1024) k_nk_scan(const uint64_t *offsets, uint3
 __global__ void __launch_bounds__(256) k_seq_hashes_compact(const uint8_t *bases, const uint64_t *offsets,
                                                             const uint64_t *packed_offsets, uint32_t n_seq, int packed,
                                                             uint64_t total, KmerCfg cfg, const uint64_t *koff, uint64_t *out,
-                                                            uint32_t *err) {
-    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+                                                            uint32_t *err, int spread) {
+    // spread = 0: one workgroup per sequence (many sequences); spread = 1: every sequence is walked by the whole grid
+    // (a few long sequences, e.g. the contigs of a genome)
+    const int wave = spread ? (int) (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : (int) (threadIdx.x >> 6);
+    const int nwaves = spread ? (int) (gridDim.x * (blockDim.x >> 6)) : (int) (blockDim.x >> 6);
     const bool aa = cfg.kmer_type == KMU_KMERAA32BIT || cfg.kmer_type == KMU_KMERAA64BIT;
-    for (uint32_t i = blockIdx.x; i < n_seq; i += gridDim.x) {
+    for (uint32_t i = spread ? 0u : blockIdx.x; i < n_seq; i += spread ? 1u : gridDim.x) {
         SeqView s;
         s.base = bases;
         s.len = offsets[i + 1] - offsets[i];
@@ -1151,10 +1174,12 @@ int launch_super_reduce(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t
 
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
                         void *d_sig, uint32_t *d_counts, uint32_t *d_err, const void *hashed = nullptr,
-                        int hashed_bytes = 0, uint64_t *part_h = nullptr, uint64_t *part_k = nullptr) {
+                        int hashed_bytes = 0, uint64_t *part_h = nullptr, uint64_t *part_k = nullptr,
+                        uint32_t skip_longer = 0) {
     const bool bottomk = p->algo == KMU_ALGO_BOTTOMK;
     SketchArgs a;
     memset(&a, 0, sizeof a);
+    a.skip_longer = skip_longer;
     a.hashed = hashed;
     a.hashed_bytes = hashed_bytes;
     a.part_h = part_h;
@@ -1193,7 +1218,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     // HBM, k_pmh_points (one wave per read, full occupancy) generates the points.  3 % faster on the ONT workload
     // (100.4 vs 103.1 ms) for ~100 GB of extra HBM traffic and 12 bytes of scratch per base, so it is not the default.
     const char *split_env = getenv("KMU_PMH_SPLIT");
-    const bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 &&
+    const bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 && !skip_longer &&
                        (size_t) 4 * (2 * (size_t) p->sketch_size + 200) * 8 <= 146 * 1024 && // four waves' slot arrays fit one workgroup
                        split_env && atoi(split_env) == 1;
     const sketch_kernel_t kern = bottomk ? (aa ? k_sketch_pmh3a<true, true> : k_sketch_pmh3a<false, true>)
@@ -1432,17 +1457,67 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
         KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &hk));
         if (n_seq) {
             KmerCfg cfg{p->kmer_type, p->kmer_size, p->fhash};
-            int grid = (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
+            const int spread = n_seq < (uint32_t) ctx->num_cus * 4 ? 1 : 0;
+            int grid = spread ? ctx->num_cus * 8 : (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
             KernelTimer t(ctx, "k_seq_hashes_compact");
             hipLaunchKernelGGL(k_seq_hashes_compact, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets,
                                ds.packed_offsets, n_seq, ds.packed, ds.total_bytes, cfg, (const uint64_t *) koff,
-                               (uint64_t *) hk, d_err);
+                               (uint64_t *) hk, d_err, spread);
         }
         KMU_HIP(ctx, hipGetLastError());
         KMU_TRY(sketch_all_hashed(ctx, p, (const uint64_t *) hk, n_items, d_sig, d_err));
     } else if (n_seq) {
         switch (p->algo) {
-        case KMU_ALGO_PROB3A: KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err)); break;
+        case KMU_ALGO_PROB3A: {
+            // Sequences far longer than one LDS pass (genomes, not reads) would take L / cap passes in the per-sequence
+            // kernel.  They go through the same global route as a sketch over all sequences -- hashes, radix partition
+            // into leaves, per-leaf slot minima, merge -- one sequence at a time, which is linear in L.
+            uint32_t skip_longer = 0;
+            std::vector<uint32_t> long_seqs;
+            if (p->block_size == 0) {
+                void *mx;
+                KMU_TRY(dev_buf(ctx, "pmh.maxlen", 64, &mx));
+                hipLaunchKernelGGL(k_max_len, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, (uint64_t *) mx);
+                uint64_t max_len = 0;
+                KMU_HIP(ctx, hipMemcpyAsync(&max_len, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (max_len > (uint64_t) LONG_SEQ_KMERS + (uint64_t) p->kmer_size) {
+                    std::vector<uint64_t> h_off((size_t) n_seq + 1);
+                    KMU_HIP(ctx, hipMemcpyAsync(h_off.data(), ds.offsets, ((size_t) n_seq + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    for (uint32_t i = 0; i < n_seq; i++) {
+                        const uint64_t L = h_off[i + 1] - h_off[i];
+                        if (L >= (uint64_t) p->kmer_size && L - p->kmer_size + 1 > LONG_SEQ_KMERS) long_seqs.push_back(i);
+                    }
+                    skip_longer = LONG_SEQ_KMERS;
+                }
+            }
+            KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err, nullptr, 0, nullptr, nullptr, skip_longer));
+            for (uint32_t i : long_seqs) {
+                DevSeqs one = ds;
+                one.offsets = ds.offsets + i;
+                one.packed_offsets = ds.packed_offsets ? ds.packed_offsets + i : nullptr;
+                one.n_seq = 1;
+                void *koff, *hk;
+                KMU_TRY(dev_buf(ctx, "all.koff", 2 * 8 + 64, &koff));
+                hipLaunchKernelGGL(k_nk_scan, dim3(1), dim3(1024), 0, ctx->stream, one.offsets, 1u, p->kmer_size, (uint64_t *) koff, d_err);
+                uint64_t n_items = 0;
+                KMU_HIP(ctx, hipMemcpyAsync(&n_items, (uint64_t *) koff + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &hk));
+                KmerCfg cfg{p->kmer_type, p->kmer_size, p->fhash};
+                {
+                    KernelTimer t(ctx, "k_seq_hashes_compact");
+                    hipLaunchKernelGGL(k_seq_hashes_compact, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, one.bases, one.offsets,
+                                       one.packed_offsets, 1u, one.packed, one.total_bytes, cfg, (const uint64_t *) koff,
+                                       (uint64_t *) hk, d_err, 1);
+                }
+                KMU_HIP(ctx, hipGetLastError());
+                KMU_TRY(sketch_all_hashed(ctx, p, (const uint64_t *) hk, n_items,
+                                          reinterpret_cast<uint8_t *>(d_sig) + (size_t) i * p->sketch_size * sigb, d_err));
+            }
+            break;
+        }
         case KMU_ALGO_SUPER:
         case KMU_ALGO_SUPER2: KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err, nullptr, 0, nullptr)); break;
         case KMU_ALGO_BOTTOMK: KMU_TRY(launch_pmh3a(ctx, p, ds, nullptr, d_sig, d_counts, d_err)); break;

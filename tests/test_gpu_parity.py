@@ -701,3 +701,27 @@ def test_probminhash_megabase_read(ctx, oracle):
     bases, off = oracle.concat(seqs)
     p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
     assert np.array_equal(np.asarray(ctx.sketch(bases, off, p)), oracle.sketch(bases, off, p))
+
+
+@pytest.mark.gpu
+def test_probminhash_genome_sized_sequences(ctx, oracle):
+    """sequences far beyond one LDS pass (genomes rather than reads) take the global partitioned route inside
+    kmu_sketch; rows of ordinary reads in the same call are unaffected; device-resident input as well"""
+    import time
+    import torch
+    rng = np.random.default_rng(56)
+    lens = (3_000, 2_600_000, 40_000, 700_000, 500)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n).tobytes() for n in lens]
+    bases, off = oracle.concat(seqs)
+    for kmer_type, k, sig in ((A.KMER64BIT, 21, A.SIG_U64), (A.KMER32BIT, 12, A.SIG_U32)):
+        p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, 128, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        want = oracle.sketch(bases, off, p)
+        t0 = time.perf_counter()
+        got = np.asarray(ctx.sketch(bases, off, p))
+        dt = time.perf_counter() - t0
+        assert np.array_equal(got, want)
+        assert dt < 2.0, "a 2.6 Mbase sequence must not take L / cap passes (%.2f s)" % dt
+        db, do = torch.from_numpy(bases.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        g2 = ctx.sketch(db, do, p)
+        ctx.synchronize()
+        assert np.array_equal(g2.cpu().numpy().view(want.dtype), want)
