@@ -53,41 +53,33 @@ def build(force=False, verbose=False):
     return OUT
 
 
-# ---- host side above the C-ABI (C++, g++): the two tools and the mirror's test program --------------------------------
+# ---- host side above the C-ABI (C++, g++): the two tools ----------------------------------------------------------------
 ROOT = os.path.dirname(HERE)
 BIN = os.path.join(HERE, "bin")
-HOST_PROGRAMS = {  # output -> (source, needs the oracle library)
-    os.path.join(BIN, "datasketcher"): (os.path.join(HERE, "tools", "datasketcher.cpp"), False),
-    os.path.join(BIN, "parsefastq"): (os.path.join(HERE, "tools", "parsefastq.cpp"), False),
-    os.path.join(ROOT, "tests", "cpp", "_build", "test_mirror"): (os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp"), True),
+HOST_PROGRAMS = {
+    os.path.join(BIN, "datasketcher"): os.path.join(HERE, "tools", "datasketcher.cpp"),
+    os.path.join(BIN, "parsefastq"): os.path.join(HERE, "tools", "parsefastq.cpp"),
 }
 
 
-def build_host(force=False, verbose=False):
-    """g++ the host programs against libkmu.so (and, for the test program only, the oracle library)."""
-    build()
+def compile_host(src, out, extra=(), force=False, verbose=False, deps=()):
+    """g++ one host program against libkmu.so (rpath relative to the program, so the tree can move)"""
     hdr = os.path.join(ROOT, "include", "kmerutils.hpp")
-    oracle_so = os.path.join(ROOT, "oracle", "_build", "libkmu_oracle.so")
-    outs = []
-    for out, (src, with_oracle) in HOST_PROGRAMS.items():
-        if with_oracle and not os.path.exists(oracle_so):
-            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-        deps = [src, hdr, OUT] + ([oracle_so] if with_oracle else [])
-        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
-            outs.append(out)
-            continue
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        rel = os.path.relpath(HERE, os.path.dirname(out))
-        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", src, "-o", out, "-L" + HERE, "-lkmu",
-               "-Wl,-rpath,$ORIGIN/" + rel, "-Wl,-rpath-link,/opt/rocm/lib"]
-        if with_oracle:
-            cmd += ["-L" + os.path.dirname(oracle_so), "-lkmu_oracle",
-                    "-Wl,-rpath,$ORIGIN/" + os.path.relpath(os.path.dirname(oracle_so), os.path.dirname(out))]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        outs.append(out)
-    return outs
+    deps = [src, hdr, OUT] + list(deps)
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", src, "-o", out, "-L" + HERE, "-lkmu",
+           "-Wl,-rpath,$ORIGIN/" + os.path.relpath(HERE, os.path.dirname(out)), "-Wl,-rpath-link,/opt/rocm/lib"] + list(extra)
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_host(force=False, verbose=False):
+    build()
+    return [compile_host(src, out, force=force, verbose=verbose) for out, src in HOST_PROGRAMS.items()]
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@ import os
 import re
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -13,7 +14,10 @@ from kmerutils_amd import build as kbuild
 from kmerutils_amd import formats
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TEST_BIN = os.path.join(ROOT, "tests", "cpp", "_build", "test_mirror")
+sys.path.insert(0, os.path.join(ROOT, "tests", "cpp"))
+import build_mirror as cppbuild  # noqa: E402  (tests/cpp/build_mirror.py)
+
+TEST_BIN = cppbuild.TEST_BIN
 DATASKETCHER = os.path.join(ROOT, "kmerutils_amd", "bin", "datasketcher")
 PARSEFASTQ = os.path.join(ROOT, "kmerutils_amd", "bin", "parsefastq")
 
@@ -24,7 +28,7 @@ with open(os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp")) as _f:
 @pytest.fixture(scope="module")
 def host_programs():
     kbuild.build_host()
-    return TEST_BIN
+    return cppbuild.build()
 
 
 def test_host_programs_build_and_refuse_to_run_without_a_device(host_programs):
