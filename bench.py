@@ -233,16 +233,39 @@ def main():
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": _describe(cfg, n_reads, total_bases), "reads_per_gpu": n_reads,
+            "config": {"workload": _describe(cfg, n_reads, total_bases), "workload_name": cfg["name"], "reads_per_gpu": n_reads,
                        "bases_per_gpu": total_bases, "kmers_per_gpu": nk, "k": cfg["k"], "sketch_size": cfg["m"],
                        "sketch": cfg["sketch"], "count": cfg["count"], "parallelism": "reads sharded x%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
+            "roofline": roofline, "alu": pmc_alu(cfg, total_bases, dom, kern[dom]["avg_ms"]) if dom else None,
+            "cpu_baseline": cpu, "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
             "checks": checks, "gen_seconds": t_gen,
         }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0  # wave-instructions / s: 256 CUs x 4 SIMDs, one full-rate VALU instruction per 4 cycles at 2.4 GHz
+
+
+def pmc_alu(cfg, total_bases, kernel, avg_ms):
+    """Instruction-issue view of an ALU-bound kernel, next to the HBM roofline the tier asks for: vector wave-instructions
+    per launch from the committed PMC pass (SQ_INSTS_VALU) / the launch time measured in this run, against the chip's
+    full-rate VALU issue peak.  null when the committed profile is not of this workload and size."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(path))
+        if d.get("workload") == cfg["name"] and abs(d.get("bases_per_gpu", 0) - total_bases) < 1e-3 * total_bases:
+            k = d["kernels"].get(kernel, {})
+            valu = k.get("SQ_INSTS_VALU_per_launch")
+            if valu and avg_ms:
+                ach = valu / (avg_ms * 1e-3)
+                return {"bound": "valu-issue", "valu_wave_insts": valu, "salu_wave_insts": k.get("SQ_INSTS_SALU_per_launch"),
+                        "achieved": ach, "peak": VALU_ISSUE_PEAK, "unit": "wave-inst/s", "frac": ach / VALU_ISSUE_PEAK}
+    except Exception:
+        pass
+    return None
 
 
 def pmc_traffic(cfg, total_bases, kernel):

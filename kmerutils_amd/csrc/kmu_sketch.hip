@@ -19,8 +19,6 @@
 
 namespace kmu {
 
-static constexpr uint64_t KEY_EMPTY = 0xFFFFFFFFFFFFFFFFull; // LDS table sentinel (the one real key equal to it is
-                                                             // counted in a side word)
 static constexpr uint64_t H_INIT = 0x7FEFFFFFFFFFFFFFull;    // bits of f64::MAX (MaxValueTracker initial value)
 static constexpr uint64_t H_BUSY = 0xFFFFFFFFFFFFFFFEull;    // slot being updated
 
@@ -1043,21 +1041,15 @@ __global__ void __launch_bounds__(256) k_pmh_reduce(const uint64_t *part_h, cons
     }
 }
 
-// longest sequence (single workgroup): out[0] = max_i (offsets[i + 1] - offsets[i])
+// longest sequence: out[0] = max_i (offsets[i + 1] - offsets[i]); out[0] must be 0 on entry
 __global__ void __launch_bounds__(1024) k_max_len(const uint64_t *offsets, uint32_t n_seq, uint64_t *out) {
-    __shared__ uint64_t wmax[16];
     uint64_t mx = 0;
-    for (uint32_t i = threadIdx.x; i < n_seq; i += blockDim.x) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_seq; i += gridDim.x * blockDim.x) {
         const uint64_t L = offsets[i + 1] - offsets[i];
         mx = L > mx ? L : mx;
     }
     mx = wave_max_u64(mx);
-    if (lane_id() == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int) (blockDim.x >> 6); w++) mx = wmax[w] > mx ? wmax[w] : mx;
-        out[0] = mx;
-    }
+    if (lane_id() == 0 && mx) atomicMax((unsigned long long *) out, (unsigned long long) mx);
 }
 
 // exclusive scan of the k-mer counts max(0, L_i - k + 1) of all sequences (single workgroup); koff[n] = total
@@ -1477,7 +1469,9 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
             if (p->block_size == 0) {
                 void *mx;
                 KMU_TRY(dev_buf(ctx, "pmh.maxlen", 64, &mx));
-                hipLaunchKernelGGL(k_max_len, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, (uint64_t *) mx);
+                KMU_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
+                const uint32_t mgrid = (uint32_t) std::min<uint64_t>(((uint64_t) n_seq + 1023) / 1024, (uint64_t) ctx->num_cus);
+                hipLaunchKernelGGL(k_max_len, dim3(mgrid ? mgrid : 1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, (uint64_t *) mx);
                 uint64_t max_len = 0;
                 KMU_HIP(ctx, hipMemcpyAsync(&max_len, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
                 KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));

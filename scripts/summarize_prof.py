@@ -2,7 +2,8 @@
 """Turn rocprofv3 output directories (gpurun_out/<name>_{trace,fetch,write}) into the small summaries committed
 under profiles/: kernel stats (our kernels + the largest others) and per-launch HBM traffic from the PMC passes.
 
-usage: scripts/summarize_prof.py <tag> <trace_dir> [<fetch_dir> <write_dir>]
+usage: scripts/summarize_prof.py <tag> <trace_dir> [<fetch_dir> <write_dir> [<insts_dir>]]
+With --bench <bench line of the traced run> the PMC summary is also written to profiles/pmc_latest.json (what bench.py reads).
 """
 import collections
 import csv
@@ -48,7 +49,25 @@ def main():
             streaming = not k.startswith("k_count_add")
             v["fetch_correction"] = 2.0 if streaming else 1.0
             v["hbm_bytes_per_launch"] = (f_kb * v["fetch_correction"] + w_kb) * 1024.0
+        if len(sys.argv) >= 6 and not sys.argv[5].startswith("--"):
+            # wave-instructions issued per launch (summed over the XCDs / shader engines the counter is sampled on)
+            acc = collections.defaultdict(lambda: collections.defaultdict(float))
+            cnt = collections.defaultdict(collections.Counter)
+            for r in csv.DictReader(open(glob.glob(os.path.join(sys.argv[5], "*", "*_counter_collection.csv"))[0])):
+                if "kmu::" in r["Kernel_Name"].split("(")[0]:
+                    k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kmu::", "").strip()
+                    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                    cnt[k][r["Counter_Name"]] += 1
+            for k in acc:
+                for name in acc[k]:
+                    pmc.setdefault(k, {})[name + "_per_launch"] = acc[k][name] / cnt[k][name]
         json.dump(pmc, open(os.path.join(out_dir, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
+        if "--bench" in sys.argv:  # the bench line of the traced run names the workload the counters belong to
+            b = json.loads(open(sys.argv[sys.argv.index("--bench") + 1]).readline())
+            json.dump({"round": tag, "source": "scripts/pmc_bench.sh", "workload": b["config"]["workload_name"],
+                       "bases_per_gpu": b["config"]["bases_per_gpu"], "kernels": pmc},
+                      open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+            json.dump(b, open(os.path.join(out_dir, "%s_bench.json" % tag), "w"))
     print(open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag)).read())
     print(json.dumps(pmc, indent=1))
 
