@@ -843,10 +843,12 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     else { pl.b1 = (pl.region_bits + 1) / 2; pl.b2 = pl.region_bits - pl.b1; }
     if (pl.b1 > 11 || pl.b2 > 11) return fail(ctx, KMU_E_UNSUPPORTED, "table too large for the two-level partitioned build");
     bool dbg_split = false;
-    if (const char *e = getenv("KMU_DBG_SPLIT")) { // timing experiments only: incomplete partition, no build
+#if KMU_DIAG // timing experiments of diagnostic builds only (scripts/dbg_split.sh): incomplete partition, no build
+    if (const char *e = getenv("KMU_DBG_SPLIT")) {
         int x = 0, y = 0;
         if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 1 && x <= 11 && y >= 1 && y <= 11 && x + y <= pl.region_bits) { pl.b1 = x; pl.b2 = y; pl.region_bits = x + y; dbg_split = true; }
     }
+#endif
     const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
     const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
     uint32_t units1 = (uint32_t) std::min<uint64_t>(nsteps, (uint64_t) ctx->num_cus * 8);
@@ -855,7 +857,9 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     units1 = (uint32_t) ((nsteps + pl.steps_per_unit - 1) / pl.steps_per_unit);
     pl.units1 = units1;
     pl.chunks2 = pl.b2 ? std::max<uint32_t>(1u, 16384u / bins1) : 1u;
+#if KMU_DIAG
     if (const char *e = getenv("KMU_DBG_CHUNKS2")) pl.chunks2 = (uint32_t) std::max(1, atoi(e));
+#endif
     const uint32_t units2 = bins1 * pl.chunks2;
     const uint64_t n_regions = 1ull << pl.region_bits;
 

@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "../../include/kmu.h"
+#ifndef KMU_DIAG
+#define KMU_DIAG 0 // diagnostic builds only (KMU_BUILD_DEFS=-DKMU_DIAG=1): phase ablations / clocks, partition experiments
+#endif
 
 struct kmu_ctx {
     int device = 0;

@@ -84,9 +84,6 @@ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (ui
 // misc words in LDS
 enum { M_READ = 0, M_NSCR = 1, M_NEXT = 2, M_DEF = 3, M_QMAX = 4 /* 4,5: u64 */, M_FLAGS = 6 /* 6,7 */, M_WORDS = 8 };
 static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions a workgroup can set aside per block
-#ifndef KMU_DIAG
-#define KMU_DIAG 0 // build with KMU_BUILD_DEFS=-DKMU_DIAG=1 for the KMU_PMH_ABLATE phase ablations / phase clocks
-#endif
 #define ABL(bits) (KMU_DIAG && (a.ablate & (bits)))
 
 static constexpr uint32_t LONG_SEQ_KMERS = 1u << 18; // longer sequences take the global partitioned route (kmu_sketch)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a diagnostics build: KMU_BUILD_DEFS=-DKMU_DIAG=1 python kmerutils_amd/build.py --force
 # diagnostics: level-2 scatter time against the number of units per level-1 partition
 cd $GRAFT_REPO_ROOT
 for c in ${CHUNKS:-1 2 4 8 16 32 64}; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a diagnostics build: KMU_BUILD_DEFS=-DKMU_DIAG=1 python kmerutils_amd/build.py --force
 # diagnostics: scatter pass time against the partition fan-out (incomplete partitions, the table is not built)
 cd $GRAFT_REPO_ROOT
 SPLITS=${SPLITS:-11,10 10,10 9,9 8,8 7,7 6,6}

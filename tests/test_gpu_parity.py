@@ -725,3 +725,15 @@ def test_probminhash_genome_sized_sequences(ctx, oracle):
         g2 = ctx.sketch(db, do, p)
         ctx.synchronize()
         assert np.array_equal(g2.cpu().numpy().view(want.dtype), want)
+        # the same sequences packed as Sequence::new(raw, 2) (what the C++ mirror's Sequence hands over)
+        packed, poff = ctx.pack2b(bases, off)
+        pp = A.SketchParams.from_buffer_copy(p)
+        pp.input_kind = A.INPUT_PACKED2
+        assert np.array_equal(np.asarray(ctx.sketch(packed, off, pp, packed_offsets=poff)), want)
+    # other sketches of a genome-sized sequence stay on their own kernels: SuperMinHash, bottom-k
+    ps = A.SketchParams(A.ALGO_SUPER, A.KMER64BIT, 21, 64, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    assert np.array_equal(np.asarray(ctx.sketch(bases, off, ps)), oracle.sketch(bases, off, ps))
+    pb = A.SketchParams(A.ALGO_BOTTOMK, A.KMER64BIT, 21, 100, A.SIG_U64, A.HASHER_INT64HASH, A.FHASH_CANON_VALUE, 0, 0, 0, 0, 0)
+    gh, gc = ctx.sketch(bases, off, pb, want_counts=True)
+    wh, wc = oracle.sketch(bases, off, pb, want_counts=True)
+    assert np.array_equal(np.asarray(gh), wh) and np.array_equal(np.asarray(gc), wc)
