@@ -1094,14 +1094,18 @@ inline detail::Batch batch_of(const FastqReads &r, size_t first, size_t last) {
     return b;
 }
 
-inline FastqReads parse_fastq_text(const uint8_t *text, size_t n, Context &ctx = Context::global()) {
+/// FASTQ or FASTA by the first byte, like needletail::parse_fastx_file (io.rs:37)
+inline FastqReads parse_fastx_text(const uint8_t *text, size_t n, Context &ctx = Context::global()) {
     FastqReads r;
-    ctx.check(kmu_ingest_fastq(ctx.raw(), text, n, KMU_MEM_HOST, nullptr, 0, nullptr, 0, nullptr, &r.info));
+    ctx.check(kmu_ingest_fastx(ctx.raw(), text, n, KMU_MEM_HOST, nullptr, 0, nullptr, 0, nullptr, &r.info));
     r.bases.resize(r.info.kept_bases + 16);
     r.offsets.resize(r.info.n_kept + 1);
-    ctx.check(kmu_ingest_fastq(ctx.raw(), text, n, KMU_MEM_HOST, r.bases.data(), r.bases.size(), r.offsets.data(),
+    ctx.check(kmu_ingest_fastx(ctx.raw(), text, n, KMU_MEM_HOST, r.bases.data(), r.bases.size(), r.offsets.data(),
                                r.offsets.size(), nullptr, &r.info));
     return r;
+}
+inline FastqReads parse_fastq_text(const uint8_t *text, size_t n, Context &ctx = Context::global()) {
+    return parse_fastx_text(text, n, ctx);
 }
 
 inline FastqReads parse_fastq_file(const std::string &fname, Context &ctx = Context::global()) {

@@ -240,7 +240,8 @@ int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint6
 int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts);
 
 /* ---- L-1 ingest: the step before the path ----------------------------------------------------
- * FASTQ text (4-line records, "\n" or "\r\n") -> the accepted reads as (bases, offsets), in file order.
+ * FASTQ / FASTA text -> the accepted reads as (bases, offsets), in file order.  kmu_ingest_fastq: 4-line records,
+ * "\n" or "\r\n".
  * Rule of the reference's readers: a record with any byte outside ACGTacgt is dropped and counted
  * (readblockseq, src/bin/datasketcher.rs:358-388; parse_with_needletail, src/io.rs:37-57).
  * Call with bases_out == offsets_out == NULL to get the sizes in *info, then with buffers of at least
@@ -256,6 +257,16 @@ typedef struct kmu_ingest_info {
     uint64_t nb_bad_reads; /* dropped records             (io.rs:47, datasketcher.rs:368) */
 } kmu_ingest_info;
 int kmu_ingest_fastq(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out, uint64_t bases_cap,
+                     uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out, kmu_ingest_info *info);
+
+/* FASTA, needletail's other format (what gsearch feeds): a line that starts with '>' opens a record; its sequence is the
+ * following lines up to the next such line with the line ends removed (record.seq()).  Same rule, outputs and calling
+ * convention as kmu_ingest_fastq.  KMU_E_BAD_ARG if the text does not start with '>'. */
+int kmu_ingest_fasta(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out, uint64_t bases_cap,
+                     uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out, kmu_ingest_info *info);
+/* needletail::parse_fastx_file (src/io.rs:37, src/bin/datasketcher.rs:211): the first byte names the format,
+ * '>' FASTA, '@' FASTQ; anything else is KMU_E_BAD_ARG.  (Compressed input is not handled: decompress first.) */
+int kmu_ingest_fastx(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out, uint64_t bases_cap,
                      uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out, kmu_ingest_info *info);
 
 /* ---- L4 signature comparison: what the callers do with the signatures next --------------------

@@ -9,8 +9,13 @@
 //      its end (a preceding '\r' is dropped); the first bytes of header and separator lines are checked ('@', '+')
 //   3. filter: non-ACGT bytes per record (same 16-bytes-per-lane classifier as the kernels of the path)
 //   4. scans of the keep flags and kept lengths, then a copy of the kept reads into one dense array.
-// Four-line FASTQ records only (what the ONT / Illumina inputs of the reference's tools are); multi-line FASTA is
-// not handled.
+// FASTQ: four-line records (what needletail accepts).  FASTA (kmu_ingest_fasta; needletail's other format, what gsearch
+// feeds): a line that starts with '>' opens a record, the lines up to the next such line are its sequence with the line
+// ends ("\n", "\r\n") removed -- record.seq() of needletail.  The device version numbers the lines as above, marks
+// header lines, scans header flags and sequence-line lengths, joins the sequence lines into one dense stream (every
+// region of the text walked by one wave, whatever the line lengths: 60-column genomes and one-line chromosomes alike),
+// and hands the stream with its record bounds to steps 3 and 4.  kmu_ingest_fastx picks the format from the first byte
+// like needletail::parse_fastx_file.
 #include <algorithm>
 
 #include "kmu_ctx.hpp"
@@ -172,78 +177,116 @@ __global__ void __launch_bounds__(256) k_ing_copy(const uint8_t *text, const uin
     if (blockIdx.x == 0 && threadIdx.x == 0) offsets_out[rank[n_records]] = out_off[n_records];
 }
 
+// ---- FASTA ---------------------------------------------------------------------------------------------------------------
+enum : uint32_t { IERR_FASTA_START = 4u };
+
+// line l occupies text[line_start[l], line_end[l]) (line end and a preceding '\r' excluded); is_hdr[l] = starts with '>'
+__global__ void __launch_bounds__(256) k_fa_lines(const uint8_t *text, uint64_t n, uint64_t n_regions, const uint64_t *line_base,
+                                                  uint64_t n_lines, uint64_t *line_start, uint64_t *line_end, uint32_t *is_hdr) {
+    const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave_global; r < n_regions; r += nwaves) {
+        uint64_t line = line_base[r];
+        for (uint32_t s = 0; s < ING_REGION; s += 1024) {
+            const uint64_t pos0 = r * ING_REGION + s + 16u * (uint32_t) lane_id();
+            uint32_t mask = newline_mask16(text, pos0, n);
+            const uint32_t c = (uint32_t) __popc(mask);
+            const uint32_t incl = wave_incl_scan_u32(c);
+            uint64_t l = line + incl - c;
+            line += (uint64_t) bcast_u32(incl, 63);
+            while (mask) {
+                const uint32_t j = (uint32_t) __ffs((int) mask) - 1u;
+                mask &= mask - 1u;
+                const uint64_t p = pos0 + j; // this newline ends line l
+                line_end[l] = (p > 0 && text[p - 1] == '\r') ? p - 1 : p;
+                if (l + 1 < n_lines) {
+                    line_start[l + 1] = p + 1;
+                    is_hdr[l + 1] = text[p + 1] == '>';
+                }
+                l++;
+            }
+        }
+    }
+    if (wave_global == 0 && lane_id() == 0) {
+        line_start[0] = 0;
+        is_hdr[0] = text[0] == '>';
+        if (text[n - 1] != '\n') line_end[n_lines - 1] = n; // last line without a line end
+    }
+}
+
+// bytes a line contributes to the sequence stream
+__global__ void __launch_bounds__(256) k_fa_lens(const uint64_t *line_start, const uint64_t *line_end, const uint32_t *is_hdr,
+                                                 uint64_t n_lines, uint64_t *seqlen) {
+    for (uint64_t l = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; l < n_lines; l += (uint64_t) gridDim.x * blockDim.x)
+        seqlen[l] = is_hdr[l] ? 0ull : line_end[l] - line_start[l];
+}
+
+// record r (the r-th header line) owns stream[rec_start[r], rec_end[r])
+__global__ void __launch_bounds__(256) k_fa_records(const uint32_t *is_hdr, const uint64_t *hdr_rank, const uint64_t *seqpos,
+                                                    uint64_t n_lines, uint64_t n_records, uint64_t *rec_start, uint64_t *rec_end) {
+    for (uint64_t l = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; l < n_lines; l += (uint64_t) gridDim.x * blockDim.x) {
+        if (!is_hdr[l]) continue;
+        const uint64_t r = hdr_rank[l];
+        rec_start[r] = seqpos[l];
+        if (r > 0) rec_end[r - 1] = seqpos[l];
+        if (r + 1 == n_records) rec_end[r] = seqpos[n_lines];
+    }
+}
+
+// the sequence lines, joined: byte i of the text, on sequence line l, goes to stream[seqpos[l] + i - line_start[l]]
+__global__ void __launch_bounds__(256) k_fa_join(const uint8_t *text, uint64_t n, uint64_t n_regions, const uint64_t *line_base,
+                                                 const uint64_t *line_start, const uint64_t *line_end, const uint32_t *is_hdr,
+                                                 const uint64_t *seqpos, uint8_t *stream) {
+    const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave_global; r < n_regions; r += nwaves) {
+        uint64_t line = line_base[r];
+        for (uint32_t s = 0; s < ING_REGION; s += 1024) {
+            const uint64_t pos0 = r * ING_REGION + s + 16u * (uint32_t) lane_id();
+            const uint32_t mask = newline_mask16(text, pos0, n);
+            const uint32_t c = (uint32_t) __popc(mask);
+            const uint32_t incl = wave_incl_scan_u32(c);
+            uint64_t l = line + incl - c; // line of this lane's first byte
+            line += (uint64_t) bcast_u32(incl, 63);
+            if (pos0 >= n) continue;
+            const uint4 v = load_chunk16(text, pos0, n);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint64_t ls = line_start[l], le = line_end[l], sp = seqpos[l];
+            bool hdr = is_hdr[l] != 0u;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint64_t i = pos0 + j;
+                if (i >= n) break;
+                if (!hdr && i < le) stream[sp + (i - ls)] = (uint8_t) (w[j >> 2] >> (8 * (j & 3)));
+                if ((mask >> j) & 1u) { // the next byte opens line l + 1
+                    l++;
+                    if (i + 1 < n) {
+                        ls = line_start[l]; le = line_end[l]; sp = seqpos[l];
+                        hdr = is_hdr[l] != 0u;
+                    }
+                }
+            }
+        }
+    }
+}
+
 } // namespace kmu
 
 using namespace kmu;
 
-extern "C" int kmu_ingest_fastq(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out,
-                                uint64_t bases_cap, uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out,
-                                kmu_ingest_info *info) {
-    if (!ctx || !info || (n_bytes && !text)) return fail(ctx, KMU_E_BAD_ARG, "null argument");
-    memset(info, 0, sizeof *info);
-    KMU_HIP(ctx, hipSetDevice(ctx->device));
-    if (n_bytes == 0) {
-        if (offsets_out && offsets_cap >= 1) {
-            const uint64_t zero = 0;
-            if (mem == KMU_MEM_HOST) offsets_out[0] = 0;
-            else KMU_HIP(ctx, hipMemcpyAsync(offsets_out, &zero, 8, hipMemcpyHostToDevice, ctx->stream));
-            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        return KMU_OK;
-    }
-    const uint8_t *d_text = text;
-    if (mem == KMU_MEM_DEVICE && ((uintptr_t) text & 15u) != 0) return fail(ctx, KMU_E_BAD_ARG, "device `text` must be 16-byte aligned");
-    if (mem == KMU_MEM_HOST) {
-        void *q;
-        KMU_TRY(dev_buf(ctx, "ing.text", n_bytes + 64, &q));
-        KMU_HIP(ctx, hipMemcpyAsync(q, text, n_bytes, hipMemcpyHostToDevice, ctx->stream));
-        d_text = (const uint8_t *) q;
-    }
-    const uint64_t n_regions = (n_bytes + ING_REGION - 1) / ING_REGION;
-    void *cnt, *lbase, *scal;
-    KMU_TRY(dev_buf(ctx, "ing.cnt", n_regions * 4, &cnt));
-    KMU_TRY(dev_buf(ctx, "ing.lbase", (n_regions + 1) * 8, &lbase));
-    KMU_TRY(dev_buf(ctx, "ing.scal", 64, &scal)); // [0..2] totals, [4] error word
-    KMU_HIP(ctx, hipMemsetAsync(scal, 0, 64, ctx->stream));
-    const int grid_w = (int) std::min<uint64_t>((n_regions + 3) / 4, (uint64_t) ctx->num_cus * 8);
-    {
-        KernelTimer t(ctx, "k_ing_count");
-        hipLaunchKernelGGL(k_ing_count, dim3(grid_w), dim3(256), 0, ctx->stream, d_text, n_bytes, n_regions, (uint32_t *) cnt);
-    }
-    {
-        KernelTimer t(ctx, "k_ing_scan");
-        hipLaunchKernelGGL(k_ing_scan<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *) cnt, n_regions,
-                           (uint64_t *) lbase);
-    }
-    uint64_t total_nl = 0;
-    uint8_t last = 0;
-    KMU_HIP(ctx, hipMemcpyAsync(&total_nl, (const uint64_t *) lbase + n_regions, 8, hipMemcpyDeviceToHost, ctx->stream));
-    KMU_HIP(ctx, hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
-    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t n_lines = total_nl + (last != '\n' ? 1 : 0);
-    if (n_lines % 4 != 0)
-        return fail(ctx, KMU_E_BAD_ARG, "invalid record: %llu lines are not a whole number of 4-line FASTQ records",
-                    (unsigned long long) n_lines);
-    const uint64_t n_records = n_lines / 4;
-    if (n_records > 0xFFFFFFFFull) return fail(ctx, KMU_E_UNSUPPORTED, "more than 2^32 records in one call");
-    info->n_records = n_records;
-    void *sstart, *send, *keep, *klen, *rank, *ooff;
-    KMU_TRY(dev_buf(ctx, "ing.sstart", (n_records + 1) * 8, &sstart));
-    KMU_TRY(dev_buf(ctx, "ing.send", (n_records + 1) * 8, &send));
+// steps 3 and 4 shared by both formats: filter the records [seq_start, seq_end) of `d_text`, scan, copy out
+static int ingest_filter_copy(kmu_ctx *ctx, const uint8_t *d_text, uint64_t n_text, uint64_t n_records, void *sstart, void *send,
+                              void *scal, int mem, uint8_t *bases_out, uint64_t bases_cap, uint64_t *offsets_out,
+                              uint64_t offsets_cap, uint32_t *record_index_out, kmu_ingest_info *info) {
+    void *keep, *klen, *rank, *ooff;
     KMU_TRY(dev_buf(ctx, "ing.keep", (n_records + 1) * 4, &keep));
     KMU_TRY(dev_buf(ctx, "ing.klen", (n_records + 1) * 8, &klen));
     KMU_TRY(dev_buf(ctx, "ing.rank", (n_records + 1) * 8, &rank));
     KMU_TRY(dev_buf(ctx, "ing.ooff", (n_records + 1) * 8, &ooff));
-    uint32_t *d_err = (uint32_t *) scal + 8;
-    {
-        KernelTimer t(ctx, "k_ing_lines");
-        hipLaunchKernelGGL(k_ing_lines, dim3(grid_w), dim3(256), 0, ctx->stream, d_text, n_bytes, n_regions,
-                           (const uint64_t *) lbase, n_records, (uint64_t *) sstart, (uint64_t *) send, d_err);
-    }
     const int grid_r = (int) std::min<uint64_t>(std::max<uint64_t>(n_records, 1), (uint64_t) ctx->num_cus * 16);
     {
         KernelTimer t(ctx, "k_ing_filter");
-        hipLaunchKernelGGL(k_ing_filter, dim3(grid_r), dim3(256), 0, ctx->stream, d_text, n_bytes, (const uint64_t *) sstart,
+        hipLaunchKernelGGL(k_ing_filter, dim3(grid_r), dim3(256), 0, ctx->stream, d_text, n_text, (const uint64_t *) sstart,
                            (const uint64_t *) send, n_records, (uint32_t *) keep, (uint64_t *) klen,
                            (unsigned long long *) scal);
     }
@@ -263,6 +306,7 @@ extern "C" int kmu_ingest_fastq(kmu_ctx *ctx, const uint8_t *text, uint64_t n_by
     const uint32_t errw = (uint32_t) h_scal[4];
     if (errw & IERR_HEADER) return fail(ctx, KMU_E_BAD_ARG, "invalid record: a header line does not start with '@'");
     if (errw & IERR_SEPARATOR) return fail(ctx, KMU_E_BAD_ARG, "invalid record: a separator line does not start with '+'");
+    info->n_records = n_records;
     info->n_kept = n_kept;
     info->kept_bases = kept_bases;
     info->n_bases = h_scal[0];
@@ -301,4 +345,162 @@ extern "C" int kmu_ingest_fastq(kmu_ctx *ctx, const uint8_t *text, uint64_t n_by
             KMU_HIP(ctx, hipMemcpyAsync(record_index_out, d_idx, n_kept * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     return finish_call(ctx, mem);
+}
+
+// text to the device (host mode), newline census and its scan; *n_lines_out = lines of the text
+static int ingest_lines(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, const uint8_t **d_text_out, void **lbase_out,
+                        void **scal_out, uint64_t *n_regions_out, int *grid_out, uint64_t *n_lines_out) {
+    const uint8_t *d_text = text;
+    if (mem == KMU_MEM_DEVICE && ((uintptr_t) text & 15u) != 0) return fail(ctx, KMU_E_BAD_ARG, "device `text` must be 16-byte aligned");
+    if (mem == KMU_MEM_HOST) {
+        void *q;
+        KMU_TRY(dev_buf(ctx, "ing.text", n_bytes + 64, &q));
+        KMU_HIP(ctx, hipMemcpyAsync(q, text, n_bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_text = (const uint8_t *) q;
+    }
+    const uint64_t n_regions = (n_bytes + ING_REGION - 1) / ING_REGION;
+    void *cnt, *lbase, *scal;
+    KMU_TRY(dev_buf(ctx, "ing.cnt", n_regions * 4, &cnt));
+    KMU_TRY(dev_buf(ctx, "ing.lbase", (n_regions + 1) * 8, &lbase));
+    KMU_TRY(dev_buf(ctx, "ing.scal", 64, &scal)); // [0..2] totals, [4] error word
+    KMU_HIP(ctx, hipMemsetAsync(scal, 0, 64, ctx->stream));
+    const int grid_w = (int) std::min<uint64_t>((n_regions + 3) / 4, (uint64_t) ctx->num_cus * 8);
+    {
+        KernelTimer t(ctx, "k_ing_count");
+        hipLaunchKernelGGL(k_ing_count, dim3(grid_w), dim3(256), 0, ctx->stream, d_text, n_bytes, n_regions, (uint32_t *) cnt);
+    }
+    {
+        KernelTimer t(ctx, "k_ing_scan");
+        hipLaunchKernelGGL(k_ing_scan<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *) cnt, n_regions,
+                           (uint64_t *) lbase);
+    }
+    uint64_t total_nl = 0;
+    uint8_t last = 0;
+    KMU_HIP(ctx, hipMemcpyAsync(&total_nl, (const uint64_t *) lbase + n_regions, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *d_text_out = d_text;
+    *lbase_out = lbase;
+    *scal_out = scal;
+    *n_regions_out = n_regions;
+    *grid_out = grid_w;
+    *n_lines_out = total_nl + (last != '\n' ? 1 : 0);
+    return KMU_OK;
+}
+
+static int ingest_empty(kmu_ctx *ctx, int mem, uint64_t *offsets_out, uint64_t offsets_cap) {
+    if (offsets_out && offsets_cap >= 1) {
+        const uint64_t zero = 0;
+        if (mem == KMU_MEM_HOST) offsets_out[0] = 0;
+        else KMU_HIP(ctx, hipMemcpyAsync(offsets_out, &zero, 8, hipMemcpyHostToDevice, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return KMU_OK;
+}
+
+extern "C" int kmu_ingest_fastq(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out,
+                                uint64_t bases_cap, uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out,
+                                kmu_ingest_info *info) {
+    if (!ctx || !info || (n_bytes && !text)) return fail(ctx, KMU_E_BAD_ARG, "null argument");
+    memset(info, 0, sizeof *info);
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_bytes == 0) return ingest_empty(ctx, mem, offsets_out, offsets_cap);
+    const uint8_t *d_text;
+    void *lbase, *scal;
+    uint64_t n_regions, n_lines;
+    int grid_w;
+    KMU_TRY(ingest_lines(ctx, text, n_bytes, mem, &d_text, &lbase, &scal, &n_regions, &grid_w, &n_lines));
+    if (n_lines % 4 != 0)
+        return fail(ctx, KMU_E_BAD_ARG, "invalid record: %llu lines are not a whole number of 4-line FASTQ records",
+                    (unsigned long long) n_lines);
+    const uint64_t n_records = n_lines / 4;
+    if (n_records > 0xFFFFFFFFull) return fail(ctx, KMU_E_UNSUPPORTED, "more than 2^32 records in one call");
+    void *sstart, *send;
+    KMU_TRY(dev_buf(ctx, "ing.sstart", (n_records + 1) * 8, &sstart));
+    KMU_TRY(dev_buf(ctx, "ing.send", (n_records + 1) * 8, &send));
+    {
+        KernelTimer t(ctx, "k_ing_lines");
+        hipLaunchKernelGGL(k_ing_lines, dim3(grid_w), dim3(256), 0, ctx->stream, d_text, n_bytes, n_regions,
+                           (const uint64_t *) lbase, n_records, (uint64_t *) sstart, (uint64_t *) send, (uint32_t *) scal + 8);
+    }
+    return ingest_filter_copy(ctx, d_text, n_bytes, n_records, sstart, send, scal, mem, bases_out, bases_cap, offsets_out,
+                              offsets_cap, record_index_out, info);
+}
+
+extern "C" int kmu_ingest_fasta(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out,
+                                uint64_t bases_cap, uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out,
+                                kmu_ingest_info *info) {
+    if (!ctx || !info || (n_bytes && !text)) return fail(ctx, KMU_E_BAD_ARG, "null argument");
+    memset(info, 0, sizeof *info);
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_bytes == 0) return ingest_empty(ctx, mem, offsets_out, offsets_cap);
+    const uint8_t *d_text;
+    void *lbase, *scal;
+    uint64_t n_regions, n_lines;
+    int grid_w;
+    KMU_TRY(ingest_lines(ctx, text, n_bytes, mem, &d_text, &lbase, &scal, &n_regions, &grid_w, &n_lines));
+    void *lstart, *lend, *hdr, *slen, *hrank, *spos;
+    KMU_TRY(dev_buf(ctx, "ing.lstart", (n_lines + 1) * 8, &lstart));
+    KMU_TRY(dev_buf(ctx, "ing.lend", (n_lines + 1) * 8, &lend));
+    KMU_TRY(dev_buf(ctx, "ing.hdr", (n_lines + 1) * 4, &hdr));
+    KMU_TRY(dev_buf(ctx, "ing.slen", (n_lines + 1) * 8, &slen));
+    KMU_TRY(dev_buf(ctx, "ing.hrank", (n_lines + 1) * 8, &hrank));
+    KMU_TRY(dev_buf(ctx, "ing.spos", (n_lines + 1) * 8, &spos));
+    const int grid_l = (int) std::min<uint64_t>((n_lines + 255) / 256, (uint64_t) ctx->num_cus * 16);
+    {
+        KernelTimer t(ctx, "k_fa_lines");
+        hipLaunchKernelGGL(k_fa_lines, dim3(grid_w), dim3(256), 0, ctx->stream, d_text, n_bytes, n_regions, (const uint64_t *) lbase,
+                           n_lines, (uint64_t *) lstart, (uint64_t *) lend, (uint32_t *) hdr);
+        hipLaunchKernelGGL(k_fa_lens, dim3(grid_l), dim3(256), 0, ctx->stream, (const uint64_t *) lstart, (const uint64_t *) lend,
+                           (const uint32_t *) hdr, n_lines, (uint64_t *) slen);
+    }
+    {
+        KernelTimer t(ctx, "k_ing_scan");
+        hipLaunchKernelGGL(k_ing_scan<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *) hdr, n_lines,
+                           (uint64_t *) hrank);
+        hipLaunchKernelGGL(k_ing_scan<uint64_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t *) slen, n_lines,
+                           (uint64_t *) spos);
+    }
+    uint64_t n_records = 0, n_stream = 0;
+    uint32_t first_hdr = 0;
+    KMU_HIP(ctx, hipMemcpyAsync(&n_records, (const uint64_t *) hrank + n_lines, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(&n_stream, (const uint64_t *) spos + n_lines, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(&first_hdr, hdr, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!first_hdr) return fail(ctx, KMU_E_BAD_ARG, "invalid record: a FASTA text starts with '>'");
+    if (n_records > 0xFFFFFFFFull) return fail(ctx, KMU_E_UNSUPPORTED, "more than 2^32 records in one call");
+    void *sstart, *send, *stream;
+    KMU_TRY(dev_buf(ctx, "ing.sstart", (n_records + 1) * 8, &sstart));
+    KMU_TRY(dev_buf(ctx, "ing.send", (n_records + 1) * 8, &send));
+    KMU_TRY(dev_buf(ctx, "ing.stream", n_stream + 64, &stream));
+    {
+        KernelTimer t(ctx, "k_fa_join");
+        hipLaunchKernelGGL(k_fa_records, dim3(grid_l), dim3(256), 0, ctx->stream, (const uint32_t *) hdr, (const uint64_t *) hrank,
+                           (const uint64_t *) spos, n_lines, n_records, (uint64_t *) sstart, (uint64_t *) send);
+        hipLaunchKernelGGL(k_fa_join, dim3(grid_w), dim3(256), 0, ctx->stream, d_text, n_bytes, n_regions, (const uint64_t *) lbase,
+                           (const uint64_t *) lstart, (const uint64_t *) lend, (const uint32_t *) hdr, (const uint64_t *) spos,
+                           (uint8_t *) stream);
+    }
+    return ingest_filter_copy(ctx, (const uint8_t *) stream, n_stream, n_records, sstart, send, scal, mem, bases_out, bases_cap,
+                              offsets_out, offsets_cap, record_index_out, info);
+}
+
+// needletail::parse_fastx_file looks at the first byte: '>' FASTA, '@' FASTQ
+extern "C" int kmu_ingest_fastx(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int mem, uint8_t *bases_out,
+                                uint64_t bases_cap, uint64_t *offsets_out, uint64_t offsets_cap, uint32_t *record_index_out,
+                                kmu_ingest_info *info) {
+    if (!ctx || !info || (n_bytes && !text)) return fail(ctx, KMU_E_BAD_ARG, "null argument");
+    uint8_t first = '@';
+    if (n_bytes) {
+        if (mem == KMU_MEM_HOST) first = text[0];
+        else {
+            KMU_HIP(ctx, hipSetDevice(ctx->device));
+            KMU_HIP(ctx, hipMemcpyAsync(&first, text, 1, hipMemcpyDeviceToHost, ctx->stream));
+            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    if (first == '>') return kmu_ingest_fasta(ctx, text, n_bytes, mem, bases_out, bases_cap, offsets_out, offsets_cap, record_index_out, info);
+    if (first == '@') return kmu_ingest_fastq(ctx, text, n_bytes, mem, bases_out, bases_cap, offsets_out, offsets_cap, record_index_out, info);
+    memset(info, 0, sizeof *info);
+    return fail(ctx, KMU_E_BAD_ARG, "invalid record: the text starts neither with '>' (FASTA) nor with '@' (FASTQ)");
 }

@@ -29,7 +29,7 @@ def main(argv=None):
     ctx = lib.Context(args.device)
     t0 = time.time()
     text = np.fromfile(args.file, dtype=np.uint8)
-    bases, offsets, info = ctx.ingest_fastq(text)
+    bases, offsets, info = ctx.ingest_fastx(text)
     if info.nb_bad_reads:
         print(" number of non acgt sequences %d " % info.nb_bad_reads, file=sys.stderr)  # datasketcher.rs:382-384
     n = int(info.n_kept)

@@ -1,4 +1,4 @@
-"""Host-side mirror of the reference's read loaders, on top of kmu_ingest_fastq (the parsing runs on the device).
+"""Host-side mirror of the reference's read loaders, on top of kmu_ingest_fastx (the parsing runs on the device).
 
   parse_with_needletail(args) -> Vec<Sequence>      src/io.rs:12-72
   readblockseq(reader, nbseq) -> Vec<Sequence>      src/bin/datasketcher.rs:358-388
@@ -10,18 +10,18 @@ from . import lib
 
 
 def parse_fastq_text(text, ctx=None):
-    """All accepted reads (ACGTacgt only) of a FASTQ text, in file order, plus the counters the reference prints
+    """All accepted reads (ACGTacgt only) of a FASTQ (or FASTA) text, in file order, plus the counters the reference prints
     (nb rec loaded, nb_bases, nb_bad_bases, nb_bad_read: io.rs:63-68).  `text`: bytes / numpy uint8 (host) or a torch
     uint8 tensor on the device (outputs then stay on the device)."""
     ctx = ctx or lib.Context()
-    bases, offsets, info = ctx.ingest_fastq(text)
+    bases, offsets, info = ctx.ingest_fastx(text)  # FASTQ or FASTA by the first byte, like needletail::parse_fastx_file
     stats = dict(nb_rec_loaded=int(info.n_kept), nb_bases=int(info.n_bases), nb_bad_bases=int(info.nb_bad_bases),
                  nb_bad_read=int(info.nb_bad_reads), nb_records=int(info.n_records))
     return bases, offsets, stats
 
 
 def parse_with_needletail(filename, ctx=None):
-    """parse_with_needletail (src/io.rs:12-72) for an uncompressed 4-line FASTQ file: the file is read as one byte
+    """parse_with_needletail (src/io.rs:12-72) for an uncompressed FASTQ or FASTA file: the file is read as one byte
     array (np.fromfile) and parsed / filtered / compacted on the device."""
     text = np.fromfile(filename, dtype=np.uint8)
     return parse_fastq_text(text, ctx)

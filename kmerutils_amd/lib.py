@@ -22,7 +22,7 @@ SYMBOLS = [
     "kmu_count_reset", "kmu_count_add_reads", "kmu_count_add_kmers", "kmu_count_query", "kmu_count_nb_distinct",
     "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
     "kmu_count_retain_part", "kmu_count_extract_by_owner", "kmu_sig_equal_pairs", "kmu_sig_equal_matrix",
-    "kmu_minhash_distance_pairs", "kmu_ingest_fastq",
+    "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx",
 ]
 
 
@@ -78,7 +78,8 @@ def load():
     L.kmu_sig_equal_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
     L.kmu_sig_equal_matrix.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
     L.kmu_minhash_distance_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, vp]
-    L.kmu_ingest_fastq.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(A.IngestInfo)]
+    for f in (L.kmu_ingest_fastq, L.kmu_ingest_fasta, L.kmu_ingest_fastx):
+        f.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(A.IngestInfo)]
     _lib = L
     return L
 
@@ -270,9 +271,18 @@ class Context:
         return (out[:rows], counts[:rows]) if want_counts else out[:rows]
 
     # ---- ingest (kmu_ingest.hip) ----
-    def ingest_fastq(self, text, want_index=False):
+    def ingest_fasta(self, text, want_index=False):
+        """kmu_ingest_fasta: like ingest_fastq for a FASTA text (multi-line records)"""
+        return self.ingest_fastq(text, want_index, fn="kmu_ingest_fasta")
+
+    def ingest_fastx(self, text, want_index=False):
+        """kmu_ingest_fastx: FASTA or FASTQ by the first byte (needletail::parse_fastx_file)"""
+        return self.ingest_fastq(text, want_index, fn="kmu_ingest_fastx")
+
+    def ingest_fastq(self, text, want_index=False, fn="kmu_ingest_fastq"):
         """kmu_ingest_fastq: FASTQ text (bytes / numpy uint8 on the host, torch uint8 tensor on the device) -> (bases,
         offsets, info[, record_index]) of the reads made of ACGTacgt only, in file order."""
+        call = getattr(self.L, fn)
         if isinstance(text, (bytes, bytearray, memoryview)):
             text = np.frombuffer(bytes(text), np.uint8)
         dev = _is_torch(text) and text.is_cuda
@@ -280,8 +290,7 @@ class Context:
         self._wait_producers(text)
         n = int(text.shape[0])
         info = A.IngestInfo()
-        self._check(self.L.kmu_ingest_fastq(self.h, _ptr(text)[0] if n else None, n, mem, None, 0, None, 0, None,
-                                            C.byref(info)))
+        self._check(call(self.h, _ptr(text)[0] if n else None, n, mem, None, 0, None, 0, None, C.byref(info)))
         if dev:
             import torch
             bases = torch.zeros(max(int(info.kept_bases), 1), dtype=torch.uint8, device=text.device)
@@ -292,8 +301,8 @@ class Context:
             offs = np.zeros(int(info.n_kept) + 1, np.uint64)
             idx = np.zeros(max(int(info.n_kept), 1), np.uint32) if want_index else None
         info2 = A.IngestInfo()
-        self._check(self.L.kmu_ingest_fastq(self.h, _ptr(text)[0] if n else None, n, mem, _ptr(bases)[0], bases.shape[0],
-                                            _ptr(offs)[0], offs.shape[0], _ptr(idx)[0], C.byref(info2)))
+        self._check(call(self.h, _ptr(text)[0] if n else None, n, mem, _ptr(bases)[0], bases.shape[0], _ptr(offs)[0],
+                         offs.shape[0], _ptr(idx)[0], C.byref(info2)))
         res = (bases[:int(info.kept_bases)], offs, info2)
         return res + (idx[:int(info.n_kept)],) if want_index else res
 

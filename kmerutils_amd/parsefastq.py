@@ -39,7 +39,7 @@ def main(argv=None):
     ctx = lib.Context(args.device)
     t0 = time.time()
     text = np.fromfile(args.file, dtype=np.uint8)
-    bases, offsets, info = ctx.ingest_fastq(text)
+    bases, offsets, info = ctx.ingest_fastx(text)
     print(" nb rec loaded = %d \nnb_bases %d\nnb_bad_bases %d\nnb_bad_read %d" %
           (info.n_kept, info.n_bases, info.nb_bad_bases, info.nb_bad_reads), file=sys.stderr)  # io.rs:63-68
     nk = int(np.maximum(np.diff(offsets.astype(np.int64)) - args.kmer_size + 1, 0).sum())

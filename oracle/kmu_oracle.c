@@ -1225,3 +1225,63 @@ int kmo_ingest_fastq(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64
     info[2] = out;
     return 0;
 }
+
+/* FASTA as needletail reads it (parse_fastx_file, src/io.rs:37, src/bin/datasketcher.rs:211): a line starting with '>'
+ * opens a record; record.seq() is the following lines up to the next such line, with the line ends ("\n", "\r\n")
+ * removed.  Same drop rule and same outputs as kmo_ingest_fastq.  A text that does not start with '>' is an invalid record. */
+int kmo_ingest_fasta(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
+                     uint64_t info[6]) {
+    memset(info, 0, 6 * sizeof(uint64_t));
+    uint64_t pos = 0, rec = 0, out = 0, kept = 0;
+    if (offsets_out) offsets_out[0] = 0;
+    if (n && text[0] != '>') return KMU_E_BAD_ARG;
+    while (pos < n) {
+        /* header line */
+        while (pos < n && text[pos] != '\n') pos++;
+        pos = pos < n ? pos + 1 : n;
+        /* sequence lines: first measured, then (if the whole record is ACGT) copied */
+        uint64_t len = 0, nb_bad = 0;
+        const uint64_t first_line = pos;
+        while (pos < n && text[pos] != '>') {
+            uint64_t e = pos;
+            while (e < n && text[e] != '\n') e++;
+            const uint64_t le = (e > pos && text[e - 1] == '\r') ? e - 1 : e;
+            nb_bad += kmo_count_non_acgt(text + pos, le - pos);
+            len += le - pos;
+            pos = e < n ? e + 1 : n;
+        }
+        info[3] += len;
+        if (nb_bad) { info[4] += nb_bad; info[5]++; }
+        else {
+            if (bases_out) {
+                uint64_t q = first_line, w = out;
+                while (q < pos) {
+                    uint64_t e = q;
+                    while (e < n && text[e] != '\n') e++;
+                    const uint64_t le = (e > q && text[e - 1] == '\r') ? e - 1 : e;
+                    memcpy(bases_out + w, text + q, le - q);
+                    w += le - q;
+                    q = e < n ? e + 1 : n;
+                }
+            }
+            out += len;
+            if (offsets_out) offsets_out[kept + 1] = out;
+            if (record_index_out) record_index_out[kept] = (uint32_t) rec;
+            kept++;
+        }
+        rec++;
+    }
+    info[0] = rec;
+    info[1] = kept;
+    info[2] = out;
+    return 0;
+}
+
+/* needletail::parse_fastx_file: the first byte names the format */
+int kmo_ingest_fastx(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
+                     uint64_t info[6]) {
+    if (n == 0 || text[0] == '@') return kmo_ingest_fastq(text, n, bases_out, offsets_out, record_index_out, info);
+    if (text[0] == '>') return kmo_ingest_fasta(text, n, bases_out, offsets_out, record_index_out, info);
+    memset(info, 0, 6 * sizeof(uint64_t));
+    return KMU_E_BAD_ARG;
+}

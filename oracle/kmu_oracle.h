@@ -91,6 +91,10 @@ int kmo_probminhash3(const uint64_t *keys, const double *weights, uint64_t n, in
 /* ingest */
 int kmo_ingest_fastq(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
                      uint64_t info[6]);
+int kmo_ingest_fasta(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
+                     uint64_t info[6]);
+int kmo_ingest_fastx(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
+                     uint64_t info[6]);
 /* signature comparison */
 uint32_t kmo_sig_equal_count(const void *a, const void *b, uint32_t m, int word_bytes);
 void kmo_minhash_distance(const uint64_t *s1, uint32_t n1, const uint64_t *s2, uint32_t n2, uint32_t out[3]);

@@ -232,10 +232,11 @@ def minhash_distance(s1, s2):
 
 
 # ---- ingest ----
-def ingest_fastq(text):
-    """(bases, offsets, info dict, record_index) of the ACGT-only reads of a 4-line FASTQ text, in file order"""
+def ingest_fastq(text, fmt="fastq"):
+    """(bases, offsets, info dict, record_index) of the ACGT-only reads of a 4-line FASTQ text (fmt "fasta": a FASTA text,
+    "fastx": by the first byte), in file order"""
     text = np.frombuffer(bytes(text), np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
-    f = lib().kmo_ingest_fastq
+    f = getattr(lib(), "kmo_ingest_" + fmt)
     f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     f.restype = C.c_int
     info = np.zeros(6, np.uint64)
@@ -250,3 +251,11 @@ def ingest_fastq(text):
         raise OracleError(rc)
     names = ("n_records", "n_kept", "kept_bases", "n_bases", "nb_bad_bases", "nb_bad_reads")
     return bases[:int(info[2])], offs, dict(zip(names, (int(x) for x in info))), idx[:int(info[1])]
+
+
+def ingest_fasta(text):
+    return ingest_fastq(text, "fasta")
+
+
+def ingest_fastx(text):
+    return ingest_fastq(text, "fastx")

@@ -616,6 +616,34 @@ TEST(test_parse_fastq_and_signature_dump) {
     std::remove(fname.c_str());
 }
 
+// needletail::parse_fastx_file also takes FASTA: multi-line records, format by the first byte
+TEST(test_parse_fasta) {
+    std::mt19937_64 rng(37);
+    std::string text;
+    std::vector<std::string> kept;
+    for (int r = 0; r < 60; r++) {
+        std::string s(rng() % 2000, 'A');
+        for (char &c : s) c = "ACGT"[rng() & 3];
+        const bool bad = r % 6 == 1 && !s.empty();
+        if (bad) s[s.size() / 3] = 'N';
+        text += ">contig" + std::to_string(r) + " len=" + std::to_string(s.size()) + "\n";
+        for (size_t i = 0; i < s.size(); i += 60) text += s.substr(i, 60) + "\n";
+        if (!bad) kept.push_back(s);
+    }
+    std::vector<uint8_t> bytes(text.begin(), text.end());
+    bytes.resize(bytes.size() + 16);
+    FastqReads reads = parse_fastx_text(bytes.data(), text.size());
+    CHECK(reads.info.n_records == 60 && reads.nb_reads() == kept.size());
+    for (size_t i = 0; i < kept.size(); i++)
+        CHECK(std::string(reads.bases.begin() + reads.offsets[i], reads.bases.begin() + reads.offsets[i + 1]) == kept[i]);
+    std::vector<uint8_t> ob(text.size() + 16);
+    std::vector<uint64_t> oo(61);
+    uint64_t info[6];
+    CHECK(kmo_ingest_fastx(bytes.data(), text.size(), ob.data(), oo.data(), nullptr, info) == 0);
+    CHECK(info[0] == 60 && info[1] == reads.info.n_kept && info[2] == reads.info.kept_bases && info[4] == reads.info.nb_bad_bases);
+    CHECK(std::equal(ob.begin(), ob.begin() + info[2], reads.bases.begin()));
+}
+
 // errors surface where the reference panics
 TEST(test_errors_where_the_reference_panics) {
     Sequence seqa(SEQSTR);

@@ -553,6 +553,77 @@ def test_ingest_fastq_errors(ctx):
     assert info.n_records == 0 and o.tolist() == [0]
 
 
+def _make_fasta(rng, n_records, width, crlf=False, final_newline=True, allow_empty=True):
+    """FASTA text: records of 0 .. 40 k bases wrapped at `width` columns (0 = one line per record), some with N, some
+    in lower case, headers that contain '>' and blanks, an occasional empty line"""
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for r in range(n_records):
+        L = int(rng.choice([0, 1, 5, 59, 60, 61, 500, 16384, 40000])) if r % 3 == 0 else int(rng.integers(1, 3000))
+        L = max(L, 0 if allow_empty else 1)
+        seq = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), size=L).tobytes()
+        if r % 7 == 5 and L > 2:
+            seq = seq[:L // 2] + b"N" + seq[L // 2 + 1:]
+        out.append(b">rec%d some>thing here" % r)
+        if width and L:
+            out += [seq[i:i + width] for i in range(0, L, width)]
+        else:
+            out.append(seq)
+        if r % 11 == 2:
+            out.append(b"")
+    text = nl.join(out)
+    return text + nl if final_newline else text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,crlf,final_newline,n", [(60, False, True, 150), (1, False, True, 12), (80, True, True, 90),
+                                                       (0, False, False, 40), (17, True, False, 60), (70, False, True, 1)])
+def test_ingest_fasta_parity(ctx, oracle, width, crlf, final_newline, n):
+    """kmu_ingest_fasta / kmu_ingest_fastx against the oracle's needletail-style reader: multi-line records, any line
+    width (single-line records longer than a walk region included), CRLF, empty lines, no final newline"""
+    import torch
+    rng = np.random.default_rng(1000 + 7 * width + n)
+    fa = _make_fasta(rng, n, width, crlf, final_newline)
+    wb, wo, winfo, widx = oracle.ingest_fasta(fa)
+    assert winfo["n_records"] == n
+    bases, offs, info, idx = ctx.ingest_fasta(fa, want_index=True)
+    assert {k: int(getattr(info, k)) for k in winfo} == winfo
+    assert np.array_equal(offs, wo) and np.array_equal(idx, widx) and bytes(bases) == bytes(wb)
+    b1, o1, info1 = ctx.ingest_fastx(fa)  # format from the first byte
+    assert bytes(b1) == bytes(wb) and np.array_equal(o1, wo)
+    t = torch.from_numpy(np.frombuffer(fa, np.uint8).copy()).cuda()
+    b2, o2, info2, i2 = ctx.ingest_fastx(t, want_index=True)
+    ctx.synchronize()
+    assert bytes(b2.cpu().numpy()) == bytes(wb) and np.array_equal(o2.cpu().numpy().astype(np.uint64), wo)
+    assert np.array_equal(i2.cpu().numpy().view(np.uint32), widx)
+
+
+@pytest.mark.gpu
+def test_ingest_fastx_dispatch_and_errors(ctx, oracle):
+    from kmerutils_amd.lib import KmuError
+    fq = b"@r0\nACGT\n+\nIIII\n@r1\nACNT\n+\nIIII\n"
+    b, o, info = ctx.ingest_fastx(fq)
+    assert bytes(b) == b"ACGT" and o.tolist() == [0, 4] and info.nb_bad_reads == 1
+    for broken in (b"ACGT\n>r0\nACGT\n", b"\n>r0\nACGT\n", b"#comment\n"):
+        with pytest.raises(KmuError) as e:
+            ctx.ingest_fastx(broken)
+        assert e.value.code == A.E_BAD_ARG
+        with pytest.raises(oracle.OracleError):
+            oracle.ingest_fastx(broken)
+    with pytest.raises(KmuError):
+        ctx.ingest_fasta(b"ACGT\n>r0\nACGT\n")
+    # a genome the way gsearch sees it: contigs of one FASTA file -> ONE signature (sketch_compressedkmer_seqs)
+    rng = np.random.default_rng(5)
+    fa = _make_fasta(rng, 40, 60, allow_empty=False)
+    bases, offs, info = ctx.ingest_fastx(fa)
+    wb, wo, _, _ = oracle.ingest_fastx(fa)
+    keep = np.diff(wo.astype(np.int64)) >= 21  # contigs shorter than k contribute nothing
+    assert keep.sum() > 10
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 21, 128, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0,
+                       A.MODE_ALL_SEQS, 0, 0, 0)
+    assert np.array_equal(np.asarray(ctx.sketch(bases, offs, p)), oracle.sketch(wb, wo, p))
+
+
 @pytest.mark.gpu
 def test_ingest_then_sketch_equals_direct(ctx, oracle):
     """end to end on the device: FASTQ text -> kmu_ingest_fastq -> kmu_sketch, against the oracle reader + oracle sketch"""
@@ -693,8 +764,8 @@ def test_parsefastq_tool_end_to_end(oracle, tmp_path):
 
 @pytest.mark.gpu
 def test_probminhash_megabase_read(ctx, oracle):
-    """a 1.3 Mbase sequence: > 100 partition passes, more keys set aside for later passes than the per-workgroup list
-    holds (the later passes then rescan the read), several staged tiles"""
+    """a 1.3 Mbase sequence next to an ordinary read (since the genome-sized route exists it is sketched there; the
+    in-LDS kernel keeps sequences up to 2^18 k-mers, i.e. up to ~25 partition passes)"""
     rng = np.random.default_rng(55)
     seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=1_300_000).tobytes(),
             rng.choice(np.frombuffer(b"ACGT", np.uint8), size=25_000).tobytes()]

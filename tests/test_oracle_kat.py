@@ -280,3 +280,49 @@ def test_ingest_oracle_hand_cases():
                    b"@r0\nACGT\n+\nIIII\n\n"):
         with pytest.raises(O.OracleError):
             O.ingest_fastq(broken)
+
+
+def test_ingest_fasta_oracle_hand_cases():
+    """FASTA the way needletail hands it over (parse_fastx_file, io.rs:37): '>' at a line start opens a record,
+    record.seq() is the following lines with the line ends removed; same drop rule as for FASTQ."""
+    from oracle import oracle as O
+    fa = (b">c0 first\nACGT\nAC\n"
+          b">c1 with N\nACGT\nNNAC\n"
+          b">c2 crlf\r\nGG\r\nCC\r\n"
+          b">c3 header only\n"
+          b">c4 > inside the header\n\nacgt\n\nT")          # empty lines, lower case, no newline at the end
+    bases, offs, info, idx = O.ingest_fasta(fa)
+    assert info == dict(n_records=5, n_kept=4, kept_bases=15, n_bases=23, nb_bad_bases=2, nb_bad_reads=1)
+    assert bytes(bases) == b"ACGTAC" + b"GGCC" + b"" + b"acgtT"
+    assert offs.tolist() == [0, 6, 10, 10, 15] and idx.tolist() == [0, 2, 3, 4]
+    # the dispatcher goes by the first byte
+    assert bytes(O.ingest_fastx(fa)[0]) == bytes(bases)
+    assert bytes(O.ingest_fastx(b"@r\nACGT\n+\nIIII\n")[0]) == b"ACGT"
+    for broken in (b"ACGT\n>c\nACGT\n", b"\n>c\nACGT\n", b"+\n"):
+        with pytest.raises(O.OracleError):
+            O.ingest_fastx(broken)
+    with pytest.raises(O.OracleError):
+        O.ingest_fasta(b"ACGT\n")
+
+
+def test_ingest_fasta_oracle_against_line_by_line_restatement():
+    """the oracle's FASTA reader against an independent few-line Python statement of the same rule, on seeded texts with
+    every line width / CRLF / final-newline combination the GPU parity test uses"""
+    from oracle import oracle as O
+    from test_gpu_parity import _make_fasta
+    for width, crlf, final_newline, n in ((60, False, True, 150), (1, False, True, 12), (80, True, True, 90),
+                                          (0, False, False, 40), (17, True, False, 60), (70, False, True, 1)):
+        fa = _make_fasta(np.random.default_rng(1000 + 7 * width + n), n, width, crlf, final_newline)
+        records, cur = [], None
+        for line in fa.replace(b"\r\n", b"\n").split(b"\n"):
+            if line.startswith(b">"):
+                cur = []
+                records.append(cur)
+            else:
+                cur.append(line)
+        seqs = [b"".join(r) for r in records]
+        kept = [s for s in seqs if all(c in b"ACGTacgt" for c in s)]
+        bases, offs, info, idx = O.ingest_fasta(fa)
+        assert info["n_records"] == n and info["n_kept"] == len(kept) and info["n_bases"] == sum(map(len, seqs))
+        assert bytes(bases) == b"".join(kept) and offs.tolist() == np.cumsum([0] + [len(s) for s in kept]).tolist()
+        assert idx.tolist() == [i for i, s in enumerate(seqs) if all(c in b"ACGTacgt" for c in s)]
