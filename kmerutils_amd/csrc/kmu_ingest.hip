@@ -83,6 +83,61 @@ __global__ void __launch_bounds__(1024) k_ing_scan(const T *in, uint64_t n, uint
     if (threadIdx.x == 0) out[n] = carry;
 }
 
+// The same scan for long arrays (the lines of a genome-sized FASTA text): tiles of 8192 values, tile sums, the
+// single-workgroup scan above over the sums, then every tile scans itself from its offset.
+static constexpr uint32_t SCAN_ITEMS = 8, SCAN_TILE = 1024 * SCAN_ITEMS;
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = ((uint64_t) (uint32_t) __shfl_up((int) (v >> 32), d, 64) << 32) | (uint32_t) __shfl_up((int) (uint32_t) v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) k_scan_tile_sums(const T *in, uint64_t n, uint64_t *tile_sum) {
+    __shared__ uint64_t wsum[16];
+    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
+    uint64_t s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_ITEMS; j++) s += base + j < n ? (uint64_t) in[base + j] : 0ull;
+    s = wave_incl_scan_u64(s);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < 16; w++) t += wsum[w];
+        tile_sum[blockIdx.x] = t;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) k_scan_tiles(const T *in, uint64_t n, const uint64_t *tile_off, uint64_t n_tiles,
+                                                     uint64_t *out) {
+    __shared__ uint64_t wsum[16];
+    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_ITEMS; j++) {
+        v[j] = base + j < n ? (uint64_t) in[base + j] : 0ull;
+        s += v[j];
+    }
+    const uint64_t incl = wave_incl_scan_u64(s);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t run = tile_off[blockIdx.x] + incl - s;
+    for (int w = 0; w < (int) (threadIdx.x >> 6); w++) run += wsum[w];
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_ITEMS; j++) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_off[n_tiles];
+}
+
 // line walk: seq_start[r] / seq_end[r] of every record
 __global__ void __launch_bounds__(256) k_ing_lines(const uint8_t *text, uint64_t n, uint64_t n_regions, const uint64_t *line_base,
                                                    uint64_t n_records, uint64_t *seq_start, uint64_t *seq_end, uint32_t *err) {
@@ -274,6 +329,23 @@ __global__ void __launch_bounds__(256) k_fa_join(const uint8_t *text, uint64_t n
 
 using namespace kmu;
 
+// exclusive scan of n values on the context's stream; out[n] = total
+template <typename T> static int device_scan(kmu_ctx *ctx, const T *in, uint64_t n, uint64_t *out) {
+    KernelTimer t(ctx, "k_ing_scan");
+    if (n <= 4 * SCAN_TILE) {
+        hipLaunchKernelGGL(k_ing_scan<T>, dim3(1), dim3(1024), 0, ctx->stream, in, n, out);
+        return KMU_OK;
+    }
+    const uint64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    void *tsum, *toff;
+    KMU_TRY(dev_buf(ctx, "ing.tsum", (n_tiles + 1) * 8, &tsum));
+    KMU_TRY(dev_buf(ctx, "ing.toff", (n_tiles + 1) * 8, &toff));
+    hipLaunchKernelGGL(k_scan_tile_sums<T>, dim3((uint32_t) n_tiles), dim3(1024), 0, ctx->stream, in, n, (uint64_t *) tsum);
+    hipLaunchKernelGGL(k_ing_scan<uint64_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t *) tsum, n_tiles, (uint64_t *) toff);
+    hipLaunchKernelGGL(k_scan_tiles<T>, dim3((uint32_t) n_tiles), dim3(1024), 0, ctx->stream, in, n, (const uint64_t *) toff, n_tiles, out);
+    return KMU_OK;
+}
+
 // steps 3 and 4 shared by both formats: filter the records [seq_start, seq_end) of `d_text`, scan, copy out
 static int ingest_filter_copy(kmu_ctx *ctx, const uint8_t *d_text, uint64_t n_text, uint64_t n_records, void *sstart, void *send,
                               void *scal, int mem, uint8_t *bases_out, uint64_t bases_cap, uint64_t *offsets_out,
@@ -290,13 +362,8 @@ static int ingest_filter_copy(kmu_ctx *ctx, const uint8_t *d_text, uint64_t n_te
                            (const uint64_t *) send, n_records, (uint32_t *) keep, (uint64_t *) klen,
                            (unsigned long long *) scal);
     }
-    {
-        KernelTimer t(ctx, "k_ing_scan");
-        hipLaunchKernelGGL(k_ing_scan<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *) keep, n_records,
-                           (uint64_t *) rank);
-        hipLaunchKernelGGL(k_ing_scan<uint64_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t *) klen, n_records,
-                           (uint64_t *) ooff);
-    }
+    KMU_TRY(device_scan(ctx, (const uint32_t *) keep, n_records, (uint64_t *) rank));
+    KMU_TRY(device_scan(ctx, (const uint64_t *) klen, n_records, (uint64_t *) ooff));
     KMU_HIP(ctx, hipGetLastError());
     uint64_t h_scal[8], n_kept = 0, kept_bases = 0;
     KMU_HIP(ctx, hipMemcpyAsync(h_scal, scal, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -369,11 +436,7 @@ static int ingest_lines(kmu_ctx *ctx, const uint8_t *text, uint64_t n_bytes, int
         KernelTimer t(ctx, "k_ing_count");
         hipLaunchKernelGGL(k_ing_count, dim3(grid_w), dim3(256), 0, ctx->stream, d_text, n_bytes, n_regions, (uint32_t *) cnt);
     }
-    {
-        KernelTimer t(ctx, "k_ing_scan");
-        hipLaunchKernelGGL(k_ing_scan<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *) cnt, n_regions,
-                           (uint64_t *) lbase);
-    }
+    KMU_TRY(device_scan(ctx, (const uint32_t *) cnt, n_regions, (uint64_t *) lbase));
     uint64_t total_nl = 0;
     uint8_t last = 0;
     KMU_HIP(ctx, hipMemcpyAsync(&total_nl, (const uint64_t *) lbase + n_regions, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -454,13 +517,8 @@ extern "C" int kmu_ingest_fasta(kmu_ctx *ctx, const uint8_t *text, uint64_t n_by
         hipLaunchKernelGGL(k_fa_lens, dim3(grid_l), dim3(256), 0, ctx->stream, (const uint64_t *) lstart, (const uint64_t *) lend,
                            (const uint32_t *) hdr, n_lines, (uint64_t *) slen);
     }
-    {
-        KernelTimer t(ctx, "k_ing_scan");
-        hipLaunchKernelGGL(k_ing_scan<uint32_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *) hdr, n_lines,
-                           (uint64_t *) hrank);
-        hipLaunchKernelGGL(k_ing_scan<uint64_t>, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t *) slen, n_lines,
-                           (uint64_t *) spos);
-    }
+    KMU_TRY(device_scan(ctx, (const uint32_t *) hdr, n_lines, (uint64_t *) hrank));
+    KMU_TRY(device_scan(ctx, (const uint64_t *) slen, n_lines, (uint64_t *) spos));
     uint64_t n_records = 0, n_stream = 0;
     uint32_t first_hdr = 0;
     KMU_HIP(ctx, hipMemcpyAsync(&n_records, (const uint64_t *) hrank + n_lines, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -35,3 +35,30 @@ for it in range(3):
 print(json.dumps({"text_GB": text.shape[0] / 1e9, "records": int(info.n_records), "kept": int(info.n_kept),
                   "bad_reads": int(info.nb_bad_reads), "seconds": dt, "text_GBps": text.shape[0] / dt / 1e9,
                   "kernels_ms": {k: round(v[1] / v[0], 3) for k, v in ctx.profile_get().items()}}))
+
+# ---- FASTA: the same bases as a genome-style file, contigs of ~1 Mbase wrapped at 60 columns -------------------------------
+W = 60
+nb = bases.shape[0] - bases.shape[0] % W
+seq = bases[:nb].clone()
+contig = int(os.environ.get("CONTIG", 1_000_020)) // W * W        # whole lines per contig
+n_contigs = (nb + contig - 1) // contig
+lines = seq.view(-1, W)
+body = torch.cat([lines, torch.full((lines.shape[0], 1), 10, dtype=torch.uint8, device=dev)], 1).reshape(-1)  # 61 bytes per line
+hdr = torch.tensor(list(b">contig\n"), dtype=torch.uint8, device=dev)
+per = contig // W * (W + 1)
+parts = []
+for c in range(n_contigs):
+    parts += [hdr, body[c * per:(c + 1) * per]]
+fa = torch.cat(parts)
+del body, parts
+torch.cuda.synchronize()
+ctx.profile_reset()
+for it in range(3):
+    t0 = time.perf_counter()
+    b, o, info = ctx.ingest_fastx(fa)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+assert int(info.n_records) == n_contigs and int(info.kept_bases) + int(info.n_bases - info.kept_bases) == nb
+print(json.dumps({"fasta_GB": fa.shape[0] / 1e9, "records": int(info.n_records), "kept": int(info.n_kept),
+                  "lines": int(lines.shape[0] + n_contigs), "seconds": dt, "text_GBps": fa.shape[0] / dt / 1e9,
+                  "kernels_ms": {k: round(v[1] / v[0], 3) for k, v in ctx.profile_get().items()}}))

@@ -542,6 +542,21 @@ def test_ingest_fastq_parity(ctx, oracle, crlf, final_newline, n_reads):
 
 
 @pytest.mark.gpu
+def test_ingest_fastq_many_short_records(ctx, oracle):
+    """70 000 records: record-level scans beyond one workgroup's single pass (tiled scan), reads shorter than a chunk"""
+    rng = np.random.default_rng(70)
+    L = rng.integers(1, 40, size=70_000)
+    seqs = [rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=int(n), p=[0.2495, 0.2495, 0.2495, 0.2495, 0.002]).tobytes()
+            for n in L]
+    fq = b"".join(b"@r\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for s in seqs)
+    wb, wo, winfo, widx = oracle.ingest_fastq(fq)
+    assert 2000 < winfo["nb_bad_reads"] < 6000
+    bases, offs, info, idx = ctx.ingest_fastx(fq, want_index=True)
+    assert {k: int(getattr(info, k)) for k in winfo} == winfo
+    assert np.array_equal(offs, wo) and np.array_equal(idx, widx) and bytes(bases) == bytes(wb)
+
+
+@pytest.mark.gpu
 def test_ingest_fastq_errors(ctx):
     from kmerutils_amd.lib import KmuError
     for broken in (b"@r0\nACGT\n+\n", b"@r0\nACGT\n", b"r0\nACGT\n+\nIIII\n", b"@r0\nACGT\n-\nIIII\n",
@@ -577,7 +592,8 @@ def _make_fasta(rng, n_records, width, crlf=False, final_newline=True, allow_emp
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("width,crlf,final_newline,n", [(60, False, True, 150), (1, False, True, 12), (80, True, True, 90),
-                                                       (0, False, False, 40), (17, True, False, 60), (70, False, True, 1)])
+                                                       (0, False, False, 40), (17, True, False, 60), (70, False, True, 1),
+                                                       (2, False, True, 120)])  # > 2^15 lines: the tiled scans
 def test_ingest_fasta_parity(ctx, oracle, width, crlf, final_newline, n):
     """kmu_ingest_fasta / kmu_ingest_fastx against the oracle's needletail-style reader: multi-line records, any line
     width (single-line records longer than a walk region included), CRLF, empty lines, no final newline"""
