@@ -36,17 +36,24 @@
 #ifndef KMERUTILS_HPP
 #define KMERUTILS_HPP
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -97,6 +104,39 @@ class Context {
 
   private:
     kmu_ctx *ctx_ = nullptr;
+};
+
+/// A buffer in the memory of the context's GPU (kmu_dev_alloc): for data that should cross PCIe once.
+class DeviceBuffer {
+  public:
+    DeviceBuffer() = default;
+    DeviceBuffer(Context &ctx, uint64_t bytes) : ctx_(&ctx), bytes_(bytes) { ctx.check(kmu_dev_alloc(ctx.raw(), bytes, &p_)); }
+    ~DeviceBuffer() { release(); }
+    DeviceBuffer(DeviceBuffer &&o) noexcept : ctx_(o.ctx_), p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept {
+        if (this != &o) {
+            release();
+            ctx_ = o.ctx_; p_ = o.p_; bytes_ = o.bytes_;
+            o.p_ = nullptr;
+        }
+        return *this;
+    }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    void *data() const { return p_; }
+    template <class T> T *as() const { return static_cast<T *>(p_); }
+    uint64_t bytes() const { return bytes_; }
+    void upload(const void *src, uint64_t n, uint64_t at = 0) { ctx_->check(kmu_copy_to_device(ctx_->raw(), as<uint8_t>() + at, src, n)); }
+    void download(void *dst, uint64_t n, uint64_t from = 0) const { ctx_->check(kmu_copy_to_host(ctx_->raw(), dst, as<uint8_t>() + from, n)); }
+
+  private:
+    void release() {
+        if (p_) (void) kmu_dev_free(ctx_->raw(), p_);
+        p_ = nullptr;
+    }
+    Context *ctx_ = nullptr;
+    void *p_ = nullptr;
+    uint64_t bytes_ = 0;
 };
 
 // =====================================================================================================================
@@ -373,9 +413,17 @@ namespace detail {
 
 struct Batch {
     std::vector<uint8_t> bytes;
-    std::vector<uint64_t> offsets;         // in bases / residues, n + 1
+    std::vector<uint64_t> offsets;         // in bases / residues, n + 1 (always on the host: sizes, block layouts)
     std::vector<uint64_t> packed_offsets;  // byte offset of every packed sequence (DNA)
     int input_kind = KMU_INPUT_ASCII;
+    // device-resident batch (reads left on the GPU by the FASTX reader): these pointers are used instead of `bytes` and
+    // the host `offsets`; the offsets index the whole device array, so a range of reads needs no copy
+    const uint8_t *dev_bytes = nullptr;
+    const uint64_t *dev_offsets = nullptr;
+    bool on_device() const { return dev_bytes != nullptr; }
+    int mem() const { return on_device() ? KMU_MEM_DEVICE : KMU_MEM_HOST; }
+    const uint8_t *bytes_ptr() const { return on_device() ? dev_bytes : bytes.data(); }
+    const uint64_t *offsets_ptr() const { return on_device() ? dev_offsets : offsets.data(); }
     uint32_t n() const { return uint32_t(offsets.size() - 1); }
     const uint64_t *packed_ptr() const { return input_kind == KMU_INPUT_PACKED2 ? packed_offsets.data() : nullptr; }
 };
@@ -447,6 +495,7 @@ inline kmu_sketch_params sketch_params(int algo, int kmer_type, size_t k, size_t
 
 /// raw `.0` of every k-mer of every sequence, generated on the device (KmerSeqIterator::next, kmergenerator.rs:75-106)
 template <class Kmer> std::vector<std::vector<Kmer>> device_kmers(Context &ctx, const Batch &b, size_t k) {
+    if (b.on_device()) throw std::invalid_argument("k-mer lists / host closures need the sequences in host memory");
     kmu_hash_params hp{};
     hp.kmer_type = Kmer::kmu_type;
     hp.kmer_size = int32_t(k);
@@ -465,18 +514,26 @@ template <class Kmer> std::vector<std::vector<Kmer>> device_kmers(Context &ctx, 
     return out;
 }
 
-/// rows of signatures for a batch, either with a device-side closure (FHash) or a host callable
+/// rows of signatures for a batch, row-major in `flat` (resized to rows * m; a caller that sketches pack after pack keeps
+/// one such buffer), either with a device-side closure (FHash) or a host callable.  Returns the number of rows.
 template <class Kmer, class Sig, class F>
-std::vector<std::vector<Sig>> run_sketch(Context &ctx, const Batch &b, int algo, size_t k, size_t m, int hasher, F fhash,
-                                         int mode, uint32_t flags = 0) {
+size_t run_sketch_flat(Context &ctx, const Batch &b, int algo, size_t k, size_t m, int hasher, F fhash, int mode,
+                       std::vector<Sig> &flat, uint32_t flags = 0) {
     const size_t rows = mode == KMU_MODE_ALL_SEQS ? 1 : b.n();
-    std::vector<Sig> flat(std::max<size_t>(rows, 1) * m);
+    flat.resize(std::max<size_t>(rows, 1) * m);
     if constexpr (std::is_same_v<F, FHash>) {
         kmu_sketch_params p =
             sketch_params(algo, Kmer::kmu_type, k, m, sig_type_of<Sig>(), hasher, int(fhash), 0, mode, b.input_kind);
         p.flags = flags;
-        ctx.check(kmu_sketch(ctx.raw(), &p, b.bytes.data(), b.offsets.data(), b.packed_ptr(), b.n(), nullptr, flat.data(),
-                             nullptr));
+        p.mem = b.mem();
+        if (b.on_device()) {   // reads already on the GPU: only the signatures cross PCIe
+            DeviceBuffer d_sig(ctx, flat.size() * sizeof(Sig));
+            ctx.check(kmu_sketch(ctx.raw(), &p, b.dev_bytes, b.dev_offsets, nullptr, b.n(), nullptr, d_sig.data(), nullptr));
+            d_sig.download(flat.data(), flat.size() * sizeof(Sig));
+        } else {
+            ctx.check(kmu_sketch(ctx.raw(), &p, b.bytes.data(), b.offsets.data(), b.packed_ptr(), b.n(), nullptr, flat.data(),
+                                 nullptr));
+        }
     } else {
         static_assert(std::is_invocable_r_v<typename Kmer::Val, F, const Kmer &>, "fhash must be Val(const Kmer&)");
         using Val = typename Kmer::Val;
@@ -493,6 +550,14 @@ std::vector<std::vector<Sig>> run_sketch(Context &ctx, const Batch &b, int algo,
         p.flags = flags;
         ctx.check(kmu_sketch_hashed(ctx.raw(), &p, hashed.data(), off.data(), b.n(), flat.data(), nullptr));
     }
+    return rows;
+}
+
+template <class Kmer, class Sig, class F>
+std::vector<std::vector<Sig>> run_sketch(Context &ctx, const Batch &b, int algo, size_t k, size_t m, int hasher, F fhash,
+                                         int mode, uint32_t flags = 0) {
+    std::vector<Sig> flat;
+    const size_t rows = run_sketch_flat<Kmer, Sig>(ctx, b, algo, k, m, hasher, fhash, mode, flat, flags);
     return split_rows(flat, rows, m);
 }
 
@@ -656,6 +721,12 @@ class SeqSketcher {
         return detail::run_sketch<Kmer, typename Kmer::Val>(ctx_, reads, KMU_ALGO_PROB3A, kmer_size_, sketch_size_,
                                                             KMU_HASHER_NOHASH, fhash, KMU_MODE_PER_SEQ);
     }
+    /// ... and with the rows left row-major in a buffer the caller keeps from pack to pack (the tools' loop)
+    template <class Kmer, class F>
+    size_t sketch_probminhash3a(const detail::Batch &reads, F fhash, std::vector<typename Kmer::Val> &rows_out) const {
+        return detail::run_sketch_flat<Kmer, typename Kmer::Val>(ctx_, reads, KMU_ALGO_PROB3A, kmer_size_, sketch_size_,
+                                                                 KMU_HASHER_NOHASH, fhash, KMU_MODE_PER_SEQ, rows_out);
+    }
     /// seqsketchjaccard.rs:272-319: ProbMinHash3 over the same weighted multiset
     template <class Kmer, class Seq, class F>
     std::vector<std::vector<typename Kmer::Val>> sketch_probminhash3(const std::vector<const Seq *> &vseq, F fhash) const {
@@ -680,6 +751,9 @@ class SeqSketcher {
     /// dump_signatures_block_u32 (seqsketchjaccard.rs:572-583)
     static void dump_signatures_block_u32(const std::vector<std::vector<uint32_t>> &signatures, std::ostream &out) {
         for (const auto &sig : signatures) out.write(reinterpret_cast<const char *>(sig.data()), std::streamsize(4 * sig.size()));
+    }
+    static void dump_signatures_block_u32(const std::vector<uint32_t> &rows, size_t n_values, std::ostream &out) {
+        out.write(reinterpret_cast<const char *>(rows.data()), std::streamsize(4 * n_values));
     }
     static constexpr uint32_t MAGIC_SIG_DUMP = 0xceabeadd;   // seqsketchjaccard.rs:570
 
@@ -795,9 +869,18 @@ class BlockSeqSketcher {
         kmu_sketch_params p = detail::sketch_params(KMU_ALGO_PROB3A, KMU_KMER32BIT, kmer_size_, sketch_size_, KMU_SIG_U32,
                                                     KMU_HASHER_NOHASH, int(fhash), int(block_size_), KMU_MODE_PER_SEQ,
                                                     b.input_kind);
+        p.mem = b.mem();
         std::vector<uint32_t> flat(std::max<uint64_t>(rows.back(), 1) * sketch_size_);
-        ctx_.check(kmu_sketch(ctx_.raw(), &p, b.bytes.data(), b.offsets.data(), b.packed_ptr(), b.n(), rows.data(), flat.data(),
-                              nullptr));
+        if (b.on_device()) {
+            DeviceBuffer d_rows(ctx_, rows.size() * 8), d_sig(ctx_, flat.size() * 4);
+            d_rows.upload(rows.data(), rows.size() * 8);
+            ctx_.check(kmu_sketch(ctx_.raw(), &p, b.dev_bytes, b.dev_offsets, nullptr, b.n(), d_rows.as<uint64_t>(), d_sig.data(),
+                                  nullptr));
+            d_sig.download(flat.data(), flat.size() * 4);
+        } else {
+            ctx_.check(kmu_sketch(ctx_.raw(), &p, b.bytes.data(), b.offsets.data(), b.packed_ptr(), b.n(), rows.data(),
+                                  flat.data(), nullptr));
+        }
         std::vector<BlockSketchedSeq> out(b.n());
         for (uint32_t i = 0; i < b.n(); i++) {
             out[i].numseq = uint32_t(numfirst + i);
@@ -940,8 +1023,7 @@ template <class Kmer> class KmerCounter : public KmerCountT<Kmer> {
     void insert_reads(const detail::Batch &b, uint8_t kmer_size) {
         ensure(kmer_size);
         flush();
-        ctx_.check(kmu_count_add_reads(counter_, b.bytes.data(), b.offsets.data(), b.packed_ptr(), b.n(), b.input_kind,
-                                       KMU_MEM_HOST));
+        ctx_.check(kmu_count_add_reads(counter_, b.bytes_ptr(), b.offsets_ptr(), b.packed_ptr(), b.n(), b.input_kind, b.mem()));
     }
     uint32_t get_count(Kmer kmer) override {
         ensure(kmer.get_nb_base());
@@ -1107,6 +1189,90 @@ inline FastqReads parse_fastx_text(const uint8_t *text, size_t n, Context &ctx =
 inline FastqReads parse_fastq_text(const uint8_t *text, size_t n, Context &ctx = Context::global()) {
     return parse_fastx_text(text, n, ctx);
 }
+
+/// The same, with the accepted reads LEFT ON THE DEVICE: the file's text goes up once, the reads never come back --
+/// sketchers and counters take ranges of them (`batch(first, last)`) and only signatures / counts cross PCIe.
+class DeviceReads {
+  public:
+    kmu_ingest_info info{};
+    std::vector<uint64_t> offsets;   // host copy (n + 1): sizes, pack boundaries, block layouts
+    size_t nb_reads() const { return offsets.empty() ? 0 : offsets.size() - 1; }
+    /// reads [first, last): no copy, the device offsets index the whole base array
+    detail::Batch batch(size_t first, size_t last) const {
+        detail::Batch b;
+        b.offsets.assign(offsets.begin() + first, offsets.begin() + last + 1);
+        b.dev_bytes = bases_.as<uint8_t>();
+        b.dev_offsets = offsets_dev_.as<uint64_t>() + first;
+        return b;
+    }
+    /// FASTQ / FASTA text already on the device (16-byte aligned) -> accepted reads on the device
+    static DeviceReads from_device_text(Context &ctx, const uint8_t *d_text, uint64_t n) {
+        DeviceReads r;
+        ctx.check(kmu_ingest_fastx(ctx.raw(), d_text, n, KMU_MEM_DEVICE, nullptr, 0, nullptr, 0, nullptr, &r.info));
+        r.bases_ = DeviceBuffer(ctx, r.info.kept_bases + 64);
+        r.offsets_dev_ = DeviceBuffer(ctx, (r.info.n_kept + 1) * 8);
+        ctx.check(kmu_ingest_fastx(ctx.raw(), d_text, n, KMU_MEM_DEVICE, r.bases_.as<uint8_t>(), r.bases_.bytes(),
+                                   r.offsets_dev_.as<uint64_t>(), r.info.n_kept + 1, nullptr, &r.info));
+        r.offsets.resize(r.info.n_kept + 1);
+        r.offsets_dev_.download(r.offsets.data(), r.offsets.size() * 8);
+        return r;
+    }
+    /// The file goes up in slabs: `n_readers` threads read slabs of it in parallel (pread), each slab is uploaded as soon
+    /// as it is in memory (uploads are serialised: one context, one thread at a time), so reading and PCIe overlap.
+    static DeviceReads from_file(const std::string &fname, Context &ctx = Context::global(), size_t slab = size_t(64) << 20,
+                                 unsigned n_readers = 4) {
+        const int fd = ::open(fname.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + fname);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) {
+            ::close(fd);
+            throw std::runtime_error("cannot stat " + fname);
+        }
+        const uint64_t n = uint64_t(st.st_size);
+        DeviceBuffer text(ctx, n + 64);
+        const uint64_t n_slabs = (n + slab - 1) / slab;
+        std::atomic<uint64_t> next{0};
+        std::mutex upload_lock;
+        std::string error;
+        auto reader = [&]() {
+            std::vector<char> host(std::min<uint64_t>(slab, std::max<uint64_t>(n, 1)));
+            for (;;) {
+                const uint64_t i = next.fetch_add(1);
+                if (i >= n_slabs) return;
+                const uint64_t at = i * slab, want = std::min<uint64_t>(slab, n - at);
+                uint64_t got = 0;
+                while (got < want) {
+                    const ssize_t r = ::pread(fd, host.data() + got, want - got, off_t(at + got));
+                    if (r <= 0) break;
+                    got += uint64_t(r);
+                }
+                std::lock_guard<std::mutex> g(upload_lock);
+                if (got != want) {
+                    error = "short read on " + fname;
+                    next = n_slabs;
+                    return;
+                }
+                try {
+                    text.upload(host.data(), want, at);
+                } catch (const std::exception &e) {
+                    error = e.what();
+                    next = n_slabs;
+                    return;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < std::max(1u, n_readers) && t < n_slabs; t++) pool.emplace_back(reader);
+        reader();
+        for (auto &t : pool) t.join();
+        ::close(fd);
+        if (!error.empty()) throw std::runtime_error(error);
+        return from_device_text(ctx, text.as<uint8_t>(), n);
+    }
+
+  private:
+    DeviceBuffer bases_, offsets_dev_;
+};
 
 inline FastqReads parse_fastq_file(const std::string &fname, Context &ctx = Context::global()) {
     std::ifstream in(fname, std::ios::binary | std::ios::ate);

@@ -155,6 +155,15 @@ const char *kmu_last_error(const kmu_ctx *ctx); /* ctx may be NULL: last error o
 int kmu_synchronize(kmu_ctx *ctx);
 void *kmu_stream(kmu_ctx *ctx); /* the hipStream_t kernels are enqueued on */
 
+/* Device buffers for callers that have no HIP binding of their own (a Rust or C host): allocate on the context's device,
+ * copy in / out on the context's stream (both copies return when the data has arrived), then hand the pointers to the
+ * KMU_MEM_DEVICE form of every entry point -- reads uploaded once can be ingested, sketched and counted without
+ * crossing PCIe again.  kmu_dev_free waits for the context's stream first. */
+int kmu_dev_alloc(kmu_ctx *ctx, uint64_t bytes, void **out);
+int kmu_dev_free(kmu_ctx *ctx, void *p);
+int kmu_copy_to_device(kmu_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
+int kmu_copy_to_host(kmu_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
+
 /* per-kernel device timing with hipEvents on the context stream (bench.py roofline object) */
 int kmu_profile_enable(kmu_ctx *ctx, int on);
 int kmu_profile_reset(kmu_ctx *ctx);

@@ -69,7 +69,7 @@ def compile_host(src, out, extra=(), force=False, verbose=False, deps=()):
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", src, "-o", out, "-L" + HERE, "-lkmu",
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", src, "-o", out, "-L" + HERE, "-lkmu",
            "-Wl,-rpath,$ORIGIN/" + os.path.relpath(HERE, os.path.dirname(out)), "-Wl,-rpath-link,/opt/rocm/lib"] + list(extra)
     if verbose:
         print(" ".join(cmd))

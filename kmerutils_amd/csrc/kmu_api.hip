@@ -280,6 +280,45 @@ int kmu_synchronize(kmu_ctx *ctx) {
 
 void *kmu_stream(kmu_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 
+// ---- device buffers for callers without a HIP binding of their own ------------------------------------------------------
+int kmu_dev_alloc(kmu_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out) return KMU_E_BAD_ARG;
+    *out = nullptr;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+        (void) hipGetLastError();
+        return fail(ctx, KMU_E_OOM, "hipMalloc of %llu bytes failed", (unsigned long long) bytes);
+    }
+    *out = p;
+    return KMU_OK;
+}
+
+int kmu_dev_free(kmu_ctx *ctx, void *p) {
+    if (!ctx) return KMU_E_BAD_ARG;
+    if (!p) return KMU_OK;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // nothing enqueued by this context may still use it
+    KMU_HIP(ctx, hipFree(p));
+    return KMU_OK;
+}
+
+int kmu_copy_to_device(kmu_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst_device || !src_host))) return KMU_E_BAD_ARG;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    KMU_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the host buffer may be reused at return
+    return KMU_OK;
+}
+
+int kmu_copy_to_host(kmu_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst_host || !src_device))) return KMU_E_BAD_ARG;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    KMU_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMU_OK;
+}
+
 int kmu_profile_enable(kmu_ctx *ctx, int on) {
     if (!ctx) return KMU_E_BAD_ARG;
     if (!on && ctx->profiling) profile_collect(ctx);

@@ -22,7 +22,8 @@ SYMBOLS = [
     "kmu_count_reset", "kmu_count_add_reads", "kmu_count_add_kmers", "kmu_count_query", "kmu_count_nb_distinct",
     "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
     "kmu_count_retain_part", "kmu_count_extract_by_owner", "kmu_sig_equal_pairs", "kmu_sig_equal_matrix",
-    "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx",
+    "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx", "kmu_dev_alloc", "kmu_dev_free",
+    "kmu_copy_to_device", "kmu_copy_to_host",
 ]
 
 
@@ -78,6 +79,10 @@ def load():
     L.kmu_sig_equal_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
     L.kmu_sig_equal_matrix.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
     L.kmu_minhash_distance_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, vp]
+    L.kmu_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.kmu_dev_free.argtypes = [vp, vp]
+    L.kmu_copy_to_device.argtypes = [vp, vp, vp, C.c_uint64]
+    L.kmu_copy_to_host.argtypes = [vp, vp, vp, C.c_uint64]
     for f in (L.kmu_ingest_fastq, L.kmu_ingest_fasta, L.kmu_ingest_fastx):
         f.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(A.IngestInfo)]
     _lib = L

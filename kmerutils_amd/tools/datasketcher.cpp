@@ -1,7 +1,7 @@
 // datasketcher -f reads.fastq -k 8 -s 200 -d out.sig [-b block_size] [--device n]
 //
 // The reference's tool (src/bin/datasketcher.rs:40-312) on the GPU path, without its `ann` sub-command (HNSW is outside
-// the path).  The FASTQ text is split into records and filtered on the device (a record with a byte outside ACGTacgt is
+// the path).  The FASTQ / FASTA text is uploaded once, split into records and filtered on the device (a record with a byte outside ACGTacgt is
 // dropped and counted, datasketcher.rs:358-388), the accepted reads are sketched in packs with ProbMinHash3a on canonical
 // Kmer32bit k-mers hashed by int32_hash (the closure of datasketcher.rs:222-226), whole or by blocks, and the signatures
 // are written in the reference's dump formats (seqsketchjaccard.rs:385-414, seqblocksketch.rs:172-226).
@@ -45,30 +45,36 @@ int main(int argc, char **argv) {
     try {
         const auto t0 = std::chrono::steady_clock::now();
         Context ctx{int(device)};
-        FastqReads reads = parse_fastq_file(fname, ctx);
+        DeviceReads reads = DeviceReads::from_file(fname, ctx);   // text up once, accepted reads stay on the device
+        const double t_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (reads.info.nb_bad_reads)   // datasketcher.rs:382-384
             std::fprintf(stderr, " number of non acgt sequences %llu \n", (unsigned long long) reads.info.nb_bad_reads);
         const size_t n = reads.nb_reads();
         const size_t sequence_pack = block_size ? 5000 : 10000;   // datasketcher.rs:212
+        double t_sketch = 0;
         if (block_size) {
             BlockSeqSketcher sketcher(size_t(block_size), size_t(kmer_size), size_t(sketch_size), ctx);
             std::ofstream out = sketcher.create_signature_dump(dumpfname);
             for (size_t nbseq = 0; nbseq < n; nbseq += sequence_pack) {
                 const size_t last = std::min(n, nbseq + sequence_pack);
-                BlockSeqSketcher::dump_blocks(out, sketcher.blocksketch_sequences(nbseq, batch_of(reads, nbseq, last),
+                BlockSeqSketcher::dump_blocks(out, sketcher.blocksketch_sequences(nbseq, reads.batch(nbseq, last),
                                                                                   kmer_revcomp_hash_fn));
             }
         } else {
             SeqSketcher sketcher(size_t(kmer_size), size_t(sketch_size), ctx);
             std::ofstream out = sketcher.create_signature_dump(dumpfname);
+            std::vector<uint32_t> rows;   // one pack of signatures, reused
             for (size_t nbseq = 0; nbseq < n; nbseq += sequence_pack) {
                 const size_t last = std::min(n, nbseq + sequence_pack);
-                SeqSketcher::dump_signatures_block_u32(
-                    sketcher.sketch_probminhash3a<Kmer32bit>(batch_of(reads, nbseq, last), kmer_revcomp_hash_fn), out);
+                const auto ts = std::chrono::steady_clock::now();
+                const size_t nrows = sketcher.sketch_probminhash3a<Kmer32bit>(reads.batch(nbseq, last), kmer_revcomp_hash_fn, rows);
+                t_sketch += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
+                SeqSketcher::dump_signatures_block_u32(rows, nrows * size_t(sketch_size), out);
             }
         }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        std::fprintf(stderr, " nb sequences sketched %zu, elapsed time (s) %.3f\n", n, dt);
+        std::fprintf(stderr, " nb sequences sketched %zu, elapsed time (s) %.3f (file -> accepted reads on the device %.3f, sketch + dump %.3f of which sketch calls %.3f)\n",
+                     n, dt, t_read, dt - t_read, t_sketch);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "datasketcher: %s\n", e.what());
         return 1;

@@ -19,9 +19,9 @@ static void usage() {
     std::exit(2);
 }
 
-template <class Kmer> static void count_and_dump(const FastqReads &reads, uint8_t kmer_size, const std::string &dumpfname, Context &ctx) {
+template <class Kmer> static void count_and_dump(const DeviceReads &reads, uint8_t kmer_size, const std::string &dumpfname, Context &ctx) {
     KmerCounterPool<Kmer> pool(std::max<uint64_t>(reads.info.kept_bases, 1024), 8, ctx);
-    pool.counter().insert_reads(batch_of(reads, 0, reads.nb_reads()), kmer_size);
+    pool.counter().insert_reads(reads.batch(0, reads.nb_reads()), kmer_size);
     std::fprintf(stderr, " nb distinct kmers %llu, nb unique kmers %llu\n", (unsigned long long) pool.get_nb_distinct(),
                  (unsigned long long) pool.get_nb_unique());
     const size_t n = pool.dump_kmer_counter(dumpfname);
@@ -56,7 +56,7 @@ int main(int argc, char **argv) {
     try {
         const auto t0 = std::chrono::steady_clock::now();
         Context ctx{int(device)};
-        FastqReads reads = parse_fastq_file(fname, ctx);
+        DeviceReads reads = DeviceReads::from_file(fname, ctx);
         std::fprintf(stderr, " nb reads %llu, nb bases %llu, nb bad bases %llu, nb reads with non acgt %llu\n",
                      (unsigned long long) reads.info.n_records, (unsigned long long) reads.info.n_bases,
                      (unsigned long long) reads.info.nb_bad_bases, (unsigned long long) reads.info.nb_bad_reads);

@@ -590,7 +590,6 @@ static void mset_init(mset_t *m, uint64_t expected) {
     memset(m->slots, 0xFF, m->nslots * 8);
 }
 static void mset_free(mset_t *m) { free(m->keys); free(m->w); free(m->slots); }
-static void mset_clear(mset_t *m) { m->n = 0; memset(m->slots, 0xFF, m->nslots * 8); }
 static void mset_grow(mset_t *m) {
     m->cap_items *= 2;
     m->keys = (uint64_t *) realloc(m->keys, m->cap_items * 8);

@@ -644,6 +644,46 @@ TEST(test_parse_fasta) {
     CHECK(std::equal(ob.begin(), ob.begin() + info[2], reads.bases.begin()));
 }
 
+// reads left on the device by the reader (what the two tools use): ranges of them sketch, block-sketch and count to the
+// same results as host-resident Sequence objects
+TEST(test_device_resident_reads) {
+    std::mt19937_64 rng(211);
+    std::string text;
+    std::vector<Sequence> seqs;
+    for (int r = 0; r < 90; r++) {
+        std::string s(30 + rng() % 700, 'A');
+        for (char &c : s) c = "ACGT"[rng() & 3];
+        text += "@r\n" + s + "\n+\n" + std::string(s.size(), 'I') + "\n";
+        seqs.emplace_back(s);
+    }
+    const std::string fname = "/tmp/kmu_test_mirror_dev.fastq";
+    { std::ofstream(fname, std::ios::binary) << text; }
+    Context &ctx = Context::global();
+    DeviceReads reads = DeviceReads::from_file(fname, ctx, 4096);   // small slabs: several uploads
+    std::remove(fname.c_str());
+    CHECK(reads.nb_reads() == 90 && reads.info.nb_bad_reads == 0);
+    auto ptrs = detail::pointers(seqs);
+    SeqSketcher sk(8, 64);
+    auto want = sk.sketch_probminhash3a<Kmer32bit>(ptrs, kmer_revcomp_hash_fn);
+    auto all = sk.sketch_probminhash3a<Kmer32bit>(reads.batch(0, 90), kmer_revcomp_hash_fn);
+    CHECK(all == want);
+    auto mid = sk.sketch_probminhash3a<Kmer32bit>(reads.batch(37, 61), kmer_revcomp_hash_fn);   // a range, no copy
+    CHECK(mid.size() == 24 && std::equal(mid.begin(), mid.end(), want.begin() + 37));
+    BlockSeqSketcher bs(100, 8, 16);
+    auto wb = bs.blocksketch_sequences(37, {ptrs.begin() + 37, ptrs.begin() + 61}, kmer_revcomp_hash_fn);
+    auto gb = bs.blocksketch_sequences(37, reads.batch(37, 61), kmer_revcomp_hash_fn);
+    CHECK(gb.size() == wb.size());
+    for (size_t i = 0; i < gb.size(); i++) {
+        CHECK(gb[i].numseq == wb[i].numseq && gb[i].sketch.size() == wb[i].sketch.size());
+        for (size_t j = 0; j < gb[i].sketch.size(); j++) CHECK(gb[i].sketch[j].sketch == wb[i].sketch[j].sketch);
+    }
+    KmerCounter<Kmer64bit> on_dev(0.03, 1 << 16, 8), on_host(0.03, 1 << 16, 8);
+    on_dev.insert_reads(reads.batch(0, 90), 21);
+    on_host.insert_reads(ptrs, 21);
+    CHECK(on_dev.get_nb_distinct() == on_host.get_nb_distinct() && on_dev.get_nb_unique() == on_host.get_nb_unique());
+    CHECK(on_dev.get_above2_count() == on_host.get_above2_count());
+}
+
 // errors surface where the reference panics
 TEST(test_errors_where_the_reference_panics) {
     Sequence seqa(SEQSTR);

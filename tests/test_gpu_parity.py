@@ -824,3 +824,29 @@ def test_probminhash_genome_sized_sequences(ctx, oracle):
     gh, gc = ctx.sketch(bases, off, pb, want_counts=True)
     wh, wc = oracle.sketch(bases, off, pb, want_counts=True)
     assert np.array_equal(np.asarray(gh), wh) and np.array_equal(np.asarray(gc), wc)
+
+
+@pytest.mark.gpu
+def test_device_buffer_helpers(ctx, oracle):
+    """kmu_dev_alloc / kmu_copy_to_device / kmu_copy_to_host / kmu_dev_free: a host without a HIP binding uploads its reads
+    once and calls the KMU_MEM_DEVICE entry points on the returned pointers"""
+    import ctypes as C
+    L = ctx.L
+    seqs = ragged_dna(12, RAGGED)
+    bases, off = oracle.concat(seqs)
+    nb, n = int(off[-1]), len(off) - 1
+    d_bases, d_off, d_sig = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for ptr, size in ((d_bases, nb + 64), (d_off, 8 * (n + 1)), (d_sig, n * 32 * 8)):
+        assert L.kmu_dev_alloc(ctx.h, size, C.byref(ptr)) == 0 and ptr.value
+    assert L.kmu_copy_to_device(ctx.h, d_bases, bases.ctypes.data_as(C.c_void_p), nb) == 0
+    assert L.kmu_copy_to_device(ctx.h, d_off, off.ctypes.data_as(C.c_void_p), 8 * (n + 1)) == 0
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 21, 32, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0,
+                       A.INPUT_ASCII, A.MEM_DEVICE, 0)
+    assert L.kmu_sketch(ctx.h, C.byref(p), d_bases, d_off, None, n, None, d_sig, None) == 0
+    got = np.zeros((n, 32), np.uint64)
+    assert L.kmu_copy_to_host(ctx.h, got.ctypes.data_as(C.c_void_p), d_sig, got.nbytes) == 0
+    p.mem = A.MEM_HOST
+    assert np.array_equal(got, oracle.sketch(bases, off, p))
+    for ptr in (d_bases, d_off, d_sig):
+        assert L.kmu_dev_free(ctx.h, ptr) == 0
+    assert L.kmu_dev_free(ctx.h, None) == 0
