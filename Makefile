@@ -1,0 +1,34 @@
+# Build without Python: libkmu.so (hipcc, gfx950), the C++ tools and the C example (g++ / gcc against the C-ABI).
+# `python -c "import __graft_entry__ as g; g.build()"` does the same and also builds the test infrastructure.
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+CC       ?= gcc
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function
+CSRC     := kmerutils_amd/csrc
+OBJDIR   := kmerutils_amd/build
+SOURCES  := kmu_api kmu_sketch kmu_sketch_super kmu_count kmu_compare kmu_ingest
+OBJS     := $(SOURCES:%=$(OBJDIR)/%.o)
+LIB      := kmerutils_amd/libkmu.so
+BIN      := kmerutils_amd/bin
+LINK     := -Lkmerutils_amd -lkmu -Wl,-rpath-link,/opt/rocm/lib
+
+all: $(LIB) $(BIN)/datasketcher $(BIN)/parsefastq examples/sketch_c
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/kmu_device.h $(CSRC)/kmu_stream.h $(CSRC)/kmu_ctx.hpp include/kmu.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+
+$(BIN)/%: kmerutils_amd/tools/%.cpp include/kmerutils.hpp include/kmu.h $(LIB)
+	@mkdir -p $(BIN)
+	$(CXX) -std=c++17 -O2 -Wall -Wextra -pthread $< -o $@ $(LINK) -Wl,-rpath,'$$ORIGIN/..'
+
+examples/sketch_c: examples/sketch.c include/kmu.h $(LIB)
+	$(CC) -std=c99 -O2 -Wall -Wextra $< -o $@ $(LINK) -Wl,-rpath,'$$ORIGIN/../kmerutils_amd'
+
+clean:
+	rm -rf $(OBJDIR) $(LIB) $(BIN) examples/sketch_c
+
+.PHONY: all clean

@@ -133,3 +133,26 @@ def test_parsefastq_tool(host_programs, tmp_path, oracle):
     assert k == 21 and np.array_equal(vals, gk) and np.array_equal(counts, np.minimum(gc, 255))
     with open(str(tmp_path / "reads.fastq.multi_kmer.bin"), "rb") as f:
         assert struct.unpack("<I", f.read(4))[0] == formats.COUNTER_MULTIPLE
+
+
+def _c_example():
+    exe = os.path.join(ROOT, "examples", "sketch_c")
+    subprocess.run(["make", "-s", "-C", ROOT, "examples/sketch_c"], check=True, capture_output=True, timeout=900)
+    return exe
+
+
+def test_c_example_builds_with_plain_gcc():
+    """examples/sketch.c: the C-ABI from C99 (gcc, no C++ / HIP headers); without a device it stops with the library's error"""
+    import torch
+    exe = _c_example()
+    assert os.access(exe, os.X_OK)
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_runs():
+    r = subprocess.run([_c_example()], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "= 1.000" in r.stdout
