@@ -1,0 +1,67 @@
+"""tests/golden/oracle_signatures.json: the oracle's signatures on the reference's own test strings, frozen.
+CPU: the oracle still reproduces them and the reference's statistical assertions hold on the frozen rows.
+GPU: the device produces the same rows through the C-ABI."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "oracle_signatures.json")))
+CASES = sorted(FIX["cases"])
+
+
+def _params(c):
+    return A.SketchParams(c["algo"], c["kmer_type"], c["k"], c["m"], c["sig_type"], c["hasher"], c["fhash"], 0, A.MODE_PER_SEQ,
+                          A.INPUT_ASCII, A.MEM_HOST, c["flags"])
+
+
+def _rows(c):
+    dt = {A.SIG_U32: np.uint32, A.SIG_F32: np.uint32, A.SIG_U64: np.uint64, A.SIG_F64: np.uint64}[c["sig_type"]]
+    return np.array(c["rows"], dtype=dt)
+
+
+def _bits(rows):
+    return rows.view(np.uint32 if rows.dtype.itemsize == 4 else np.uint64) if rows.dtype.kind == "f" else rows
+
+
+def test_fixture_is_what_the_committed_script_writes():
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_oracle_signatures as G
+    assert sorted(c[0] for c in G.CASES) == CASES
+    for case in G.CASES:
+        _, _, _, rows = G.compute(case)
+        assert np.array_equal(rows, _rows(FIX["cases"][case[0]])), case[0]
+
+
+def test_reference_assertions_hold_on_the_frozen_rows():
+    """the thresholds of the reference's tests (seqsketchjaccard.rs:784-785, 850, 902-909, 942-943, 992-1004;
+    aautils/setsketchert.rs:1264, 1369) evaluated on the fixture"""
+    def jac(rows, i, j):
+        return float((rows[i] == rows[j]).mean())
+    c = FIX["cases"]
+    for name, k in (("pminhasha_kmer_smallb_revcomp", 5), ("pminhasha_k16b32bit", 16), ("pminhash_kmer64bit", 16),
+                    ("pminhash_kmer64bit_rand08", 16), ("superminhash_16b32bit_fnv_f64", 16),
+                    ("superminhash_16b32bit_nohash_f32", 16)):
+        rows = _rows(c[name])
+        jac_theo_0 = (40 - k) / (80 - k)
+        assert jac(rows, 0, 1) >= 0.75 * jac_theo_0, name
+        assert jac(rows, 0, 2) >= 1.0, name          # canonical k-mers: a sequence and its reverse complement
+    rows = _rows(c["pminhasha_kmer_smallb_identity"])
+    assert jac(rows, 0, 1) >= 0.75 * (40 - 5) / (80 - 5) and jac(rows, 0, 2) <= 0.1
+    for name in ("seqaa_probminhash_64bit", "seqaa_probminhash_32bit", "seqaa_superminhash_64bit_f64"):
+        rows = _rows(c[name])
+        assert abs(jac(rows, 0, 1) - 0.5) < 0.1, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_device_reproduces_the_frozen_rows(ctx, oracle, name):
+    c = FIX["cases"][name]
+    bases, off = oracle.concat([s.encode() for s in c["sequences"]])
+    got = _bits(np.asarray(ctx.sketch(bases, off, _params(c))))
+    assert np.array_equal(got, _rows(c))
