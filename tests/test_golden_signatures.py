@@ -58,6 +58,14 @@ def test_reference_assertions_hold_on_the_frozen_rows():
         assert abs(jac(rows, 0, 1) - 0.5) < 0.1, name
 
 
+@pytest.fixture(scope="module")
+def ctx():
+    from kmerutils_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
 def test_device_reproduces_the_frozen_rows(ctx, oracle, name):
