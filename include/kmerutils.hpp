@@ -12,6 +12,7 @@
  *   sketching     SeqSketcherParams, SketchAlgo, DataType    src/sketcharg.rs:13-78
  *                 SeqSketcherT (trait)                       src/sketching/setsketchert.rs:54-80
  *                 ProbHash3aSketch / SuperHashSketch / SuperHash2Sketch   setsketchert.rs:85-336, 904-1046
+ *                 OptDensHashSketch / RevOptDensHashSketch                setsketchert.rs:343-599
  *                 SeqSketcher                                src/sketching/seqsketchjaccard.rs:117-415
  *                 jaccard_index_probminhash3a, probminhash_get_jaccard_objects, compute_*_jaccard
  *                                                            seqsketchjaccard.rs:58-108, 423-495
@@ -682,6 +683,26 @@ template <class Kmer, class S> class SuperHashSketch : public detail::SketcherIm
   public:
     explicit SuperHashSketch(const SeqSketcherParams &params, Context &ctx = Context::global())
         : detail::SketcherImpl<Kmer, S, KMU_ALGO_SUPER>(params, SketchAlgo::SUPER, KMU_HASHER_NOHASH, ctx) {}
+};
+
+/// OptDensHashSketch<Kmer, S>: one-permutation hashing + optimal densification, S = f32 / f64 (setsketchert.rs:343-463;
+/// AA: aautils/setsketchert.rs:482-612)
+template <class Kmer, class S> class OptDensHashSketch : public detail::SketcherImpl<Kmer, S, KMU_ALGO_OPTDENS> {
+    static_assert(std::is_floating_point_v<S>, "OptDensHashSketch: S is f32 or f64");
+
+  public:
+    explicit OptDensHashSketch(const SeqSketcherParams &params, Context &ctx = Context::global())
+        : detail::SketcherImpl<Kmer, S, KMU_ALGO_OPTDENS>(params, SketchAlgo::OPTDENS, KMU_HASHER_NOHASH, ctx) {}
+};
+
+/// RevOptDensHashSketch<Kmer, S>: reverse optimal densification, robust when the sketch is larger than the sequence
+/// (setsketchert.rs:474-599; AA: aautils/setsketchert.rs:616-746)
+template <class Kmer, class S> class RevOptDensHashSketch : public detail::SketcherImpl<Kmer, S, KMU_ALGO_REVOPTDENS> {
+    static_assert(std::is_floating_point_v<S>, "RevOptDensHashSketch: S is f32 or f64");
+
+  public:
+    explicit RevOptDensHashSketch(const SeqSketcherParams &params, Context &ctx = Context::global())
+        : detail::SketcherImpl<Kmer, S, KMU_ALGO_REVOPTDENS>(params, SketchAlgo::REVOPTDENS, KMU_HASHER_NOHASH, ctx) {}
 };
 
 /// the `H: Hasher` parameter of SuperHash2Sketch

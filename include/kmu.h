@@ -85,8 +85,12 @@ typedef enum kmu_algo {
     KMU_ALGO_SUPER = 1,  /* SuperMinHash   (probminhash crate), src/sketching/setsketchert.rs:255-297 */
     KMU_ALGO_SUPER2 = 2, /* SuperMinHash2  (integer sketch),   src/sketching/setsketchert.rs:963-1004 */
     KMU_ALGO_BOTTOMK = 3, /* MinHashCount / MinInvHashCountKmer, src/sketching/minhash.rs:62-99,219-265 */
-    KMU_ALGO_PROB3 = 4    /* ProbMinHash3 (SeqSketcher::sketch_probminhash3, seqsketchjaccard.rs:272-319): the same point
+    KMU_ALGO_PROB3 = 4,   /* ProbMinHash3 (SeqSketcher::sketch_probminhash3, seqsketchjaccard.rs:272-319): the same point
                            * process as ProbMinHash3a handled key by key; the signature is the same per-slot arg-min */
+    KMU_ALGO_OPTDENS = 5, /* OptDensHashSketch: one-permutation hashing + optimal densification (Shrivastava 2017),
+                           * src/sketching/setsketchert.rs:343-463, src/aautils/setsketchert.rs:482-612; sig F32 / F64 */
+    KMU_ALGO_REVOPTDENS = 6 /* RevOptDensHashSketch: the same with reverse densification (Mai et al. 2019), meant for
+                           * sketches larger than the sequences, setsketchert.rs:474-599, aautils/setsketchert.rs:616-746 */
 } kmu_algo;
 
 typedef enum kmu_sig_type { KMU_SIG_U32 = 0, KMU_SIG_U64 = 1, KMU_SIG_F32 = 2, KMU_SIG_F64 = 3 } kmu_sig_type;
@@ -119,7 +123,7 @@ typedef struct kmu_sketch_params {
     int32_t kmer_type;   /* kmu_kmer_type */
     int32_t kmer_size;
     int32_t sketch_size; /* m */
-    int32_t sig_type;    /* kmu_sig_type; PROB3A/BOTTOMK: must match Kmer::Val width; SUPER: F32/F64 */
+    int32_t sig_type;    /* kmu_sig_type; PROB3A/BOTTOMK: must match Kmer::Val width; SUPER / OPTDENS / REVOPTDENS: F32/F64 */
     int32_t hasher;      /* kmu_hasher */
     int32_t fhash;       /* kmu_fhash */
     int32_t block_size;  /* 0 = whole sequence; >0 = BlockSeqSketcher (src/sketching/seqblocksketch.rs:97-149) */

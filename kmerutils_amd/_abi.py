@@ -15,7 +15,7 @@ INPUT_ASCII, INPUT_PACKED2 = 0, 1
 KMER32BIT, KMER16B32BIT, KMER64BIT, KMERAA32BIT, KMERAA64BIT = 0, 1, 2, 3, 4
 (FHASH_IDENTITY_RAW, FHASH_VALUE_MASKED, FHASH_CANON_RAW, FHASH_CANON_INVHASH, FHASH_INVHASH_RAW, FHASH_CANON_VALUE,
  FHASH_CANON_NTHASH, FHASH_CANON_NTHASH_8B) = range(8)
-ALGO_PROB3A, ALGO_SUPER, ALGO_SUPER2, ALGO_BOTTOMK, ALGO_PROB3 = 0, 1, 2, 3, 4
+ALGO_PROB3A, ALGO_SUPER, ALGO_SUPER2, ALGO_BOTTOMK, ALGO_PROB3, ALGO_OPTDENS, ALGO_REVOPTDENS = 0, 1, 2, 3, 4, 5, 6
 SIG_U32, SIG_U64, SIG_F32, SIG_F64 = 0, 1, 2, 3
 HASHER_NOHASH, HASHER_FNV1A, HASHER_INT64HASH = 0, 1, 2
 MODE_PER_SEQ, MODE_ALL_SEQS = 0, 1

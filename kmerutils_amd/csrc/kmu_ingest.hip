@@ -308,10 +308,8 @@ __global__ void __launch_bounds__(256) k_fa_join(const uint8_t *text, uint64_t n
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             uint64_t ls = line_start[l], le = line_end[l], sp = seqpos[l];
             bool hdr = is_hdr[l] != 0u;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
+            for (int j = 0; j < 16 && pos0 + j < n; j++) {
                 const uint64_t i = pos0 + j;
-                if (i >= n) break;
                 if (!hdr && i < le) stream[sp + (i - ls)] = (uint8_t) (w[j >> 2] >> (8 * (j & 3)));
                 if ((mask >> j) & 1u) { // the next byte opens line l + 1
                     l++;

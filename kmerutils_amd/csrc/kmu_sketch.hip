@@ -1141,6 +1141,10 @@ static int sketch_params_check(kmu_ctx *ctx, const kmu_sketch_params *p) {
     case KMU_ALGO_SUPER:
         if (p->sig_type != KMU_SIG_F32 && p->sig_type != KMU_SIG_F64) return fail(ctx, KMU_E_BAD_ARG, "SuperMinHash signature is f32/f64");
         break;
+    case KMU_ALGO_OPTDENS:
+    case KMU_ALGO_REVOPTDENS:
+        if (p->sig_type != KMU_SIG_F32 && p->sig_type != KMU_SIG_F64) return fail(ctx, KMU_E_BAD_ARG, "OptDens / RevOptDens signature is f32/f64");
+        break;
     case KMU_ALGO_SUPER2:
         if (p->sig_type != KMU_SIG_U32 && p->sig_type != KMU_SIG_U64) return fail(ctx, KMU_E_BAD_ARG, "SuperMinHash2 signature is u32/u64");
         break;
@@ -1159,7 +1163,10 @@ namespace kmu {
 int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err,
                  const void *hashed, int hashed_bytes, uint64_t *part_rows);
 int launch_super_reduce(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *part_rows, uint64_t n_parts, void *d_sig);
+int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err, const void *hashed,
+                int hashed_bytes);
 }
+static bool algo_is_dens(int algo) { return algo == KMU_ALGO_OPTDENS || algo == KMU_ALGO_REVOPTDENS; }
 
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
                         void *d_sig, uint32_t *d_counts, uint32_t *d_err, const void *hashed = nullptr,
@@ -1435,6 +1442,13 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
             KMU_TRY(dev_buf(ctx, "out.sig", (size_t) p->sketch_size * sigb + 64, &q));
             d_sig = q;
         }
+        if (algo_is_dens(p->algo)) { // one set of bins for every sequence, filled in place (setsketchert.rs:429-463)
+            KMU_TRY(launch_dens(ctx, p, ds, d_sig, d_err, nullptr, 0));
+            if (p->mem == KMU_MEM_HOST)
+                KMU_HIP(ctx, hipMemcpyAsync(sig_out, d_sig, (size_t) p->sketch_size * sigb, hipMemcpyDeviceToHost, ctx->stream));
+            if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
+            return finish_call(ctx, p->mem);
+        }
         // sketch_compressedkmer_seqs (setsketchert.rs:160-202, :299-335): one multiset / one stream over every
         // sequence.  fhash values of all k-mers, compact; then the pre-hashed all-sequences path.
         void *koff, *hk;
@@ -1511,6 +1525,8 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
         }
         case KMU_ALGO_SUPER:
         case KMU_ALGO_SUPER2: KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err, nullptr, 0, nullptr)); break;
+        case KMU_ALGO_OPTDENS:
+        case KMU_ALGO_REVOPTDENS: KMU_TRY(launch_dens(ctx, p, ds, d_sig, d_err, nullptr, 0)); break;
         case KMU_ALGO_BOTTOMK: KMU_TRY(launch_pmh3a(ctx, p, ds, nullptr, d_sig, d_counts, d_err)); break;
         }
     }
@@ -1564,7 +1580,14 @@ extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, co
     }
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
-    if (p->mode == KMU_MODE_ALL_SEQS) {
+    if (algo_is_dens(p->algo)) {
+        DevSeqs ds;
+        ds.bases = reinterpret_cast<const uint8_t *>(d_vals);
+        ds.offsets = d_off;
+        ds.n_seq = n_seq;
+        ds.total_bytes = 1;
+        KMU_TRY(launch_dens(ctx, p, ds, d_sig, d_err, d_vals, w));
+    } else if (p->mode == KMU_MODE_ALL_SEQS) {
         const uint64_t *v64 = (const uint64_t *) d_vals;
         if (w == 4) { // widen to u64 once (the all-sequences path partitions u64 keys)
             void *q;

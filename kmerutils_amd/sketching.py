@@ -6,6 +6,7 @@ Names and argument meaning follow the reference so that callers (gsearch-style c
   ProbHash3aSketch             src/sketching/setsketchert.rs:85-203      (trait SeqSketcherT :54-80)
   SuperHashSketch              src/sketching/setsketchert.rs:211-336
   SuperHash2Sketch             src/sketching/setsketchert.rs:904-1046
+  OptDensHashSketch / RevOptDensHashSketch   src/sketching/setsketchert.rs:343-599
   SeqSketcher                  src/sketching/seqsketchjaccard.rs:117-415 (sketch_probminhash3a :211, _superminhash :328)
   BlockSeqSketcher             src/sketching/seqblocksketch.rs:79-227
 A Rust closure `fhash` cannot cross the FFI: pass one of the FHASH_* modes (the closures the reference's own callers
@@ -20,6 +21,7 @@ from . import lib
 
 class SketchAlgo:
     PROB3A, SUPER, SUPER2, BOTTOMK, PROB3 = A.ALGO_PROB3A, A.ALGO_SUPER, A.ALGO_SUPER2, A.ALGO_BOTTOMK, A.ALGO_PROB3
+    OPTDENS, REVOPTDENS = A.ALGO_OPTDENS, A.ALGO_REVOPTDENS
 
 
 class DataType:
@@ -120,6 +122,18 @@ class SuperHashSketch(_SketcherBase):
 
     def _sig_type(self):
         return A.SIG_F32 if self.sig == "f32" else A.SIG_F64
+
+
+class OptDensHashSketch(SuperHashSketch):
+    """OptDensHashSketch<Kmer, S>: one-permutation hashing + optimal densification, type Sig = f32 / f64, NoHashHasher
+    (setsketchert.rs:343-463; AA: aautils/setsketchert.rs:482-612)"""
+    algo = SketchAlgo.OPTDENS
+
+
+class RevOptDensHashSketch(SuperHashSketch):
+    """RevOptDensHashSketch<Kmer, S>: the same with reverse optimal densification, for sketches larger than the sequences
+    (setsketchert.rs:474-599; AA: aautils/setsketchert.rs:616-746)"""
+    algo = SketchAlgo.REVOPTDENS
 
 
 class SuperHash2Sketch(_SketcherBase):

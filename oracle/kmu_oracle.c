@@ -834,6 +834,82 @@ static void smh_sketch(smh_t *s, uint64_t hval, uint32_t flags) {
     s->item_rank += 1;
 }
 
+/* ---- One-permutation hashing + densification (UNPINNED: crate probminhash, module densminhash:
+ * OptDensMinHash / RevOptDensMinHash; call sites src/sketching/setsketchert.rs:385-463, 521-599,
+ * src/aautils/setsketchert.rs:482-746).  `sketch(&item)`: seed the RNG from hasher(item), draw r in [0,1) and a bin
+ * k in [0,m); the bin keeps its smallest r.  `end_sketch()` fills the bins no item fell into:
+ *   OptDens    -- Shrivastava, "Optimal densification for fast and accurate minwise hashing" (ICML 2017): an empty bin
+ *                 i tries j = h(i, attempt), attempt = 1, 2, ... until j is a bin that was filled by an item, and copies it;
+ *   RevOptDens -- Mai, Rao, Kapilevich, Rossi, Abbasi-Yadkori, Sinha, "On densification for minwise hashing" (UAI 2019):
+ *                 the other way round, in rounds: every bin filled by an item offers itself to the bin h(j, round); a bin
+ *                 still empty takes the first offer of the round (smallest j).  Rounds go on until no bin is empty.
+ * Both papers leave the 2-universal hash h open; the crate's choice is not known here, h below (a SplitMix64 finaliser of
+ * the pair, reduced by multiply-high) is THIS implementation's.  hsketch starts at F::from(u32::MAX) like SuperMinHash's.
+ * A sketch that saw no item stays at its initial value. */
+typedef struct {
+    int m, f32;
+    double *hs;       /* f32 sketches hold values that are exact f32 numbers */
+    uint8_t *filled;  /* by an item */
+    int64_t nb_empty;
+} oph_t;
+
+static double oph_large(int f32) { return f32 ? (double) 4294967296.0f : 4294967295.0; }
+
+static void oph_init(oph_t *s, int m, int f32) {
+    s->m = m;
+    s->f32 = f32;
+    s->hs = (double *) malloc((size_t) m * 8);
+    s->filled = (uint8_t *) calloc((size_t) m, 1);
+    s->nb_empty = m;
+    for (int i = 0; i < m; i++) s->hs[i] = oph_large(f32);
+}
+static void oph_free(oph_t *s) { free(s->hs); free(s->filled); }
+
+static void oph_sketch(oph_t *s, uint64_t hval, uint32_t flags) {
+    uint64_t st[4];
+    kmo_xoshiro_seed(hval, st);
+    const double r = s->f32 ? (double) unif01_f32(st) : unif01_f64(st);
+    const uint64_t k = unif_usize(st, 0, (uint64_t) s->m, flags);
+    if (r <= s->hs[k]) {
+        s->hs[k] = r;
+        if (!s->filled[k]) { s->filled[k] = 1; s->nb_empty--; }
+    }
+}
+
+static uint64_t dens_hash(uint64_t bin, uint64_t attempt, uint64_t m) {
+    uint64_t z = ((bin << 32) | (attempt & 0xFFFFFFFFull)) + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return (uint64_t) (((unsigned __int128) z * m) >> 64);
+}
+
+static void oph_end_sketch(oph_t *s, int rev) {
+    const int m = s->m;
+    if (s->nb_empty == 0 || s->nb_empty == m) return;
+    if (!rev) {
+        for (int i = 0; i < m; i++) {
+            if (s->filled[i]) continue;
+            for (uint64_t attempt = 1;; attempt++) {
+                const uint64_t j = dens_hash((uint64_t) i, attempt, (uint64_t) m);
+                if (s->filled[j]) { s->hs[i] = s->hs[j]; break; }
+            }
+        }
+        return;
+    }
+    uint8_t *now = (uint8_t *) malloc((size_t) m);
+    memcpy(now, s->filled, (size_t) m);
+    int64_t left = s->nb_empty;
+    for (uint64_t round = 1; left > 0; round++) {
+        for (int j = 0; j < m && left > 0; j++) {
+            if (!s->filled[j]) continue;
+            const uint64_t i = dens_hash((uint64_t) j, round, (uint64_t) m);
+            if (!now[i]) { s->hs[i] = s->hs[j]; now[i] = 1; left--; }
+        }
+    }
+    free(now);
+}
+
 /* ====================================================================================================
  * bottom-k with multiplicities: MinHashCount::push, src/sketching/minhash.rs:62-99 (u16 counts) and
  * MinInvHashCountKmer::push :219-265 (u8 counts).  Literal: max-heap + map, `<=` acceptance.
@@ -875,6 +951,8 @@ static int sketch_params_check(const kmu_sketch_params *p) {
         if (p->hasher != KMU_HASHER_NOHASH) return KMU_E_BAD_ARG; /* every call site uses NoHashHasher */
         break;
     case KMU_ALGO_SUPER:
+    case KMU_ALGO_OPTDENS:
+    case KMU_ALGO_REVOPTDENS:
         if (p->sig_type != KMU_SIG_F32 && p->sig_type != KMU_SIG_F64) return KMU_E_BAD_ARG;
         break;
     case KMU_ALGO_SUPER2:
@@ -896,9 +974,12 @@ typedef struct {
     int w; /* bytes of Kmer::Val */
     mset_t ms;
     smh_t smh;
+    oph_t oph;
     botk_t bk;
     int open;
 } sk_state_t;
+
+static int is_dens(int algo) { return algo == KMU_ALGO_OPTDENS || algo == KMU_ALGO_REVOPTDENS; }
 
 static void sk_begin(sk_state_t *st, const kmu_sketch_params *p, uint64_t expected) {
     st->p = p;
@@ -906,6 +987,7 @@ static void sk_begin(sk_state_t *st, const kmu_sketch_params *p, uint64_t expect
     if (p->algo == KMU_ALGO_PROB3A || p->algo == KMU_ALGO_PROB3) mset_init(&st->ms, expected);
     else if (p->algo == KMU_ALGO_SUPER) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_F32 ? 1 : 0);
     else if (p->algo == KMU_ALGO_SUPER2) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_U32 ? 3 : 2);
+    else if (is_dens(p->algo)) oph_init(&st->oph, p->sketch_size, p->sig_type == KMU_SIG_F32);
     else botk_init(&st->bk, p->sketch_size);
     st->open = 1;
 }
@@ -915,6 +997,8 @@ static void sk_feed(sk_state_t *st, const uint64_t *hashed, uint64_t n) {
         for (uint64_t i = 0; i < n; i++) mset_add(&st->ms, hashed[i], 1.0);
     } else if (p->algo == KMU_ALGO_SUPER || p->algo == KMU_ALGO_SUPER2) {
         for (uint64_t i = 0; i < n; i++) smh_sketch(&st->smh, hasher_finish(p->hasher, hashed[i], st->w), p->flags);
+    } else if (is_dens(p->algo)) {
+        for (uint64_t i = 0; i < n; i++) oph_sketch(&st->oph, hasher_finish(p->hasher, hashed[i], st->w), p->flags);
     } else {
         /* MinHashCount counts are u16, MinInvHashCountKmer (hasher = int64_hash) u8; both wrap in release */
         uint32_t cmask = p->hasher == KMU_HASHER_INT64HASH ? 0xFFu : 0xFFFFu;
@@ -941,6 +1025,11 @@ static int sk_end(sk_state_t *st, void *sig_row, uint32_t *count_row) {
         if (p->sig_type == KMU_SIG_U32) for (int i = 0; i < m; i++) ((uint32_t *) sig_row)[i] = (uint32_t) st->smh.hi[i];
         else memcpy(sig_row, st->smh.hi, (size_t) m * 8);
         smh_free(&st->smh);
+    } else if (is_dens(p->algo)) {
+        oph_end_sketch(&st->oph, p->algo == KMU_ALGO_REVOPTDENS); /* "do not forget to close sketching (it calls densification!)" */
+        if (p->sig_type == KMU_SIG_F32) for (int i = 0; i < m; i++) ((float *) sig_row)[i] = (float) st->oph.hs[i];
+        else memcpy(sig_row, st->oph.hs, (size_t) m * 8);
+        oph_free(&st->oph);
     } else {
         for (int i = 0; i < m; i++) {
             ((uint64_t *) sig_row)[i] = i < st->bk.n ? st->bk.h[i] : UINT64_MAX;

@@ -13,10 +13,12 @@
  *              Restated from source in the tree, without a reference KAT of their own (hand cases in
  *              tests/test_oracle_kat.py): the FASTQ reader rule (io.rs / datasketcher.rs), the signature comparison
  *              functions (seqsketchjaccard.rs, seqblocksketch.rs, minhash.rs).
- *   UNPINNED : Wang invertible hashes, xoshiro seeding, ProbMinHash3a / ProbMinHash3, SuperMinHash, SuperMinHash2 internals.
+ *   UNPINNED : Wang invertible hashes, xoshiro seeding, ProbMinHash3a / ProbMinHash3, SuperMinHash, SuperMinHash2,
+ *              OptDensMinHash / RevOptDensMinHash internals.
  *              They live in the un-vendored crate `probminhash = "0.1"` (reference Cargo.toml:89), which is
  *              not in /root/reference and cannot be built here (no Rust toolchain).  They are restated from
- *              Ertl's papers (arXiv 1706.05698, 1911.00675) and the crate's structure as recalled; the
+ *              Ertl's papers (arXiv 1706.05698, 1911.00675), Shrivastava (ICML 2017) and Mai et al. (UAI 2019) for the
+ *              densified sketches, and the crate's structure as recalled; the
  *              reference's own tests pin them only statistically => "parity unpinned".
  */
 #ifndef KMU_ORACLE_H

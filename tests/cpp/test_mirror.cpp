@@ -301,6 +301,54 @@ TEST(test_seqsketcher_trait_dna) {
                                   KMU_FHASH_CANON_INVHASH));
 }
 
+// setsketchert.rs:1075-1146 and :1150-1230: sequences of 60 bases sketched to 800 (OptDens) and 8000 (RevOptDens) bins --
+// almost every bin is filled by densification, and the estimate still has to come out at the true 0.5
+template <template <class, class> class Sketcher, class S> void check_densified(size_t sketch_size, int algo, int sig_type) {
+    const std::string str1 = "ATCATGCCCCTTTAGAAAATTTCCGGATCATCGTACGGAGCATGCGTACAACGTCGATGC";
+    const std::string str2 = "ATCATGCCCCTTTAGAAAATTTCCGGATCATCATGCCCCTTTAGAAAATTTCCGGATC";
+    Sequence seq1(str1), seq2(str2);
+    std::vector<const Sequence *> vseq{&seq1, &seq2};
+    SeqSketcherParams sketch_args(5, sketch_size, SketchAlgo::OPTDENS, DataType::DNA);
+    Sketcher<Kmer32bit, S> sketcher(sketch_args);
+    auto signatures = sketcher.sketch_compressedkmer(vseq, kmer_hash_fn);
+    CHECK(std::fabs(equal_fraction(signatures[0], signatures[1]) - 0.5) < 1. / 10.);   // :1124 / :1145 / :1208 / :1229
+    Ascii a;
+    a.add(str1); a.add(str2);
+    CHECK(signatures == oracle_sketch<S>(a, algo, KMU_KMER32BIT, 5, int(sketch_size), sig_type, KMU_HASHER_NOHASH,
+                                         KMU_FHASH_VALUE_MASKED));
+    auto all = sketcher.sketch_compressedkmer_seqs(vseq, kmer_hash_fn);
+    CHECK(all.size() == 1);
+    CHECK(all == oracle_sketch<S>(a, algo, KMU_KMER32BIT, 5, int(sketch_size), sig_type, KMU_HASHER_NOHASH,
+                                  KMU_FHASH_VALUE_MASKED, KMU_MODE_ALL_SEQS));
+}
+TEST(test_seq_optdensminhash_trait) {
+    check_densified<OptDensHashSketch, double>(800, KMU_ALGO_OPTDENS, KMU_SIG_F64);
+    check_densified<OptDensHashSketch, float>(800, KMU_ALGO_OPTDENS, KMU_SIG_F32);
+}
+TEST(test_seq_revoptdensminhash_trait) {
+    check_densified<RevOptDensHashSketch, double>(8000, KMU_ALGO_REVOPTDENS, KMU_SIG_F64);
+    check_densified<RevOptDensHashSketch, float>(8000, KMU_ALGO_REVOPTDENS, KMU_SIG_F32);
+}
+
+// aautils/setsketchert.rs:1394-1466
+TEST(test_seqaa_optdensminhash_trait_32bit) {
+    SequenceAA seq1 = SequenceAA::from_str(AA1), seq2 = SequenceAA::from_str(AA2);
+    std::vector<const SequenceAA *> vseq{&seq1, &seq2};
+    SeqSketcherParams sketch_args(5, 80, SketchAlgo::OPTDENS, DataType::AA);
+    Ascii a;
+    a.add(AA1); a.add(AA2);
+    OptDensHashSketch<KmerAA32bit, double> sketcher_f64(sketch_args);
+    auto s64 = sketcher_f64.sketch_compressedkmeraa(vseq, kmer_hash_fn);
+    CHECK(std::fabs(equal_fraction(s64[0], s64[1]) - 0.5) < 1. / 10.);   // :1444
+    CHECK(s64 == oracle_sketch<double>(a, KMU_ALGO_OPTDENS, KMU_KMERAA32BIT, 5, 80, KMU_SIG_F64, KMU_HASHER_NOHASH,
+                                       KMU_FHASH_VALUE_MASKED));
+    OptDensHashSketch<KmerAA32bit, float> sketcher_f32(sketch_args);
+    auto s32 = sketcher_f32.sketch_compressedkmeraa(vseq, kmer_hash_fn);
+    CHECK(std::fabs(equal_fraction(s32[0], s32[1]) - 0.5) < 1. / 10.);   // :1465
+    CHECK(s32 == oracle_sketch<float>(a, KMU_ALGO_OPTDENS, KMU_KMERAA32BIT, 5, 80, KMU_SIG_F32, KMU_HASHER_NOHASH,
+                                      KMU_FHASH_VALUE_MASKED));
+}
+
 // an arbitrary closure (evaluated on the host, sketched on the device) gives what the named closure gives on the device
 TEST(test_closure_fallback_equals_device_closure) {
     Sequence seqa(SEQSTR);
