@@ -6,7 +6,7 @@
 // `end_sketch`: bins no item fell into are filled from bins that were -- OptDens: an empty bin probes h(i, attempt) until
 // it meets a filled one (Shrivastava 2017); RevOptDens: in rounds, every filled bin offers itself to bin h(j, round), an
 // empty bin takes the smallest j (Mai et al. 2019).  (Inner arithmetic: crate probminhash::densminhash, not in the
-// reference tree -- "parity unpinned", see oracle/kmu_oracle.c for what is restated and what is this implementation's.)
+// reference tree -- "parity unpinned", DESIGN.md section 5 says what is restated and what is this implementation's.)
 //
 // Device mapping.  The sketch is a per-bin minimum over items, so items are independent: one lane per k-mer occurrence,
 // `ds_min_u64` on the order-preserving bit pattern of the (positive) value; no multiset, no staging.
