@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ont_k31", choices=["ont_k31", "ont_k31_sketch", "ont_k31_count", "c3_k8",
-                                                                "c2_count", "c1_super", "c5_aa"])
+                                                                "c2_count", "c1_super", "c5_aa", "ont_k31_optdens"])
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU")
     ap.add_argument("--bases", type=float, default=0, help="override total bases per GPU")
     ap.add_argument("--genome", type=int, default=100_000_000)
@@ -53,6 +53,8 @@ def workload_cfg(args):
         cfg.update(count=False)
     elif w == "ont_k31_count":
         cfg.update(sketch=False)
+    elif w == "ont_k31_optdens":  # the same reads through OptDensHashSketch (one-permutation hashing, f64 bins)
+        cfg.update(count=False, algo=A.ALGO_OPTDENS, sig=A.SIG_F64)
     elif w == "c3_k8":
         cfg.update(k=8, kmer_type=A.KMER32BIT, sig=A.SIG_U32, count=False)
     elif w == "c2_count":
@@ -199,6 +201,7 @@ def main():
             "k_sketch_pmh3a": total_bases + n_reads * cfg["m"] * sigw,   # the sketch path's bytes
             "k_pmh_points": nk * 12 + n_reads * cfg["m"] * sigw,        # (key, weight) lists in, rows out
             "k_sketch_super": total_bases + n_reads * cfg["m"] * sigw,
+            "k_oph_reads": total_bases + n_reads * cfg["m"] * sigw,
             "k_count_add_flat": total_bases + nk * 16,
             "k_part_hist1": total_bases,
             "k_part_scatter1": total_bases + nk * 8,
