@@ -1005,6 +1005,73 @@ MinHashDist mininvhash_distance(const MinInvHashCountKmer<Kmer> &a, const MinInv
     return MinHashDist{double(out[0]) / double(out[2]), double(out[0]) / double(out[1]), out[0], out[1]};
 }
 
+/// HashCount<u32> of seqminhash.rs: a kept hash and its multiplicity
+struct HashCount {
+    uint64_t hashed;
+    uint16_t count;
+};
+
+namespace detail {
+inline int range_kmer_type(size_t kmer_size) {
+    if (kmer_size == 16) return KMU_KMER16B32BIT;
+    if (kmer_size >= 9 && kmer_size <= 15) return KMU_KMER32BIT;
+    throw std::invalid_argument("sketch_seqrange: unimplemented kmer_size");   // upstream panics (seqminhash.rs:53, :111)
+}
+/// the bases [start, end) of a packed sequence as a one-sequence ASCII batch (KmerSeqIterator::set_range keeps the k-mers
+/// that lie inside the range)
+inline Batch range_batch(const Sequence &seq, size_t start, size_t end) {
+    if (end <= start || end > seq.size()) throw std::invalid_argument("bad range");   // set_range -> Err -> panic("bad range")
+    Batch b;
+    b.bytes.resize(end - start + 16, 0);
+    for (size_t i = start; i < end; i++) b.bytes[i - start] = Alphabet2b::decode(seq.get_base(i));
+    b.offsets = {0, end - start};
+    return b;
+}
+}  // namespace detail
+
+/// sketch_seqrange_superminhash(seq, range, kmer_size, sketch_size) -> Vec<f64> (seqminhash.rs:19-62):
+/// SuperMinHash<f64, u32, NoHashHasher> over int32_hash(canonical k-mer); kmer_size 16 (Kmer16b32bit) or 9..15 (Kmer32bit)
+inline std::vector<double> sketch_seqrange_superminhash(const Sequence &seq, std::pair<size_t, size_t> range, size_t kmer_size,
+                                                        size_t sketch_size, Context &ctx = Context::global()) {
+    kmu_sketch_params p = detail::sketch_params(KMU_ALGO_SUPER, detail::range_kmer_type(kmer_size), kmer_size, sketch_size,
+                                                KMU_SIG_F64, KMU_HASHER_NOHASH, KMU_FHASH_CANON_INVHASH, 0, KMU_MODE_PER_SEQ,
+                                                KMU_INPUT_ASCII);
+    detail::Batch b = detail::range_batch(seq, range.first, range.second);
+    std::vector<double> sig(sketch_size);
+    ctx.check(kmu_sketch(ctx.raw(), &p, b.bytes.data(), b.offsets.data(), nullptr, 1, nullptr, sig.data(), nullptr));
+    return sig;
+}
+
+/// sketch_seqrange_minhash(...) -> Vec<HashCount<u32>> (seqminhash.rs:65-119): MinHashCount<u32, NoHashHasher> over the same
+/// values; returned ascending by hash (upstream: heap order)
+inline std::vector<HashCount> sketch_seqrange_minhash(const Sequence &seq, std::pair<size_t, size_t> range, size_t kmer_size,
+                                                      size_t sketch_size, Context &ctx = Context::global()) {
+    kmu_sketch_params p = detail::sketch_params(KMU_ALGO_BOTTOMK, detail::range_kmer_type(kmer_size), kmer_size, sketch_size,
+                                                KMU_SIG_U64, KMU_HASHER_NOHASH, KMU_FHASH_CANON_INVHASH, 0, KMU_MODE_PER_SEQ,
+                                                KMU_INPUT_ASCII);
+    detail::Batch b = detail::range_batch(seq, range.first, range.second);
+    std::vector<uint64_t> h(sketch_size);
+    std::vector<uint32_t> c(sketch_size);
+    ctx.check(kmu_sketch(ctx.raw(), &p, b.bytes.data(), b.offsets.data(), nullptr, 1, nullptr, h.data(), c.data()));
+    std::vector<HashCount> out;
+    for (size_t i = 0; i < sketch_size && h[i] != UINT64_MAX; i++) out.push_back({h[i], uint16_t(c[i])});
+    return out;
+}
+
+/// minhash_distance(&sk1, &sk2) -> MinHashDist (minhash.rs:134-190)
+inline MinHashDist minhash_distance(const std::vector<HashCount> &sk1, const std::vector<HashCount> &sk2,
+                                    Context &ctx = Context::global()) {
+    const size_t m = std::max(sk1.size(), sk2.size());
+    std::vector<uint64_t> ha(std::max<size_t>(m, 1), UINT64_MAX), hb(std::max<size_t>(m, 1), UINT64_MAX);
+    for (size_t i = 0; i < sk1.size(); i++) ha[i] = sk1[i].hashed;
+    for (size_t i = 0; i < sk2.size(); i++) hb[i] = sk2[i].hashed;
+    const uint32_t zero = 0;
+    uint32_t out[3] = {0, 0, 0};
+    ctx.check(kmu_minhash_distance_pairs(ctx.raw(), ha.data(), 1, hb.data(), 1, uint32_t(ha.size()), &zero, &zero, 1,
+                                         KMU_MEM_HOST, out));
+    return MinHashDist{double(out[0]) / double(out[2]), double(out[0]) / double(out[1]), out[0], out[1]};
+}
+
 // =====================================================================================================================
 // counting (kmercount.rs)
 // =====================================================================================================================

@@ -214,6 +214,38 @@ class BlockSeqSketcher:
         return rows, numseq, numblock
 
 
+# ---- sketches of a range of one sequence (src/sketching/seqminhash.rs) --------------------------------------------------
+def _range_kmer_type(kmer_size):
+    if kmer_size == 16:
+        return A.KMER16B32BIT
+    if 9 <= kmer_size <= 15:
+        return A.KMER32BIT
+    raise ValueError("sketch_seqrange_*: unimplemented kmer_size %d (seqminhash.rs:53, :111)" % kmer_size)
+
+
+def sketch_seqrange_superminhash(seq, rng, kmer_size, sketch_size, ctx=None):
+    """seqminhash.rs:19-62: SuperMinHash<f64, u32, NoHashHasher> over int32_hash(canonical k-mer) of the k-mers inside
+    seq[rng[0]:rng[1]] (KmerSeqIterator::set_range).  `seq`: bytes; returns the f64 sketch."""
+    ctx = ctx or default_context()
+    p = A.SketchParams(A.ALGO_SUPER, _range_kmer_type(kmer_size), kmer_size, sketch_size, A.SIG_F64, A.HASHER_NOHASH,
+                       A.FHASH_CANON_INVHASH, 0, A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_HOST, 0)
+    bases, offsets = _as_arrays([bytes(seq)[rng[0]:rng[1]]])
+    return np.asarray(ctx.sketch(bases, offsets, p))[0]
+
+
+def sketch_seqrange_minhash(seq, rng, kmer_size, sketch_size, ctx=None):
+    """seqminhash.rs:65-119: MinHashCount<u32, NoHashHasher> (bottom-k with u16 multiplicities) over the same values.
+    Returns (hashes ascending, counts): the HashCount list of get_sketchcount, sorted."""
+    ctx = ctx or default_context()
+    p = A.SketchParams(A.ALGO_BOTTOMK, _range_kmer_type(kmer_size), kmer_size, sketch_size, A.SIG_U64, A.HASHER_NOHASH,
+                       A.FHASH_CANON_INVHASH, 0, A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_HOST, 0)
+    bases, offsets = _as_arrays([bytes(seq)[rng[0]:rng[1]]])
+    h, c = ctx.sketch(bases, offsets, p, want_counts=True)
+    h, c = np.asarray(h)[0], np.asarray(c)[0]
+    n = int((h != np.uint64(0xFFFFFFFFFFFFFFFF)).sum())
+    return h[:n], c[:n]
+
+
 # ---- what the callers do with the signatures next (SURVEY.md 8f-3): all on the device through libkmu -----------
 def probminhash_get_jaccard_objects(siga, sigb, ctx=None):
     """probminhash_get_jaccard_objects(siga, sigb) -> (jp, Some(common objects) | None), src/sketching/

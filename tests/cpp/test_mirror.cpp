@@ -438,6 +438,60 @@ TEST(test_mininvhash_count_range_intersection) {
     for (auto &e : sketch_a) CHECK(e.count == 1);
 }
 
+// seqminhash.rs:127-191: bottom-k sketches of two overlapping ranges
+TEST(test_minhash_overlapping_ranges) {
+    Sequence seq(SEQSTR);
+    for (size_t kmer_size : {size_t(16), size_t(10)}) {
+        auto sk1 = sketch_seqrange_minhash(seq, {1, 65}, kmer_size, 20);
+        auto sk2 = sketch_seqrange_minhash(seq, {35, 75}, kmer_size, 20);
+        MinHashDist resdist = minhash_distance(sk1, sk2);
+        if (kmer_size == 16) CHECK(resdist.total >= 3);   // :155
+        else CHECK(resdist.total == 20);                  // :190
+        // the oracle on the same two ranges
+        Ascii a;
+        a.add(SEQSTR.substr(1, 64)); a.add(SEQSTR.substr(35, 40));
+        kmu_sketch_params p{};
+        p.algo = KMU_ALGO_BOTTOMK; p.kmer_type = kmer_size == 16 ? KMU_KMER16B32BIT : KMU_KMER32BIT; p.kmer_size = int(kmer_size);
+        p.sketch_size = 20; p.sig_type = KMU_SIG_U64; p.hasher = KMU_HASHER_NOHASH; p.fhash = KMU_FHASH_CANON_INVHASH;
+        std::vector<uint64_t> h(40);
+        std::vector<uint32_t> c(40);
+        std::vector<uint8_t> bytes = a.bytes;
+        bytes.resize(bytes.size() + 16);
+        CHECK(kmo_sketch(&p, bytes.data(), a.off.data(), nullptr, 2, nullptr, h.data(), c.data()) == 0);
+        CHECK(sk1.size() == 20 && sk2.size() == 20);
+        for (size_t i = 0; i < 20; i++) {
+            CHECK(sk1[i].hashed == h[i] && sk1[i].count == c[i]);
+            CHECK(sk2[i].hashed == h[20 + i] && sk2[i].count == c[20 + i]);
+        }
+        uint32_t want[3];
+        kmo_minhash_distance(h.data(), 20, h.data() + 20, 20, want);
+        CHECK(resdist.common == want[0] && resdist.total == want[1]);
+    }
+    bool threw = false;
+    try {
+        sketch_seqrange_minhash(seq, {70, 90}, 16, 20);   // range beyond the sequence: set_range fails, upstream panics
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    CHECK(threw);
+}
+
+// seqminhash.rs:195-258: SuperMinHash sketches of the same ranges
+TEST(test_superminhash_overlapping_ranges) {
+    Sequence seq(SEQSTR);
+    struct Case { size_t k, m; double thresh; };
+    for (Case cs : {Case{16, 50, 0.15}, Case{10, 20, 0.2}}) {
+        auto sk1 = sketch_seqrange_superminhash(seq, {1, 65}, cs.k, cs.m);
+        auto sk2 = sketch_seqrange_superminhash(seq, {35, 75}, cs.k, cs.m);
+        CHECK(compute_superminhash_jaccard(sk1, sk2) >= cs.thresh);   // :224 / :256
+        Ascii a;
+        a.add(SEQSTR.substr(1, 64)); a.add(SEQSTR.substr(35, 40));
+        auto want = oracle_sketch<double>(a, KMU_ALGO_SUPER, cs.k == 16 ? KMU_KMER16B32BIT : KMU_KMER32BIT, int(cs.k), int(cs.m),
+                                          KMU_SIG_F64, KMU_HASHER_NOHASH, KMU_FHASH_CANON_INVHASH);
+        CHECK(sk1 == want[0] && sk2 == want[1]);
+    }
+}
+
 // =========================================================================================================================
 // sketching, amino acids (aautils/setsketchert.rs tests)
 // =========================================================================================================================

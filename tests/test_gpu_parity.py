@@ -850,3 +850,22 @@ def test_device_buffer_helpers(ctx, oracle):
     for ptr in (d_bases, d_off, d_sig):
         assert L.kmu_dev_free(ctx.h, ptr) == 0
     assert L.kmu_dev_free(ctx.h, None) == 0
+
+
+@pytest.mark.gpu
+def test_seqrange_sketches_of_seqminhash(ctx, oracle):
+    """kmerutils_amd.sketching.sketch_seqrange_minhash / _superminhash (src/sketching/seqminhash.rs:19-119) with the
+    reference's tests :127-258 (two overlapping ranges of the 80-base string; `total == 20` is exact)"""
+    from kmerutils_amd import sketching as S
+    seq = b"TCAAAGGGAAACATTCAAAATCAGTATGCGCCCGTTCAGTTACGTATTGCTCTCGCTAATGAGATGGGCTGGGTACAGAG"
+    for k, check in ((16, lambda t: t >= 3), (10, lambda t: t == 20)):
+        h1, c1 = S.sketch_seqrange_minhash(seq, (1, 65), k, 20, ctx=ctx)
+        h2, c2 = S.sketch_seqrange_minhash(seq, (35, 75), k, 20, ctx=ctx)
+        cont, jac, common, total = S.minhash_distance(h1[None, :], h2[None, :], [0], [0], ctx=ctx)
+        assert check(int(total[0])) and int(common[0]) == oracle.minhash_distance(h1, h2)[0]
+    for k, m, thresh in ((16, 50, 0.15), (10, 20, 0.2)):
+        s1 = S.sketch_seqrange_superminhash(seq, (1, 65), k, m, ctx=ctx)
+        s2 = S.sketch_seqrange_superminhash(seq, (35, 75), k, m, ctx=ctx)
+        assert float((s1 == s2).mean()) >= thresh
+    with pytest.raises(ValueError):
+        S.sketch_seqrange_superminhash(seq, (1, 65), 8, 20, ctx=ctx)

@@ -326,3 +326,21 @@ def test_ingest_fasta_oracle_against_line_by_line_restatement():
         assert info["n_records"] == n and info["n_kept"] == len(kept) and info["n_bases"] == sum(map(len, seqs))
         assert bytes(bases) == b"".join(kept) and offs.tolist() == np.cumsum([0] + [len(s) for s in kept]).tolist()
         assert idx.tolist() == [i for i, s in enumerate(seqs) if all(c in b"ACGTacgt" for c in s)]
+
+
+def test_seqminhash_reference_tests_on_the_oracle():
+    """src/sketching/seqminhash.rs:127-258: sketches of two overlapping ranges [1, 65) and [35, 75) of the 80-base test
+    string -- bottom-k (MinHashCount<u32, NoHashHasher> over int32_hash(canonical)) and SuperMinHash<f64, u32, NoHashHasher>.
+    `resdist.3 == 20` (:190) is an exact assertion on minhash_distance; the others are thresholds."""
+    from oracle import oracle as O
+    S = b"TCAAAGGGAAACATTCAAAATCAGTATGCGCCCGTTCAGTTACGTATTGCTCTCGCTAATGAGATGGGCTGGGTACAGAG"
+    bases, off = O.concat([S[1:65], S[35:75]])  # KmerSeqIterator::set_range(b, e): the k-mers inside [b, e)
+    for kmer_type, k, total_check in ((A.KMER16B32BIT, 16, lambda t: t >= 3), (A.KMER32BIT, 10, lambda t: t == 20)):
+        p = A.SketchParams(A.ALGO_BOTTOMK, kmer_type, k, 20, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        h, c = O.sketch(bases, off, p, want_counts=True)
+        common, total, i = O.minhash_distance(h[0], h[1])
+        assert total_check(total) and common > 0                                   # :155, :190
+    for kmer_type, k, m, thresh in ((A.KMER16B32BIT, 16, 50, 0.15), (A.KMER32BIT, 10, 20, 0.2)):
+        p = A.SketchParams(A.ALGO_SUPER, kmer_type, k, m, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        r = O.sketch(bases, off, p)
+        assert float((r[0] == r[1]).mean()) >= thresh                              # :224, :256
