@@ -20,6 +20,8 @@
  *      KMU_INPUT_PACKED2: offsets are in *bases*; sequence i starts at byte `packed_byte_offsets[i]`
  *                         and is packed exactly as reference `Sequence::new(raw,2)`
  *                         (src/base/sequence.rs:48-73: 4 bases / byte, first base in bits 7..6).
+ *    offsets[0] need not be 0: `offsets + first` with n_seq = last - first names the reads [first, last) of a larger
+ *    array without copying anything (the base pointer stays the array's).
  *  - a kmu_ctx is used from one thread at a time; distinct contexts may run concurrently.
  */
 #ifndef KMU_H

@@ -53,25 +53,40 @@ int stage_sequences(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
         return KMU_OK;
     }
     if (mem != KMU_MEM_HOST) return fail(ctx, KMU_E_BAD_ARG, "bad mem %d", mem);
-    uint64_t total_bases = offsets[n_seq];
-    uint64_t total_bytes = total_bases;
+    // The sequences may be a range of a larger set (offsets[0] > 0): only their bytes go up, offsets re-based to 0.
+    const uint64_t off0 = offsets[0];
+    uint64_t first_byte = off0, end_byte = offsets[n_seq];
     if (out->packed) {
-        // the last sequence ends at packed_offsets[n-1] + ceil(L/4)
-        total_bytes = 0;
+        // sequence i occupies packed_offsets[i] .. + ceil(L_i / 4)
+        first_byte = n_seq ? packed_offsets[0] : 0;
+        end_byte = first_byte;
         for (uint32_t i = 0; i < n_seq; i++) {
-            uint64_t e = packed_offsets[i] + (offsets[i + 1] - offsets[i] + 3) / 4;
-            total_bytes = std::max(total_bytes, e);
+            first_byte = std::min(first_byte, packed_offsets[i]);
+            end_byte = std::max(end_byte, packed_offsets[i] + (offsets[i + 1] - offsets[i] + 3) / 4);
+        }
+    }
+    const uint64_t total_bytes = end_byte - first_byte;
+    const uint64_t *h_off = offsets, *h_poff = packed_offsets;
+    if (off0 != 0 || first_byte != 0) {
+        out->h_offsets.resize((size_t) n_seq + 1);
+        for (uint32_t i = 0; i <= n_seq; i++) out->h_offsets[i] = offsets[i] - off0;
+        h_off = out->h_offsets.data();
+        if (out->packed) {
+            out->h_packed_offsets.resize((size_t) n_seq + 1);
+            for (uint32_t i = 0; i < n_seq; i++) out->h_packed_offsets[i] = packed_offsets[i] - first_byte;
+            h_poff = out->h_packed_offsets.data();
         }
     }
     void *d_b, *d_o, *d_p = nullptr;
     KMU_TRY(dev_buf(ctx, "in.bases", total_bytes + 64, &d_b));
     KMU_TRY(dev_buf(ctx, "in.offsets", (size_t) (n_seq + 1) * 8, &d_o));
-    KMU_HIP(ctx, hipMemcpyAsync(d_b, bases, total_bytes, hipMemcpyHostToDevice, ctx->stream));
-    KMU_HIP(ctx, hipMemcpyAsync(d_o, offsets, (size_t) (n_seq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(d_b, bases + first_byte, total_bytes, hipMemcpyHostToDevice, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(d_o, h_off, (size_t) (n_seq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (out->packed) {
         KMU_TRY(dev_buf(ctx, "in.poffsets", (size_t) (n_seq + 1) * 8, &d_p));
-        KMU_HIP(ctx, hipMemcpyAsync(d_p, packed_offsets, (size_t) n_seq * 8, hipMemcpyHostToDevice, ctx->stream));
+        KMU_HIP(ctx, hipMemcpyAsync(d_p, h_poff, (size_t) n_seq * 8, hipMemcpyHostToDevice, ctx->stream));
     }
+    if (h_off != offsets) KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the temporaries are read by the copies above
     out->bases = (const uint8_t *) d_b;
     out->offsets = (const uint64_t *) d_o;
     out->packed_offsets = (const uint64_t *) d_p;
@@ -412,8 +427,9 @@ int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases
     KMU_TRY(stage_sequences(ctx, bases, offsets, packed_offsets, n_seq, p->input_kind, p->mem, &ds));
     uint64_t *d_out = out;
     uint64_t total = 0;
+    const uint64_t off0 = p->mem == KMU_MEM_HOST && n_seq ? offsets[0] : 0; // host ranges are staged re-based to 0
     if (p->mem == KMU_MEM_HOST) {
-        total = offsets[n_seq];
+        total = offsets[n_seq] - off0;
         void *q;
         KMU_TRY(dev_buf(ctx, "out.u64", (size_t) total * 8 + 8, &q));
         d_out = (uint64_t *) q;
@@ -430,7 +446,7 @@ int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases
     }
     KMU_HIP(ctx, hipGetLastError());
     if (p->mem == KMU_MEM_HOST)
-        KMU_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t) total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipMemcpyAsync(out + off0, d_out, (size_t) total * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
     return finish_call(ctx, p->mem);
 }

@@ -139,9 +139,10 @@ __device__ __forceinline__ uint32_t wave_find_read_from(const uint64_t *offsets,
 
 // One wave step (64 words = 1024 bases) of the flat base stream: f(canon) for every k-mer that lies inside one read.
 // Returns a non-zero mask if this lane saw a non-ACGT byte.
+// The reads occupy [offsets[0], total) of the stream: `start` = offsets[0] need not be 0 (a range of a larger read set).
 template <typename F>
 __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
-                                                    uint64_t total, int k, uint64_t st, uint32_t &r_hint, F &&f) {
+                                                    uint64_t total, uint64_t start, int k, uint64_t st, uint32_t &r_hint, F &&f) {
     SeqView s;
     s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
     const int lane = lane_id();
@@ -156,7 +157,7 @@ __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const 
     uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
     r_hint = r;
     const uint64_t g0 = widx * 16;
-    const bool in = g0 < total;
+    const bool in = g0 < total && g0 + 16 > start;
     uint64_t rend = 0;
     if (in) {
         rend = offsets[r + 1];
@@ -165,7 +166,7 @@ __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const 
     const uint64_t hi = ((uint64_t) w0 << 32) | w1;
     const int sh = 64 - 2 * k;
     // A wave whose lanes all sit well inside a read (long reads: most waves) skips the per-k-mer boundary tests.
-    if (__all(!in || rend - g0 >= (uint64_t) (15 + k))) {
+    if (__all(!in || (g0 >= start && rend - g0 >= (uint64_t) (15 + k)))) {
         if (in) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -180,7 +181,7 @@ __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const 
         for (int j = 0; j < 16; j++) {
             const uint64_t g = g0 + j;
             while (g >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; }
-            if (g + k <= rend) {
+            if (g >= start && g + k <= rend) {
                 uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
                 uint64_t val = v >> sh;
                 uint64_t rc = revcomp_val(val, k);
@@ -196,13 +197,13 @@ __device__ __forceinline__ uint32_t flat_step_canon(const uint8_t *bases, const 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_count_add_flat(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
                                                         int k, CountTable t, uint32_t *err) {
-    const uint64_t total = offsets[n_seq];
+    const uint64_t total = offsets[n_seq], start = offsets[0];
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
     const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
     uint32_t anybad = 0, full = 0, r_hint = 0xFFFFFFFFu;
     for (uint64_t st = wave_global; st < nsteps; st += nwaves_global)
-        anybad |= flat_step_canon(bases, offsets, n_seq, total, k, st, r_hint, [&](uint64_t canon) {
+        anybad |= flat_step_canon(bases, offsets, n_seq, total, start, k, st, r_hint, [&](uint64_t canon) {
             if (!count_insert(t, canon, 1u)) full = 1;
         });
     if (anybad) atomicOr(err, DERR_NON_ACGT);
@@ -337,14 +338,14 @@ __global__ void __launch_bounds__(256) k_part_hist1(const uint8_t *bases, const 
     const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1;
     for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) lh[b] = 0;
     __syncthreads();
-    const uint64_t total = offsets[n_seq];
+    const uint64_t total = offsets[n_seq], start = offsets[0];
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
     const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t bad = 0, r_hint = 0xFFFFFFFFu;
     for (uint64_t st = s0 + wave; st < s1; st += nwaves)
-        bad |= flat_step_canon(bases, offsets, n_seq, total, k, st, r_hint, [&](uint64_t canon) {
+        bad |= flat_step_canon(bases, offsets, n_seq, total, start, k, st, r_hint, [&](uint64_t canon) {
             atomicAdd(&lh[pl.owner_parts ? kmer_owner(canon, pl.owner_w32, pl.owner_parts)
                                          : region_of(canon, pl.region_bits) >> pl.b2], 1u);
         });
@@ -522,8 +523,8 @@ __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t to
 }
 
 // up to 16 canonical k-mers of this lane for wave step `st` (CKEY_EMPTY where a k-mer would straddle a read end)
-__device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_t n_seq, uint64_t total, int k, uint64_t st,
-                                                bool active, uint32_t w0, uint32_t ex, uint32_t &r_hint,
+__device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_t n_seq, uint64_t total, uint64_t start, int k,
+                                                uint64_t st, bool active, uint32_t w0, uint32_t ex, uint32_t &r_hint,
                                                 uint64_t (&it)[16]) {
 #pragma unroll
     for (int j = 0; j < 16; j++) it[j] = CKEY_EMPTY;
@@ -537,7 +538,7 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
     uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
     r_hint = r;
     const uint64_t g0 = widx * 16;
-    const bool in = g0 < total;
+    const bool in = g0 < total && g0 + 16 > start;
     uint64_t rend = 0;
     if (in) {
         rend = offsets[r + 1];
@@ -545,7 +546,7 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
     }
     const uint64_t hi = ((uint64_t) w0 << 32) | w1;
     const int sh = 64 - 2 * k;
-    if (__all(!in || rend - g0 >= (uint64_t) (15 + k))) { // every lane well inside a read: no per-k-mer boundary tests
+    if (__all(!in || (g0 >= start && rend - g0 >= (uint64_t) (15 + k)))) { // every lane well inside a read: no per-k-mer boundary tests
         if (in) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -560,7 +561,7 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
         for (int j = 0; j < 16; j++) {
             const uint64_t g = g0 + j;
             while (g >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; }
-            if (g + k <= rend) {
+            if (g >= start && g + k <= rend) {
                 uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
                 uint64_t val = v >> sh;
                 uint64_t rc = revcomp_val(val, k);
@@ -583,7 +584,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     }
     if (threadIdx.x == 0) l.lstart[bins1] = 0;
     lds_barrier();
-    const uint64_t total = offsets[n_seq];
+    const uint64_t total = offsets[n_seq], start = offsets[0];
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
     const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     flat_step_load(bases, total, s0 + wave, s0 + wave < s1, w0, ex);
     for (uint64_t t0 = s0; t0 < s1; t0 += nwaves) {
         uint64_t it[16];
-        flat_step_items(offsets, n_seq, total, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
+        flat_step_items(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
         // the next step's words are requested now; their latency hides under the tile sort
         flat_step_load(bases, total, t0 + nwaves + wave, t0 + nwaves + wave < s1, w0, ex);
         if (pl.owner_parts) tile_scatter<IT_OWNER>(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
@@ -1149,6 +1150,38 @@ void kmu_count_destroy(kmu_counter *c) {
     delete c;
 }
 
+namespace kmu {
+__global__ void __launch_bounds__(256) k_rebase_offsets(const uint64_t *in, uint64_t n, uint64_t shift, uint64_t *out) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = in[i] - shift;
+}
+}
+
+// Length of the flat base stream the (unpacked) sequences occupy.  The sequences may be a range of a larger read set
+// (offsets[0] > 0, e.g. `offsets + first` of device-resident reads): host input was staged re-based to 0; for device input
+// the base pointer is moved forward by whole wave-steps and a re-based copy of the offsets is used, so that neither the
+// scratch sizes nor the walk depend on what lies before the range (the kernels skip the few bases left before offsets[0]).
+static int flat_stream_extent(kmu_ctx *ctx, const uint64_t *host_offsets, uint32_t n_seq, int mem, DevSeqs &ds, uint64_t *total_out) {
+    if (mem == KMU_MEM_HOST) {
+        *total_out = n_seq ? host_offsets[n_seq] - host_offsets[0] : 0;
+        return KMU_OK;
+    }
+    uint64_t first = 0, last = 0;
+    KMU_HIP(ctx, hipMemcpyAsync(&first, ds.offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(&last, ds.offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t shift = first & ~(uint64_t) 1023;
+    if (shift) {
+        void *q;
+        KMU_TRY(dev_buf(ctx, "in.offsets", ((size_t) n_seq + 1) * 8, &q));
+        const int grid = (int) std::min<uint64_t>(((uint64_t) n_seq + 256) / 256, (uint64_t) ctx->num_cus * 8);
+        hipLaunchKernelGGL(k_rebase_offsets, dim3(grid), dim3(256), 0, ctx->stream, ds.offsets, (uint64_t) n_seq + 1, shift, (uint64_t *) q);
+        ds.bases += shift;
+        ds.offsets = (const uint64_t *) q;
+    }
+    *total_out = last - shift;
+    return KMU_OK;
+}
+
 int kmu_count_add_reads(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, const uint64_t *packed_offsets,
                         uint32_t n_seq, int input_kind, int mem) {
     if (!c) return KMU_E_BAD_ARG;
@@ -1163,11 +1196,7 @@ int kmu_count_add_reads(kmu_counter *c, const uint8_t *bases, const uint64_t *of
         uint64_t total_bases = 0;
         const char *force = getenv("KMU_COUNT_PATH"); // "direct" / "partitioned": diagnostics
         if (!ds.packed) {
-            if (mem == KMU_MEM_HOST) total_bases = offsets[n_seq];
-            else {
-                KMU_HIP(ctx, hipMemcpyAsync(&total_bases, ds.offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
-                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            }
+            KMU_TRY(flat_stream_extent(ctx, offsets, n_seq, mem, ds, &total_bases));
             // the streaming build pays off once the batch is a sizeable fraction of the table
             partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
             if (force && !strcmp(force, "direct")) partitioned = false;
@@ -1398,11 +1427,7 @@ int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint6
     DevSeqs ds;
     KMU_TRY(stage_sequences(ctx, bases, offsets, nullptr, n_seq, KMU_INPUT_ASCII, mem, &ds));
     uint64_t total_bases = 0;
-    if (mem == KMU_MEM_HOST) total_bases = offsets[n_seq];
-    else {
-        KMU_HIP(ctx, hipMemcpyAsync(&total_bases, ds.offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
-        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    KMU_TRY(flat_stream_extent(ctx, offsets, n_seq, mem, ds, &total_bases));
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
     KMU_TRY(extract_by_owner(c, ds, total_bases, n_parts, dev_kmers_out, part_bounds_out, d_err));

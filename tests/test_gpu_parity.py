@@ -869,3 +869,55 @@ def test_seqrange_sketches_of_seqminhash(ctx, oracle):
         assert float((s1 == s2).mean()) >= thresh
     with pytest.raises(ValueError):
         S.sketch_seqrange_superminhash(seq, (1, 65), 8, 20, ctx=ctx)
+
+
+@pytest.mark.gpu
+def test_ranges_of_a_larger_read_set(ctx, oracle, monkeypatch):
+    """offsets[0] > 0: a call may name a range of reads of a larger array (`offsets + first`, what the C++ tools do with
+    device-resident reads).  Counting (direct and partitioned paths, owner grouping), sketching, k-mer hashes, packing and
+    the non-ACGT census see exactly the reads of the range, for host and for device input."""
+    import torch
+    rng = np.random.default_rng(3)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in rng.integers(30, 3000, size=400)]
+    bases, off = oracle.concat(seqs)
+    db, do = torch.from_numpy(bases.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 21, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    for first, last in ((0, 400), (37, 211), (399, 400), (150, 400)):
+        sub_b, sub_o = oracle.concat(seqs[first:last])
+        oc = oracle.Counter(A.KMER64BIT, 21, 8, 1 << 20)
+        oc.add_reads(sub_b, sub_o)
+        wk, wc = oc.dump(1)
+        for path in ("partitioned", "direct"):
+            monkeypatch.setenv("KMU_COUNT_PATH", path)
+            for dev in (False, True):
+                c = ctx.counter(A.KMER64BIT, 21, 8, 1 << 20)
+                if dev:
+                    c.add_reads(db, do[first:last + 1])
+                else:
+                    c.add_reads(bases, off[first:last + 1].copy())
+                gk, gc = c.dump(1)
+                assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (first, last, path, dev)
+                c.close()
+        monkeypatch.delenv("KMU_COUNT_PATH")
+        c = ctx.counter(A.KMER64BIT, 21, 8, 1 << 20)
+        kmers, bounds = c.extract_by_owner(db, do[first:last + 1], 3)
+        canon = oracle.kmer_hashes(sub_b, sub_o, A.KMER64BIT, 21, A.FHASH_CANON_VALUE)
+        valid = np.concatenate([np.arange(int(sub_o[i]), int(sub_o[i + 1]) - 20) for i in range(last - first)
+                                if sub_o[i + 1] - sub_o[i] >= 21])
+        assert int(bounds[-1]) == valid.size
+        assert np.array_equal(np.sort(kmers.cpu().numpy().view(np.uint64)), np.sort(canon[valid]))
+        c.close()
+        want = oracle.sketch(sub_b, sub_o, p)
+        assert np.array_equal(np.asarray(ctx.sketch(bases, off[first:last + 1].copy(), p)), want)
+        g = ctx.sketch(db, do[first:last + 1], p)
+        ctx.synchronize()
+        assert np.array_equal(g.cpu().numpy().view(np.uint64), want)
+        # per-position hashes land at the caller's absolute positions
+        hk = ctx.kmer_hashes(bases, off[first:last + 1].copy(), A.KMER64BIT, 21, A.FHASH_CANON_INVHASH,
+                             out=np.zeros(int(off[-1]), np.uint64))
+        wh = oracle.kmer_hashes(sub_b, sub_o, A.KMER64BIT, 21, A.FHASH_CANON_INVHASH)
+        assert np.array_equal(hk[int(off[first]):int(off[last])], wh[:int(sub_o[-1])])
+        assert not hk[:int(off[first])].any() and not hk[int(off[last]):].any()
+        packed, poff = ctx.pack2b(bases, off[first:last + 1].copy())
+        assert bytes(packed) == b"".join(bytes(oracle.pack2b(s)) for s in seqs[first:last])
+        assert not ctx.count_non_acgt(bases, off[first:last + 1].copy()).any()
