@@ -1558,9 +1558,10 @@ extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, co
     const uint64_t *d_off = offsets;
     void *d_sig = sig_out;
     uint32_t *d_counts = counts_out;
-    uint64_t n_items = 0;
+    uint64_t n_items = 0, first_item = 0; // the values of the sequences are hashed[offsets[0] .. offsets[n_seq])
     if (p->mem == KMU_MEM_HOST) {
         n_items = offsets[n_seq];
+        first_item = n_seq ? offsets[0] : 0;
         void *q;
         KMU_TRY(dev_buf(ctx, "in.bases", n_items * w + 64, &q));
         KMU_HIP(ctx, hipMemcpyAsync(q, hashed, n_items * w, hipMemcpyHostToDevice, ctx->stream));
@@ -1576,6 +1577,7 @@ extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, co
         }
     } else {
         KMU_HIP(ctx, hipMemcpyAsync(&n_items, offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_seq) KMU_HIP(ctx, hipMemcpyAsync(&first_item, offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
         KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     uint32_t *d_err;
@@ -1588,12 +1590,13 @@ extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, co
         ds.total_bytes = 1;
         KMU_TRY(launch_dens(ctx, p, ds, d_sig, d_err, d_vals, w));
     } else if (p->mode == KMU_MODE_ALL_SEQS) {
-        const uint64_t *v64 = (const uint64_t *) d_vals;
+        n_items -= first_item;
+        const uint64_t *v64 = (const uint64_t *) d_vals + first_item;
         if (w == 4) { // widen to u64 once (the all-sequences path partitions u64 keys)
             void *q;
             KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &q));
             hipLaunchKernelGGL(k_widen_u32, dim3((unsigned) std::min<uint64_t>((n_items + 255) / 256 + 1, 65535)), dim3(256), 0,
-                               ctx->stream, (const uint32_t *) d_vals, n_items, (uint64_t *) q);
+                               ctx->stream, (const uint32_t *) d_vals + first_item, n_items, (uint64_t *) q);
             v64 = (const uint64_t *) q;
         }
         KMU_TRY(sketch_all_hashed(ctx, p, v64, n_items, d_sig, d_err));

@@ -918,6 +918,12 @@ def test_ranges_of_a_larger_read_set(ctx, oracle, monkeypatch):
         wh = oracle.kmer_hashes(sub_b, sub_o, A.KMER64BIT, 21, A.FHASH_CANON_INVHASH)
         assert np.array_equal(hk[int(off[first]):int(off[last])], wh[:int(sub_o[-1])])
         assert not hk[:int(off[first])].any() and not hk[int(off[last]):].any()
+        # pre-hashed values of a range, per sequence and for all of them
+        vals = np.arange(int(off[-1]), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        for mode in (A.MODE_PER_SEQ, A.MODE_ALL_SEQS):
+            ph = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 21, 32, A.SIG_U64, 0, A.FHASH_IDENTITY_RAW, 0, mode, 0, 0, 0)
+            wantv = oracle.sketch_hashed(vals[int(off[first]):int(off[last])].copy(), sub_o, ph)
+            assert np.array_equal(np.asarray(ctx.sketch_hashed(vals, off[first:last + 1].copy(), ph)), wantv)
         packed, poff = ctx.pack2b(bases, off[first:last + 1].copy())
         assert bytes(packed) == b"".join(bytes(oracle.pack2b(s)) for s in seqs[first:last])
         assert not ctx.count_non_acgt(bases, off[first:last + 1].copy()).any()
