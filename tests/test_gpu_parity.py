@@ -912,6 +912,16 @@ def test_ranges_of_a_larger_read_set(ctx, oracle, monkeypatch):
         g = ctx.sketch(db, do[first:last + 1], p)
         ctx.synchronize()
         assert np.array_equal(g.cpu().numpy().view(np.uint64), want)
+        for algo, sig, mode in ((A.ALGO_SUPER, A.SIG_F64, A.MODE_PER_SEQ), (A.ALGO_OPTDENS, A.SIG_F64, A.MODE_PER_SEQ),
+                                (A.ALGO_REVOPTDENS, A.SIG_F32, A.MODE_ALL_SEQS), (A.ALGO_PROB3A, A.SIG_U64, A.MODE_ALL_SEQS),
+                                (A.ALGO_SUPER2, A.SIG_U64, A.MODE_ALL_SEQS), (A.ALGO_BOTTOMK, A.SIG_U64, A.MODE_PER_SEQ)):
+            pa = A.SketchParams(algo, A.KMER64BIT, 21, 48, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, mode, 0, 0, 0)
+            wa = oracle.sketch(sub_b, sub_o, pa)
+            ga = ctx.sketch(db, do[first:last + 1], pa)
+            ctx.synchronize()
+            assert np.array_equal(ga.cpu().numpy().view(np.uint8), np.ascontiguousarray(wa).view(np.uint8)), (algo, mode)
+            gh = np.asarray(ctx.sketch(bases, off[first:last + 1].copy(), pa))
+            assert np.array_equal(np.ascontiguousarray(gh).view(np.uint8), np.ascontiguousarray(wa).view(np.uint8)), (algo, mode)
         # per-position hashes land at the caller's absolute positions
         hk = ctx.kmer_hashes(bases, off[first:last + 1].copy(), A.KMER64BIT, 21, A.FHASH_CANON_INVHASH,
                              out=np.zeros(int(off[-1]), np.uint64))
