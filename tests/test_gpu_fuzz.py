@@ -156,3 +156,40 @@ def test_aa_sketch_sweep(ctx, oracle, seed):
         assert np.array_equal(np.asarray(got[0]), want[0]) and np.array_equal(np.asarray(got[1]), want[1])
     else:
         assert np.asarray(got).tobytes() == np.asarray(want).tobytes(), (kmer_type, k, algo, m, fhash, mode)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_dens_sketch_sweep(ctx, oracle, seed):
+    """OptDens / RevOptDens: DNA and amino acids, f32 / f64, both hashers and index draws, per sequence and for all; sketch
+    sizes from 2 to 6000 against reads from 1 base to 60 k (empty bins: from none to almost all)"""
+    rng = np.random.default_rng(4000 + seed)
+    algo = int(rng.choice([A.ALGO_OPTDENS, A.ALGO_REVOPTDENS]))
+    m = int(rng.choice([1, 2, 7, 64, 200, 333, 1000, 6000]))
+    sig = int(rng.choice([A.SIG_F32, A.SIG_F64]))
+    hasher = int(rng.choice([A.HASHER_NOHASH, A.HASHER_FNV1A]))
+    flags = A.FLAG_RAND08 if rng.random() < 0.25 else 0
+    mode = A.MODE_ALL_SEQS if rng.random() < 0.3 else A.MODE_PER_SEQ
+    if rng.random() < 0.25:
+        kmer_type = int(rng.choice([A.KMERAA32BIT, A.KMERAA64BIT]))
+        k = int(rng.integers(1, 7 if kmer_type == A.KMERAA32BIT else 13))
+        fhash = int(rng.choice([A.FHASH_IDENTITY_RAW, A.FHASH_VALUE_MASKED, A.FHASH_INVHASH_RAW]))
+        aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+        seqs = [rng.choice(aa, size=int(rng.integers(1, 30) if i % 5 == 0 else rng.integers(20, 1500))).tobytes()
+                for i in range(int(rng.integers(1, 30)))]
+    else:
+        kmer_type, k = _kmer_choice(rng)
+        fhash = int(rng.choice([A.FHASH_IDENTITY_RAW, A.FHASH_VALUE_MASKED, A.FHASH_CANON_RAW, A.FHASH_CANON_INVHASH,
+                                A.FHASH_INVHASH_RAW, A.FHASH_CANON_VALUE]))
+        seqs = _reads(rng, int(rng.integers(1, 40)), str(rng.choice(["normal", "short", "long", "repeat"])))
+    bases, off = oracle.concat(seqs)
+    p = A.SketchParams(algo, kmer_type, k, m, sig, hasher, fhash, 0, mode, A.INPUT_ASCII, A.MEM_HOST, flags)
+    try:
+        want = oracle.sketch(bases, off, p)
+    except oracle.OracleError as e:
+        from kmerutils_amd.lib import KmuError
+        with pytest.raises(KmuError) as g:
+            ctx.sketch(bases, off, p)
+        assert A.STATUS_NAMES[g.value.code] == str(e)
+        return
+    got = np.asarray(ctx.sketch(bases, off, p))
+    assert got.shape == want.shape and got.tobytes() == np.asarray(want).tobytes(), (algo, kmer_type, k, m, sig, fhash, mode)
