@@ -591,7 +591,28 @@ template <class Kmer> class KmerGenerator {
 enum class DataType { DNA, AA };                                              // sketcharg.rs:13-16
 enum class SketchAlgo { PROB3A, SUPER, SUPER2, OPTDENS, REVOPTDENS, HLL };    // sketcharg.rs:26-33
 
-class SeqSketcherParams {   // sketcharg.rs:40-78
+namespace detail {
+inline const char *const ALGO_NAMES[6] = {"PROB3A", "SUPER", "SUPER2", "OPTDENS", "REVOPTDENS", "HLL"};
+inline const char *const DATA_NAMES[2] = {"DNA", "AA"};
+/// value of "key" in a flat JSON object written by serde_json (no nesting, no escapes in what these structs hold)
+inline std::string json_field(const std::string &text, const std::string &key) {
+    const std::string tag = "\"" + key + "\":";
+    const size_t at = text.find(tag);
+    if (at == std::string::npos) throw std::runtime_error("missing field " + key);
+    size_t b = at + tag.size(), e = b;
+    while (e < text.size() && text[e] != ',' && text[e] != '}') e++;
+    std::string v = text.substr(b, e - b);
+    if (v.size() >= 2 && v.front() == '"') v = v.substr(1, v.size() - 2);
+    return v;
+}
+inline std::string read_text_file(const std::string &path) {
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("reload_json could not open file " + path);
+    return std::string((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+}
+}  // namespace detail
+
+class SeqSketcherParams {   // sketcharg.rs:40-138
   public:
     SeqSketcherParams(size_t kmer_size, size_t sketch_size, SketchAlgo algo, DataType data_t)
         : kmer_size_(kmer_size), sketch_size_(sketch_size), algo_(algo), data_t_(data_t) {}
@@ -599,6 +620,24 @@ class SeqSketcherParams {   // sketcharg.rs:40-78
     size_t get_sketch_size() const { return sketch_size_; }
     SketchAlgo get_algo() const { return algo_; }
     DataType get_data_t() const { return data_t_; }
+    /// dump_json: serde_json::to_writer(&self) -- {"kmer_size":8,"sketch_size":200,"algo":"PROB3A","data_t":"DNA"}
+    void dump_json(const std::string &filename) const {
+        std::ofstream out(filename);
+        if (!out) throw std::runtime_error("SeqSketcher dump failed");
+        out << "{\"kmer_size\":" << kmer_size_ << ",\"sketch_size\":" << sketch_size_ << ",\"algo\":\""
+            << detail::ALGO_NAMES[int(algo_)] << "\",\"data_t\":\"" << detail::DATA_NAMES[int(data_t_)] << "\"}";
+    }
+    /// reload_json(dirpath): <dirpath>/sketchparams_dump.json
+    static SeqSketcherParams reload_json(const std::string &dirpath) {
+        const std::string text = detail::read_text_file(dirpath + "/sketchparams_dump.json");
+        const std::string algo = detail::json_field(text, "algo"), data_t = detail::json_field(text, "data_t");
+        int ai = -1, di = -1;
+        for (int i = 0; i < 6; i++) if (algo == detail::ALGO_NAMES[i]) ai = i;
+        for (int i = 0; i < 2; i++) if (data_t == detail::DATA_NAMES[i]) di = i;
+        if (ai < 0 || di < 0) throw std::runtime_error("reload_json: unknown algo / data_t");
+        return SeqSketcherParams(std::stoul(detail::json_field(text, "kmer_size")), std::stoul(detail::json_field(text, "sketch_size")),
+                                 SketchAlgo(ai), DataType(di));
+    }
 
   private:
     size_t kmer_size_, sketch_size_;
@@ -761,6 +800,16 @@ class SeqSketcher {
                                            KMU_HASHER_FNV1A, fhash, KMU_MODE_PER_SEQ);
     }
 
+    /// dump_json / reload_json (seqsketchjaccard.rs:142-201): {"kmer_size":..,"sketch_size":..}
+    void dump_json(const std::string &filename) const {
+        std::ofstream out(filename);
+        if (!out) throw std::runtime_error("SeqSketcher dump failed");
+        out << "{\"kmer_size\":" << kmer_size_ << ",\"sketch_size\":" << sketch_size_ << "}";
+    }
+    static SeqSketcher reload_json(const std::string &dirpath, Context &ctx = Context::global()) {
+        const std::string text = detail::read_text_file(dirpath + "/sketchparams_dump.json");
+        return SeqSketcher(std::stoul(detail::json_field(text, "kmer_size")), std::stoul(detail::json_field(text, "sketch_size")), ctx);
+    }
     /// create_signature_dump: magic, sig_size = 4, sketch_size, kmer_size as four u32 (seqsketchjaccard.rs:385-414)
     std::ofstream create_signature_dump(const std::string &dumpfname) const {
         std::ofstream out(dumpfname, std::ios::binary);
@@ -781,6 +830,39 @@ class SeqSketcher {
   private:
     size_t kmer_size_, sketch_size_;
     Context &ctx_;
+};
+
+/// SigSketchFileReader::new / next (seqsketchjaccard.rs:586-712).  Upstream's `next` reads the bytes of a row but returns an
+/// empty Vec (:690-708); this reader returns the row.
+class SigSketchFileReader {
+  public:
+    explicit SigSketchFileReader(const std::string &fname) : in_(fname, std::ios::binary) {
+        uint32_t head[4] = {0, 0, 0, 0};
+        if (!in_) throw std::runtime_error("SigSketchFileReader could not open file " + fname);
+        in_.read(reinterpret_cast<char *>(head), 16);
+        if (in_.gcount() < 4) throw std::runtime_error("SigSketchFileReader could no read magic");
+        if (head[0] != SeqSketcher::MAGIC_SIG_DUMP) throw std::runtime_error("file is not a dump of signature");
+        if (in_.gcount() < 16) throw std::runtime_error("SigSketchFileReader could no read sketch_size");
+        sig_size_ = head[1];
+        sketch_size_ = head[2];
+        kmer_size_ = uint8_t(head[3]);
+        if (sig_size_ != 4) throw std::runtime_error("SigSketchFileReader , sig_size != 4 not yet implemented");
+    }
+    uint8_t get_kmer_size() const { return kmer_size_; }
+    size_t get_signature_length() const { return sketch_size_; }
+    size_t get_signature_size() const { return sig_size_; }
+    /// the next signature, or nothing at the end of the file
+    std::optional<std::vector<uint32_t>> next() {
+        std::vector<uint32_t> row(sketch_size_);
+        in_.read(reinterpret_cast<char *>(row.data()), std::streamsize(4 * sketch_size_));
+        if (size_t(in_.gcount()) < 4 * sketch_size_) return std::nullopt;
+        return row;
+    }
+
+  private:
+    std::ifstream in_;
+    size_t sig_size_ = 0, sketch_size_ = 0;
+    uint8_t kmer_size_ = 0;
 };
 
 // =====================================================================================================================

@@ -11,6 +11,8 @@ what the Julia companion reads); where upstream's own reader disagrees with its 
 
 All integers little-endian (`to_le_bytes`, or `transmute` on the little-endian hosts the reference runs on).
 """
+import json
+import os
 import struct
 
 import numpy as np
@@ -169,3 +171,29 @@ def load_kmer_counter(fname, val_bytes):
         if kmer_size <= 14:
             vals = vals & np.uint64(0x0FFFFFFF)
         return kmer_size, vals, rec["c"].copy()
+
+
+# ---- sketching parameters as JSON (serde_json::to_writer of the structs) ---------------------------------------------------
+_ALGO_NAMES = ["PROB3A", "SUPER", "SUPER2", "OPTDENS", "REVOPTDENS", "HLL"]  # enum SketchAlgo, src/sketcharg.rs:26-33
+_DATA_NAMES = ["DNA", "AA"]                                                  # enum DataType, src/sketcharg.rs:13-16
+
+
+def dump_sketcher_params_json(filename, kmer_size, sketch_size, algo=None, data_t=None):
+    """SeqSketcherParams::dump_json (src/sketcharg.rs:79-106): {"kmer_size":..,"sketch_size":..,"algo":"PROB3A","data_t":"DNA"};
+    SeqSketcher::dump_json (src/sketching/seqsketchjaccard.rs:142-169) when algo / data_t are None: the two sizes only.
+    serde writes unit variants as their names, fields in declaration order, no whitespace."""
+    d = {"kmer_size": int(kmer_size), "sketch_size": int(sketch_size)}
+    if algo is not None:
+        d["algo"] = algo if isinstance(algo, str) else _ALGO_NAMES[algo]
+        d["data_t"] = data_t if isinstance(data_t, str) else _DATA_NAMES[data_t or 0]
+    with open(filename, "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+
+
+def reload_sketcher_params_json(dirpath):
+    """reload_json(dirpath): reads <dirpath>/sketchparams_dump.json (sketcharg.rs:109-138, seqsketchjaccard.rs:172-201)"""
+    with open(os.path.join(dirpath, "sketchparams_dump.json")) as f:
+        d = json.load(f)
+    if "algo" in d and d["algo"] not in _ALGO_NAMES:
+        raise ValueError("unknown SketchAlgo %r" % d["algo"])
+    return d

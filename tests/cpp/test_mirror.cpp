@@ -706,16 +706,35 @@ TEST(test_parse_fastq_and_signature_dump) {
         std::ofstream out = sketcher.create_signature_dump(fname);
         SeqSketcher::dump_signatures_block_u32(sigs, out);
     }
-    std::ifstream in(fname, std::ios::binary);
-    uint32_t head[4];
-    in.read(reinterpret_cast<char *>(head), 16);
-    CHECK(head[0] == 0xceabeadd && head[1] == 4 && head[2] == 200 && head[3] == 8);   // seqsketchjaccard.rs:385-414
-    for (const auto &sig : sigs) {
-        std::vector<uint32_t> row(200);
-        in.read(reinterpret_cast<char *>(row.data()), 800);
-        CHECK(in.gcount() == 800 && row == sig);
+    {
+        std::ifstream in(fname, std::ios::binary);
+        uint32_t head[4];
+        in.read(reinterpret_cast<char *>(head), 16);
+        CHECK(head[0] == 0xceabeadd && head[1] == 4 && head[2] == 200 && head[3] == 8);   // seqsketchjaccard.rs:385-414
     }
+    SigSketchFileReader reader(fname);   // test_reload_sketch_file, seqsketchjaccard.rs:1015
+    CHECK(reader.get_kmer_size() == 8 && reader.get_signature_length() == 200 && reader.get_signature_size() == 4);
+    for (const auto &sig : sigs) {
+        auto row = reader.next();
+        CHECK(row.has_value() && *row == sig);
+    }
+    CHECK(!reader.next().has_value());
     std::remove(fname.c_str());
+    // the parameter dumps next to it (serde_json layout)
+    const std::string dir = "/tmp/kmu_test_mirror_json";
+    (void) std::system(("mkdir -p " + dir).c_str());
+    SeqSketcherParams(8, 200, SketchAlgo::PROB3A, DataType::DNA).dump_json(dir + "/sketchparams_dump.json");
+    {
+        std::ifstream in(dir + "/sketchparams_dump.json");
+        std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        CHECK(text == "{\"kmer_size\":8,\"sketch_size\":200,\"algo\":\"PROB3A\",\"data_t\":\"DNA\"}");
+    }
+    SeqSketcherParams back = SeqSketcherParams::reload_json(dir);
+    CHECK(back.get_kmer_size() == 8 && back.get_sketch_size() == 200 && back.get_algo() == SketchAlgo::PROB3A && back.get_data_t() == DataType::DNA);
+    sketcher.dump_json(dir + "/sketchparams_dump.json");
+    SeqSketcher again = SeqSketcher::reload_json(dir);
+    CHECK(again.get_kmer_size() == 8 && again.get_sketch_size() == 200);
+    (void) std::system(("rm -rf " + dir).c_str());
 }
 
 // needletail::parse_fastx_file also takes FASTA: multi-line records, format by the first byte

@@ -70,3 +70,16 @@ def test_kmer_count_dump_layout_and_roundtrip(tmp_path):
     assert raw[14:19] == struct.pack("<I", 0x2A | (8 << 28)) + bytes([4])
     k, v, c = F.load_kmer_counter(fn, 4)
     assert k == 8 and v.tolist() == [0x2A] and c.tolist() == [4]
+
+
+def test_sketcher_params_json(tmp_path):
+    """serde_json layout of SeqSketcherParams / SeqSketcher (src/sketcharg.rs:40-138, seqsketchjaccard.rs:117-201)"""
+    fn = tmp_path / "sketchparams_dump.json"
+    F.dump_sketcher_params_json(str(fn), 8, 200, "PROB3A", "DNA")
+    assert fn.read_text() == '{"kmer_size":8,"sketch_size":200,"algo":"PROB3A","data_t":"DNA"}'
+    assert F.reload_sketcher_params_json(str(tmp_path)) == dict(kmer_size=8, sketch_size=200, algo="PROB3A", data_t="DNA")
+    F.dump_sketcher_params_json(str(fn), 12, 128, 4, 1)  # enum ordinals: REVOPTDENS, AA
+    assert fn.read_text() == '{"kmer_size":12,"sketch_size":128,"algo":"REVOPTDENS","data_t":"AA"}'
+    F.dump_sketcher_params_json(str(fn), 16, 50)       # SeqSketcher: the two sizes
+    assert fn.read_text() == '{"kmer_size":16,"sketch_size":50}'
+    assert F.reload_sketcher_params_json(str(tmp_path)) == dict(kmer_size=16, sketch_size=50)
