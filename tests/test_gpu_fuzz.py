@@ -193,3 +193,81 @@ def test_dens_sketch_sweep(ctx, oracle, seed):
         return
     got = np.asarray(ctx.sketch(bases, off, p))
     assert got.shape == want.shape and got.tobytes() == np.asarray(want).tobytes(), (algo, kmer_type, k, m, sig, fhash, mode)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_counter_usage_sweep(ctx, oracle, seed, monkeypatch):
+    """random sequences of counter operations against the oracle counter: batches of reads from the host, from the device
+    (whole arrays and ranges of them), packed; explicit k-mer lists; merges of exported entries; the build path forced
+    both ways; queries, totals and dumps in between; reset and reuse"""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    kmer_type, k = _kmer_choice(rng)
+    bits = int(rng.choice([8, 16]))
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=30_000).tobytes()
+
+    def batch():
+        n = int(rng.integers(1, 120))
+        seqs = []
+        for _ in range(n):
+            L = int(rng.integers(1, 900))
+            s0 = int(rng.integers(0, len(genome) - L))
+            seqs.append(genome[s0:s0 + L])   # overlapping samples of one genome: real multiplicities
+        return oracle.concat(seqs)
+
+    c = ctx.counter(kmer_type, k, bits, 1 << 17)
+    o = oracle.Counter(kmer_type, k, bits, 1 << 17)
+    for step in range(int(rng.integers(3, 9))):
+        op = str(rng.choice(["host", "device", "range", "packed", "kmers", "merge", "reset", "forced"]))
+        bases, off = batch()
+        if op == "reset" and step > 0:
+            c.reset()
+            o = oracle.Counter(kmer_type, k, bits, 1 << 17)
+            continue
+        if op == "forced":
+            monkeypatch.setenv("KMU_COUNT_PATH", str(rng.choice(["direct", "partitioned"])))
+            c.add_reads(bases, off)
+            monkeypatch.delenv("KMU_COUNT_PATH")
+            o.add_reads(bases, off)
+        elif op == "device":
+            c.add_reads(torch.from_numpy(bases.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda())
+            o.add_reads(bases, off)
+        elif op == "range":
+            n = len(off) - 1
+            a = int(rng.integers(0, n))
+            b = int(rng.integers(a + 1, n + 1))
+            c.add_reads(torch.from_numpy(bases.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()[a:b + 1])
+            sb = bases[int(off[a]):int(off[b])].copy()
+            if sb.size == 0:
+                sb = np.zeros(16, np.uint8)
+            o.add_reads(sb, (off[a:b + 1] - off[a]).astype(np.uint64))
+        elif op == "packed":
+            packed, poff = ctx.pack2b(bases, off)
+            c.add_reads(packed, off, A.INPUT_PACKED2, poff)
+            o.add_reads(bases, off)
+        elif op == "kmers":
+            canon = oracle.kmer_hashes(bases, off, kmer_type, k, A.FHASH_CANON_VALUE)
+            valid = [np.arange(int(off[i]), int(off[i + 1]) - k + 1) for i in range(len(off) - 1) if off[i + 1] - off[i] >= k]
+            if valid:
+                v = canon[np.concatenate(valid)]
+                c.add_kmers(v.copy())
+                o.add_kmers(v)
+        elif op == "merge":
+            c2 = ctx.counter(kmer_type, k, 16, 1 << 16)
+            c2.add_reads(bases, off)
+            kk, cc = c2.export_part(0, 1)
+            c.merge_entries(kk.copy(), cc.copy())
+            c2.close()
+            o.add_reads(bases, off)
+        else:
+            c.add_reads(bases, off)
+            o.add_reads(bases, off)
+        if rng.random() < 0.5:
+            probe = np.concatenate([o.dump(1)[0][:40], rng.integers(0, 1 << 30, size=10).astype(np.uint64)])
+            assert np.array_equal(c.query(probe), o.query(probe)), (step, op)
+    assert c.nb_distinct() == o.nb_distinct() and c.nb_unique() == o.nb_unique()
+    for mc in (1, 2, 5):
+        gk, gc = c.dump(mc)
+        wk, wc = o.dump(mc)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc), mc
+    c.close()
