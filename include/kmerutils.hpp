@@ -454,6 +454,18 @@ inline Batch gather(const std::vector<const SequenceAA *> &vseq) {
     return b;
 }
 
+/// a packed (Sequence) batch as ASCII, for the entry points that take unpacked bases only
+inline Batch unpacked(const Batch &b) {
+    if (b.input_kind != KMU_INPUT_PACKED2) return b;
+    Batch a;
+    a.offsets = b.offsets;
+    a.bytes.resize(b.offsets.back() + 16, 0);
+    for (uint32_t i = 0; i < b.n(); i++)
+        for (uint64_t p = 0, len = b.offsets[i + 1] - b.offsets[i]; p < len; p++)
+            a.bytes[b.offsets[i] + p] = Alphabet2b::decode(uint8_t(b.bytes[b.packed_offsets[i] + (p >> 2)] >> (6 - 2 * (p & 3))));
+    return a;
+}
+
 template <class Seq> std::vector<const Seq *> pointers(const std::vector<Seq> &v) {
     std::vector<const Seq *> p;
     p.reserve(v.size());
@@ -1241,6 +1253,11 @@ template <class Kmer> class KmerCounter : public KmerCountT<Kmer> {
         return {std::move(k), std::move(c)};
     }
     uint8_t kmer_size() const { return kmer_size_; }
+    /// the device counter with everything inserted so far (null before the first insertion)
+    kmu_counter *raw() {
+        if (counter_) flush();
+        return counter_;
+    }
 
   private:
     void ensure(uint8_t k) {
@@ -1309,6 +1326,78 @@ template <class Kmer> class KmerCounterPool {
   private:
     KmerCounter<Kmer> counter_;
 };
+
+/// KmerFilter1 (kmercount.rs:985-1089): which 16-mers occur exactly once in a read set, and where.  Upstream keeps two cuckoo
+/// filters (approximate, randomised per process); the exact device table answers the same questions.
+class KmerFilter1 {
+  public:
+    struct OnceKmers {   // records of dump_in_file_once_kmer16b32bit, in file order
+        std::vector<uint64_t> kmin;
+        std::vector<uint32_t> numseq, numkmer;
+    };
+    KmerFilter1(uint8_t size, uint32_t capacity, Context &ctx = Context::global()) : counter_(0.03, capacity, 8, ctx), ctx_(ctx) {
+        if (size != 16) throw std::invalid_argument("KmerFilter1 holds Kmer16b32bit");
+    }
+    /// insert_kmer16b32bit(kmer): the caller passes the canonical k-mer (kmercount.rs:1108-1109)
+    void insert_kmer16b32bit(Kmer16b32bit kmer) { counter_.insert_kmer(kmer); }
+    void insert_reads(const detail::Batch &reads) { counter_.insert_reads(reads, 16); }
+    uint64_t get_nb_once() { return counter_.get_nb_unique(); }   // once_f.len()
+    OnceKmers once_positions(const detail::Batch &reads) {
+        const detail::Batch b = detail::unpacked(reads);   // kmu_count_once_positions takes unpacked bases
+        OnceKmers r;
+        kmu_counter *c = counter_.raw();
+        if (!c) return r;
+        uint64_t n = 0;
+        ctx_.check(kmu_count_once_positions(c, b.bytes_ptr(), b.offsets_ptr(), b.n(), b.mem(), nullptr, nullptr, nullptr, 0, &n));
+        r.kmin.resize(n); r.numseq.resize(n); r.numkmer.resize(n);
+        if (n == 0) return r;
+        if (b.on_device()) {
+            DeviceBuffer dk(ctx_, n * 8), ds(ctx_, n * 4), dp(ctx_, n * 4);
+            ctx_.check(kmu_count_once_positions(c, b.dev_bytes, b.dev_offsets, b.n(), KMU_MEM_DEVICE, dk.as<uint64_t>(), ds.as<uint32_t>(),
+                                                dp.as<uint32_t>(), n, &n));
+            dk.download(r.kmin.data(), n * 8); ds.download(r.numseq.data(), n * 4); dp.download(r.numkmer.data(), n * 4);
+        } else {
+            ctx_.check(kmu_count_once_positions(c, b.bytes.data(), b.offsets.data(), b.n(), KMU_MEM_HOST, r.kmin.data(),
+                                                r.numseq.data(), r.numkmer.data(), n, &n));
+        }
+        return r;
+    }
+    /// dump_in_file_once_kmer16b32bit(fname, seqvec) (kmercount.rs:1031-1082): COUNTER_UNIQUE u32, kmer_size u8, number of
+    /// k-mers u64, then (kmer u32, numseq u32, numkmer u32) per record.  Returns the number of k-mers dumped.
+    size_t dump_in_file_once_kmer16b32bit(const std::string &fname, const detail::Batch &seqvec) {
+        OnceKmers r = once_positions(seqvec);
+        std::ofstream out(fname, std::ios::binary);
+        if (!out) throw std::runtime_error("cannot open " + fname);
+        const uint32_t magic = COUNTER_UNIQUE;
+        const uint8_t k = 16;
+        const uint64_t n = r.kmin.size();
+        out.write(reinterpret_cast<const char *>(&magic), 4);
+        out.write(reinterpret_cast<const char *>(&k), 1);
+        out.write(reinterpret_cast<const char *>(&n), 8);
+        for (size_t i = 0; i < r.kmin.size(); i++) {
+            const uint32_t rec[3] = {uint32_t(r.kmin[i]), r.numseq[i], r.numkmer[i]};
+            out.write(reinterpret_cast<const char *>(rec), 12);
+        }
+        return r.kmin.size();
+    }
+    size_t dump_in_file_once_kmer16b32bit(const std::string &fname, const std::vector<Sequence> &seqvec) {
+        return dump_in_file_once_kmer16b32bit(fname, detail::gather(detail::pointers(seqvec)));
+    }
+    static constexpr uint32_t COUNTER_UNIQUE = 0xcea2bbdd;   // kmercount.rs:35
+
+  private:
+    KmerCounter<Kmer16b32bit> counter_;
+    Context &ctx_;
+};
+
+/// filter1_kmer_16b32bit(&seqvec) -> KmerFilter1 (kmercount.rs:1093-1123)
+inline std::unique_ptr<KmerFilter1> filter1_kmer_16b32bit(const std::vector<Sequence> &seqvec, Context &ctx = Context::global()) {
+    uint64_t bases = 0;
+    for (const Sequence &s : seqvec) bases += s.size();
+    auto f = std::make_unique<KmerFilter1>(16, uint32_t(std::min<uint64_t>(std::max<uint64_t>(bases, 1024), 0xFFFFFFFFu)), ctx);
+    f->insert_reads(detail::gather(detail::pointers(seqvec)));
+    return f;
+}
 
 /// count_kmer_threaded_one_to_many(seqvec, nb_threads, count_size, kmer_size) -> KmerCounterPool (kmercount.rs:881-974).
 /// `nb_threads` is kept for the signature (inside one GPU there is no key-space dispatch); `count_size` = bits per counter.

@@ -238,6 +238,12 @@ int kmu_count_nb_unique(kmu_counter *c, uint64_t *out);   /* kmercount.rs:285-28
  * Call with kmers_out == NULL to get the number of records in *n_out; records are sorted by k-mer value. */
 int kmu_count_dump(kmu_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,
                    uint64_t *n_out);
+/* The k-mers seen exactly once, with where they sit (KmerFilter1::dump_in_file_once_kmer16b32bit, kmercount.rs:1031-1082;
+ * the `Unicity` branch of parsefastq): for every k-mer occurrence of the given reads, in (sequence, position) order, whose
+ * canonical k-mer has count exactly 1 in the counter: canonical value, sequence number, k-mer rank in its sequence.
+ * Unpacked (ASCII) input.  Call with kmers_out == NULL for the number of records in *n_out. */
+int kmu_count_once_positions(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
+                             uint64_t *kmers_out, uint32_t *numseq_out, uint32_t *numkmer_out, uint64_t cap, uint64_t *n_out);
 /* multi-GPU merge (one process per GPU): export the entries whose owner (int64_hash(kmer) % n_parts,
  * kmercount.rs:412-420) is `part` as device/host arrays, and merge entries received from peers.
  * The exchange itself is done by the host layer (RCCL all_to_all over xGMI). */

@@ -210,6 +210,93 @@ __global__ void __launch_bounds__(256) k_count_add_flat(const uint8_t *bases, co
     if (full) atomicOr(err, DERR_TABLE_FULL);
 }
 
+// ---- k-mers seen exactly once, with their positions (KmerFilter1, src/base/kmercount.rs:985-1082) ----------------------
+// One wave step of the flat stream: bit j of the returned mask = "the k-mer starting at this lane's base j lies inside one
+// read and its canonical value has count 1"; canon[j], and the read of base j in rd[j], are filled for those bits.
+__device__ __forceinline__ uint32_t once_step(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, uint64_t total,
+                                              uint64_t start, int k, uint64_t st, uint32_t &r_hint, const CountTable &t,
+                                              uint64_t (&canon)[16], uint32_t (&rd)[16]) {
+    SeqView s;
+    s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
+    const int lane = lane_id();
+    const uint64_t widx = st * 64 + lane;
+    uint32_t bad, bad2;
+    uint32_t w0 = load_code_word(s, widx, bad);
+    uint32_t ex = load_code_word(s, st * 64 + 64 + (uint64_t) (lane & 1), bad2);
+    uint32_t e0 = bcast_u32(ex, 0), e1 = bcast_u32(ex, 1);
+    uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
+    if (lane == 63) { w1 = e0; w2 = e1; }
+    if (lane == 62) { w2 = e0; }
+    uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
+    r_hint = r;
+    const uint64_t g0 = widx * 16;
+    uint32_t mask = 0;
+    if (g0 < total && g0 + 16 > start) {
+        uint64_t rend = offsets[r + 1];
+        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+        const int sh = 64 - 2 * k;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint64_t g = g0 + j;
+            while (g >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; }
+            if (g >= start && g + k <= rend) {
+                const uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
+                const uint64_t val = v >> sh, rc = revcomp_val(val, k);
+                const uint64_t c = rc < val ? rc : val;
+                if (count_lookup(t, c) == 1u) {
+                    mask |= 1u << j;
+                    canon[j] = c;
+                    rd[j] = r;
+                }
+            }
+        }
+    }
+    return mask;
+}
+
+__global__ void __launch_bounds__(256) k_once_count(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
+                                                    CountTable t, uint32_t *cnt) {
+    const uint64_t total = offsets[n_seq], start = offsets[0];
+    const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
+    const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    uint32_t r_hint = 0xFFFFFFFFu;
+    for (uint64_t st = wave_global; st < nsteps; st += nwaves_global) {
+        uint64_t canon[16];
+        uint32_t rd[16];
+        const uint32_t mask = once_step(bases, offsets, n_seq, total, start, k, st, r_hint, t, canon, rd);
+        const uint32_t incl = wave_incl_scan_u32((uint32_t) __popc(mask));
+        if (lane_id() == 63) cnt[st] = incl;
+    }
+}
+
+// the same walk; step st writes its records at base[st] .. in (sequence, position) order
+__global__ void __launch_bounds__(256) k_once_emit(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
+                                                   CountTable t, const uint64_t *base, uint64_t *kmers_out,
+                                                   uint32_t *numseq_out, uint32_t *numkmer_out) {
+    const uint64_t total = offsets[n_seq], start = offsets[0];
+    const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
+    const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    uint32_t r_hint = 0xFFFFFFFFu;
+    for (uint64_t st = wave_global; st < nsteps; st += nwaves_global) {
+        uint64_t canon[16];
+        uint32_t rd[16];
+        const uint32_t mask = once_step(bases, offsets, n_seq, total, start, k, st, r_hint, t, canon, rd);
+        const uint32_t c = (uint32_t) __popc(mask);
+        uint64_t at = base[st] + (wave_incl_scan_u32(c) - c);
+        const uint64_t g0 = (st * 64 + (uint64_t) lane_id()) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((mask >> j) & 1u) {
+                kmers_out[at] = canon[j];
+                numseq_out[at] = rd[j];
+                numkmer_out[at] = (uint32_t) (g0 + j - offsets[rd[j]]);
+                at++;
+            }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_count_add_reads(const uint8_t *bases, const uint64_t *offsets,
                                                          const uint64_t *packed_offsets, uint32_t n_seq, int packed,
                                                          uint64_t total_bytes, int k, CountTable t, uint32_t *err) {
@@ -1417,6 +1504,62 @@ int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts) {
     if (rc) return rc;
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KMU_OK;
+}
+
+int kmu_count_once_positions(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
+                             uint64_t *kmers_out, uint32_t *numseq_out, uint32_t *numkmer_out, uint64_t cap, uint64_t *n_out) {
+    if (!c || !n_out || (kmers_out && (!numseq_out || !numkmer_out))) return KMU_E_BAD_ARG;
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    *n_out = 0;
+    if (n_seq == 0) return KMU_OK;
+    DevSeqs ds;
+    KMU_TRY(stage_sequences(ctx, bases, offsets, nullptr, n_seq, KMU_INPUT_ASCII, mem, &ds));
+    uint64_t total_bases = 0;
+    KMU_TRY(flat_stream_extent(ctx, offsets, n_seq, mem, ds, &total_bases));
+    if (total_bases == 0) return KMU_OK;
+    KMU_TRY(materialize(c));
+    const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
+    void *cnt, *base;
+    KMU_TRY(dev_buf(ctx, "once.cnt", nsteps * 4 + 64, &cnt));
+    KMU_TRY(dev_buf(ctx, "once.base", (nsteps + 1) * 8 + 64, &base));
+    const int grid = (int) std::min<uint64_t>((nsteps + 3) / 4, (uint64_t) ctx->num_cus * 8);
+    {
+        KernelTimer tm(ctx, "k_once_count");
+        hipLaunchKernelGGL(k_once_count, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, n_seq, c->p.kmer_size,
+                           table_of(c), (uint32_t *) cnt);
+    }
+    KMU_TRY(device_scan_u32(ctx, (const uint32_t *) cnt, nsteps, (uint64_t *) base));
+    uint64_t n = 0;
+    KMU_HIP(ctx, hipMemcpyAsync(&n, (const uint64_t *) base + nsteps, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    if (!kmers_out) return KMU_OK; // size query
+    if (cap < n) return fail(ctx, KMU_E_BAD_ARG, "output too small: %llu records", (unsigned long long) n);
+    if (n == 0) return KMU_OK;
+    uint64_t *d_k = kmers_out;
+    uint32_t *d_s = numseq_out, *d_p = numkmer_out;
+    if (mem == KMU_MEM_HOST) {
+        void *q;
+        KMU_TRY(dev_buf(ctx, "once.k", n * 8 + 64, &q));
+        d_k = (uint64_t *) q;
+        KMU_TRY(dev_buf(ctx, "once.s", n * 4 + 64, &q));
+        d_s = (uint32_t *) q;
+        KMU_TRY(dev_buf(ctx, "once.p", n * 4 + 64, &q));
+        d_p = (uint32_t *) q;
+    }
+    {
+        KernelTimer tm(ctx, "k_once_emit");
+        hipLaunchKernelGGL(k_once_emit, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, n_seq, c->p.kmer_size,
+                           table_of(c), (const uint64_t *) base, d_k, d_s, d_p);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    if (mem == KMU_MEM_HOST) {
+        KMU_HIP(ctx, hipMemcpyAsync(kmers_out, d_k, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipMemcpyAsync(numseq_out, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipMemcpyAsync(numkmer_out, d_p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return finish_call(ctx, mem);
 }
 
 int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,

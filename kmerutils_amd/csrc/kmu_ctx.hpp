@@ -181,6 +181,9 @@ inline bool kmer_is_aa(int t) { return t == KMU_KMERAA32BIT || t == KMU_KMERAA64
 inline int kmer_val_bytes(int t) { return (t == KMU_KMER64BIT || t == KMU_KMERAA64BIT) ? 8 : 4; }
 bool fhash_valid(int fhash, int kmer_type);
 
+// exclusive scan of n u32 values into u64 offsets, out[n] = total (kmu_ingest.hip)
+int device_scan_u32(kmu_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t *out);
+
 // radix partition of a device u64 array by the top bits of fmix64(key) (kmu_count.hip)
 int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits, const uint64_t **items_out,
                   const uint64_t **bounds_out, bool hashed_out = false);

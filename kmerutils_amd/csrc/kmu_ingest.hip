@@ -344,6 +344,11 @@ template <typename T> static int device_scan(kmu_ctx *ctx, const T *in, uint64_t
     return KMU_OK;
 }
 
+namespace kmu {
+// exclusive scan of n u32 values into u64 (out[n] = total), for the other modules
+int device_scan_u32(kmu_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t *out) { return device_scan<uint32_t>(ctx, in, n, out); }
+}
+
 // steps 3 and 4 shared by both formats: filter the records [seq_start, seq_end) of `d_text`, scan, copy out
 static int ingest_filter_copy(kmu_ctx *ctx, const uint8_t *d_text, uint64_t n_text, uint64_t n_records, void *sstart, void *send,
                               void *scal, int mem, uint8_t *bases_out, uint64_t bases_cap, uint64_t *offsets_out,

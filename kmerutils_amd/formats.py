@@ -157,6 +157,42 @@ def dump_kmer_counter(fname, kmers, counts, kmer_size, val_bytes):
     return len(kmers)
 
 
+def dump_once_kmers(fname, kmers, numseq, numkmer, kmer_size, val_bytes=4):
+    """KmerFilter1::dump_in_file_once_kmer16b32bit (kmercount.rs:1031-1082): COUNTER_UNIQUE u32, kmer_size u8, number of
+    k-mers u64, then per record `Kmer::dump` (the u32 word for Kmer16b32bit / Kmer32bit, size byte + u64 for Kmer64bit),
+    numseq u32, numkmer u32.  Records as returned by kmu_count_once_positions (file order)."""
+    kmers = np.asarray(kmers, np.uint64)
+    with open(fname, "wb") as f:
+        f.write(struct.pack("<IBQ", COUNTER_UNIQUE, kmer_size, len(kmers)))
+        if val_bytes == 8:
+            rec = np.zeros(len(kmers), dtype=[("k", "u1"), ("v", "<u8"), ("s", "<u4"), ("p", "<u4")])
+            rec["k"] = kmer_size
+        else:
+            rec = np.zeros(len(kmers), dtype=[("v", "<u4"), ("s", "<u4"), ("p", "<u4")])
+        words = kmers if val_bytes == 8 else kmers.astype(np.uint32)
+        if val_bytes == 4 and kmer_size <= 14:
+            words = words | np.uint32(kmer_size << 28)
+        rec["v"], rec["s"], rec["p"] = words, np.asarray(numseq, np.uint32), np.asarray(numkmer, np.uint32)
+        f.write(rec.tobytes())
+    return len(kmers)
+
+
+def load_once_kmers(fname, val_bytes=4):
+    """(kmer_size, kmers uint64, numseq, numkmer) from a COUNTER_UNIQUE dump"""
+    with open(fname, "rb") as f:
+        magic, kmer_size, n = struct.unpack("<IBQ", f.read(13))
+        if magic != COUNTER_UNIQUE:
+            raise IOError("not a dump of unique k-mers")
+        if val_bytes == 8:
+            rec = np.frombuffer(f.read(), dtype=[("k", "u1"), ("v", "<u8"), ("s", "<u4"), ("p", "<u4")], count=n)
+            return kmer_size, rec["v"].astype(np.uint64), rec["s"].copy(), rec["p"].copy()
+        rec = np.frombuffer(f.read(), dtype=[("v", "<u4"), ("s", "<u4"), ("p", "<u4")], count=n)
+        vals = rec["v"].astype(np.uint64)
+        if kmer_size <= 14:
+            vals = vals & np.uint64(0x0FFFFFFF)
+        return kmer_size, vals, rec["s"].copy(), rec["p"].copy()
+
+
 def load_kmer_counter(fname, val_bytes):
     """(kmer_size, canonical values uint64, counts uint8) from a COUNTER_MULTIPLE dump"""
     with open(fname, "rb") as f:

@@ -61,3 +61,46 @@ def count_kmer_threaded_one_to_many(seqvec, nb_threads, count_size, kmer_size, c
     kc = KmerCounter(kmer_size, capacity, count_size, ctx=ctx)
     kc.insert_reads((bases, offsets))
     return kc
+
+
+class KmerFilter1:
+    """KmerFilter1 (kmercount.rs:985-1089): which 16-mers occur exactly once, and where.  Upstream keeps two cuckoo filters
+    (approximate, randomised); here the exact device table answers the same questions.  `insert_reads` stands for the loop
+    of filter1_kmer_16b32bit (generate, canonicalise, insert)."""
+
+    def __init__(self, size=16, capacity=1 << 20, ctx=None):
+        if size != 16:
+            raise ValueError("KmerFilter1 holds Kmer16b32bit")
+        self.kmer_size = size
+        self.ctx = ctx or default_context()
+        self._c = lib.Counter(self.ctx, A.KMER16B32BIT, 16, 8, capacity)
+
+    def insert_kmer16b32bit(self, canonical_values):
+        self._c.add_kmers(np.atleast_1d(np.asarray(canonical_values, dtype=np.uint64)).copy())
+
+    def insert_reads(self, vseq):
+        bases, offsets = _as_arrays(vseq)
+        self._c.add_reads(bases, offsets)
+
+    def get_nb_once(self):
+        """once_f.len()"""
+        return self._c.nb_unique()
+
+    def once_positions(self, vseq):
+        """(kmin, numseq, numkmer) of every occurrence of a once-k-mer in the reads, in file order"""
+        bases, offsets = _as_arrays(vseq)
+        return self._c.once_positions(bases, offsets)
+
+    def dump_in_file_once_kmer16b32bit(self, fname, seqvec):
+        """kmercount.rs:1031-1082; returns the number of k-mers dumped"""
+        from . import formats
+        k, s, p = self.once_positions(seqvec)
+        return formats.dump_once_kmers(fname, np.asarray(k), np.asarray(s), np.asarray(p), 16, 4)
+
+
+def filter1_kmer_16b32bit(seqvec, ctx=None):
+    """kmercount.rs:1093-1123: a KmerFilter1 fed with the canonical 16-mers of every sequence"""
+    bases, offsets = _as_arrays(seqvec)
+    f = KmerFilter1(16, max(1024, int(offsets[-1])), ctx=ctx)
+    f.insert_reads((bases, offsets))
+    return f

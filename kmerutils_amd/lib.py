@@ -23,7 +23,7 @@ SYMBOLS = [
     "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
     "kmu_count_retain_part", "kmu_count_extract_by_owner", "kmu_sig_equal_pairs", "kmu_sig_equal_matrix",
     "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx", "kmu_dev_alloc", "kmu_dev_free",
-    "kmu_copy_to_device", "kmu_copy_to_host",
+    "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions",
 ]
 
 
@@ -79,6 +79,7 @@ def load():
     L.kmu_sig_equal_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
     L.kmu_sig_equal_matrix.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
     L.kmu_minhash_distance_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, vp]
+    L.kmu_count_once_positions.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint64, u64p]
     L.kmu_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.kmu_dev_free.argtypes = [vp, vp]
     L.kmu_copy_to_device.argtypes = [vp, vp, vp, C.c_uint64]
@@ -426,6 +427,26 @@ class Counter:
         c = np.zeros(max(n.value, 1), np.uint32)
         self.ctx._check(self.L.kmu_count_dump(self.h, min_count, _ptr(k)[0], _ptr(c)[0], n.value, C.byref(n)))
         return k[:n.value], c[:n.value]
+
+    def once_positions(self, bases, offsets):
+        """kmu_count_once_positions: (canonical k-mers, numseq, numkmer) of the occurrences whose k-mer has count 1, in
+        (sequence, position) order; numpy arrays for host input, torch cuda tensors for device input"""
+        mem = Context._mem(bases, offsets)
+        self.ctx._wait_producers(bases)
+        n = C.c_uint64(0)
+        nseq = len(offsets) - 1
+        self.ctx._check(self.L.kmu_count_once_positions(self.h, _ptr(bases)[0], _ptr(offsets)[0], nseq, mem, None, None, None, 0,
+                                                        C.byref(n)))
+        if mem == A.MEM_DEVICE:
+            import torch
+            k = torch.zeros(max(n.value, 1), dtype=torch.int64, device=bases.device)
+            s = torch.zeros(max(n.value, 1), dtype=torch.int32, device=bases.device)
+            p = torch.zeros(max(n.value, 1), dtype=torch.int32, device=bases.device)
+        else:
+            k, s, p = np.zeros(max(n.value, 1), np.uint64), np.zeros(max(n.value, 1), np.uint32), np.zeros(max(n.value, 1), np.uint32)
+        self.ctx._check(self.L.kmu_count_once_positions(self.h, _ptr(bases)[0], _ptr(offsets)[0], nseq, mem, _ptr(k)[0], _ptr(s)[0],
+                                                        _ptr(p)[0], n.value, C.byref(n)))
+        return k[:n.value], s[:n.value], p[:n.value]
 
     def export_part(self, part, n_parts, device=None):
         """entries owned by `part`: (kmers, counts) as numpy arrays, or torch cuda tensors when device is given"""

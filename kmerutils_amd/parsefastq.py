@@ -31,8 +31,10 @@ def kmer_type_for(k):
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="parsefastq", description=__doc__.splitlines()[0])
     ap.add_argument("-f", "--file", required=True)
-    ap.add_argument("-s", "--kmer_size", type=int, required=True)
+    ap.add_argument("-s", "--kmer_size", type=int, default=16)
     ap.add_argument("--outdir", default=".", help="directory of <file>.multi_kmer.bin (the tool writes to the cwd)")
+    ap.add_argument("--unique", action="store_true", help="dump the 16-mers seen exactly once with their positions "
+                    "(KmerProcessing::Unicity, parsefastq.rs:238-247) instead of counting")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
     kmer_type, val_bytes = kmer_type_for(args.kmer_size)
@@ -42,6 +44,17 @@ def main(argv=None):
     bases, offsets, info = ctx.ingest_fastx(text)
     print(" nb rec loaded = %d \nnb_bases %d\nnb_bad_bases %d\nnb_bad_read %d" %
           (info.n_kept, info.n_bases, info.nb_bad_bases, info.nb_bad_reads), file=sys.stderr)  # io.rs:63-68
+    if args.unique:  # filter1_kmer_16b32bit + dump_in_file_once_kmer16b32bit -> <file>.once_kmer.bin
+        from . import kmercount
+        flt = kmercount.KmerFilter1(16, max(1024, int(info.kept_bases)), ctx=ctx)
+        if info.n_kept:
+            flt.insert_reads((bases, offsets))
+        out = os.path.join(args.outdir, os.path.basename(args.file) + ".once_kmer.bin")
+        print("dumping unique kmers in file : %s " % out, file=sys.stderr)
+        n = flt.dump_in_file_once_kmer16b32bit(out, (bases, offsets)) if info.n_kept else formats.dump_once_kmers(out, [], [], [], 16)
+        print("dump_in_file_once_kmer16b32bit, number of kmer dumped : %d " % n, file=sys.stderr)
+        ctx.close()
+        return 0
     nk = int(np.maximum(np.diff(offsets.astype(np.int64)) - args.kmer_size + 1, 0).sum())
     counter = ctx.counter(kmer_type, args.kmer_size, 8, max(nk, 1024))
     if info.n_kept:

@@ -1,9 +1,10 @@
-// parsefastq -f reads.fastq kmer --count -s <kmer size> [-t threads] [-b 2] [--outdir dir] [--device n]
+// parsefastq -f reads.fastq kmer (--count -s <kmer size> | --unique) [-t threads] [-b 2] [--outdir dir] [--device n]
 //
 // The counting branch of the reference's tool (src/bin/parsefastq.rs:215-236: `kmer --count`) on the GPU path: the FASTQ
 // text is filtered on the device like parse_with_needletail does on the host (src/io.rs:37-57), every canonical k-mer of
 // the accepted reads is counted (count_kmer_threaded_one_to_many, src/base/kmercount.rs:881-974) and the k-mers seen at
-// least twice are written as a COUNTER_MULTIPLE dump to <fastq>.multi_kmer.bin (kmercount.rs:467-531).
+// least twice are written as a COUNTER_MULTIPLE dump to <fastq>.multi_kmer.bin (kmercount.rs:467-531).  `--unique` is the
+// Unicity branch (parsefastq.rs:238-247): the 16-mers seen exactly once, with (sequence, position), to <fastq>.once_kmer.bin.
 // Kmer type by size as upstream: k <= 14 Kmer32bit, k == 16 Kmer16b32bit, else Kmer64bit (k <= 31).
 #include <chrono>
 #include <cstdio>
@@ -15,7 +16,7 @@
 using namespace kmerutils;
 
 static void usage() {
-    std::fprintf(stderr, "usage: parsefastq -f <fastq> kmer --count -s <kmer size> [-t <threads>] [-b 2] [--outdir <dir>] [--device <n>]\n");
+    std::fprintf(stderr, "usage: parsefastq -f <fastq> kmer (--count -s <kmer size> | --unique) [-t <threads>] [-b 2] [--outdir <dir>] [--device <n>]\n");
     std::exit(2);
 }
 
@@ -31,7 +32,7 @@ template <class Kmer> static void count_and_dump(const DeviceReads &reads, uint8
 int main(int argc, char **argv) {
     std::string fname, outdir = ".";
     long kmer_size = 0, device = 0;
-    bool count = false, kmer_cmd = false;
+    bool count = false, kmer_cmd = false, unique = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * {
@@ -41,6 +42,7 @@ int main(int argc, char **argv) {
         if (a == "-f" || a == "--file") fname = next();
         else if (a == "kmer") kmer_cmd = true;
         else if (a == "--count") count = true;
+        else if (a == "--unique" || a == "-u") unique = true;
         else if (a == "-s" || a == "--size") kmer_size = std::atol(next());
         else if (a == "-t" || a == "--threads") next();   // accepted: the device needs no thread count
         else if (a == "-b" || a == "--bits") {
@@ -52,7 +54,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = std::atol(next());
         else usage();
     }
-    if (fname.empty() || !kmer_cmd || !count || kmer_size < 1 || kmer_size > 31) usage();
+    if (fname.empty() || !kmer_cmd || (!count && !unique) || (count && (kmer_size < 1 || kmer_size > 31))) usage();
     try {
         const auto t0 = std::chrono::steady_clock::now();
         Context ctx{int(device)};
@@ -63,7 +65,16 @@ int main(int argc, char **argv) {
         // the tool writes <basename>.multi_kmer.bin into the working directory (parsefastq.rs:207-211)
         const size_t slash = fname.rfind('/');
         const std::string dumpfname = outdir + "/" + (slash == std::string::npos ? fname : fname.substr(slash + 1)) + ".multi_kmer.bin";
-        if (kmer_size <= 14) count_and_dump<Kmer32bit>(reads, uint8_t(kmer_size), dumpfname, ctx);
+        if (unique) {   // KmerProcessing::Unicity (parsefastq.rs:238-247): filter1_kmer_16b32bit + the once-k-mer dump
+            KmerFilter1 filter(16, uint32_t(std::min<uint64_t>(std::max<uint64_t>(reads.info.kept_bases, 1024), 0xFFFFFFFFu)), ctx);
+            detail::Batch all = reads.batch(0, reads.nb_reads());
+            filter.insert_reads(all);
+            const std::string oncefname = outdir + "/" + (slash == std::string::npos ? fname : fname.substr(slash + 1)) + ".once_kmer.bin";
+            std::fprintf(stderr, "dumping unique kmers in file : %s \n", oncefname.c_str());
+            const size_t n = filter.dump_in_file_once_kmer16b32bit(oncefname, all);
+            std::fprintf(stderr, "dump_in_file_once_kmer16b32bit, number of kmer dumped : %zu (distinct once-k-mers %llu)\n", n,
+                         (unsigned long long) filter.get_nb_once());
+        } else if (kmer_size <= 14) count_and_dump<Kmer32bit>(reads, uint8_t(kmer_size), dumpfname, ctx);
         else if (kmer_size == 16) count_and_dump<Kmer16b32bit>(reads, uint8_t(kmer_size), dumpfname, ctx);
         else count_and_dump<Kmer64bit>(reads, uint8_t(kmer_size), dumpfname, ctx);
         std::fprintf(stderr, " elapsed time (s) %.3f\n",

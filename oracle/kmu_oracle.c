@@ -1200,6 +1200,33 @@ int kmo_count_add_reads(kmo_counter *c, const uint8_t *bases, const uint64_t *of
     }
     return 0;
 }
+/* KmerFilter1::dump_in_file_once_kmer16b32bit (src/base/kmercount.rs:1031-1082): "as kmer generation is fast we generate
+ * once more all kmers and check for those that are in once_f": for every sequence (numseq) and every k-mer of it (numkmer),
+ * if the canonical k-mer was seen exactly once, the record (kmin, numseq, numkmer).  Outputs may be NULL (count only). */
+int kmo_count_once_positions(kmo_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, uint64_t *kmers_out,
+                             uint32_t *numseq_out, uint32_t *numkmer_out, uint64_t *n_out) {
+    kmu_hash_params hp = {c->p.kmer_type, c->p.kmer_size, KMU_FHASH_CANON_VALUE, KMU_INPUT_ASCII, KMU_MEM_HOST, 0};
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < n_seq; i++) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        if (L < (uint64_t) hp.kmer_size) continue;
+        uint64_t *hk = (uint64_t *) malloc(L * 8);
+        uint64_t off2[2] = {0, L};
+        int rc = kmo_kmer_hashes(&hp, bases + offsets[i], off2, 0, 1, hk);
+        if (rc) { free(hk); return rc; }
+        for (uint64_t p = 0; p + (uint64_t) hp.kmer_size <= L; p++) {
+            uint32_t cnt = 0;
+            kmo_count_query(c, &hk[p], 1, &cnt);
+            if (cnt == 1) {
+                if (kmers_out) { kmers_out[n] = hk[p]; numseq_out[n] = i; numkmer_out[n] = (uint32_t) p; }
+                n++;
+            }
+        }
+        free(hk);
+    }
+    *n_out = n;
+    return 0;
+}
 static uint32_t count_clamp(const kmo_counter *c, uint32_t v) {
     uint32_t mx = c->p.counter_bits == 8 ? 255u : 65535u;
     return v > mx ? mx : v;

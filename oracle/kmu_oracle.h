@@ -88,6 +88,9 @@ uint64_t kmo_count_nb_unique(kmo_counter *c);
 int kmo_count_dump(kmo_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,
                    uint64_t *n_out);
 
+int kmo_count_once_positions(kmo_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, uint64_t *kmers_out,
+                             uint32_t *numseq_out, uint32_t *numkmer_out, uint64_t *n_out);
+
 int kmo_probminhash3(const uint64_t *keys, const double *weights, uint64_t n, int key_bytes, int m, uint32_t flags,
                      uint64_t *sig_out);
 /* ingest */

@@ -198,6 +198,18 @@ class Counter:
     def nb_unique(self):
         return int(lib().kmo_count_nb_unique(self.h))
 
+    def once_positions(self, bases, offsets):
+        """(kmin, numseq, numkmer) of the k-mer occurrences whose canonical k-mer was seen exactly once, in file order"""
+        f = lib().kmo_count_once_positions
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = C.c_uint64(0)
+        rc = f(self.h, _p(bases), _p(offsets), len(offsets) - 1, None, None, None, C.byref(n))
+        if rc:
+            raise OracleError(rc)
+        k, s, p = np.zeros(max(n.value, 1), np.uint64), np.zeros(max(n.value, 1), np.uint32), np.zeros(max(n.value, 1), np.uint32)
+        f(self.h, _p(bases), _p(offsets), len(offsets) - 1, _p(k), _p(s), _p(p), C.byref(n))
+        return k[:n.value], s[:n.value], p[:n.value]
+
     def dump(self, min_count=2):
         n = C.c_uint64(0)
         lib().kmo_count_dump(self.h, min_count, None, None, 0, C.byref(n))

@@ -667,6 +667,54 @@ TEST(test_count_kmer_threaded_one_to_many) {
     std::remove(fname.c_str());
 }
 
+// KmerFilter1 / filter1_kmer_16b32bit (kmercount.rs:985-1123): the 16-mers seen exactly once and where they sit
+TEST(test_kmer_filter1_once_kmers) {
+    std::mt19937_64 rng(985);
+    std::string genome(5000, 'A');
+    for (char &c : genome) c = "ACGT"[rng() & 3];
+    std::vector<Sequence> seqvec;
+    Ascii a;
+    for (int r = 0; r < 120; r++) {
+        const size_t len = 10 + rng() % 300, pos = rng() % (genome.size() - len);
+        seqvec.emplace_back(genome.substr(pos, len));
+        a.add(genome.substr(pos, len));
+    }
+    auto filter = filter1_kmer_16b32bit(seqvec);
+    kmu_count_params cp{};
+    cp.kmer_type = KMU_KMER16B32BIT; cp.kmer_size = 16; cp.counter_bits = 8; cp.capacity_hint = 1 << 18;
+    kmo_counter *oc = kmo_count_create(&cp);
+    std::vector<uint8_t> bytes = a.bytes;
+    bytes.resize(bytes.size() + 16);
+    CHECK(kmo_count_add_reads(oc, bytes.data(), a.off.data(), uint32_t(seqvec.size())) == 0);
+    uint64_t n = 0;
+    CHECK(kmo_count_once_positions(oc, bytes.data(), a.off.data(), uint32_t(seqvec.size()), nullptr, nullptr, nullptr, &n) == 0);
+    std::vector<uint64_t> wk(n);
+    std::vector<uint32_t> ws(n), wp(n);
+    kmo_count_once_positions(oc, bytes.data(), a.off.data(), uint32_t(seqvec.size()), wk.data(), ws.data(), wp.data(), &n);
+    CHECK(n > 50 && filter->get_nb_once() == kmo_count_nb_unique(oc));
+    kmo_count_destroy(oc);
+    auto got = filter->once_positions(detail::gather(detail::pointers(seqvec)));
+    CHECK(got.kmin == wk && got.numseq == ws && got.numkmer == wp);
+    // every record names a k-mer that really sits there, as its canonical form
+    for (size_t i = 0; i < n; i += 7) {
+        auto kmers = KmerGenerator<Kmer16b32bit>(16).generate_kmer(seqvec[ws[i]]);
+        const Kmer16b32bit kmin = kmers[wp[i]].reverse_complement().min(kmers[wp[i]]);
+        CHECK(kmin.v == uint32_t(wk[i]));
+    }
+    const std::string fname = "/tmp/kmu_test_mirror.once_kmer.bin";
+    CHECK(filter->dump_in_file_once_kmer16b32bit(fname, seqvec) == n);
+    std::ifstream in(fname, std::ios::binary);
+    uint32_t magic; uint8_t k; uint64_t nrec;
+    in.read(reinterpret_cast<char *>(&magic), 4); in.read(reinterpret_cast<char *>(&k), 1); in.read(reinterpret_cast<char *>(&nrec), 8);
+    CHECK(magic == 0xcea2bbdd && k == 16 && nrec == n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t rec[3];
+        in.read(reinterpret_cast<char *>(rec), 12);
+        CHECK(rec[0] == uint32_t(wk[i]) && rec[1] == ws[i] && rec[2] == wp[i]);
+    }
+    std::remove(fname.c_str());
+}
+
 // =========================================================================================================================
 // io: the FASTQ reader rule (io.rs:37-57, datasketcher.rs:358-388) and the signature dump
 // =========================================================================================================================

@@ -156,3 +156,23 @@ def test_c_example_runs():
     r = subprocess.run([_c_example()], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "= 1.000" in r.stdout
+
+
+@pytest.mark.gpu
+def test_parsefastq_tool_unique_branch(host_programs, tmp_path, oracle):
+    """parsefastq -f .. kmer --unique: <file>.once_kmer.bin holds the oracle's once-16-mers with their positions"""
+    fq, reads = _fastq(tmp_path, 13, 80)
+    r = subprocess.run([PARSEFASTQ, "-f", fq, "kmer", "--unique", "--outdir", str(tmp_path)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr
+    k, vals, numseq, numkmer = formats.load_once_kmers(str(tmp_path / "reads.fastq.once_kmer.bin"))
+    bases, off = oracle.concat(reads)
+    g = oracle.Counter(A.KMER16B32BIT, 16, 8, 1 << 20)
+    g.add_reads(bases, off)
+    wk, ws, wp = g.once_positions(bases, off)
+    assert k == 16 and np.array_equal(vals, wk) and np.array_equal(numseq, ws) and np.array_equal(numkmer, wp)
+    # and the Python mirror of the tool writes the same file
+    from kmerutils_amd import parsefastq
+    os.makedirs(str(tmp_path / "py"), exist_ok=True)
+    assert parsefastq.main(["-f", fq, "--unique", "--outdir", str(tmp_path / "py")]) == 0
+    assert (tmp_path / "py" / "reads.fastq.once_kmer.bin").read_bytes() == (tmp_path / "reads.fastq.once_kmer.bin").read_bytes()

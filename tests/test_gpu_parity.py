@@ -937,3 +937,49 @@ def test_ranges_of_a_larger_read_set(ctx, oracle, monkeypatch):
         packed, poff = ctx.pack2b(bases, off[first:last + 1].copy())
         assert bytes(packed) == b"".join(bytes(oracle.pack2b(s)) for s in seqs[first:last])
         assert not ctx.count_non_acgt(bases, off[first:last + 1].copy()).any()
+
+
+@pytest.mark.gpu
+def test_once_kmers_with_positions(ctx, oracle, tmp_path):
+    """kmu_count_once_positions: the contract of KmerFilter1 (kmercount.rs:985-1082) -- the k-mers seen exactly once in the
+    read set, each with (numseq, numkmer), in file order; host and device input, a range of reads, three k-mer types; and
+    the COUNTER_UNIQUE dump round trip"""
+    import torch
+    from kmerutils_amd import formats
+    rng = np.random.default_rng(985)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=20_000).tobytes()
+    seqs = []
+    for i in range(300):
+        L = int(rng.integers(5, 700))
+        s0 = int(rng.integers(0, len(genome) - L))
+        s = genome[s0:s0 + L]
+        seqs.append(s if i % 3 else s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")))  # both strands
+    bases, off = oracle.concat(seqs)
+    db, do = torch.from_numpy(bases.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    for kmer_type, k, vb in ((A.KMER16B32BIT, 16, 4), (A.KMER64BIT, 25, 8), (A.KMER32BIT, 11, 4)):
+        c = ctx.counter(kmer_type, k, 8, 1 << 18)
+        o = oracle.Counter(kmer_type, k, 8, 1 << 18)
+        c.add_reads(bases, off)
+        o.add_reads(bases, off)
+        wk, ws, wp = o.once_positions(bases, off)
+        assert 100 < wk.size < off[-1]
+        gk, gs, gp = c.once_positions(bases, off)
+        assert np.array_equal(gk, wk) and np.array_equal(gs, ws) and np.array_equal(gp, wp)
+        dk, dsq, dp = c.once_positions(db, do)
+        ctx.synchronize()
+        assert np.array_equal(dk.cpu().numpy().view(np.uint64), wk) and np.array_equal(dsq.cpu().numpy().view(np.uint32), ws)
+        assert np.array_equal(dp.cpu().numpy().view(np.uint32), wp)
+        # every reported k-mer is unique in the table; the positions of a range of reads are relative to the range
+        assert (c.query(gk) == 1).all() and o.nb_unique() == np.unique(wk).size
+        rk, rs, rp = c.once_positions(db, do[100:181])
+        sel = (ws >= 100) & (ws < 180)
+        assert np.array_equal(rk.cpu().numpy().view(np.uint64), wk[sel])
+        assert np.array_equal(rs.cpu().numpy().view(np.uint32), ws[sel] - 100) and np.array_equal(rp.cpu().numpy().view(np.uint32), wp[sel])
+        fn = str(tmp_path / "reads.once_kmer.bin")
+        assert formats.dump_once_kmers(fn, gk, gs, gp, k, vb) == gk.size
+        k2, vk, vs, vp = formats.load_once_kmers(fn, vb)
+        assert k2 == k and np.array_equal(vk, wk) and np.array_equal(vs, ws) and np.array_equal(vp, wp)
+        c.close()
+    # nothing counted yet: no record
+    c = ctx.counter(A.KMER64BIT, 25, 8, 1 << 12)
+    assert c.once_positions(bases, off)[0].size == 0
