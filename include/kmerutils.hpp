@@ -1239,8 +1239,20 @@ template <class Kmer> class KmerCounter : public KmerCountT<Kmer> {
         ctx_.check(kmu_count_nb_unique(counter_, &n));
         return n;
     }
-    /// (canonical value, count) of the k-mers seen at least twice, sorted by value (get_above2_count, kmercount.rs:100-105)
-    std::pair<std::vector<uint64_t>, std::vector<uint32_t>> get_above2_count() {
+    /// get_above2_count(kmer) (kmercount.rs:100-105): the count if the k-mer was seen at least twice, else 0
+    uint32_t get_above2_count(Kmer kmer) {
+        const uint32_t c = get_count(kmer);
+        return c >= 2 ? c : 0;
+    }
+    /// eliminate_once_kmer (kmercount.rs:110-117): forget the k-mers seen once
+    void eliminate_once_kmer() {
+        if (!counter_) return;
+        flush();
+        ctx_.check(kmu_count_eliminate_once(counter_));
+    }
+    uint8_t get_count_nb_bits() const { return nb_bits_; }
+    /// (canonical value, count) of the k-mers seen at least twice, sorted by value: what dump_kmer_counter writes
+    std::pair<std::vector<uint64_t>, std::vector<uint32_t>> above2_entries() {
         if (!counter_) return {};
         flush();
         uint64_t n = 0;
@@ -1291,14 +1303,16 @@ template <class Kmer> class KmerCounterPool {
     uint32_t get_count(Kmer kmer) { return counter_.get_count(kmer); }
     uint64_t get_nb_distinct() { return counter_.get_nb_distinct(); }
     uint64_t get_nb_unique() { return counter_.get_nb_unique(); }
-    std::pair<std::vector<uint64_t>, std::vector<uint32_t>> get_above2_count() { return counter_.get_above2_count(); }
+    uint32_t get_above2_count(Kmer kmer) { return counter_.get_above2_count(kmer); }   // kmercount.rs:439-444
+    uint8_t get_count_nb_bits() const { return counter_.get_count_nb_bits(); }
+    std::pair<std::vector<uint64_t>, std::vector<uint32_t>> above2_entries() { return counter_.above2_entries(); }
     KmerCounter<Kmer> &counter() { return counter_; }
 
     /// dump_kmer_counter (kmercount.rs:467-531): COUNTER_MULTIPLE u32, kmer_size u8, bytes per count u8 (= 1), number of
     /// k-mers u64, then per k-mer `Kmer::dump` + count u8.  Records come sorted by value (upstream: order of first
     /// occurrence; the order carries no meaning for a reader).  Returns the number of records.
     size_t dump_kmer_counter(const std::string &fname) {
-        auto [kmers, counts] = counter_.get_above2_count();
+        auto [kmers, counts] = counter_.above2_entries();
         std::ofstream out(fname, std::ios::binary);
         if (!out) throw std::runtime_error("dump_kmer_counter: cannot open " + fname);
         const uint32_t magic = COUNTER_MULTIPLE;

@@ -238,6 +238,8 @@ int kmu_count_nb_unique(kmu_counter *c, uint64_t *out);   /* kmercount.rs:285-28
  * Call with kmers_out == NULL to get the number of records in *n_out; records are sorted by k-mer value. */
 int kmu_count_dump(kmu_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,
                    uint64_t *n_out);
+/* KmerCounter::eliminate_once_kmer (kmercount.rs:110-117): forget the k-mers seen once; counts >= 2 are kept */
+int kmu_count_eliminate_once(kmu_counter *c);
 /* The k-mers seen exactly once, with where they sit (KmerFilter1::dump_in_file_once_kmer16b32bit, kmercount.rs:1031-1082;
  * the `Unicity` branch of parsefastq): for every k-mer occurrence of the given reads, in (sequence, position) order, whose
  * canonical k-mer has count exactly 1 in the counter: canonical value, sequence number, k-mer rank in its sequence.

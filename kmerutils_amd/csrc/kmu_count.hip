@@ -1506,6 +1506,25 @@ int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts) {
     return KMU_OK;
 }
 
+// KmerCounter::eliminate_once_kmer (kmercount.rs:110-117): the singletons are dropped, counts >= 2 stay
+int kmu_count_eliminate_once(kmu_counter *c) {
+    if (!c) return KMU_E_BAD_ARG;
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t n = 0;
+    KMU_TRY(select_entries(c, 2u, 0xFFFFFFFFu, 0, 0, nullptr, nullptr, 0, KMU_MEM_DEVICE, false, &n));
+    void *k = nullptr, *cc = nullptr;
+    KMU_TRY(dev_buf(ctx, "cnt.keep.k", n * 8 + 8, &k));
+    KMU_TRY(dev_buf(ctx, "cnt.keep.c", n * 4 + 8, &cc));
+    uint64_t n2 = 0;
+    KMU_TRY(select_entries(c, 2u, 0xFFFFFFFFu, 0, 0, (uint64_t *) k, (uint32_t *) cc, n, KMU_MEM_DEVICE, false, &n2));
+    KMU_TRY(kmu_count_reset(c));
+    int rc = add_entries(c, (const uint64_t *) k, (const uint32_t *) cc, n2, KMU_MEM_DEVICE);
+    if (rc) return rc;
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMU_OK;
+}
+
 int kmu_count_once_positions(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
                              uint64_t *kmers_out, uint32_t *numseq_out, uint32_t *numkmer_out, uint64_t cap, uint64_t *n_out) {
     if (!c || !n_out || (kmers_out && (!numseq_out || !numkmer_out))) return KMU_E_BAD_ARG;

@@ -43,9 +43,21 @@ class KmerCounter:
     def get_nb_unique(self):
         return self._c.nb_unique()
 
-    def get_above2_count(self):
-        """(kmer, count) with count >= 2, sorted by k-mer (dump_kmer_counter, kmercount.rs:500-525)"""
+    def get_above2_count(self, compressed_values):
+        """KmerCounter::get_above2_count (kmercount.rs:100-105): the count if the k-mer was seen at least twice, else 0"""
+        c = self.get_count(compressed_values)
+        return np.where(c >= 2, c, 0).astype(np.uint32)
+
+    def above2_entries(self):
+        """(kmer, count) with count >= 2, sorted by k-mer: what dump_kmer_counter writes (kmercount.rs:500-525)"""
         return self._c.dump(2)
+
+    def eliminate_once_kmer(self):
+        """kmercount.rs:110-117: forget the k-mers seen once"""
+        self._c.eliminate_once()
+
+    def get_count_nb_bits(self):
+        return self._c.p.counter_bits
 
     @property
     def raw(self):

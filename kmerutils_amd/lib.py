@@ -23,7 +23,7 @@ SYMBOLS = [
     "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
     "kmu_count_retain_part", "kmu_count_extract_by_owner", "kmu_sig_equal_pairs", "kmu_sig_equal_matrix",
     "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx", "kmu_dev_alloc", "kmu_dev_free",
-    "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions",
+    "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions", "kmu_count_eliminate_once",
 ]
 
 
@@ -79,6 +79,7 @@ def load():
     L.kmu_sig_equal_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
     L.kmu_sig_equal_matrix.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
     L.kmu_minhash_distance_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, vp]
+    L.kmu_count_eliminate_once.argtypes = [vp]
     L.kmu_count_once_positions.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint64, u64p]
     L.kmu_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.kmu_dev_free.argtypes = [vp, vp]
@@ -427,6 +428,10 @@ class Counter:
         c = np.zeros(max(n.value, 1), np.uint32)
         self.ctx._check(self.L.kmu_count_dump(self.h, min_count, _ptr(k)[0], _ptr(c)[0], n.value, C.byref(n)))
         return k[:n.value], c[:n.value]
+
+    def eliminate_once(self):
+        """kmu_count_eliminate_once: drop the k-mers seen once"""
+        self.ctx._check(self.L.kmu_count_eliminate_once(self.h))
 
     def once_positions(self, bases, offsets):
         """kmu_count_once_positions: (canonical k-mers, numseq, numkmer) of the occurrences whose k-mer has count 1, in

@@ -590,6 +590,9 @@ TEST(test_kmer_counter) {
     for (size_t i = 2; i < vkmer.size(); i++) CHECK(countvec[i] == std::min<uint64_t>(truth[vkmer[i].v], 255));   // exact, saturating
     CHECK(kmer_counter.get_nb_unique() == 1);
     CHECK(kmer_counter.get_nb_distinct() == vkmer.size());
+    kmer_counter.eliminate_once_kmer();   // :110-117: the singleton goes, the others stay as they were
+    CHECK(kmer_counter.get_nb_unique() == 0 && kmer_counter.get_count(vkmer[0]) == 0 && kmer_counter.get_count(vkmer[1]) == 2);
+    CHECK(kmer_counter.get_nb_distinct() == vkmer.size() - 1);
 }
 
 // kmercount.rs:1580-1621
@@ -641,7 +644,7 @@ TEST(test_count_kmer_threaded_one_to_many) {
     std::vector<uint64_t> wk(n);
     std::vector<uint32_t> wc(n);
     kmo_count_dump(oc, 2, wk.data(), wc.data(), n, &n);
-    auto [gk, gc] = pool->get_above2_count();
+    auto [gk, gc] = pool->above2_entries();
     CHECK(gk == wk && gc == wc);
     // queries go through canonical k-mers, as the reference's callers do
     auto kmers = KmerGenerator<Kmer64bit>(kmer_size).generate_kmer(seqvec[0]);
@@ -650,7 +653,9 @@ TEST(test_count_kmer_threaded_one_to_many) {
         uint32_t want = 0;
         kmo_count_query(oc, &canonical.v, 1, &want);
         CHECK(pool->get_count(canonical) == want && want >= 1);
+        CHECK(pool->get_above2_count(canonical) == (want >= 2 ? want : 0));   // kmercount.rs:100-105
     }
+    CHECK(pool->get_count_nb_bits() == 8);
     kmo_count_destroy(oc);
     const std::string fname = "/tmp/kmu_test_mirror.multi_kmer.bin";
     CHECK(pool->dump_kmer_counter(fname) == gk.size());
@@ -850,7 +855,7 @@ TEST(test_device_resident_reads) {
     on_dev.insert_reads(reads.batch(0, 90), 21);
     on_host.insert_reads(ptrs, 21);
     CHECK(on_dev.get_nb_distinct() == on_host.get_nb_distinct() && on_dev.get_nb_unique() == on_host.get_nb_unique());
-    CHECK(on_dev.get_above2_count() == on_host.get_above2_count());
+    CHECK(on_dev.above2_entries() == on_host.above2_entries());
 }
 
 // errors surface where the reference panics
