@@ -1426,6 +1426,114 @@ std::unique_ptr<KmerCounterPool<Kmer>> count_kmer_threaded_one_to_many(const std
     return pool;
 }
 
+namespace detail {
+template <class Kmer> std::unique_ptr<KmerCounter<Kmer>> count_kmer(const std::vector<Sequence> &seqvec, uint8_t kmer_size, Context &ctx) {
+    uint64_t bases = 0;
+    for (const Sequence &s : seqvec) bases += s.size();
+    // upstream sizes its filters for 1.2e9 k-mers (kmercount.rs:303); the exact table only needs the batch
+    auto counter = std::make_unique<KmerCounter<Kmer>>(0.03, std::max<uint64_t>(bases, 1024), 8, ctx);
+    counter->insert_reads(pointers(seqvec), kmer_size);
+    return counter;
+}
+}  // namespace detail
+
+/// count_kmer16b32bit(&seqvec) (kmercount.rs:332-338): every canonical 16-mer, 8-bit counts
+inline std::unique_ptr<KmerCounter<Kmer16b32bit>> count_kmer16b32bit(const std::vector<Sequence> &seqvec, Context &ctx = Context::global()) {
+    return detail::count_kmer<Kmer16b32bit>(seqvec, 16, ctx);
+}
+/// count_kmer32bit(&seqvec, kmer_size) (kmercount.rs:340-347): k <= 14
+inline std::unique_ptr<KmerCounter<Kmer32bit>> count_kmer32bit(const std::vector<Sequence> &seqvec, size_t kmer_size,
+                                                              Context &ctx = Context::global()) {
+    if (kmer_size >= 15) throw std::invalid_argument("count_kmer32bit cannot count kmer of size greater than 14");   // panics upstream
+    return detail::count_kmer<Kmer32bit>(seqvec, uint8_t(kmer_size), ctx);
+}
+/// count_kmer64bit(&seqvec, kmer_size) (kmercount.rs:351-362): 16 < k <= 32 upstream; k = 32 is broken there, refused here
+inline std::unique_ptr<KmerCounter<Kmer64bit>> count_kmer64bit(const std::vector<Sequence> &seqvec, size_t kmer_size,
+                                                              Context &ctx = Context::global()) {
+    if (kmer_size > 32) throw std::invalid_argument("count_kmer64bit cannot count kmer of size greater than 32");
+    if (kmer_size <= 16) throw std::invalid_argument("count_kmer64bit is too expensive, use count_kmer32bit");
+    return detail::count_kmer<Kmer64bit>(seqvec, uint8_t(kmer_size), ctx);
+}
+/// count_kmer_thread_independant(seqvec, nb_threads, kmer_size) (kmercount.rs:797-867): upstream's other threaded driver
+/// (reads split over threads, k-mers dispatched by key); one GPU holds the whole key space, so the same pool comes out
+template <class Kmer>
+std::unique_ptr<KmerCounterPool<Kmer>> count_kmer_thread_independant(const std::vector<Sequence> &seqvec, size_t nb_threads,
+                                                                      uint8_t kmer_size, Context &ctx = Context::global()) {
+    return count_kmer_threaded_one_to_many<Kmer>(seqvec, nb_threads, 8, kmer_size, ctx);
+}
+
+/// KmerCountReload (kmercount.rs:1132-1500): a dump of the counter read back -- for up-to-32-bit k-mers, as upstream
+struct KmerCoord {   // kmercount.rs: read_num, pos
+    uint32_t read_num, pos;
+};
+enum class CounterType { Unique, Multiple };
+class KmerCountReload {
+  public:
+    uint32_t get_kmer_size() const { return kmer_size_; }
+    size_t get_nb_kmer() const { return nb_kmer_; }
+    /// get_coord_from_rank (kmercount.rs:1479-1486)
+    std::optional<KmerCoord> get_coord_from_rank(size_t rank) const {
+        if (rank < positions_.size()) return positions_[rank];
+        return std::nullopt;
+    }
+    /// get_multi_kmer_counts (kmercount.rs:1489-1500): here in file order
+    std::optional<std::vector<uint16_t>> get_multi_kmer_counts() const {
+        if (type_ != CounterType::Multiple) return std::nullopt;
+        return counts_;
+    }
+    const std::vector<uint32_t> &kmers() const { return kmers_; }   // the u32 words as dumped (Kmer32bit carries k in its top nibble)
+    /// load_multiple_kmers_from_file (kmercount.rs:1209-1351): COUNTER_MULTIPLE, kmer_size u8, bytes per count u8, number u64,
+    /// then (kmer u32, count) until the end of the file (upstream's header count is approximate, :1200-1207)
+    static std::unique_ptr<KmerCountReload> load_multiple_kmers_from_file(const std::string &fname) {
+        std::ifstream in(fname, std::ios::binary);
+        uint32_t magic = 0;
+        uint8_t k = 0, nbc = 0;
+        uint64_t n = 0;
+        in.read(reinterpret_cast<char *>(&magic), 4); in.read(reinterpret_cast<char *>(&k), 1);
+        in.read(reinterpret_cast<char *>(&nbc), 1); in.read(reinterpret_cast<char *>(&n), 8);
+        if (!in || magic != 0xcea2bbff || (nbc != 1 && nbc != 2) || k > 16) return nullptr;
+        auto r = std::unique_ptr<KmerCountReload>(new KmerCountReload(CounterType::Multiple, k, n));
+        for (;;) {
+            uint32_t kmer = 0;
+            uint16_t c = 0;
+            in.read(reinterpret_cast<char *>(&kmer), 4);
+            in.read(reinterpret_cast<char *>(&c), nbc);
+            if (!in) break;
+            r->kmers_.push_back(kmer);
+            r->counts_.push_back(c);
+        }
+        return r;
+    }
+    /// load_unique_kmer_from_file (kmercount.rs:1356-1470): COUNTER_UNIQUE, kmer_size u8, number u64, then (kmer u32, numseq u32,
+    /// numkmer u32)
+    static std::unique_ptr<KmerCountReload> load_unique_kmer_from_file(const std::string &fname) {
+        std::ifstream in(fname, std::ios::binary);
+        uint32_t magic = 0;
+        uint8_t k = 0;
+        uint64_t n = 0;
+        in.read(reinterpret_cast<char *>(&magic), 4); in.read(reinterpret_cast<char *>(&k), 1); in.read(reinterpret_cast<char *>(&n), 8);
+        if (!in || magic != 0xcea2bbdd) return nullptr;
+        auto r = std::unique_ptr<KmerCountReload>(new KmerCountReload(CounterType::Unique, k, n));
+        for (;;) {
+            uint32_t rec[3];
+            in.read(reinterpret_cast<char *>(rec), 12);
+            if (!in) break;
+            r->kmers_.push_back(rec[0]);
+            r->positions_.push_back(KmerCoord{rec[1], rec[2]});
+        }
+        return r;
+    }
+
+  private:
+    KmerCountReload(CounterType t, uint32_t k, size_t n) : type_(t), kmer_size_(k), nb_kmer_(n) {}
+    CounterType type_;
+    uint32_t kmer_size_;
+    size_t nb_kmer_;
+    std::vector<uint32_t> kmers_;
+    std::vector<KmerCoord> positions_;
+    std::vector<uint16_t> counts_;
+};
+
 // =====================================================================================================================
 // io: the reader rule of datasketcher / parsefastq, on the device
 // =====================================================================================================================

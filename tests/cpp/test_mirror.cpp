@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <filesystem>
 #include <map>
 #include <random>
 #include <sstream>
@@ -708,6 +709,37 @@ TEST(test_kmer_filter1_once_kmers) {
     }
     const std::string fname = "/tmp/kmu_test_mirror.once_kmer.bin";
     CHECK(filter->dump_in_file_once_kmer16b32bit(fname, seqvec) == n);
+    {   // KmerCountReload (kmercount.rs:1356-1486) reads the dump back
+        auto reload = KmerCountReload::load_unique_kmer_from_file(fname);
+        CHECK(reload && reload->get_kmer_size() == 16 && reload->get_nb_kmer() == n && reload->kmers().size() == n);
+        for (size_t i = 0; i < n; i += 11) {
+            auto coord = reload->get_coord_from_rank(i);
+            CHECK(coord && coord->read_num == ws[i] && coord->pos == wp[i] && reload->kmers()[i] == uint32_t(wk[i]));
+        }
+        CHECK(!reload->get_coord_from_rank(n) && !reload->get_multi_kmer_counts());
+    }
+    {   // the serial drivers count_kmer16b32bit / count_kmer32bit / count_kmer64bit (kmercount.rs:332-362) and the multiple dump
+        auto c16 = count_kmer16b32bit(seqvec);
+        CHECK(c16->get_nb_unique() == filter->get_nb_once());
+        auto pool = count_kmer_thread_independant<Kmer16b32bit>(seqvec, 4, 16);
+        CHECK(pool->get_nb_distinct() == c16->get_nb_distinct() && pool->above2_entries() == c16->above2_entries());
+        const std::string mname = "/tmp/kmu_test_mirror16.multi_kmer.bin";
+        const size_t nm = pool->dump_kmer_counter(mname);
+        auto multi = KmerCountReload::load_multiple_kmers_from_file(mname);
+        CHECK(multi && multi->get_kmer_size() == 16 && multi->kmers().size() == nm);
+        auto counts = multi->get_multi_kmer_counts();
+        auto [ek, ec] = pool->above2_entries();
+        CHECK(counts && counts->size() == nm);
+        for (size_t i = 0; i < nm; i++) CHECK(multi->kmers()[i] == uint32_t(ek[i]) && (*counts)[i] == std::min<uint32_t>(ec[i], 255));
+        std::remove(mname.c_str());
+        bool threw = false;
+        try { count_kmer32bit(seqvec, 15); } catch (const std::invalid_argument &) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { count_kmer64bit(seqvec, 16); } catch (const std::invalid_argument &) { threw = true; }
+        CHECK(threw);
+        CHECK(count_kmer32bit(seqvec, 11)->get_nb_distinct() > 0 && count_kmer64bit(seqvec, 21)->get_nb_distinct() > 0);
+    }
     std::ifstream in(fname, std::ios::binary);
     uint32_t magic; uint8_t k; uint64_t nrec;
     in.read(reinterpret_cast<char *>(&magic), 4); in.read(reinterpret_cast<char *>(&k), 1); in.read(reinterpret_cast<char *>(&nrec), 8);
@@ -775,7 +807,7 @@ TEST(test_parse_fastq_and_signature_dump) {
     std::remove(fname.c_str());
     // the parameter dumps next to it (serde_json layout)
     const std::string dir = "/tmp/kmu_test_mirror_json";
-    (void) std::system(("mkdir -p " + dir).c_str());
+    std::filesystem::create_directories(dir);
     SeqSketcherParams(8, 200, SketchAlgo::PROB3A, DataType::DNA).dump_json(dir + "/sketchparams_dump.json");
     {
         std::ifstream in(dir + "/sketchparams_dump.json");
@@ -787,7 +819,7 @@ TEST(test_parse_fastq_and_signature_dump) {
     sketcher.dump_json(dir + "/sketchparams_dump.json");
     SeqSketcher again = SeqSketcher::reload_json(dir);
     CHECK(again.get_kmer_size() == 8 && again.get_sketch_size() == 200);
-    (void) std::system(("rm -rf " + dir).c_str());
+    std::filesystem::remove_all(dir);
 }
 
 // needletail::parse_fastx_file also takes FASTA: multi-line records, format by the first byte
