@@ -197,6 +197,12 @@ int kmu_pack2b(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint
 int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
                     const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out);
 
+/* The same values without the gaps: fhash of every k-mer of sequence 0, then of sequence 1, ... (uint64, zero-extended).
+ * Call with out == NULL for the number of values in *n_out.  (What a rank feeds to the owner exchange of a distributed
+ * ProbMinHash sketch, see kmu_sketch_hashed_partial.) */
+int kmu_kmer_hashes_compact(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                            const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out, uint64_t cap, uint64_t *n_out);
+
 /* ---- L3 sketching: SeqSketcherT::sketch_compressedkmer{,_seqs}  (src/sketching/setsketchert.rs:54-80),
  * SeqSketcher::sketch_probminhash3a / sketch_superminhash (src/sketching/seqsketchjaccard.rs:211,328),
  * BlockSeqSketcher::blocksketch_sequences (src/sketching/seqblocksketch.rs:152-167),
@@ -219,6 +225,22 @@ int kmu_block_layout(const uint64_t *offsets, uint32_t n_seq, uint32_t block_siz
  * kmer_type width). */
 int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const void *hashed, const uint64_t *offsets,
                       uint32_t n_seq, void *sig_out, uint32_t *counts_out);
+
+/* One signature for sequences spread over several GPUs (sketch_compressedkmer_seqs across ranks, one process per GPU):
+ * every rank turns its share into per-slot minima -- a "partial" of kmu_sketch_partial_words(p) uint64 words -- the ranks
+ * exchange these small arrays (all-gather over RCCL) and every rank merges them into the signature.
+ *   SuperMinHash / SuperMinHash2 / OptDens / RevOptDens treat k-mer occurrences independently: a rank's share is its reads.
+ *   ProbMinHash weighs a key by its multiplicity over ALL sequences: the shares must be DISJOINT KEY SETS -- hash the k-mers
+ *   (kmu_kmer_hashes), exchange the values by owner, and feed what a rank receives to kmu_sketch_hashed_partial.
+ * `mode` and `block_size` of the parameters are ignored (one multiset over everything given); `mem` says where the partial
+ * and the other buffers live.  A partial of no data at all merges as the neutral element. */
+uint32_t kmu_sketch_partial_words(const kmu_sketch_params *p);
+int kmu_sketch_partial(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_t *bases, const uint64_t *offsets,
+                       const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *partial_out);
+int kmu_sketch_hashed_partial(kmu_ctx *ctx, const kmu_sketch_params *p, const void *hashed, const uint64_t *offsets, uint32_t n_seq,
+                              uint64_t *partial_out);
+/* partials: n_parts x kmu_sketch_partial_words(p) words; sig_out: sketch_size signatures */
+int kmu_sketch_merge_partials(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *partials, uint32_t n_parts, void *sig_out);
 
 /* ---- L3 counting: KmerCountT (src/base/kmercount.rs:48-59), KmerCounter::insert_kmer :241-267,
  * count_kmer_threaded_one_to_many :881-974, KmerCounterPool :424-565 --------------------------------- */

@@ -22,6 +22,9 @@ struct kmu_ctx {
     bool own_stream = false;
     bool async_device = false;
     std::string err;
+    // kmu_sketch_partial / kmu_sketch_hashed_partial: where the all-sequences paths leave their per-slot minima instead of
+    // turning them into a signature (device memory; null in every other call)
+    uint64_t *partial_out = nullptr;
     // grow-on-demand device scratch buffers, keyed by purpose (never shrunk; freed with the context)
     struct Buf {
         void *p = nullptr;

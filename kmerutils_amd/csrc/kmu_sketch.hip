@@ -1009,13 +1009,14 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
 }
 
 // merge the slot minima of disjoint key sets (leaves): per slot the smallest (h, key); one workgroup per slot
+// (stride: words between the rows of consecutive parts; part_out: write (h, key) to part_out[t], part_out[m + t] instead)
 __global__ void __launch_bounds__(256) k_pmh_reduce(const uint64_t *part_h, const uint64_t *part_k, uint64_t n_parts, int m,
-                                                    int sig_bytes, void *sig_out) {
+                                                    uint64_t stride, int sig_bytes, void *sig_out, uint64_t *part_out) {
     __shared__ uint64_t sh[256], sk[256];
     const int t = blockIdx.x;
     uint64_t bh = H_INIT, bk = 0;
     for (uint64_t i = threadIdx.x; i < n_parts; i += blockDim.x) {
-        const uint64_t h = part_h[i * m + t], key = part_k[i * m + t];
+        const uint64_t h = part_h[i * stride + t], key = part_k[i * stride + t];
         if (h < bh || (h == bh && h != H_INIT && key < bk)) { bh = h; bk = key; }
     }
     sh[threadIdx.x] = bh;
@@ -1032,6 +1033,11 @@ __global__ void __launch_bounds__(256) k_pmh_reduce(const uint64_t *part_h, cons
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        if (part_out) {
+            part_out[t] = sh[0];
+            part_out[m + t] = sk[0];
+            return;
+        }
         const uint64_t v = sh[0] == H_INIT ? 0ull : sk[0];
         if (sig_bytes == 4) reinterpret_cast<uint32_t *>(sig_out)[t] = (uint32_t) v;
         else reinterpret_cast<uint64_t *>(sig_out)[t] = v;
@@ -1165,6 +1171,7 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
 int launch_super_reduce(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *part_rows, uint64_t n_parts, void *d_sig);
 int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err, const void *hashed,
                 int hashed_bytes);
+int launch_dens_merge(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *parts, uint32_t n_parts, void *d_sig);
 }
 static bool algo_is_dens(int algo) { return algo == KMU_ALGO_OPTDENS || algo == KMU_ALGO_REVOPTDENS; }
 
@@ -1357,7 +1364,7 @@ static int sketch_all_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const uin
         {
             KernelTimer t(ctx, "k_pmh_reduce");
             hipLaunchKernelGGL(k_pmh_reduce, dim3(m), dim3(256), 0, ctx->stream, (const uint64_t *) ph, (const uint64_t *) pk,
-                               n_leaves, m, kmer_val_bytes(p->kmer_type), d_sig);
+                               n_leaves, m, (uint64_t) m, kmer_val_bytes(p->kmer_type), d_sig, ctx->partial_out);
         }
         KMU_HIP(ctx, hipGetLastError());
         return KMU_OK;
@@ -1614,6 +1621,151 @@ extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, co
         if (counts_out && p->mode != KMU_MODE_ALL_SEQS)
             KMU_HIP(ctx, hipMemcpyAsync(counts_out, d_counts, rows * m * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
+    return finish_call(ctx, p->mem);
+}
+
+// ---- one signature for sequences held by several GPUs ------------------------------------------------------------------
+// Every rank turns ITS share into per-slot minima (a "partial"), the ranks exchange these small arrays (all-gather) and each
+// merges them.  SuperMinHash / SuperMinHash2 / OptDens / RevOptDens sketch k-mer occurrences independently, so a rank's share
+// is simply its sequences.  ProbMinHash weighs a key by its multiplicity over ALL sequences: the shares must hold disjoint
+// key sets (exchange the hashed k-mers by owner first, as counting does), then per-slot (h, key) minima merge exactly.
+extern "C" uint32_t kmu_sketch_partial_words(const kmu_sketch_params *p) {
+    if (!p || p->sketch_size < 1) return 0;
+    const bool prob = p->algo == KMU_ALGO_PROB3A || p->algo == KMU_ALGO_PROB3;
+    return (uint32_t) p->sketch_size * (prob ? 2u : 1u);
+}
+
+static int partial_begin(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu_sketch_params *p, uint64_t *partial_out, uint64_t **d_part) {
+    if (!ctx || !p_in || !partial_out) return KMU_E_BAD_ARG;
+    *p = *p_in;
+    p->mode = KMU_MODE_ALL_SEQS;
+    p->block_size = 0;
+    if (p->algo == KMU_ALGO_BOTTOMK) return fail(ctx, KMU_E_UNSUPPORTED, "the reference has no bottom-k sketch over a list of sequences");
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    *d_part = partial_out;
+    if (p->mem == KMU_MEM_HOST) {
+        void *q;
+        KMU_TRY(dev_buf(ctx, "out.partial", (size_t) kmu_sketch_partial_words(p) * 8 + 64, &q));
+        *d_part = (uint64_t *) q;
+    }
+    return KMU_OK;
+}
+
+static int partial_end(kmu_ctx *ctx, const kmu_sketch_params *p, int rc, uint64_t *partial_out, const uint64_t *d_part) {
+    ctx->partial_out = nullptr;
+    if (rc != KMU_OK) return rc;
+    if (p->mem == KMU_MEM_HOST) {
+        KMU_HIP(ctx, hipMemcpyAsync(partial_out, d_part, (size_t) kmu_sketch_partial_words(p) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return KMU_OK;
+}
+
+extern "C" int kmu_sketch_partial(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uint8_t *bases, const uint64_t *offsets,
+                                  const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *partial_out) {
+    kmu_sketch_params p;
+    uint64_t *d_part = nullptr;
+    KMU_TRY(partial_begin(ctx, p_in, &p, partial_out, &d_part));
+    void *scratch_sig; // the signature slot of the inner call is not used
+    KMU_TRY(dev_buf(ctx, "out.sig", (size_t) p.sketch_size * 8 + 64, &scratch_sig));
+    std::vector<uint64_t> host_sig(p.mem == KMU_MEM_HOST ? (size_t) p.sketch_size : 0);
+    ctx->partial_out = d_part;
+    const int rc = kmu_sketch(ctx, &p, bases, offsets, packed_offsets, n_seq, nullptr,
+                              p.mem == KMU_MEM_HOST ? (void *) host_sig.data() : scratch_sig, nullptr);
+    return partial_end(ctx, &p, rc, partial_out, d_part);
+}
+
+extern "C" int kmu_sketch_hashed_partial(kmu_ctx *ctx, const kmu_sketch_params *p_in, const void *hashed, const uint64_t *offsets,
+                                         uint32_t n_seq, uint64_t *partial_out) {
+    kmu_sketch_params p;
+    uint64_t *d_part = nullptr;
+    KMU_TRY(partial_begin(ctx, p_in, &p, partial_out, &d_part));
+    void *scratch_sig;
+    KMU_TRY(dev_buf(ctx, "out.sig", (size_t) p.sketch_size * 8 + 64, &scratch_sig));
+    std::vector<uint64_t> host_sig(p.mem == KMU_MEM_HOST ? (size_t) p.sketch_size : 0);
+    ctx->partial_out = d_part;
+    const int rc = kmu_sketch_hashed(ctx, &p, hashed, offsets, n_seq, p.mem == KMU_MEM_HOST ? (void *) host_sig.data() : scratch_sig,
+                                     nullptr);
+    return partial_end(ctx, &p, rc, partial_out, d_part);
+}
+
+extern "C" int kmu_sketch_merge_partials(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uint64_t *partials, uint32_t n_parts,
+                                         void *sig_out) {
+    if (!ctx || !p_in || !partials || !sig_out || n_parts == 0) return KMU_E_BAD_ARG;
+    kmu_sketch_params p_res;
+    KMU_TRY(resolve_algo(ctx, p_in, &p_res));
+    const kmu_sketch_params *p = &p_res;
+    KMU_TRY(sketch_params_check(ctx, p));
+    if (p->algo == KMU_ALGO_BOTTOMK) return fail(ctx, KMU_E_UNSUPPORTED, "no bottom-k sketch over a list of sequences");
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    const int m = p->sketch_size;
+    const size_t sigb = (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    const uint64_t words = kmu_sketch_partial_words(p);
+    const uint64_t *d_parts = partials;
+    void *d_sig = sig_out;
+    if (p->mem == KMU_MEM_HOST) {
+        void *q;
+        KMU_TRY(dev_buf(ctx, "in.partials", (size_t) n_parts * words * 8 + 64, &q));
+        KMU_HIP(ctx, hipMemcpyAsync(q, partials, (size_t) n_parts * words * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_parts = (const uint64_t *) q;
+        KMU_TRY(dev_buf(ctx, "out.sig", (size_t) m * sigb + 64, &q));
+        d_sig = q;
+    }
+    if (p->algo == KMU_ALGO_PROB3A) {
+        hipLaunchKernelGGL(k_pmh_reduce, dim3(m), dim3(256), 0, ctx->stream, d_parts, d_parts + m, (uint64_t) n_parts, m, words,
+                           kmer_val_bytes(p->kmer_type), d_sig, (uint64_t *) nullptr);
+    } else if (algo_is_dens(p->algo)) {
+        KMU_TRY(launch_dens_merge(ctx, p, d_parts, n_parts, d_sig));
+    } else {
+        KMU_TRY(launch_super_reduce(ctx, p, d_parts, n_parts, d_sig));
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    if (p->mem == KMU_MEM_HOST) KMU_HIP(ctx, hipMemcpyAsync(sig_out, d_sig, (size_t) m * sigb, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_call(ctx, p->mem);
+}
+
+// fhash of every k-mer of every sequence, one after the other (no gaps for the positions that start no k-mer): what a rank
+// hands to the owner exchange of a distributed ProbMinHash sketch.  out == NULL: only the number of values in *n_out.
+extern "C" int kmu_kmer_hashes_compact(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                                       const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out, uint64_t cap, uint64_t *n_out) {
+    if (!ctx || !p || !n_out) return KMU_E_BAD_ARG;
+    KMU_TRY(check_kmer(ctx, p->kmer_type, p->kmer_size));
+    if (!fhash_valid(p->fhash, p->kmer_type)) return fail(ctx, KMU_E_BAD_ARG, "fhash %d not valid for kmer_type %d", p->fhash, p->kmer_type);
+    if (p->input_kind == KMU_INPUT_PACKED2 && (kmer_is_aa(p->kmer_type) || p->fhash == KMU_FHASH_CANON_NTHASH_8B))
+        return fail(ctx, KMU_E_BAD_ARG, "packed input not valid for this kmer_type / fhash");
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    *n_out = 0;
+    if (n_seq == 0) return KMU_OK;
+    DevSeqs ds;
+    KMU_TRY(stage_sequences(ctx, bases, offsets, packed_offsets, n_seq, p->input_kind, p->mem, &ds));
+    uint32_t *d_err;
+    KMU_TRY(get_err_word(ctx, &d_err));
+    void *koff;
+    KMU_TRY(dev_buf(ctx, "all.koff", ((size_t) n_seq + 1) * 8, &koff));
+    hipLaunchKernelGGL(k_nk_scan, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, p->kmer_size, (uint64_t *) koff, d_err);
+    uint64_t n_items = 0;
+    KMU_HIP(ctx, hipMemcpyAsync(&n_items, (uint64_t *) koff + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n_items;
+    if (!out) return KMU_OK;
+    if (cap < n_items) return fail(ctx, KMU_E_BAD_ARG, "output too small: %llu values", (unsigned long long) n_items);
+    uint64_t *d_out = out;
+    if (p->mem == KMU_MEM_HOST) {
+        void *q;
+        KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &q));
+        d_out = (uint64_t *) q;
+    }
+    {
+        KmerCfg cfg{p->kmer_type, p->kmer_size, p->fhash};
+        const int spread = n_seq < (uint32_t) ctx->num_cus * 4 ? 1 : 0;
+        const int grid = spread ? ctx->num_cus * 8 : (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
+        KernelTimer t(ctx, "k_seq_hashes_compact");
+        hipLaunchKernelGGL(k_seq_hashes_compact, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, ds.packed_offsets,
+                           n_seq, ds.packed, ds.total_bytes, cfg, (const uint64_t *) koff, d_out, d_err, spread);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    if (p->mem == KMU_MEM_HOST) KMU_HIP(ctx, hipMemcpyAsync(out, d_out, n_items * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
     return finish_call(ctx, p->mem);
 }

@@ -371,11 +371,49 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
             hipLaunchKernelGGL(k_oph_finish, dim3(1), dim3(256), lds_full, ctx->stream, a);
         }
     }
-    if (all) {
+    if (all && ctx->partial_out) { // the bins before densification are what other ranks' bins are merged with
+        KMU_HIP(ctx, hipMemcpyAsync(ctx->partial_out, a.row, (size_t) 8 * a.m, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (all) {
         a.out_row = 0;
         KernelTimer t(ctx, "k_oph_finish");
         hipLaunchKernelGGL(k_oph_finish, dim3(1), dim3(256), lds_full, ctx->stream, a);
     }
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+
+__global__ void __launch_bounds__(256) k_oph_merge(const uint64_t *parts, uint32_t n_parts, int m, uint64_t *row) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    uint64_t best = parts[t];
+    for (uint32_t i = 1; i < n_parts; i++) {
+        const uint64_t v = parts[(uint64_t) i * m + t];
+        best = v < best ? v : best;
+    }
+    row[t] = best;
+}
+
+// bins of several ranks (device memory, n_parts x m patterns) -> one densified signature row
+int launch_dens_merge(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *parts, uint32_t n_parts, void *d_sig) {
+    DensArgs a;
+    memset(&a, 0, sizeof a);
+    a.m = p->sketch_size;
+    a.f32 = p->sig_type == KMU_SIG_F32;
+    a.rev = p->algo == KMU_ALGO_REVOPTDENS;
+    a.sig_out = d_sig;
+    const size_t lds_full = ((size_t) 8 * a.m + 4 * ((size_t) (a.m + 31) / 32) + 16 + (a.rev ? (size_t) 4 * a.m : 0) + 15) & ~(size_t) 15;
+    if (lds_full > 160 * 1024) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d: the bins do not fit the LDS", a.m);
+    if (lds_full > 64 * 1024 &&
+        hipFuncSetAttribute((const void *) k_oph_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void) hipGetLastError();
+        return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d needs %zu B of LDS", a.m, lds_full);
+    }
+    void *row;
+    KMU_TRY(dev_buf(ctx, "dens.row", (size_t) 8 * a.m + 64, &row));
+    a.row = (uint64_t *) row;
+    hipLaunchKernelGGL(k_oph_merge, dim3((a.m + 255) / 256), dim3(256), 0, ctx->stream, parts, n_parts, a.m, a.row);
+    a.out_row = 0;
+    hipLaunchKernelGGL(k_oph_finish, dim3(1), dim3(256), lds_full, ctx->stream, a);
     KMU_HIP(ctx, hipGetLastError());
     return KMU_OK;
 }

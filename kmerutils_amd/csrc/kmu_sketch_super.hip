@@ -212,8 +212,9 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
 }
 
 // element-wise minimum of the partial slot arrays (order-preserving bit patterns); one thread per slot
+// (raw_out: leave the 64-bit slot patterns there instead of a signature)
 __global__ void __launch_bounds__(256) k_super_reduce(const uint64_t *part_rows, uint64_t n_parts, int m, int mode,
-                                                      void *sig_out) {
+                                                      void *sig_out, uint64_t *raw_out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     uint64_t best = super_init_bits(mode);
@@ -221,7 +222,8 @@ __global__ void __launch_bounds__(256) k_super_reduce(const uint64_t *part_rows,
         const uint64_t v = part_rows[i * m + t];
         best = v < best ? v : best;
     }
-    if (mode == 0 || mode == 2) reinterpret_cast<uint64_t *>(sig_out)[t] = best;
+    if (raw_out) raw_out[t] = best;
+    else if (mode == 0 || mode == 2) reinterpret_cast<uint64_t *>(sig_out)[t] = best;
     else reinterpret_cast<uint32_t *>(sig_out)[t] = (uint32_t) best;
 }
 
@@ -229,7 +231,7 @@ int launch_super_reduce(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t
     int mode = p->algo == KMU_ALGO_SUPER ? (p->sig_type == KMU_SIG_F32 ? 1 : 0) : (p->sig_type == KMU_SIG_U32 ? 3 : 2);
     KernelTimer t(ctx, "k_super_reduce");
     hipLaunchKernelGGL(k_super_reduce, dim3((p->sketch_size + 255) / 256), dim3(256), 0, ctx->stream, part_rows, n_parts,
-                       p->sketch_size, mode, d_sig);
+                       p->sketch_size, mode, d_sig, ctx->partial_out);
     KMU_HIP(ctx, hipGetLastError());
     return KMU_OK;
 }

@@ -179,3 +179,60 @@ def gather_rows(local_rows, group=None):
     outs = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad, group=group)
     return torch.cat([o[:int(k.item())] for o, k in zip(outs, ns)], 0)
+
+
+def sketch_seqs_distributed(ctx, bases, offsets, params, group=None):
+    """`sketch_compressedkmer_seqs` over sequences held by several ranks: ONE signature for the union of every rank's reads,
+    the same on every rank (and the same as one process would compute for the concatenated list).
+
+    SuperMinHash / SuperMinHash2 / OptDens / RevOptDens treat k-mer occurrences independently: every rank reduces its reads
+    to per-slot minima (`kmu_sketch_partial`), one all-gather of these m-word arrays, local merge.
+    ProbMinHash3a weighs a key by its multiplicity over ALL reads, so per-rank minima of the local reads would be wrong:
+    the fhash values of the local k-mers (`kmu_kmer_hashes_compact`) are exchanged by owner rank first -- one all-to-all, the
+    exchange counting uses -- every rank sketches the disjoint key set it owns (`kmu_sketch_hashed_partial`), and the
+    (h, key) minima are all-gathered and merged per slot.  `bases` / `offsets`: torch tensors on the context's device."""
+    import torch
+    import torch.distributed as dist
+    from . import _abi as A
+    p = A.SketchParams.from_buffer_copy(params)
+    p.mode = A.MODE_ALL_SEQS
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return ctx.sketch(bases, offsets, p)[0]
+    rank = dist.get_rank(group)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = bases.device
+    if p.algo in (A.ALGO_PROB3A, A.ALGO_PROB3):
+        vals = ctx.kmer_hashes_compact(bases, offsets, p.kmer_type, p.kmer_size, p.fhash)
+        ctx.synchronize()
+        owner = torch.remainder((vals * -7046029254386353131) >> 33, world)  # any function of the value, the same on every rank
+        order = torch.argsort(owner, stable=True)
+        grouped = vals[order]
+        counts = torch.bincount(owner, minlength=world).to(torch.int64)
+        cdev = dev if nccl else torch.device("cpu")
+        all_n = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(all_n, counts.to(cdev), group=group)
+        recv_n = [int(all_n[q][rank].item()) for q in range(world)]
+        bounds = torch.cumsum(counts, 0).cpu().tolist()
+        send_list = [grouped[(bounds[q - 1] if q else 0):bounds[q]] for q in range(world)]
+        if not nccl:  # gloo rehearsals stage the exchange through host memory
+            send_list = [t.cpu() for t in send_list]
+        recv = _all_to_all_var(send_list, recv_n, torch.int64, cdev, group)
+        mine = (torch.cat(recv) if recv else torch.zeros(0, dtype=torch.int64)).to(dev)
+        n_mine = int(mine.numel())
+        if A.kmer_val_bytes(p.kmer_type) == 4:
+            mine = mine.to(torch.int32)
+        if n_mine == 0:
+            mine = torch.zeros(1, dtype=mine.dtype, device=dev)
+        off2 = torch.tensor([0, n_mine], dtype=torch.int64, device=dev)
+        part = ctx.sketch_hashed_partial(mine.contiguous(), off2, p)
+    else:
+        part = ctx.sketch_partial(bases, offsets, p)
+    ctx.synchronize()
+    cpart = part if nccl else part.cpu()
+    parts = [torch.zeros_like(cpart) for _ in range(world)]
+    dist.all_gather(parts, cpart, group=group)
+    allp = torch.stack(parts).to(dev)
+    sig = ctx.sketch_merge_partials(allp.contiguous(), p)
+    ctx.synchronize()
+    return sig

@@ -23,7 +23,8 @@ SYMBOLS = [
     "kmu_count_nb_unique", "kmu_count_dump", "kmu_count_export_part", "kmu_count_merge_entries",
     "kmu_count_retain_part", "kmu_count_extract_by_owner", "kmu_sig_equal_pairs", "kmu_sig_equal_matrix",
     "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx", "kmu_dev_alloc", "kmu_dev_free",
-    "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions", "kmu_count_eliminate_once",
+    "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions", "kmu_count_eliminate_once", "kmu_sketch_partial_words",
+    "kmu_sketch_partial", "kmu_sketch_hashed_partial", "kmu_sketch_merge_partials", "kmu_kmer_hashes_compact",
 ]
 
 
@@ -79,6 +80,12 @@ def load():
     L.kmu_sig_equal_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
     L.kmu_sig_equal_matrix.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
     L.kmu_minhash_distance_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, vp]
+    L.kmu_kmer_hashes_compact.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, C.c_uint64, u64p]
+    L.kmu_sketch_partial_words.argtypes = [C.POINTER(A.SketchParams)]
+    L.kmu_sketch_partial_words.restype = C.c_uint32
+    L.kmu_sketch_partial.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp]
+    L.kmu_sketch_hashed_partial.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, C.c_uint32, vp]
+    L.kmu_sketch_merge_partials.argtypes = [vp, C.POINTER(A.SketchParams), vp, C.c_uint32, vp]
     L.kmu_count_eliminate_once.argtypes = [vp]
     L.kmu_count_once_positions.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint64, u64p]
     L.kmu_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
@@ -208,6 +215,24 @@ class Context:
                                            _ptr(packed_offsets)[0], n, _ptr(out)[0]))
         return out
 
+    def kmer_hashes_compact(self, bases, offsets, kmer_type, k, fhash, input_kind=A.INPUT_ASCII, packed_offsets=None):
+        """kmu_kmer_hashes_compact: fhash of every k-mer, sequence after sequence, no gaps (uint64 / int64 tensor)"""
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets)
+        self._wait_producers(bases)
+        hp = A.HashParams(kmer_type, k, fhash, input_kind, mem, 0)
+        cnt = C.c_uint64(0)
+        self._check(self.L.kmu_kmer_hashes_compact(self.h, C.byref(hp), _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0],
+                                                   n, None, 0, C.byref(cnt)))
+        if mem == A.MEM_DEVICE:
+            import torch
+            out = torch.zeros(max(cnt.value, 1), dtype=torch.int64, device=bases.device)
+        else:
+            out = np.zeros(max(cnt.value, 1), np.uint64)
+        self._check(self.L.kmu_kmer_hashes_compact(self.h, C.byref(hp), _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0],
+                                                   n, _ptr(out)[0], cnt.value, C.byref(cnt)))
+        return out[:cnt.value]
+
     def block_layout(self, offsets_host, block_size):
         n = len(offsets_host) - 1
         out = np.zeros(n + 1, np.uint64)
@@ -276,6 +301,52 @@ class Context:
         self._check(self.L.kmu_sketch_hashed(self.h, C.byref(p), _ptr(hashed)[0], _ptr(offsets)[0], n, _ptr(out)[0],
                                              _ptr(counts)[0]))
         return (out[:rows], counts[:rows]) if want_counts else out[:rows]
+
+    # ---- one signature over several GPUs: partial slot minima + merge ----
+    def _partial_buf(self, p, like, n_parts=1):
+        words = int(self.L.kmu_sketch_partial_words(C.byref(p)))
+        if like is not None and _is_torch(like) and like.is_cuda:
+            import torch
+            return torch.zeros((n_parts, words), dtype=torch.int64, device=like.device)
+        return np.zeros((n_parts, words), np.uint64)
+
+    def sketch_partial(self, bases, offsets, params, packed_offsets=None):
+        """kmu_sketch_partial: per-slot minima of these sequences (one row of kmu_sketch_partial_words words)"""
+        mem = self._mem(bases, offsets)
+        self._wait_producers(bases)
+        p = A.SketchParams.from_buffer_copy(params)
+        p.mem = mem
+        out = self._partial_buf(p, bases)
+        self._check(self.L.kmu_sketch_partial(self.h, C.byref(p), _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0],
+                                              len(offsets) - 1, _ptr(out)[0]))
+        return out[0]
+
+    def sketch_hashed_partial(self, hashed, offsets, params):
+        """kmu_sketch_hashed_partial: the same for caller-hashed values (disjoint key sets per rank for ProbMinHash)"""
+        mem = self._mem(hashed, offsets)
+        self._wait_producers(hashed)
+        p = A.SketchParams.from_buffer_copy(params)
+        p.mem = mem
+        out = self._partial_buf(p, hashed)
+        self._check(self.L.kmu_sketch_hashed_partial(self.h, C.byref(p), _ptr(hashed)[0], _ptr(offsets)[0], len(offsets) - 1,
+                                                     _ptr(out)[0]))
+        return out[0]
+
+    def sketch_merge_partials(self, partials, params):
+        """kmu_sketch_merge_partials: [n_parts, words] partial rows -> one signature row"""
+        mem = self._mem(partials)
+        self._wait_producers(partials)
+        p = A.SketchParams.from_buffer_copy(params)
+        p.mem = mem
+        m = p.sketch_size
+        if mem == A.MEM_DEVICE:
+            import torch
+            tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32, A.SIG_F64: torch.float64}[p.sig_type]
+            out = torch.zeros(m, dtype=tdt, device=partials.device)
+        else:
+            out = np.zeros(m, dtype=A.SIG_NP[p.sig_type])
+        self._check(self.L.kmu_sketch_merge_partials(self.h, C.byref(p), _ptr(partials)[0], int(partials.shape[0]), _ptr(out)[0]))
+        return out
 
     # ---- ingest (kmu_ingest.hip) ----
     def ingest_fasta(self, text, want_index=False):

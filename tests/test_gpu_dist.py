@@ -46,6 +46,13 @@ def _worker(rank, world, port, ret):
         mine = box["sig"].cpu().numpy().view(np.uint64)
         want = O.sketch(bases, off, p)[r0:r1]
         ok = ok and np.array_equal(mine, want)
+        # ONE signature for the union of both ranks' reads (sketch_compressedkmer_seqs across ranks): the weighted sketch
+        # goes through the owner exchange, the unweighted ones through an all-gather of per-rank minima
+        for algo, sig in ((A.ALGO_PROB3A, A.SIG_U64), (A.ALGO_SUPER, A.SIG_F64), (A.ALGO_OPTDENS, A.SIG_F64), (A.ALGO_SUPER2, A.SIG_U64)):
+            pa = A.SketchParams(algo, A.KMER64BIT, 31, 96, sig, 0, A.FHASH_CANON_INVHASH, 0, A.MODE_ALL_SEQS, 0, 0, 0)
+            got = kdist.sketch_seqs_distributed(ctx, sb, so, pa)
+            want_all = O.sketch(bases, off, pa)[0]
+            ok = ok and np.array_equal(got.cpu().numpy().view(np.uint8), np.ascontiguousarray(want_all).view(np.uint8))
         ret[rank] = bool(ok)
         ctx.close()
     finally:

@@ -983,3 +983,55 @@ def test_once_kmers_with_positions(ctx, oracle, tmp_path):
     # nothing counted yet: no record
     c = ctx.counter(A.KMER64BIT, 25, 8, 1 << 12)
     assert c.once_positions(bases, off)[0].size == 0
+
+
+@pytest.mark.gpu
+def test_partial_sketches_merge_to_the_all_sequences_sketch(ctx, oracle):
+    """kmu_sketch_partial / kmu_sketch_hashed_partial / kmu_sketch_merge_partials: the signature of a list of sequences
+    from the per-slot minima of shares of it -- shares of the sequences for the unweighted sketches, disjoint key sets for
+    ProbMinHash -- equals kmu_sketch(ALL_SEQS) of the whole list (and the oracle's); host and device buffers"""
+    import torch
+    rng = np.random.default_rng(160)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=40_000).tobytes()
+    seqs = []
+    for _ in range(90):
+        L = int(rng.integers(10, 2500))
+        s0 = int(rng.integers(0, len(genome) - L))
+        seqs.append(genome[s0:s0 + L])   # overlapping samples: multiplicities well above 1
+    bases, off = oracle.concat(seqs)
+    shares = [(0, 25), (25, 26), (26, 90)]
+    for algo, sig, m in ((A.ALGO_SUPER, A.SIG_F64, 128), (A.ALGO_SUPER, A.SIG_F32, 64), (A.ALGO_SUPER2, A.SIG_U64, 200),
+                         (A.ALGO_SUPER2, A.SIG_U32, 64), (A.ALGO_OPTDENS, A.SIG_F64, 3000), (A.ALGO_REVOPTDENS, A.SIG_F32, 500)):
+        p = A.SketchParams(algo, A.KMER64BIT, 21, m, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, A.MODE_ALL_SEQS, 0, 0, 0)
+        want = np.ascontiguousarray(oracle.sketch(bases, off, p)).view(np.uint8)
+        parts = np.stack([np.asarray(ctx.sketch_partial(bases, off[a:b + 1].copy(), p)) for a, b in shares])
+        got = np.asarray(ctx.sketch_merge_partials(parts, p))
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint8), want.reshape(-1)), (algo, sig)
+        db, do = torch.from_numpy(bases.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        dparts = torch.stack([ctx.sketch_partial(db, do[a:b + 1], p) for a, b in shares])
+        gd = ctx.sketch_merge_partials(dparts, p)
+        ctx.synchronize()
+        assert np.array_equal(gd.cpu().numpy().view(np.uint8), want.reshape(-1)), (algo, sig)
+    # ProbMinHash: the weight of a key is its multiplicity over ALL sequences -> shares are disjoint key sets
+    for kmer_type, k, sig in ((A.KMER64BIT, 21, A.SIG_U64), (A.KMER32BIT, 9, A.SIG_U32)):
+        p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, 150, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, A.MODE_ALL_SEQS, 0, 0, 0)
+        want = oracle.sketch(bases, off, p)[0]
+        h = oracle.kmer_hashes(bases, off, kmer_type, k, A.FHASH_CANON_INVHASH)
+        valid = np.concatenate([np.arange(int(off[i]), int(off[i + 1]) - k + 1) for i in range(len(off) - 1) if off[i + 1] - off[i] >= k])
+        vals = h[valid]
+        owner = (vals * np.uint64(0x9E3779B97F4A7C15) >> np.uint64(40)) % np.uint64(3)
+        dt = np.uint32 if sig == A.SIG_U32 else np.uint64
+        parts = []
+        for r in range(3):
+            mine = vals[owner == r].astype(dt)
+            if r == 2:  # one share handed over as two "sequences": still one multiset
+                o2 = np.array([0, mine.size // 3, mine.size], np.uint64)
+            else:
+                o2 = np.array([0, mine.size], np.uint64)
+            parts.append(np.asarray(ctx.sketch_hashed_partial(mine, o2, p)))
+        parts.append(np.asarray(ctx.sketch_hashed_partial(np.zeros(1, dt), np.array([0, 0], np.uint64), p)))  # a rank without data
+        got = np.asarray(ctx.sketch_merge_partials(np.stack(parts), p))
+        assert np.array_equal(got, want)
+        # and splitting by SEQUENCES instead is (as it must be) not the same thing: weights would be partial
+        naive = np.stack([np.asarray(ctx.sketch_partial(bases, off[a:b + 1].copy(), p)) for a, b in shares])
+        assert not np.array_equal(np.asarray(ctx.sketch_merge_partials(naive, p)), want)
