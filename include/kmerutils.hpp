@@ -13,6 +13,7 @@
  *                 SeqSketcherT (trait)                       src/sketching/setsketchert.rs:54-80
  *                 ProbHash3aSketch / SuperHashSketch / SuperHash2Sketch   setsketchert.rs:85-336, 904-1046
  *                 OptDensHashSketch / RevOptDensHashSketch                setsketchert.rs:343-599
+ *                 HyperLogLogSketch, SetSketchParams, HllSeqsThreading    setsketchert.rs:600-896
  *                 SeqSketcher                                src/sketching/seqsketchjaccard.rs:117-415
  *                 jaccard_index_probminhash3a, probminhash_get_jaccard_objects, compute_*_jaccard
  *                                                            seqsketchjaccard.rs:58-108, 423-495
@@ -754,6 +755,59 @@ template <class Kmer, class S> class RevOptDensHashSketch : public detail::Sketc
   public:
     explicit RevOptDensHashSketch(const SeqSketcherParams &params, Context &ctx = Context::global())
         : detail::SketcherImpl<Kmer, S, KMU_ALGO_REVOPTDENS>(params, SketchAlgo::REVOPTDENS, KMU_HASHER_NOHASH, ctx) {}
+};
+
+/// probminhash::setsketcher::SetSketchParams as HyperLogLogSketch::new takes it (defaults of the crate, as recalled)
+struct SetSketchParams {
+    double b = 1.001;
+    size_t m = 4096;
+    double a = 20.;
+    uint32_t q = 65534;
+};
+/// HllSeqsThreading (setsketchert.rs:600-636): how upstream splits a list of sequences over threads; kept for the signature
+struct HllSeqsThreading {
+    size_t nb_iter_thread = 4, thread_threshold = 10000000;
+    size_t get_nb_iter_threads() const { return nb_iter_thread; }
+    size_t get_thread_threshold() const { return thread_threshold; }
+};
+
+/// HyperLogLogSketch<Kmer, S>::new(&seq_params, hll_params, hll_threads) (setsketchert.rs:640-896; AA:
+/// aautils/setsketchert.rs:780-1011): SetSketch registers, S = u16 / u32 / u64; the sketch has hll_params.m registers
+template <class Kmer, class S> class HyperLogLogSketch : public SeqSketcherT<Kmer, S> {
+    static_assert(std::is_same_v<S, uint16_t> || std::is_same_v<S, uint32_t> || std::is_same_v<S, uint64_t>, "S is u16, u32 or u64");
+
+  public:
+    using Seq = typename SeqSketcherT<Kmer, S>::Seq;
+    HyperLogLogSketch(const SeqSketcherParams &seq_params, SetSketchParams hll_params, HllSeqsThreading hll_threads = {},
+                      Context &ctx = Context::global())
+        : params_(seq_params), hll_(hll_params), threads_(hll_threads), ctx_(ctx) {}
+    size_t get_kmer_size() const override { return params_.get_kmer_size(); }
+    size_t get_sketch_size() const override { return params_.get_sketch_size(); }
+    SketchAlgo get_algo() const override { return SketchAlgo::HLL; }
+    std::vector<std::vector<S>> sketch_compressedkmer(const std::vector<const Seq *> &vseq, FHash fhash) const override {
+        return run(vseq, fhash, KMU_MODE_PER_SEQ);
+    }
+    std::vector<std::vector<S>> sketch_compressedkmer_seqs(const std::vector<const Seq *> &vseq, FHash fhash) const override {
+        return run(vseq, fhash, KMU_MODE_ALL_SEQS);
+    }
+
+  private:
+    std::vector<std::vector<S>> run(const std::vector<const Seq *> &vseq, FHash fhash, int mode) const {
+        kmu_hll_params hp{hll_.b, hll_.a, hll_.q, 0};
+        ctx_.check(kmu_set_hll_params(ctx_.raw(), &hp));
+        const detail::Batch b = detail::gather(vseq);
+        const int sig = std::is_same_v<S, uint16_t> ? KMU_SIG_U16 : std::is_same_v<S, uint32_t> ? KMU_SIG_U32 : KMU_SIG_U64;
+        kmu_sketch_params p = detail::sketch_params(KMU_ALGO_HLL, Kmer::kmu_type, params_.get_kmer_size(), hll_.m, sig,
+                                                    KMU_HASHER_NOHASH, int(fhash), 0, mode, b.input_kind);
+        const size_t rows = mode == KMU_MODE_ALL_SEQS ? 1 : b.n();
+        std::vector<S> flat(std::max<size_t>(rows, 1) * hll_.m);
+        ctx_.check(kmu_sketch(ctx_.raw(), &p, b.bytes.data(), b.offsets.data(), b.packed_ptr(), b.n(), nullptr, flat.data(), nullptr));
+        return detail::split_rows(flat, rows, hll_.m);
+    }
+    SeqSketcherParams params_;
+    SetSketchParams hll_;
+    HllSeqsThreading threads_;
+    Context &ctx_;
 };
 
 /// the `H: Hasher` parameter of SuperHash2Sketch

@@ -91,11 +91,13 @@ typedef enum kmu_algo {
                            * process as ProbMinHash3a handled key by key; the signature is the same per-slot arg-min */
     KMU_ALGO_OPTDENS = 5, /* OptDensHashSketch: one-permutation hashing + optimal densification (Shrivastava 2017),
                            * src/sketching/setsketchert.rs:343-463, src/aautils/setsketchert.rs:482-612; sig F32 / F64 */
-    KMU_ALGO_REVOPTDENS = 6 /* RevOptDensHashSketch: the same with reverse densification (Mai et al. 2019), meant for
+    KMU_ALGO_REVOPTDENS = 6, /* RevOptDensHashSketch: the same with reverse densification (Mai et al. 2019), meant for
                            * sketches larger than the sequences, setsketchert.rs:474-599, aautils/setsketchert.rs:616-746 */
+    KMU_ALGO_HLL = 7      /* HyperLogLogSketch: SetSketch registers (Ertl 2021), setsketchert.rs:640-896,
+                           * aautils/setsketchert.rs:780-1011; sig U16 / U32 / U64; parameters: kmu_set_hll_params */
 } kmu_algo;
 
-typedef enum kmu_sig_type { KMU_SIG_U32 = 0, KMU_SIG_U64 = 1, KMU_SIG_F32 = 2, KMU_SIG_F64 = 3 } kmu_sig_type;
+typedef enum kmu_sig_type { KMU_SIG_U32 = 0, KMU_SIG_U64 = 1, KMU_SIG_F32 = 2, KMU_SIG_F64 = 3, KMU_SIG_U16 = 4 /* HLL only */ } kmu_sig_type;
 
 /* std::hash::Hasher used to seed the per-element RNG */
 typedef enum kmu_hasher {
@@ -169,6 +171,17 @@ int kmu_dev_alloc(kmu_ctx *ctx, uint64_t bytes, void **out);
 int kmu_dev_free(kmu_ctx *ctx, void *p);
 int kmu_copy_to_device(kmu_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
 int kmu_copy_to_host(kmu_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
+
+/* SetSketchParams of the following KMU_ALGO_HLL calls on this context (probminhash::setsketcher::SetSketchParams, passed to
+ * HyperLogLogSketch::new, setsketchert.rs:660-672): register base b > 1, rate a > 0, register limit q (values 0 .. q + 1).
+ * m is the call's sketch_size.  Defaults: b = 1.001, a = 20, q = 65534. */
+typedef struct kmu_hll_params {
+    double b;
+    double a;
+    uint32_t q;
+    uint32_t reserved;
+} kmu_hll_params;
+int kmu_set_hll_params(kmu_ctx *ctx, const kmu_hll_params *hp);
 
 /* per-kernel device timing with hipEvents on the context stream (bench.py roofline object) */
 int kmu_profile_enable(kmu_ctx *ctx, int on);

@@ -15,8 +15,8 @@ INPUT_ASCII, INPUT_PACKED2 = 0, 1
 KMER32BIT, KMER16B32BIT, KMER64BIT, KMERAA32BIT, KMERAA64BIT = 0, 1, 2, 3, 4
 (FHASH_IDENTITY_RAW, FHASH_VALUE_MASKED, FHASH_CANON_RAW, FHASH_CANON_INVHASH, FHASH_INVHASH_RAW, FHASH_CANON_VALUE,
  FHASH_CANON_NTHASH, FHASH_CANON_NTHASH_8B) = range(8)
-ALGO_PROB3A, ALGO_SUPER, ALGO_SUPER2, ALGO_BOTTOMK, ALGO_PROB3, ALGO_OPTDENS, ALGO_REVOPTDENS = 0, 1, 2, 3, 4, 5, 6
-SIG_U32, SIG_U64, SIG_F32, SIG_F64 = 0, 1, 2, 3
+ALGO_PROB3A, ALGO_SUPER, ALGO_SUPER2, ALGO_BOTTOMK, ALGO_PROB3, ALGO_OPTDENS, ALGO_REVOPTDENS, ALGO_HLL = 0, 1, 2, 3, 4, 5, 6, 7
+SIG_U32, SIG_U64, SIG_F32, SIG_F64, SIG_U16 = 0, 1, 2, 3, 4
 HASHER_NOHASH, HASHER_FNV1A, HASHER_INT64HASH = 0, 1, 2
 MODE_PER_SEQ, MODE_ALL_SEQS = 0, 1
 FLAG_RAND08 = 0x1
@@ -67,4 +67,9 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
 
-SIG_NP = {SIG_U32: "uint32", SIG_U64: "uint64", SIG_F32: "float32", SIG_F64: "float64"}
+SIG_NP = {SIG_U32: "uint32", SIG_U64: "uint64", SIG_F32: "float32", SIG_F64: "float64", SIG_U16: "uint16"}
+
+
+class HllParams(C.Structure):
+    """kmu_hll_params: SetSketchParams (b, a, q); m is the sketch size of the call"""
+    _fields_ = [("b", C.c_double), ("a", C.c_double), ("q", C.c_uint32), ("reserved", C.c_uint32)]

@@ -295,6 +295,13 @@ int kmu_synchronize(kmu_ctx *ctx) {
 
 void *kmu_stream(kmu_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 
+int kmu_set_hll_params(kmu_ctx *ctx, const kmu_hll_params *hp) {
+    if (!ctx || !hp) return KMU_E_BAD_ARG;
+    if (!(hp->b > 1.0) || !(hp->a > 0.0) || hp->q == 0 || hp->q >= 0xFFFFFFFEu) return fail(ctx, KMU_E_BAD_ARG, "SetSketchParams: b > 1, a > 0, q >= 1");
+    ctx->hll = *hp;
+    return KMU_OK;
+}
+
 // ---- device buffers for callers without a HIP binding of their own ------------------------------------------------------
 int kmu_dev_alloc(kmu_ctx *ctx, uint64_t bytes, void **out) {
     if (!ctx || !out) return KMU_E_BAD_ARG;

@@ -25,6 +25,7 @@ struct kmu_ctx {
     // kmu_sketch_partial / kmu_sketch_hashed_partial: where the all-sequences paths leave their per-slot minima instead of
     // turning them into a signature (device memory; null in every other call)
     uint64_t *partial_out = nullptr;
+    kmu_hll_params hll = {1.001, 20.0, 65534u, 0u}; // SetSketchParams of KMU_ALGO_HLL calls (kmu_set_hll_params)
     // grow-on-demand device scratch buffers, keyed by purpose (never shrunk; freed with the context)
     struct Buf {
         void *p = nullptr;

@@ -1151,6 +1151,11 @@ static int sketch_params_check(kmu_ctx *ctx, const kmu_sketch_params *p) {
     case KMU_ALGO_REVOPTDENS:
         if (p->sig_type != KMU_SIG_F32 && p->sig_type != KMU_SIG_F64) return fail(ctx, KMU_E_BAD_ARG, "OptDens / RevOptDens signature is f32/f64");
         break;
+    case KMU_ALGO_HLL:
+        if (p->sig_type != KMU_SIG_U16 && p->sig_type != KMU_SIG_U32 && p->sig_type != KMU_SIG_U64)
+            return fail(ctx, KMU_E_BAD_ARG, "SetSketch registers are u16 / u32 / u64");
+        if (p->sig_type == KMU_SIG_U16 && ctx->hll.q + 1 > 65535u) return fail(ctx, KMU_E_BAD_ARG, "q + 1 does not fit u16 registers");
+        break;
     case KMU_ALGO_SUPER2:
         if (p->sig_type != KMU_SIG_U32 && p->sig_type != KMU_SIG_U64) return fail(ctx, KMU_E_BAD_ARG, "SuperMinHash2 signature is u32/u64");
         break;
@@ -1173,7 +1178,8 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
                 int hashed_bytes);
 int launch_dens_merge(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *parts, uint32_t n_parts, void *d_sig);
 }
-static bool algo_is_dens(int algo) { return algo == KMU_ALGO_OPTDENS || algo == KMU_ALGO_REVOPTDENS; }
+// the sketches kept as m bins / registers with one independent update per k-mer occurrence (kmu_sketch_dens.hip)
+static bool algo_is_dens(int algo) { return algo == KMU_ALGO_OPTDENS || algo == KMU_ALGO_REVOPTDENS || algo == KMU_ALGO_HLL; }
 
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
                         void *d_sig, uint32_t *d_counts, uint32_t *d_err, const void *hashed = nullptr,
@@ -1417,7 +1423,7 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     DevSeqs ds;
     KMU_TRY(stage_sequences(ctx, bases, offsets, packed_offsets, n_seq, p->input_kind, p->mem, &ds));
-    const size_t sigb = (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    const size_t sigb = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
     uint64_t rows = n_seq;
     const uint64_t *d_block_rows = nullptr;
     void *d_sig = sig_out;
@@ -1533,8 +1539,10 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
         case KMU_ALGO_SUPER:
         case KMU_ALGO_SUPER2: KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err, nullptr, 0, nullptr)); break;
         case KMU_ALGO_OPTDENS:
-        case KMU_ALGO_REVOPTDENS: KMU_TRY(launch_dens(ctx, p, ds, d_sig, d_err, nullptr, 0)); break;
+        case KMU_ALGO_REVOPTDENS:
+        case KMU_ALGO_HLL: KMU_TRY(launch_dens(ctx, p, ds, d_sig, d_err, nullptr, 0)); break;
         case KMU_ALGO_BOTTOMK: KMU_TRY(launch_pmh3a(ctx, p, ds, nullptr, d_sig, d_counts, d_err)); break;
+        default: return fail(ctx, KMU_E_UNSUPPORTED, "no per-sequence kernel for algo %d", p->algo);
         }
     }
     if (p->mem == KMU_MEM_HOST) {
@@ -1558,7 +1566,7 @@ extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, co
         return fail(ctx, KMU_E_UNSUPPORTED, "the reference has no bottom-k sketch over a list of sequences");
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     const int w = kmer_val_bytes(p->kmer_type);
-    const size_t sigb = (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    const size_t sigb = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
     const int m = p->sketch_size;
     const uint64_t rows = p->mode == KMU_MODE_ALL_SEQS ? 1 : n_seq;
     const void *d_vals = hashed;
@@ -1700,7 +1708,7 @@ extern "C" int kmu_sketch_merge_partials(kmu_ctx *ctx, const kmu_sketch_params *
     if (p->algo == KMU_ALGO_BOTTOMK) return fail(ctx, KMU_E_UNSUPPORTED, "no bottom-k sketch over a list of sequences");
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     const int m = p->sketch_size;
-    const size_t sigb = (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    const size_t sigb = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
     const uint64_t words = kmu_sketch_partial_words(p);
     const uint64_t *d_parts = partials;
     void *d_sig = sig_out;

@@ -40,6 +40,10 @@ struct DensArgs {
     int f32;      // signature is f32 (bins hold f32 bit patterns)
     int val_w32;  // Kmer::Val is 32 bits
     int rev;      // reverse densification
+    int hll;      // SetSketch registers instead of bins: maxima of k = floor(1 - log_b x), no densification
+    int sig_bytes; // 2 / 4 / 8: width of a signature entry
+    uint32_t q;   // SetSketch: registers are clamped to [0, q + 1]
+    double inv_am, inv_ln_b; // SetSketch: 1 / (a m), 1 / ln b
     const void *hashed; // pre-hashed input (offsets count values), else null
     int hashed_bytes;
     uint32_t skip_longer; // sequences with more k-mers are left to k_oph_long
@@ -80,6 +84,70 @@ __device__ __forceinline__ SeqView dens_view(const DensArgs &a, uint32_t r) {
     return sv;
 }
 
+// natural logarithm of a positive normal double from +, -, *, / only (the oracle carries the same few lines): x = 2^e f with
+// f in (sqrt(1/2), sqrt(2)], log f = 2 s (1 + z/3 + ... + z^10/21), s = (f - 1) / (f + 1), z = s^2
+__device__ __forceinline__ double kmu_log(double x) {
+    uint64_t bits = (uint64_t) __double_as_longlong(x);
+    int e = (int) ((bits >> 52) & 0x7FF) - 1023;
+    double f = __longlong_as_double((long long) ((bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+    if (f > 1.4142135623730951) { f = f * 0.5; e += 1; }
+    const double s = (f - 1.0) / (f + 1.0), z = s * s;
+    double poly = 1.0 / 21.0;
+    poly = poly * z + 1.0 / 19.0;
+    poly = poly * z + 1.0 / 17.0;
+    poly = poly * z + 1.0 / 15.0;
+    poly = poly * z + 1.0 / 13.0;
+    poly = poly * z + 1.0 / 11.0;
+    poly = poly * z + 1.0 / 9.0;
+    poly = poly * z + 1.0 / 7.0;
+    poly = poly * z + 1.0 / 5.0;
+    poly = poly * z + 1.0 / 3.0;
+    poly = poly * z + 1.0;
+    return (double) e * 0.6931471805599453 + 2.0 * s * poly;
+}
+
+// K_low of this workgroup's registers, refreshed by one wave (registers only grow, so the word only grows).
+// Every lane of the wave calls this (uniform control flow).
+__device__ __forceinline__ void hll_refresh_klow(const DensArgs &a, const uint64_t *hs, uint32_t *klow) {
+    uint64_t mn = ~0ull;
+    for (int i = lane_id(); i < a.m; i += 64) {
+        const uint64_t v = *(volatile const uint64_t *) &hs[i];
+        mn = v < mn ? v : mn;
+    }
+    mn = ~wave_max_u64(~mn);
+    if (lane_id() == 0) atomicMax(klow, (uint32_t) mn);
+}
+
+// SetSketch (Ertl 2021, Algorithm 1, SetSketch1), one element per lane (`have`), the wave in lock step: ascending
+// x_j = x_{j-1} + Exp(1) / (a m); k = clamp(floor(1 - log_b x_j)); a lane stops at its first k <= K_low (any lower bound of
+// this workgroup's registers: later k are no larger); else a uniformly drawn register takes max(K_i, k).  While the
+// registers are young every element runs long, so K_low is refreshed inside the loop (all lanes take part).
+__device__ __forceinline__ void hll_wave_items(const DensArgs &a, uint64_t *hs, uint32_t *klow, bool have, uint64_t value) {
+    Xoshiro rng;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    if (have) rng.seed(hasher_finish(a.hasher, value, a.val_w32 != 0));
+    double x = 0.0;
+    int j = 0;
+    uint32_t round = 0;
+    bool active = have;
+    while (__any(active)) {
+        if (active) {
+            x += -kmu_log(1.0 - rng.unif01()) * a.inv_am;
+            const double t = 1.0 - kmu_log(x) * a.inv_ln_b;
+            uint32_t k = 0;
+            if (t >= (double) a.q + 1.0) k = a.q + 1u;
+            else if (t > 0.0) k = (uint32_t) t;
+            if (k <= *(volatile const uint32_t *) klow) active = false;
+            else {
+                const uint32_t i = rng.unif_index(0u, (uint32_t) a.m, a.rand08 != 0);
+                atomicMax((unsigned long long *) &hs[i], (unsigned long long) k);
+                if (++j >= a.m) active = false;
+            }
+        }
+        if ((++round & 31u) == 0u) hll_refresh_klow(a, hs, klow);
+    }
+}
+
 // one item: r and bin from its own RNG stream, minimum into the bin
 __device__ __forceinline__ void oph_item(const DensArgs &a, uint64_t *hs, uint64_t value) {
     Xoshiro rng;
@@ -92,9 +160,51 @@ __device__ __forceinline__ void oph_item(const DensArgs &a, uint64_t *hs, uint64
 }
 
 // the items of words [st0, st1) x 64 of one sequence, waves striding by `stride` steps from `first`
-__device__ __forceinline__ uint32_t oph_walk(const DensArgs &a, const SeqView &sv, uint64_t *hs, bool aa, uint64_t nk,
-                                             uint64_t first, uint64_t stride) {
+__device__ __forceinline__ uint32_t oph_walk(const DensArgs &a, const SeqView &sv, uint64_t *hs, uint32_t *klow, bool aa,
+                                             uint64_t nk, uint64_t first, uint64_t stride) {
     uint32_t bad = 0;
+    if (a.hll) {
+        // the values of a step are collected first (the visit is per lane and per position), then worked off slot by slot
+        // with the whole wave in step -- hll_wave_items needs uniform control flow
+        if (a.hashed_bytes) {
+            for (uint64_t p0 = first * 64; p0 < nk; p0 += stride * 64) {
+                const uint64_t p = p0 + lane_id();
+                uint64_t v = 0;
+                if (p < nk)
+                    v = a.hashed_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t *>(a.hashed)[sv.begin + p]
+                                            : reinterpret_cast<const uint64_t *>(a.hashed)[sv.begin + p];
+                hll_wave_items(a, hs, klow, p < nk, v);
+                if (((p0 / (stride * 64)) & 15u) == 15u) hll_refresh_klow(a, hs, klow);
+            }
+            return 0;
+        }
+        const uint64_t st1 = aa ? (sv.len + 63) / 64 : (seq_num_words(sv) + 63) / 64;
+        for (uint64_t st = first; st < st1; st += stride) {
+            uint64_t vals[16];
+            uint32_t mask = 0;
+            if (aa) {
+                bad |= wave_step_kmers_aa(sv, a.cfg.k, st, 0, nk, [&](uint64_t, uint64_t val, uint64_t rc) {
+                    vals[0] = apply_fhash(a.cfg, val, rc);
+                    mask = 1u;
+                });
+            } else {
+                const uint64_t p0 = (st * 64 + (uint64_t) lane_id()) * 16; // position + lead of this lane's first base
+                const uint32_t lead = seq_lead(sv);
+                bad |= wave_step_kmers(sv, a.cfg.k, st, 0, nk, [&](uint64_t pos, uint64_t val, uint64_t rc) {
+                    const uint32_t slot = (uint32_t) (pos + lead - p0);
+                    vals[slot] = apply_fhash(a.cfg, val, rc);
+                    mask |= 1u << slot;
+                });
+            }
+#pragma unroll
+            for (int slot = 0; slot < 16; slot++) {
+                if (!__any(mask >> slot & 1u)) continue; // uniform
+                hll_wave_items(a, hs, klow, (mask >> slot & 1u) != 0u, vals[slot]);
+            }
+            hll_refresh_klow(a, hs, klow);
+        }
+        return bad;
+    }
     auto visit = [&](uint64_t, uint64_t val, uint64_t rc) { oph_item(a, hs, apply_fhash(a.cfg, val, rc)); };
     if (a.hashed_bytes) {
         for (uint64_t p = first * 64 + lane_id(); p < nk; p += stride * 64) {
@@ -172,8 +282,20 @@ __device__ __forceinline__ void oph_densify(const DensArgs &a, uint64_t *hs, uin
 
 __device__ __forceinline__ void oph_store_row(const DensArgs &a, const uint64_t *hs, uint64_t row) {
     for (int t = threadIdx.x; t < a.m; t += blockDim.x) {
-        if (a.f32) reinterpret_cast<uint32_t *>(a.sig_out)[row * a.m + t] = (uint32_t) hs[t];
+        if (a.sig_bytes == 2) reinterpret_cast<uint16_t *>(a.sig_out)[row * a.m + t] = (uint16_t) hs[t];
+        else if (a.sig_bytes == 4) reinterpret_cast<uint32_t *>(a.sig_out)[row * a.m + t] = (uint32_t) hs[t];
         else reinterpret_cast<uint64_t *>(a.sig_out)[row * a.m + t] = hs[t];
+    }
+}
+
+// neutral element of a bin / register, and the merge of a workgroup's array into the global row
+__device__ __forceinline__ uint64_t oph_neutral(const DensArgs &a) { return a.hll ? 0ull : oph_large_bits(a.f32); }
+__device__ __forceinline__ void oph_merge_to_row(const DensArgs &a, const uint64_t *hs) {
+    const uint64_t neutral = oph_neutral(a);
+    for (int s = threadIdx.x; s < a.m; s += blockDim.x) {
+        if (hs[s] == neutral) continue;
+        if (a.hll) atomicMax((unsigned long long *) &a.row[s], (unsigned long long) hs[s]);
+        else atomicMin((unsigned long long *) &a.row[s], (unsigned long long) hs[s]);
     }
 }
 
@@ -195,12 +317,12 @@ __global__ void __launch_bounds__(256) k_oph_reads(DensArgs a) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
     const bool aa = a.cfg.kmer_type == KMU_KMERAA32BIT || a.cfg.kmer_type == KMU_KMERAA64BIT;
-    const uint64_t large = oph_large_bits(a.f32);
+    const uint64_t large = oph_neutral(a);
     for (int s = tid; s < a.m; s += nthreads) {
         hs[s] = large;
         if (a.rev && !ALL) claim[s] = 0xFFFFFFFFu;
     }
-    if (tid == 0) cnt[2] = atomicAdd(a.queue, 1u);
+    if (tid == 0) { cnt[2] = atomicAdd(a.queue, 1u); cnt[3] = 0; } // cnt[3]: K_low of the registers (SetSketch)
     __syncthreads();
     for (;;) {
         const uint32_t r = cnt[2];
@@ -216,41 +338,41 @@ __global__ void __launch_bounds__(256) k_oph_reads(DensArgs a) {
         if (!skip) {
             uint32_t bad = 0;
             if (nk == 0 && !a.hashed_bytes) bad = wave_validate_seq(sv, wave, nwaves, aa);
-            else bad = oph_walk(a, sv, hs, aa, nk, (uint64_t) wave, (uint64_t) nwaves);
+            else bad = oph_walk(a, sv, hs, &cnt[3], aa, nk, (uint64_t) wave, (uint64_t) nwaves);
             if (bad) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
         }
         __syncthreads();
         if (!ALL && !skip) {
-            oph_densify(a, hs, filled, claim, cnt);
+            if (!a.hll) oph_densify(a, hs, filled, claim, cnt);
             oph_store_row(a, hs, (uint64_t) r);
             __syncthreads();
             for (int s = tid; s < a.m; s += nthreads) hs[s] = large;
+            if (tid == 0) cnt[3] = 0;
         }
         if (tid == 0) cnt[2] = r_next;
         __syncthreads();
     }
-    if (ALL)
-        for (int s = tid; s < a.m; s += nthreads)
-            if (hs[s] != large) atomicMin((unsigned long long *) &a.row[s], (unsigned long long) hs[s]);
+    if (ALL) oph_merge_to_row(a, hs);
 }
 
 // one long sequence, walked by the whole grid; bins merged into a.row
 __global__ void __launch_bounds__(256) k_oph_long(DensArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *hs = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *klow = reinterpret_cast<uint32_t *>(hs + a.m);
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
     const bool aa = a.cfg.kmer_type == KMU_KMERAA32BIT || a.cfg.kmer_type == KMU_KMERAA64BIT;
-    const uint64_t large = oph_large_bits(a.f32);
+    const uint64_t large = oph_neutral(a);
     for (int s = tid; s < a.m; s += nthreads) hs[s] = large;
+    if (tid == 0) *klow = 0;
     __syncthreads();
     const SeqView sv = dens_view(a, a.long_seq);
     const uint64_t nk = sv.len >= (uint64_t) a.cfg.k ? sv.len - a.cfg.k + 1 : 0;
-    const uint32_t bad = oph_walk(a, sv, hs, aa, nk, (uint64_t) blockIdx.x * nwaves + wave, (uint64_t) gridDim.x * nwaves);
+    const uint32_t bad = oph_walk(a, sv, hs, klow, aa, nk, (uint64_t) blockIdx.x * nwaves + wave, (uint64_t) gridDim.x * nwaves);
     if (bad) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
     __syncthreads();
-    for (int s = tid; s < a.m; s += nthreads)
-        if (hs[s] != large) atomicMin((unsigned long long *) &a.row[s], (unsigned long long) hs[s]);
+    oph_merge_to_row(a, hs);
 }
 
 __global__ void __launch_bounds__(256) k_oph_fill(uint64_t *row, int m, uint64_t bits) {
@@ -269,7 +391,7 @@ __global__ void __launch_bounds__(256) k_oph_finish(DensArgs a) {
         if (a.rev) claim[s] = 0xFFFFFFFFu;
     }
     __syncthreads();
-    oph_densify(a, hs, filled, claim, cnt);
+    if (!a.hll) oph_densify(a, hs, filled, claim, cnt);
     oph_store_row(a, hs, a.out_row);
 }
 
@@ -284,6 +406,30 @@ __global__ void __launch_bounds__(1024) k_dens_max_len(const uint64_t *offsets, 
 }
 
 static constexpr uint32_t DENS_LONG_KMERS = 1u << 20; // longer sequences are spread over the grid
+
+// kmu_log on the host (for 1 / ln b): the same operations in the same order
+static double host_log(double x) {
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int) ((bits >> 52) & 0x7FF) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double f;
+    memcpy(&f, &bits, 8);
+    if (f > 1.4142135623730951) { f = f * 0.5; e += 1; }
+    const double s = (f - 1.0) / (f + 1.0), z = s * s;
+    double poly = 1.0 / 21.0;
+    poly = poly * z + 1.0 / 19.0;
+    poly = poly * z + 1.0 / 17.0;
+    poly = poly * z + 1.0 / 15.0;
+    poly = poly * z + 1.0 / 13.0;
+    poly = poly * z + 1.0 / 11.0;
+    poly = poly * z + 1.0 / 9.0;
+    poly = poly * z + 1.0 / 7.0;
+    poly = poly * z + 1.0 / 5.0;
+    poly = poly * z + 1.0 / 3.0;
+    poly = poly * z + 1.0;
+    return (double) e * 0.6931471805599453 + 2.0 * s * poly;
+}
 
 // OptDens / RevOptDens for every mode of kmu_sketch / kmu_sketch_hashed
 int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err, const void *hashed,
@@ -305,6 +451,13 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
     a.f32 = p->sig_type == KMU_SIG_F32;
     a.val_w32 = kmer_val_bytes(p->kmer_type) == 4;
     a.rev = p->algo == KMU_ALGO_REVOPTDENS;
+    a.hll = p->algo == KMU_ALGO_HLL;
+    a.sig_bytes = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    if (a.hll) { // SetSketchParams of the context; 1 / ln b with the kernels' own logarithm (same formula on the host)
+        a.q = ctx->hll.q;
+        a.inv_am = 1.0 / (ctx->hll.a * (double) a.m);
+        a.inv_ln_b = 1.0 / host_log(ctx->hll.b);
+    }
     a.sig_out = d_sig;
     a.err = d_err;
     const bool all = p->mode == KMU_MODE_ALL_SEQS;
@@ -327,7 +480,7 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
     a.queue = (uint32_t *) q;
     KMU_TRY(dev_buf(ctx, "dens.row", (size_t) 8 * a.m + 64, &row));
     a.row = (uint64_t *) row;
-    const uint64_t large = a.f32 ? (uint64_t) 0x4F800000u /* 2^32 as f32 */ : 0x41EFFFFFFFE00000ull /* 4294967295.0 */;
+    const uint64_t large = a.hll ? 0ull : a.f32 ? (uint64_t) 0x4F800000u /* 2^32 as f32 */ : 0x41EFFFFFFFE00000ull /* 4294967295.0 */;
     auto fill_row = [&]() {
         hipLaunchKernelGGL(k_oph_fill, dim3((a.m + 255) / 256), dim3(256), 0, ctx->stream, a.row, a.m, large);
     };
@@ -382,13 +535,13 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
     return KMU_OK;
 }
 
-__global__ void __launch_bounds__(256) k_oph_merge(const uint64_t *parts, uint32_t n_parts, int m, uint64_t *row) {
+__global__ void __launch_bounds__(256) k_oph_merge(const uint64_t *parts, uint32_t n_parts, int m, int take_max, uint64_t *row) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m) return;
     uint64_t best = parts[t];
     for (uint32_t i = 1; i < n_parts; i++) {
         const uint64_t v = parts[(uint64_t) i * m + t];
-        best = v < best ? v : best;
+        best = (take_max ? v > best : v < best) ? v : best;
     }
     row[t] = best;
 }
@@ -400,6 +553,8 @@ int launch_dens_merge(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *
     a.m = p->sketch_size;
     a.f32 = p->sig_type == KMU_SIG_F32;
     a.rev = p->algo == KMU_ALGO_REVOPTDENS;
+    a.hll = p->algo == KMU_ALGO_HLL;
+    a.sig_bytes = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
     a.sig_out = d_sig;
     const size_t lds_full = ((size_t) 8 * a.m + 4 * ((size_t) (a.m + 31) / 32) + 16 + (a.rev ? (size_t) 4 * a.m : 0) + 15) & ~(size_t) 15;
     if (lds_full > 160 * 1024) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d: the bins do not fit the LDS", a.m);
@@ -411,7 +566,7 @@ int launch_dens_merge(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *
     void *row;
     KMU_TRY(dev_buf(ctx, "dens.row", (size_t) 8 * a.m + 64, &row));
     a.row = (uint64_t *) row;
-    hipLaunchKernelGGL(k_oph_merge, dim3((a.m + 255) / 256), dim3(256), 0, ctx->stream, parts, n_parts, a.m, a.row);
+    hipLaunchKernelGGL(k_oph_merge, dim3((a.m + 255) / 256), dim3(256), 0, ctx->stream, parts, n_parts, a.m, a.hll, a.row);
     a.out_row = 0;
     hipLaunchKernelGGL(k_oph_finish, dim3(1), dim3(256), lds_full, ctx->stream, a);
     KMU_HIP(ctx, hipGetLastError());

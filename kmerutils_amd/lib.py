@@ -24,7 +24,7 @@ SYMBOLS = [
     "kmu_count_retain_part", "kmu_count_extract_by_owner", "kmu_sig_equal_pairs", "kmu_sig_equal_matrix",
     "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx", "kmu_dev_alloc", "kmu_dev_free",
     "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions", "kmu_count_eliminate_once", "kmu_sketch_partial_words",
-    "kmu_sketch_partial", "kmu_sketch_hashed_partial", "kmu_sketch_merge_partials", "kmu_kmer_hashes_compact",
+    "kmu_sketch_partial", "kmu_sketch_hashed_partial", "kmu_sketch_merge_partials", "kmu_kmer_hashes_compact", "kmu_set_hll_params",
 ]
 
 
@@ -80,6 +80,7 @@ def load():
     L.kmu_sig_equal_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
     L.kmu_sig_equal_matrix.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
     L.kmu_minhash_distance_pairs.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.c_int, vp]
+    L.kmu_set_hll_params.argtypes = [vp, C.POINTER(A.HllParams)]
     L.kmu_kmer_hashes_compact.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, C.c_uint64, u64p]
     L.kmu_sketch_partial_words.argtypes = [C.POINTER(A.SketchParams)]
     L.kmu_sketch_partial_words.restype = C.c_uint32
@@ -147,6 +148,11 @@ class Context:
     @property
     def stream(self):
         return self.L.kmu_stream(self.h)
+
+    def set_hll_params(self, b=1.001, a=20.0, q=65534):
+        """kmu_set_hll_params: SetSketchParams of the following ALGO_HLL sketches on this context"""
+        hp = A.HllParams(b, a, q, 0)
+        self._check(self.L.kmu_set_hll_params(self.h, C.byref(hp)))
 
     # ---- profiling ----
     def profile_enable(self, on=True):
@@ -261,7 +267,7 @@ class Context:
             if mem == A.MEM_DEVICE:
                 import torch
                 tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
-                       A.SIG_F64: torch.float64}[p.sig_type]
+                       A.SIG_F64: torch.float64, A.SIG_U16: torch.int16}[p.sig_type]
                 out = torch.zeros((max(rows, 1), m), dtype=tdt, device=bases.device)
                 if want_counts and counts_out is None:
                     counts_out = torch.zeros((max(rows, 1), m), dtype=torch.int32, device=bases.device)
@@ -290,7 +296,7 @@ class Context:
         if mem == A.MEM_DEVICE:
             import torch
             tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
-                   A.SIG_F64: torch.float64}[p.sig_type]
+                   A.SIG_F64: torch.float64, A.SIG_U16: torch.int16}[p.sig_type]
             out = torch.zeros((max(rows, 1), m), dtype=tdt, device=hashed.device)
             if want_counts:
                 counts = torch.zeros((max(rows, 1), m), dtype=torch.int32, device=hashed.device)
@@ -341,7 +347,8 @@ class Context:
         m = p.sketch_size
         if mem == A.MEM_DEVICE:
             import torch
-            tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32, A.SIG_F64: torch.float64}[p.sig_type]
+            tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32, A.SIG_F64: torch.float64,
+                   A.SIG_U16: torch.int16}[p.sig_type]
             out = torch.zeros(m, dtype=tdt, device=partials.device)
         else:
             out = np.zeros(m, dtype=A.SIG_NP[p.sig_type])

@@ -21,7 +21,7 @@ from . import lib
 
 class SketchAlgo:
     PROB3A, SUPER, SUPER2, BOTTOMK, PROB3 = A.ALGO_PROB3A, A.ALGO_SUPER, A.ALGO_SUPER2, A.ALGO_BOTTOMK, A.ALGO_PROB3
-    OPTDENS, REVOPTDENS = A.ALGO_OPTDENS, A.ALGO_REVOPTDENS
+    OPTDENS, REVOPTDENS, HLL = A.ALGO_OPTDENS, A.ALGO_REVOPTDENS, A.ALGO_HLL
 
 
 class DataType:
@@ -134,6 +134,34 @@ class RevOptDensHashSketch(SuperHashSketch):
     """RevOptDensHashSketch<Kmer, S>: the same with reverse optimal densification, for sketches larger than the sequences
     (setsketchert.rs:474-599; AA: aautils/setsketchert.rs:616-746)"""
     algo = SketchAlgo.REVOPTDENS
+
+
+class SetSketchParams:
+    """probminhash::setsketcher::SetSketchParams as HyperLogLogSketch::new takes it: b, m, a, q (defaults of the crate)"""
+
+    def __init__(self, b=1.001, m=4096, a=20.0, q=65534):
+        self.b, self.m, self.a, self.q = b, m, a, q
+
+
+class HyperLogLogSketch(_SketcherBase):
+    """HyperLogLogSketch<Kmer, S>::new(seq_params, hll_params, hll_threads) (setsketchert.rs:640-896): SetSketch registers,
+    type Sig = u16 / u32 / u64.  `hll_threads` (HllSeqsThreading) is accepted for the signature; the device needs no split."""
+    algo = SketchAlgo.HLL
+
+    def __init__(self, params, hll_params=None, hll_threads=None, sig="u16", kmer_type=None, ctx=None):
+        super().__init__(params, kmer_type, ctx)
+        self.hll_params = hll_params or SetSketchParams()
+        self.sig = sig
+
+    def _sig_type(self):
+        return {"u16": A.SIG_U16, "u32": A.SIG_U32, "u64": A.SIG_U64}[self.sig]
+
+    def _params(self, fhash, mode, block_size=0, flags=0):
+        h = self.hll_params
+        self.ctx.set_hll_params(h.b, h.a, h.q)
+        p = super()._params(fhash, mode, block_size, flags)
+        p.sketch_size = h.m  # the sketcher's size is SetSketchParams.m (setsketchert.rs:702-703)
+        return p
 
 
 class SuperHash2Sketch(_SketcherBase):

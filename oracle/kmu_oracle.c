@@ -101,6 +101,8 @@ int kmo_encode_aa(uint8_t c) {
  * L1  k-mer value types.  `raw` is the tuple field `.0` zero-extended to 64 bits.
  * ==================================================================================================== */
 
+typedef struct { double b, a; uint32_t q; } hll_params_t;
+
 static int kmer_is_aa(int t) { return t == KMU_KMERAA32BIT || t == KMU_KMERAA64BIT; }
 static int kmer_val_bytes(int t) { return (t == KMU_KMER64BIT || t == KMU_KMERAA64BIT) ? 8 : 4; }
 
@@ -910,6 +912,87 @@ static void oph_end_sketch(oph_t *s, int rev) {
     free(now);
 }
 
+/* ---- SetSketch (UNPINNED: crate probminhash, module setsketcher: SetSketcher / SetSketchParams; call sites
+ * src/sketching/setsketchert.rs:640-896, src/aautils/setsketchert.rs:780-1011; the reference holds NO test of it).
+ * Restated from Ertl, "SetSketch: filling the gap between MinHash and HyperLogLog" (VLDB 2021, arXiv 2101.00314),
+ * Algorithm 1 in its SetSketch1 form: registers K_1..K_m start at 0; for an element, a generator seeded by its hash yields
+ * ascending x_1 < x_2 < ... with x_j = x_{j-1} + Exp(1) / (a m); k = clamp(floor(1 - log_b x_j), 0, q + 1); the loop ends
+ * as soon as k <= K_low (a lower bound of all registers: later x are larger, k can only fall); otherwise a register i drawn
+ * uniformly (with replacement) takes max(K_i, k).  Parameters of the crate's SetSketchParams as recalled: b = 1.001,
+ * m = 4096, a = 20, q = 2^16 - 2 by default.  Which of the paper's two variants the crate implements, its order of draws
+ * and its logarithm are not known here: the draws below follow this library's other restatements, and log is the
+ * series kmo_log (so that oracle and device agree bit for bit; any correctly rounded log gives the same registers except
+ * at exact ties of floor()).  The registers do not depend on K_low (it only prunes work), so it is refreshed lazily. */
+static hll_params_t g_hll = {1.001, 20.0, 65534u};
+void kmo_set_hll_params(double b, double a, uint32_t q) { g_hll.b = b; g_hll.a = a; g_hll.q = q; }
+
+/* natural logarithm of a positive normal double from +, -, *, / only: x = 2^e f, f in (sqrt(1/2), sqrt(2)],
+ * log f = 2 s (1 + z/3 + z^2/5 + ... + z^10/21), s = (f - 1) / (f + 1), z = s^2 (next term < 1e-18) */
+double kmo_log(double x) {
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int e = (int) ((bits >> 52) & 0x7FF) - 1023;
+    bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double f;
+    memcpy(&f, &bits, 8);
+    if (f > 1.4142135623730951) { f = f * 0.5; e += 1; }
+    const double s = (f - 1.0) / (f + 1.0), z = s * s;
+    double poly = 1.0 / 21.0;
+    poly = poly * z + 1.0 / 19.0;
+    poly = poly * z + 1.0 / 17.0;
+    poly = poly * z + 1.0 / 15.0;
+    poly = poly * z + 1.0 / 13.0;
+    poly = poly * z + 1.0 / 11.0;
+    poly = poly * z + 1.0 / 9.0;
+    poly = poly * z + 1.0 / 7.0;
+    poly = poly * z + 1.0 / 5.0;
+    poly = poly * z + 1.0 / 3.0;
+    poly = poly * z + 1.0;
+    return (double) e * 0.6931471805599453 + 2.0 * s * poly;
+}
+
+typedef struct {
+    int m;
+    uint32_t q, klow, since;
+    double inv_am, inv_ln_b;
+    uint32_t *K;
+} hll_t;
+
+static void hll_init(hll_t *s, int m) {
+    s->m = m;
+    s->q = g_hll.q;
+    s->klow = 0;
+    s->since = 0;
+    s->inv_am = 1.0 / (g_hll.a * (double) m);
+    s->inv_ln_b = 1.0 / kmo_log(g_hll.b);
+    s->K = (uint32_t *) calloc((size_t) m, 4);
+}
+static void hll_free(hll_t *s) { free(s->K); }
+
+static void hll_sketch(hll_t *s, uint64_t hval, uint32_t flags) {
+    uint64_t st[4];
+    kmo_xoshiro_seed(hval, st);
+    double x = 0.0;
+    for (int j = 0; j < s->m; j++) {
+        x += -kmo_log(1.0 - unif01_f64(st)) * s->inv_am;
+        const double t = 1.0 - kmo_log(x) * s->inv_ln_b;
+        uint32_t k = 0;
+        if (t >= (double) s->q + 1.0) k = s->q + 1;
+        else if (t > 0.0) k = (uint32_t) t; /* floor of a positive value */
+        if (k <= s->klow) break;
+        const uint64_t i = unif_usize(st, 0, (uint64_t) s->m, flags);
+        if (k > s->K[i]) {
+            s->K[i] = k;
+            if (++s->since >= (uint32_t) s->m) { /* "if w >= m: K_low <- min(K)" */
+                uint32_t mn = s->K[0];
+                for (int t2 = 1; t2 < s->m; t2++) mn = s->K[t2] < mn ? s->K[t2] : mn;
+                s->klow = mn;
+                s->since = 0;
+            }
+        }
+    }
+}
+
 /* ====================================================================================================
  * bottom-k with multiplicities: MinHashCount::push, src/sketching/minhash.rs:62-99 (u16 counts) and
  * MinInvHashCountKmer::push :219-265 (u8 counts).  Literal: max-heap + map, `<=` acceptance.
@@ -938,7 +1021,9 @@ static void botk_push(botk_t *b, uint64_t new_hash, uint32_t count_mask) {
  * L3  sketch drivers (same contract as kmu_sketch / kmu_sketch_hashed)
  * ==================================================================================================== */
 
-static size_t sig_bytes(int sig_type) { return (sig_type == KMU_SIG_U32 || sig_type == KMU_SIG_F32) ? 4 : 8; }
+static size_t sig_bytes(int sig_type) {
+    return sig_type == KMU_SIG_U16 ? 2 : (sig_type == KMU_SIG_U32 || sig_type == KMU_SIG_F32) ? 4 : 8;
+}
 
 static int sketch_params_check(const kmu_sketch_params *p) {
     if (p->algo != KMU_ALGO_BOTTOMK && p->sketch_size < 2) return KMU_E_BAD_ARG;
@@ -961,6 +1046,10 @@ static int sketch_params_check(const kmu_sketch_params *p) {
     case KMU_ALGO_BOTTOMK:
         if (p->sig_type != KMU_SIG_U64) return KMU_E_BAD_ARG;
         break;
+    case KMU_ALGO_HLL:
+        if (p->sig_type != KMU_SIG_U16 && p->sig_type != KMU_SIG_U32 && p->sig_type != KMU_SIG_U64) return KMU_E_BAD_ARG;
+        if (p->sig_type == KMU_SIG_U16 && g_hll.q + 1 > 65535u) return KMU_E_BAD_ARG;
+        break;
     default: return KMU_E_BAD_ARG;
     }
     if (p->block_size < 0) return KMU_E_BAD_ARG;
@@ -975,6 +1064,7 @@ typedef struct {
     mset_t ms;
     smh_t smh;
     oph_t oph;
+    hll_t hll;
     botk_t bk;
     int open;
 } sk_state_t;
@@ -988,6 +1078,7 @@ static void sk_begin(sk_state_t *st, const kmu_sketch_params *p, uint64_t expect
     else if (p->algo == KMU_ALGO_SUPER) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_F32 ? 1 : 0);
     else if (p->algo == KMU_ALGO_SUPER2) smh_init(&st->smh, p->sketch_size, p->sig_type == KMU_SIG_U32 ? 3 : 2);
     else if (is_dens(p->algo)) oph_init(&st->oph, p->sketch_size, p->sig_type == KMU_SIG_F32);
+    else if (p->algo == KMU_ALGO_HLL) hll_init(&st->hll, p->sketch_size);
     else botk_init(&st->bk, p->sketch_size);
     st->open = 1;
 }
@@ -999,6 +1090,8 @@ static void sk_feed(sk_state_t *st, const uint64_t *hashed, uint64_t n) {
         for (uint64_t i = 0; i < n; i++) smh_sketch(&st->smh, hasher_finish(p->hasher, hashed[i], st->w), p->flags);
     } else if (is_dens(p->algo)) {
         for (uint64_t i = 0; i < n; i++) oph_sketch(&st->oph, hasher_finish(p->hasher, hashed[i], st->w), p->flags);
+    } else if (p->algo == KMU_ALGO_HLL) {
+        for (uint64_t i = 0; i < n; i++) hll_sketch(&st->hll, hasher_finish(p->hasher, hashed[i], st->w), p->flags);
     } else {
         /* MinHashCount counts are u16, MinInvHashCountKmer (hasher = int64_hash) u8; both wrap in release */
         uint32_t cmask = p->hasher == KMU_HASHER_INT64HASH ? 0xFFu : 0xFFFFu;
@@ -1030,6 +1123,13 @@ static int sk_end(sk_state_t *st, void *sig_row, uint32_t *count_row) {
         if (p->sig_type == KMU_SIG_F32) for (int i = 0; i < m; i++) ((float *) sig_row)[i] = (float) st->oph.hs[i];
         else memcpy(sig_row, st->oph.hs, (size_t) m * 8);
         oph_free(&st->oph);
+    } else if (p->algo == KMU_ALGO_HLL) {
+        for (int i = 0; i < m; i++) {
+            if (p->sig_type == KMU_SIG_U16) ((uint16_t *) sig_row)[i] = (uint16_t) st->hll.K[i];
+            else if (p->sig_type == KMU_SIG_U32) ((uint32_t *) sig_row)[i] = st->hll.K[i];
+            else ((uint64_t *) sig_row)[i] = st->hll.K[i];
+        }
+        hll_free(&st->hll);
     } else {
         for (int i = 0; i < m; i++) {
             ((uint64_t *) sig_row)[i] = i < st->bk.n ? st->bk.h[i] : UINT64_MAX;

@@ -14,7 +14,7 @@
  *              tests/test_oracle_kat.py): the FASTQ reader rule (io.rs / datasketcher.rs), the signature comparison
  *              functions (seqsketchjaccard.rs, seqblocksketch.rs, minhash.rs).
  *   UNPINNED : Wang invertible hashes, xoshiro seeding, ProbMinHash3a / ProbMinHash3, SuperMinHash, SuperMinHash2,
- *              OptDensMinHash / RevOptDensMinHash internals.
+ *              OptDensMinHash / RevOptDensMinHash, SetSketcher internals.
  *              They live in the un-vendored crate `probminhash = "0.1"` (reference Cargo.toml:89), which is
  *              not in /root/reference and cannot be built here (no Rust toolchain).  They are restated from
  *              Ertl's papers (arXiv 1706.05698, 1911.00675), Shrivastava (ICML 2017) and Mai et al. (UAI 2019) for the
@@ -96,6 +96,10 @@ int kmo_probminhash3(const uint64_t *keys, const double *weights, uint64_t n, in
 /* ingest */
 int kmo_ingest_fastq(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
                      uint64_t info[6]);
+/* SetSketch (KMU_ALGO_HLL): parameters of the following kmo_sketch calls (defaults b = 1.001, a = 20, q = 65534); kmo_log is the
+ * logarithm both sides use */
+void kmo_set_hll_params(double b, double a, uint32_t q);
+double kmo_log(double x);
 int kmo_ingest_fasta(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,
                      uint64_t info[6]);
 int kmo_ingest_fastx(const uint8_t *text, uint64_t n, uint8_t *bases_out, uint64_t *offsets_out, uint32_t *record_index_out,

@@ -271,3 +271,11 @@ def ingest_fasta(text):
 
 def ingest_fastx(text):
     return ingest_fastq(text, "fastx")
+
+
+def set_hll_params(b=1.001, a=20.0, q=65534):
+    """SetSketchParams of the following KMU_ALGO_HLL sketches"""
+    f = lib().kmo_set_hll_params
+    f.argtypes = [C.c_double, C.c_double, C.c_uint32]
+    f.restype = None
+    f(b, a, q)

@@ -350,6 +350,38 @@ TEST(test_seqaa_optdensminhash_trait_32bit) {
                                       KMU_FHASH_VALUE_MASKED));
 }
 
+// HyperLogLogSketch (setsketchert.rs:640-896).  The reference holds no test of it; this one checks what its callers rely on:
+// rows in sequence order, one row of hll_params.m registers for a list, registers of a list = maximum over its sequences
+// (SetSketcher::merge, :868-885), equal to the oracle's registers
+TEST(test_hyperloglog_sketch_trait) {
+    std::mt19937_64 rng(640);
+    std::vector<Sequence> seqs;
+    Ascii a;
+    for (size_t len : {size_t(30000), size_t(800), size_t(12000)}) {
+        std::string s(len, 'A');
+        for (char &c : s) c = "ACGT"[rng() & 3];
+        seqs.emplace_back(s);
+        a.add(s);
+    }
+    auto vseq = detail::pointers(seqs);
+    SeqSketcherParams seq_params(21, 1024, SketchAlgo::HLL, DataType::DNA);
+    SetSketchParams hll_params;
+    hll_params.m = 1024;
+    HyperLogLogSketch<Kmer64bit, uint16_t> sketcher(seq_params, hll_params, HllSeqsThreading{});
+    CHECK(sketcher.get_algo() == SketchAlgo::HLL && sketcher.get_kmer_size() == 21);
+    auto per_seq = sketcher.sketch_compressedkmer(vseq, kmer_revcomp_hash_fn);
+    auto all = sketcher.sketch_compressedkmer_seqs(vseq, kmer_revcomp_hash_fn);
+    CHECK(per_seq.size() == 3 && all.size() == 1 && all[0].size() == 1024);
+    for (size_t t = 0; t < 1024; t++) CHECK(all[0][t] == std::max(per_seq[0][t], std::max(per_seq[1][t], per_seq[2][t])));
+    kmo_set_hll_params(hll_params.b, hll_params.a, hll_params.q);
+    CHECK(per_seq == oracle_sketch<uint16_t>(a, KMU_ALGO_HLL, KMU_KMER64BIT, 21, 1024, KMU_SIG_U16, KMU_HASHER_NOHASH,
+                                             KMU_FHASH_CANON_INVHASH));
+    HyperLogLogSketch<Kmer64bit, uint32_t> sketcher32(seq_params, hll_params);
+    CHECK(sketcher32.sketch_compressedkmer_seqs(vseq, kmer_revcomp_hash_fn) ==
+          oracle_sketch<uint32_t>(a, KMU_ALGO_HLL, KMU_KMER64BIT, 21, 1024, KMU_SIG_U32, KMU_HASHER_NOHASH,
+                                  KMU_FHASH_CANON_INVHASH, KMU_MODE_ALL_SEQS));
+}
+
 // an arbitrary closure (evaluated on the host, sketched on the device) gives what the named closure gives on the device
 TEST(test_closure_fallback_equals_device_closure) {
     Sequence seqa(SEQSTR);

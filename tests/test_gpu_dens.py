@@ -132,3 +132,59 @@ def test_genome_sized_sequence_and_errors(ctx, oracle):
     for bad in (params(A.ALGO_OPTDENS, A.KMER64BIT, 21, 64, A.SIG_U64), params(A.ALGO_REVOPTDENS, A.KMER64BIT, 21, 60000, A.SIG_F64)):
         with pytest.raises(KmuError):
             ctx.sketch(bases, off, bad)
+
+
+# ---- SetSketch registers (KMU_ALGO_HLL, HyperLogLogSketch of src/sketching/setsketchert.rs:640-896) ------------------------
+@pytest.mark.parametrize("m,sig", [(256, A.SIG_U16), (4096, A.SIG_U32), (1000, A.SIG_U64)])
+def test_hll_registers_match_the_oracle(ctx, oracle, m, sig):
+    """per sequence, one for all, caller-hashed values, a genome-sized sequence; default and non-default SetSketchParams"""
+    rng = np.random.default_rng(640 + m)
+    seqs = _reads(rng, [25, 4000, 60000, 300, 9]) + [b"ACGT" * 500]
+    bases, off = oracle.concat(seqs)
+    for b, a, q in ((1.001, 20.0, 65534), (1.05, 5.0, 254)):
+        if sig == A.SIG_U16 or q < 60000:
+            pass
+        ctx.set_hll_params(b, a, q)
+        oracle.set_hll_params(b, a, q)
+        for mode in (A.MODE_PER_SEQ, A.MODE_ALL_SEQS):
+            p = params(A.ALGO_HLL, A.KMER64BIT, 21, m, sig, mode=mode)
+            want = oracle.sketch(bases, off, p)
+            got = np.asarray(ctx.sketch(bases, off, p))
+            assert got.dtype == want.dtype and np.array_equal(got, want), (m, sig, b, mode)
+            assert want.max() <= q + 1
+        vals = rng.integers(0, 1 << 62, size=30000, dtype=np.uint64)
+        voff = np.array([0, 50, 50, 30000], np.uint64)
+        p = params(A.ALGO_HLL, A.KMER64BIT, 21, m, sig, hasher=A.HASHER_FNV1A, flags=A.FLAG_RAND08)
+        assert np.array_equal(np.asarray(ctx.sketch_hashed(vals, voff, p)), oracle.sketch_hashed(vals, voff, p))
+    ctx.set_hll_params()
+    oracle.set_hll_params()
+
+
+def test_hll_large_inputs_properties_and_partials(ctx, oracle):
+    """a 1.5 Mbase sequence (whole grid), amino acids, the cardinality the registers imply, and mergeability: registers of
+    shares merge by maximum to the registers of the whole (kmu_sketch_partial / kmu_sketch_merge_partials)"""
+    import math
+    rng = np.random.default_rng(641)
+    seqs = _reads(rng, [1_500_000, 3000, 200_000])
+    bases, off = oracle.concat(seqs)
+    m = 4096
+    p = params(A.ALGO_HLL, A.KMER64BIT, 25, m, A.SIG_U16, mode=A.MODE_ALL_SEQS)
+    want = oracle.sketch(bases, off, p)
+    got = np.asarray(ctx.sketch(bases, off, p))
+    assert np.array_equal(got, want)
+    pp = params(A.ALGO_HLL, A.KMER64BIT, 25, m, A.SIG_U16)
+    assert np.array_equal(np.asarray(ctx.sketch(bases, off, pp)), oracle.sketch(bases, off, pp))
+    # Ertl's estimator: n = m (1 - 1/b) / (a ln b sum b^-K); distinct canonical 25-mers of random sequences ~ all of them
+    K = got[0].astype(np.float64)
+    b, a = 1.001, 20.0
+    est = m * (1 - 1 / b) / (a * math.log(b) * np.sum(b ** (-K)))
+    n_true = np.unique(oracle.kmer_hashes(bases, off, A.KMER64BIT, 25, A.FHASH_CANON_INVHASH)[
+        np.concatenate([np.arange(int(off[i]), int(off[i + 1]) - 24) for i in range(3)])]).size
+    assert abs(est - n_true) / n_true < 0.08
+    parts = np.stack([np.asarray(ctx.sketch_partial(bases, off[a0:b0 + 1].copy(), p)) for a0, b0 in ((0, 1), (1, 3))])
+    assert np.array_equal(np.asarray(ctx.sketch_merge_partials(parts, p)), want[0])
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    prot = [rng.choice(aa, size=int(n)).tobytes() for n in (40, 900, 30000)]
+    pb, po = oracle.concat(prot)
+    pa = params(A.ALGO_HLL, A.KMERAA64BIT, 7, 512, A.SIG_U32, fhash=A.FHASH_VALUE_MASKED)
+    assert np.array_equal(np.asarray(ctx.sketch(pb, po, pa)), oracle.sketch(pb, po, pa))

@@ -163,3 +163,43 @@ def test_probminhash3_equals_3a_in_the_oracle():
             p3 = A.SketchParams(A.ALGO_PROB3, kt, k, m, sig, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
             p3a = A.SketchParams(A.ALGO_PROB3A, kt, k, m, sig, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
             assert np.array_equal(O.sketch(b, o, p3), O.sketch(b, o, p3a))
+
+
+def test_setsketch_oracle_properties():
+    """KMU_ALGO_HLL restates Ertl's SetSketch1 (the crate's own version is not in the tree and the reference holds no test of
+    HyperLogLogSketch): the restatement must at least have the properties the paper proves -- registers of a union are the
+    maxima (what HyperLogLogSketch::sketch_compressedkmer_seqs relies on when it merges blocks, setsketchert.rs:868-885), the
+    cardinality estimator m (1 - 1/b) / (a ln b sum b^-K) is unbiased to about 1/sqrt(m), registers stay inside [0, q + 1] --
+    and its logarithm must be a logarithm"""
+    import ctypes as C
+    import math
+    from oracle import oracle as O
+    L = O.lib()
+    L.kmo_log.restype = C.c_double
+    L.kmo_log.argtypes = [C.c_double]
+    rng = np.random.default_rng(2101)
+    for x in list(rng.random(500) * 8) + [1e-12, 1e-3, 0.5, 1.0, 1.001, 2.0, 1e9]:
+        assert abs(L.kmo_log(x) - math.log(x)) < 1e-15 * max(1.0, abs(math.log(x)))
+    m = 4096
+    p = A.SketchParams(A.ALGO_HLL, A.KMER64BIT, 21, m, A.SIG_U32, A.HASHER_NOHASH, A.FHASH_IDENTITY_RAW, 0, 0, 0, 0, 0)
+    b, a = 1.001, 20.0
+    for n in (2000, 100_000):
+        vals = rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+        K = O.sketch_hashed(vals, np.array([0, n], np.uint64), p)[0].astype(np.float64)
+        est = m * (1 - 1 / b) / (a * math.log(b) * np.sum(b ** (-K)))
+        assert abs(est - n) / n < 0.06, (n, est)
+        assert K.max() <= 65535
+    v1 = rng.integers(0, 1 << 62, size=30_000, dtype=np.uint64)
+    v2 = np.concatenate([v1[:10_000], rng.integers(0, 1 << 62, size=20_000, dtype=np.uint64)])
+    p16 = A.SketchParams(A.ALGO_HLL, A.KMER64BIT, 21, 1024, A.SIG_U16, A.HASHER_NOHASH, A.FHASH_IDENTITY_RAW, 0, 0, 0, 0, 0)
+    k1 = O.sketch_hashed(v1, np.array([0, v1.size], np.uint64), p16)[0]
+    k2 = O.sketch_hashed(v2, np.array([0, v2.size], np.uint64), p16)[0]
+    ku = O.sketch_hashed(np.concatenate([v1, v2]), np.array([0, v1.size + v2.size], np.uint64), p16)[0]
+    assert np.array_equal(np.maximum(k1, k2), ku)
+    # inserting an element twice changes nothing; a small q clamps
+    kd = O.sketch_hashed(np.concatenate([v1, v1]), np.array([0, 2 * v1.size], np.uint64), p16)[0]
+    assert np.array_equal(kd, k1)
+    O.set_hll_params(1.2, 20.0, 30)
+    kq = O.sketch_hashed(v1, np.array([0, v1.size], np.uint64), p16)[0]
+    O.set_hll_params()
+    assert kq.max() == 31
