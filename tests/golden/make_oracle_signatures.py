@@ -30,6 +30,8 @@ def revcomp(s):
 
 
 DNA = [SEQSTR, SEQSTR[:40], revcomp(SEQSTR)]
+DENS = [b"ATCATGCCCCTTTAGAAAATTTCCGGATCATCGTACGGAGCATGCGTACAACGTCGATGC",   # setsketchert.rs:1081-1083
+        b"ATCATGCCCCTTTAGAAAATTTCCGGATCATCATGCCCCTTTAGAAAATTTCCGGATC"]
 CASES = [
     # name, sequences, algo, kmer_type, k, m, sig, hasher, fhash, flags
     ("pminhasha_kmer_smallb_revcomp", DNA, A.ALGO_PROB3A, A.KMER32BIT, 5, 200, A.SIG_U32, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0),
@@ -43,6 +45,11 @@ CASES = [
     ("seqaa_probminhash_64bit", [AA1, AA2], A.ALGO_PROB3A, A.KMERAA64BIT, 5, 400, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0),
     ("seqaa_probminhash_32bit", [AA1, AA2], A.ALGO_PROB3A, A.KMERAA32BIT, 5, 400, A.SIG_U32, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0),
     ("seqaa_superminhash_64bit_f64", [AA1, AA2], A.ALGO_SUPER, A.KMERAA64BIT, 5, 128, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0),
+    # setsketchert.rs:1075-1230 (m cut from 800 / 8000 to 400 / 1000), aautils/setsketchert.rs:1394
+    ("seq_optdensminhash_f64", DENS, A.ALGO_OPTDENS, A.KMER32BIT, 5, 400, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0),
+    ("seq_revoptdensminhash_f32", DENS, A.ALGO_REVOPTDENS, A.KMER32BIT, 5, 1000, A.SIG_F32, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0),
+    ("seqaa_optdensminhash_32bit_f64", [AA1, AA2], A.ALGO_OPTDENS, A.KMERAA32BIT, 5, 80, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0),
+    ("hyperloglog_u16_default_params", DNA, A.ALGO_HLL, A.KMER64BIT, 16, 256, A.SIG_U16, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0),
 ]
 
 

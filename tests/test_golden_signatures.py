@@ -21,7 +21,7 @@ def _params(c):
 
 
 def _rows(c):
-    dt = {A.SIG_U32: np.uint32, A.SIG_F32: np.uint32, A.SIG_U64: np.uint64, A.SIG_F64: np.uint64}[c["sig_type"]]
+    dt = {A.SIG_U32: np.uint32, A.SIG_F32: np.uint32, A.SIG_U64: np.uint64, A.SIG_F64: np.uint64, A.SIG_U16: np.uint16}[c["sig_type"]]
     return np.array(c["rows"], dtype=dt)
 
 
@@ -53,7 +53,8 @@ def test_reference_assertions_hold_on_the_frozen_rows():
         assert jac(rows, 0, 2) >= 1.0, name          # canonical k-mers: a sequence and its reverse complement
     rows = _rows(c["pminhasha_kmer_smallb_identity"])
     assert jac(rows, 0, 1) >= 0.75 * (40 - 5) / (80 - 5) and jac(rows, 0, 2) <= 0.1
-    for name in ("seqaa_probminhash_64bit", "seqaa_probminhash_32bit", "seqaa_superminhash_64bit_f64"):
+    for name in ("seqaa_probminhash_64bit", "seqaa_probminhash_32bit", "seqaa_superminhash_64bit_f64", "seq_optdensminhash_f64",
+                 "seq_revoptdensminhash_f32", "seqaa_optdensminhash_32bit_f64"):   # setsketchert.rs:1124, 1208; aautils :1444
         rows = _rows(c[name])
         assert abs(jac(rows, 0, 1) - 0.5) < 0.1, name
 
@@ -73,3 +74,10 @@ def test_device_reproduces_the_frozen_rows(ctx, oracle, name):
     bases, off = oracle.concat([s.encode() for s in c["sequences"]])
     got = _bits(np.asarray(ctx.sketch(bases, off, _params(c))))
     assert np.array_equal(got, _rows(c))
+
+
+def test_frozen_hll_rows_merge_by_maximum():
+    """the HLL case holds (seq, its first half, its reverse complement) sketched on canonical k-mers: the reverse complement
+    has the same registers, the half has registers no larger"""
+    rows = _rows(FIX["cases"]["hyperloglog_u16_default_params"])
+    assert np.array_equal(rows[0], rows[2]) and (rows[1] <= rows[0]).all() and rows[0].max() > 0
