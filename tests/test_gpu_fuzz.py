@@ -2,12 +2,16 @@
 bit for bit with the oracle.  Complements the hand-picked cases of test_gpu_parity.py with odd sizes: sketch sizes 1 ..
 4000, every k the value types allow, reads shorter than k, reads longer than one LDS pass, highly repetitive reads,
 blocks, one-signature-for-all, both hashers, flags."""
+import os
+
 import numpy as np
 import pytest
 
 from kmerutils_amd import _abi as A
 
 pytestmark = pytest.mark.gpu
+# KMU_FUZZ_SCALE=10 runs ten times as many seeds per sweep (an occasional long run; the default keeps the suite short)
+SCALE = int(os.environ.get("KMU_FUZZ_SCALE", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +56,7 @@ def _kmer_choice(rng):
     return t, int(rng.integers(15, 32))
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(64 * SCALE))
 def test_sketch_sweep(ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     kmer_type, k = _kmer_choice(rng)
@@ -99,7 +103,7 @@ def test_sketch_sweep(ctx, oracle, seed):
         assert a.shape == b.shape and a.tobytes() == b.tobytes(), (kmer_type, k, algo, m, fhash, kind, block, mode)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_count_sweep(ctx, oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     kmer_type, k = _kmer_choice(rng)
@@ -121,7 +125,7 @@ def test_count_sweep(ctx, oracle, seed):
     assert np.array_equal(c.query(probe), o.query(probe))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_aa_sketch_sweep(ctx, oracle, seed):
     rng = np.random.default_rng(3000 + seed)
     kmer_type = int(rng.choice([A.KMERAA32BIT, A.KMERAA64BIT]))
@@ -158,7 +162,7 @@ def test_aa_sketch_sweep(ctx, oracle, seed):
         assert np.asarray(got).tobytes() == np.asarray(want).tobytes(), (kmer_type, k, algo, m, fhash, mode)
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(32 * SCALE))
 def test_dens_sketch_sweep(ctx, oracle, seed):
     """OptDens / RevOptDens: DNA and amino acids, f32 / f64, both hashers and index draws, per sequence and for all; sketch
     sizes from 2 to 6000 against reads from 1 base to 60 k (empty bins: from none to almost all)"""
@@ -195,7 +199,7 @@ def test_dens_sketch_sweep(ctx, oracle, seed):
     assert got.shape == want.shape and got.tobytes() == np.asarray(want).tobytes(), (algo, kmer_type, k, m, sig, fhash, mode)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * SCALE))
 def test_counter_usage_sweep(ctx, oracle, seed, monkeypatch):
     """random sequences of counter operations against the oracle counter: batches of reads from the host, from the device
     (whole arrays and ranges of them), packed; explicit k-mer lists; merges of exported entries; the build path forced
