@@ -83,7 +83,9 @@ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (ui
 
 // misc words in LDS
 enum { M_READ = 0, M_NSCR = 1, M_NEXT = 2, M_DEF = 3, M_QMAX = 4 /* 4,5: u64 */, M_FLAGS = 6 /* 6,7 */, M_WORDS = 8 };
-static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions a workgroup can set aside per block
+static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions a workgroup can set aside per block,
+static constexpr uint32_t DEF_PARTS = 32;           //   one sub-list of DEF_CAP / DEF_PARTS keys per later partition
+static constexpr uint32_t DEF_SEG = DEF_CAP / DEF_PARTS;
 #define ABL(bits) (KMU_DIAG && (a.ablate & (bits)))
 
 static constexpr uint32_t LONG_SEQ_KMERS = 1u << 18; // longer sequences take the global partitioned route (kmu_sketch)
@@ -338,7 +340,8 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     uint32_t *misc = bst + NBUCKETS + 1;
     misc += (8 - ((NBUCKETS + 1) & 7)) & 7; // keep the u64 at misc[M_QMAX] 8-byte aligned
     uint32_t *wtot = misc + M_WORDS;
-    uint32_t *words = wtot + 16;
+    uint32_t *defc = wtot + 16; // keys set aside for partition p + 1 (DEF_PARTS counters)
+    uint32_t *words = defc + DEF_PARTS;
     words += (4 - ((uintptr_t) words >> 2 & 3)) & 3; // 16-byte aligned: raw chunks are parked here as uint4
     uint64_t *qmax_sh = reinterpret_cast<uint64_t *>(&misc[M_QMAX]);
     const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -466,7 +469,6 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             // A block that needs several partition passes is scanned (extracted, hashed) ONCE: pass 0 sets the keys of the
             // later partitions aside in a global list, the later passes read their keys from there.
             bool def_valid = false; // uniform
-            uint32_t def_n = 0;
             for (bool block_done = (P == 0); !block_done;) {
                 bool restart_block = false; // uniform
                 def_valid = false;
@@ -500,19 +502,24 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 __syncthreads(); // orders the scratch stores above
                             }
                             // ---- A1: bucket ranks of the keys of this partition in [q0, q1) ------------------------
-                            const bool defer_on = !BOTTOMK && P > 1 && part == 0 && !rounds_mode; // this pass fills the list
+                            // this pass fills the sub-lists (one per later partition; more partitions than sub-lists: rescan)
+                            const bool defer_on = !BOTTOMK && P > 1 && P <= DEF_PARTS + 1 && part == 0 && !rounds_mode;
                             const bool from_list = !BOTTOMK && part > 0 && !rounds_mode && def_valid;
+                            if (defer_on) {
+                                if ((uint32_t) tid < DEF_PARTS) defc[tid] = 0;
+                                if (tid == 0) misc[M_DEF] = 0; // becomes 1 if a sub-list overflows
+                                lds_barrier();
+                            }
                             if (from_list) {
-                                for (uint32_t i = tid; i < def_n; i += nthreads) {
-                                    const uint64_t key = ld_scr(&def_keys[i]);
-                                    const uint32_t h = mix32(key);
-                                    if (mulhi32(h * 0x85EBCA6Bu, P) == part) {
-                                        const uint32_t b = h >> (32 - BUCKET_BITS);
-                                        const uint32_t rank = atomicAdd(&bst[b], 1u);
-                                        if (rank < 65536u) { // (a pass of a partitioned block parks its keys: use_park)
-                                            const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
-                                            if (si < (uint32_t) KREG * nthreads && si < cap) { dk[si] = key; dw[si] = (b << 16) | rank; }
-                                        }
+                                const uint32_t seg_n = uniform_u32(defc[part - 1]);
+                                const uint64_t *seg = def_keys + (uint64_t) (part - 1) * DEF_SEG;
+                                for (uint32_t i = tid; i < seg_n; i += nthreads) {
+                                    const uint64_t key = ld_scr(&seg[i]);
+                                    const uint32_t b = mix32(key) >> (32 - BUCKET_BITS);
+                                    const uint32_t rank = atomicAdd(&bst[b], 1u);
+                                    if (rank < 65536u) { // (a pass of a partitioned block parks its keys: use_park)
+                                        const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
+                                        if (si < (uint32_t) KREG * nthreads && si < cap) { dk[si] = key; dw[si] = (b << 16) | rank; }
                                     }
                                 }
                             }
@@ -579,11 +586,13 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                                 if (BOTTOMK) key = hasher_finish(a.hasher, key, sig32);
                                                 h = mix32(key);
                                                 if (ABL(2u)) go = false;
-                                                if (P > 1 && mulhi32(h * 0x85EBCA6Bu, P) != part) {
+                                                const uint32_t kp = P > 1 ? mulhi32(h * 0x85EBCA6Bu, P) : 0u;
+                                                if (kp != part) {
                                                     go = false;
-                                                    if (defer_on) { // a later pass will pick it up without re-hashing
-                                                        const uint32_t di = atomicAdd(&misc[M_DEF], 1u);
-                                                        if (di < DEF_CAP) st_scr(&def_keys[di], key);
+                                                    if (defer_on) { // its own pass will pick it up without re-hashing
+                                                        const uint32_t di = atomicAdd(&defc[kp - 1], 1u);
+                                                        if (di < DEF_SEG) st_scr(&def_keys[(uint64_t) (kp - 1) * DEF_SEG + di], key);
+                                                        else misc[M_DEF] = 1u;
                                                     }
                                                 }
                                             } else if (val == 0x1234567ull) full = true;
@@ -607,10 +616,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                             if (tid == 0 && !next_posted) { misc[M_NEXT] = r_next; next_posted = true; }
                             __syncthreads();
-                            if (defer_on) { // the list is complete (every position was scanned), provided it fitted
-                                def_n = uniform_u32(misc[M_DEF]);
-                                def_valid = def_n <= DEF_CAP;
-                            }
+                            if (defer_on) def_valid = uniform_u32(misc[M_DEF]) == 0u; // complete (every position scanned) if all fitted
                             // ---- A2: counts -> starts, dense placement ---------------------------------------------
                             phase(2); // A1
                             r_follow = uniform_u32(misc[M_NEXT]);
@@ -834,7 +840,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                             if (overflow || last_round) {
                                 bucket_clear(bst);
-                                if (tid == 0) { misc[M_NSCR] = 0; misc[M_DEF] = 0; }
+                                if (tid == 0) misc[M_NSCR] = 0;
                                 lds_barrier(); // the points are final (-> signature row); bst is clean for the next pass
                                 phase(7); // B2 + clear
                             }
@@ -1251,7 +1257,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     // LDS budget: dense keys 8 cap | weights 4 cap | slot minima 16 m | buckets 4 (NB+1) | misc | staged words
     // (bottom-k re-uses the staged-word area for its per-bucket distinct counts: NBUCKETS + 1 words)
     a.tile_words = (aa && !bottomk) ? 4 : (lds_max > 64 * 1024 || bottomk ? 4096 + 2 : 1024 + 2);
-    size_t fixed = (size_t) 16 * a.m + 4 * ((size_t) NBUCKETS + 1 + 8) + 4 * (M_WORDS + 16) +
+    size_t fixed = (size_t) 16 * a.m + 4 * ((size_t) NBUCKETS + 1 + 8) + 4 * (M_WORDS + 16 + DEF_PARTS) +
                    4 * ((size_t) a.tile_words + 4) + 64;
     if (fixed + 12 * 256 > lds_max) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS", a.m);
     uint32_t cap = (uint32_t) ((lds_max - fixed) / 12);
