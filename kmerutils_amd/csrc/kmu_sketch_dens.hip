@@ -44,6 +44,8 @@ struct DensArgs {
     int sig_bytes; // 2 / 4 / 8: width of a signature entry
     uint32_t q;   // SetSketch: registers are clamped to [0, q + 1]
     double inv_am, inv_ln_b; // SetSketch: 1 / (a m), 1 / ln b
+    uint32_t idx_thresh;  // rand 0.9 Uniform<usize>(0, m): reject while lo < (2^32 - m) % m
+    uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
     const void *hashed; // pre-hashed input (offsets count values), else null
     int hashed_bytes;
     uint32_t skip_longer; // sequences with more k-mers are left to k_oph_long
@@ -82,6 +84,21 @@ __device__ __forceinline__ SeqView dens_view(const DensArgs &a, uint32_t r) {
         sv.total = a.total_bytes ? a.total_bytes : a.offsets[a.n_seq];
     }
     return sv;
+}
+
+// Uniform<usize>(0, m) with the rejection bounds computed once on the host (the sketch size is fixed for the launch)
+__device__ __forceinline__ uint32_t dens_draw_bin(const DensArgs &a, Xoshiro &rng) {
+    if (a.rand08) {
+        for (;;) {
+            const uint64_t v = rng.next();
+            const uint64_t hi = __umul64hi(v, (uint64_t) a.m), lo = v * (uint64_t) a.m;
+            if (lo <= a.idx_zone) return (uint32_t) hi;
+        }
+    }
+    for (;;) {
+        const uint64_t mm = (uint64_t) rng.next_u32() * (uint32_t) a.m;
+        if ((uint32_t) mm >= a.idx_thresh) return (uint32_t) (mm >> 32);
+    }
 }
 
 // natural logarithm of a positive normal double from +, -, *, / only (the oracle carries the same few lines): x = 2^e f with
@@ -139,7 +156,7 @@ __device__ __forceinline__ void hll_wave_items(const DensArgs &a, uint64_t *hs, 
             else if (t > 0.0) k = (uint32_t) t;
             if (k <= *(volatile const uint32_t *) klow) active = false;
             else {
-                const uint32_t i = rng.unif_index(0u, (uint32_t) a.m, a.rand08 != 0);
+                const uint32_t i = dens_draw_bin(a, rng);
                 atomicMax((unsigned long long *) &hs[i], (unsigned long long) k);
                 if (++j >= a.m) active = false;
             }
@@ -155,15 +172,17 @@ __device__ __forceinline__ void oph_item(const DensArgs &a, uint64_t *hs, uint64
     uint64_t bits;
     if (a.f32) bits = (uint64_t) __float_as_uint(rng.unif01_f32());
     else bits = (uint64_t) __double_as_longlong(rng.unif01());
-    const uint32_t k = rng.unif_index(0u, (uint32_t) a.m, a.rand08 != 0);
+    const uint32_t k = dens_draw_bin(a, rng);
     atomicMin((unsigned long long *) &hs[k], (unsigned long long) bits);
 }
 
 // the items of words [st0, st1) x 64 of one sequence, waves striding by `stride` steps from `first`
+// (HLL: compile-time, so that the bins kernels do not carry the registers of the SetSketch loop)
+template <bool HLL>
 __device__ __forceinline__ uint32_t oph_walk(const DensArgs &a, const SeqView &sv, uint64_t *hs, uint32_t *klow, bool aa,
                                              uint64_t nk, uint64_t first, uint64_t stride) {
     uint32_t bad = 0;
-    if (a.hll) {
+    if constexpr (HLL) {
         // the values of a step are collected first (the visit is per lane and per position), then worked off slot by slot
         // with the whole wave in step -- hll_wave_items needs uniform control flow
         if (a.hashed_bytes) {
@@ -308,7 +327,7 @@ __device__ __forceinline__ void oph_lds(const DensArgs &a, uint8_t *smem, uint64
     claim = cnt + 4;
 }
 
-template <bool ALL>
+template <bool ALL, bool HLL>
 __global__ void __launch_bounds__(256) k_oph_reads(DensArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *hs;
@@ -338,7 +357,7 @@ __global__ void __launch_bounds__(256) k_oph_reads(DensArgs a) {
         if (!skip) {
             uint32_t bad = 0;
             if (nk == 0 && !a.hashed_bytes) bad = wave_validate_seq(sv, wave, nwaves, aa);
-            else bad = oph_walk(a, sv, hs, &cnt[3], aa, nk, (uint64_t) wave, (uint64_t) nwaves);
+            else bad = oph_walk<HLL>(a, sv, hs, &cnt[3], aa, nk, (uint64_t) wave, (uint64_t) nwaves);
             if (bad) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
         }
         __syncthreads();
@@ -356,6 +375,7 @@ __global__ void __launch_bounds__(256) k_oph_reads(DensArgs a) {
 }
 
 // one long sequence, walked by the whole grid; bins merged into a.row
+template <bool HLL>
 __global__ void __launch_bounds__(256) k_oph_long(DensArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint64_t *hs = reinterpret_cast<uint64_t *>(smem);
@@ -369,7 +389,7 @@ __global__ void __launch_bounds__(256) k_oph_long(DensArgs a) {
     __syncthreads();
     const SeqView sv = dens_view(a, a.long_seq);
     const uint64_t nk = sv.len >= (uint64_t) a.cfg.k ? sv.len - a.cfg.k + 1 : 0;
-    const uint32_t bad = oph_walk(a, sv, hs, klow, aa, nk, (uint64_t) blockIdx.x * nwaves + wave, (uint64_t) gridDim.x * nwaves);
+    const uint32_t bad = oph_walk<HLL>(a, sv, hs, klow, aa, nk, (uint64_t) blockIdx.x * nwaves + wave, (uint64_t) gridDim.x * nwaves);
     if (bad) atomicOr(a.err, aa ? DERR_BAD_AA : DERR_NON_ACGT);
     __syncthreads();
     oph_merge_to_row(a, hs);
@@ -453,6 +473,8 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
     a.rev = p->algo == KMU_ALGO_REVOPTDENS;
     a.hll = p->algo == KMU_ALGO_HLL;
     a.sig_bytes = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    a.idx_thresh = (0u - (uint32_t) a.m) % (uint32_t) a.m;
+    a.idx_zone = 0xFFFFFFFFFFFFFFFFull - (0xFFFFFFFFFFFFFFFFull - (uint64_t) a.m + 1ull) % (uint64_t) a.m;
     if (a.hll) { // SetSketchParams of the context; 1 / ln b with the kernels' own logarithm (same formula on the host)
         a.q = ctx->hll.q;
         a.inv_am = 1.0 / (ctx->hll.a * (double) a.m);
@@ -466,7 +488,9 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
     const size_t lds_max = 160 * 1024;
     if (lds_full > lds_max)
         return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d: the bins of a densified sketch (%zu B) do not fit the LDS", a.m, lds_full);
-    const void *fns[4] = {(const void *) k_oph_reads<false>, (const void *) k_oph_reads<true>, (const void *) k_oph_long,
+    const void *fns[7] = {(const void *) k_oph_reads<false, false>, (const void *) k_oph_reads<true, false>,
+                          (const void *) k_oph_reads<false, true>,  (const void *) k_oph_reads<true, true>,
+                          (const void *) k_oph_long<false>,         (const void *) k_oph_long<true>,
                           (const void *) k_oph_finish};
     if (lds_full > 64 * 1024)
         for (const void *fn : fns)
@@ -510,15 +534,18 @@ int launch_dens(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, voi
     if (all) fill_row();
     {
         KernelTimer t(ctx, "k_oph_reads");
-        if (all) hipLaunchKernelGGL(k_oph_reads<true>, dim3(grid), dim3(256), lds_full, ctx->stream, a);
-        else hipLaunchKernelGGL(k_oph_reads<false>, dim3(grid), dim3(256), lds_full, ctx->stream, a);
+        if (all && a.hll) hipLaunchKernelGGL((k_oph_reads<true, true>), dim3(grid), dim3(256), lds_full, ctx->stream, a);
+        else if (all) hipLaunchKernelGGL((k_oph_reads<true, false>), dim3(grid), dim3(256), lds_full, ctx->stream, a);
+        else if (a.hll) hipLaunchKernelGGL((k_oph_reads<false, true>), dim3(grid), dim3(256), lds_full, ctx->stream, a);
+        else hipLaunchKernelGGL((k_oph_reads<false, false>), dim3(grid), dim3(256), lds_full, ctx->stream, a);
     }
     const int grid_long = ctx->num_cus * (int) std::max<size_t>(1, std::min<size_t>(8, lds_max / std::max<size_t>(lds_acc, 1024)));
     for (uint32_t i : long_seqs) {
         if (!all) fill_row();
         a.long_seq = i;
         KernelTimer t(ctx, "k_oph_long");
-        hipLaunchKernelGGL(k_oph_long, dim3(grid_long), dim3(256), lds_acc, ctx->stream, a);
+        if (a.hll) hipLaunchKernelGGL(k_oph_long<true>, dim3(grid_long), dim3(256), lds_acc, ctx->stream, a);
+        else hipLaunchKernelGGL(k_oph_long<false>, dim3(grid_long), dim3(256), lds_acc, ctx->stream, a);
         if (!all) {
             a.out_row = i;
             hipLaunchKernelGGL(k_oph_finish, dim3(1), dim3(256), lds_full, ctx->stream, a);
