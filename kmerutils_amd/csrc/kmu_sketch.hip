@@ -63,6 +63,11 @@ struct SketchArgs {
     uint32_t *lst_w;
     uint32_t *lst_n;
     uint32_t *queue2;     // read counter of k_pmh_points
+    // The PLAIN instantiation leaves a sequence whose k-mers overflow a pass (repetitive reads: rounds with carry lists) to
+    // the general one: it appends the sequence to redo_list (count in queue[56]); the second launch walks read_list.
+    uint32_t *redo_list;
+    const uint32_t *read_list; // non-null: queue entry q stands for sequence read_list[q]
+    uint32_t n_queue;          // queue entries (n_seq, or the length of read_list)
     uint32_t tile_words;  // staged code words per tile (16 bases each)
     uint32_t idx_thresh;  // rand 0.9 Uniform<usize>(0, m): reject while lo < (2^32 - m) % m
     uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
@@ -326,8 +331,17 @@ __device__ __forceinline__ void bucket_clear(uint32_t *bst) {
 // the allocator then spills loop-carried state around the read header and the kernel as a whole is slower.)
 // EMIT: stop after the multiset and write the distinct (key, weight) pairs of the read to global lists (k_pmh_points
 // generates the points from there, one wave per read at full occupancy) instead of running pass B here.
-template <bool AA, bool BOTTOMK, bool EMIT = false>
+// PLAIN: whole unpacked sequences to signature rows (the throughput case): the packed-input, block and partial-row paths
+// are compiled out of that instantiation.
+template <bool AA, bool BOTTOMK, bool EMIT = false, bool PLAIN = false>
 __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
+    if constexpr (PLAIN) { // the compiler sees constants wherever these are read below
+        a.packed = 0;
+        a.block_size = 0;
+        a.part_h = nullptr;
+        a.part_k = nullptr;
+        a.packed_offsets = nullptr;
+    }
     const KmerCfg cfg = a.cfg;
     const bool sig32 = a.sig_bytes == 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -373,9 +387,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
         misc[M_READ] = q_next++;
     }
     __syncthreads();
-    auto view_of = [&](uint32_t r) {
+    auto seq_of = [&](uint32_t q) -> uint32_t { return (!PLAIN && a.read_list) ? uniform_u32(a.read_list[q]) : q; };
+    auto view_of = [&](uint32_t q) {
         // (the header words come back in vector registers although `r` is uniform: handing them to the scalar unit
         // keeps every length, bound and address derived from them off the vector ALU)
+        const uint32_t r = seq_of(q);
         SeqView v;
         v.base = a.bases;
         v.len = uniform_u64(a.offsets[r + 1] - a.offsets[r]);
@@ -421,7 +437,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     lds_barrier();
     uint32_t r = uniform_u32(misc[M_READ]);
     if (ph_on) ph_t = __builtin_readcyclecounter();
-    while (r < a.n_seq) {
+    while (r < a.n_queue) {
         // Thread 0 takes the next read now (the atomic's latency hides under this read's work), posts it in
         // misc[M_NEXT] before the first barrier after the ranks are taken, and everybody picks it up behind that barrier.
         uint32_t r_next = 0, r_follow = 0xFFFFFFFFu;
@@ -464,6 +480,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
             if (ABL(64u)) P = 0;
             uint32_t bad = 0;
             bool full = false;
+            bool redo = false; // uniform; PLAIN only
             // k-mer occurrences of positions [q0, q1) that belong to partition `part` take a bucket rank; the first
             // KREG * nthreads positions of a SINGLE pass keep their key in registers, the rest goes to the scratch.
             // A block that needs several partition passes is scanned (extracted, hashed) ONCE: pass 0 sets the keys of the
@@ -491,7 +508,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                         for (uint32_t q0 = pb; q0 < pe && !overflow; q0 += round_len) {
                             const uint32_t q1 = pe - q0 > round_len ? q0 + round_len : pe;
                             const bool last_round = q1 == pe;
-                            if (carry_n) { // carried pairs take their ranks first (misc[M_NSCR] is 0 between passes)
+                            if (!PLAIN && carry_n) { // carried pairs take their ranks first (misc[M_NSCR] is 0 between passes)
                                 if (tid == 0) misc[M_NSCR] = carry_n;
                                 for (uint32_t i = tid; i < carry_n; i += nthreads) {
                                     const uint64_t key = ld_scr(&scr_keys[i]);
@@ -552,7 +569,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     // Where a key waits for the scan: in registers (one pass over a read that fits: its first
                                     // KREG * nthreads positions), parked unsorted in the still unused dense arrays (a pass of
                                     // a partitioned read keeps 1/P of the positions it scans), else in the global scratch.
-                                    const bool use_park = !rounds_mode && P > 1 && carry_n == 0;
+                                    const bool use_park = !rounds_mode && P > 1 && (PLAIN || carry_n == 0);
                                     const bool use_regs = !rounds_mode && !use_park && tile == 0 && pr == tp0;
 #pragma unroll
                                     for (int q = 0; q < KREG; q++) {
@@ -606,7 +623,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                                         const uint32_t si = atomicAdd(&misc[M_NSCR], 1u);
                                                         if (use_park) {
                                                             if (si < (uint32_t) KREG * nthreads && si < cap) { dk[si] = key; dw[si] = (b << 16) | rank; }
-                                                        } else if (si < cap) { st_scr(&scr_keys[si], key); st_scr(&scr_info[si], (b << 16) | rank); st_scr(&scr_w[si], 1u); }
+                                                        } else if (!PLAIN && si < cap) { st_scr(&scr_keys[si], key); st_scr(&scr_info[si], (b << 16) | rank); st_scr(&scr_w[si], 1u); }
                                                     }
                                                 }
                                             } else if (h == 0x12345u) full = true;
@@ -620,9 +637,9 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             // ---- A2: counts -> starts, dense placement ---------------------------------------------
                             phase(2); // A1
                             r_follow = uniform_u32(misc[M_NEXT]);
-                            if (nv_r != r_follow && r_follow < a.n_seq) { nv = view_of(r_follow); nv_r = r_follow; }
+                            if (nv_r != r_follow && r_follow < a.n_queue) { nv = view_of(r_follow); nv_r = r_follow; }
                             // parked keys move to the registers (the barriers of the scan separate this from the placement)
-                            const bool parked_pass = !rounds_mode && P > 1 && carry_n == 0;
+                            const bool parked_pass = !rounds_mode && P > 1 && (PLAIN || carry_n == 0);
                             const uint32_t n_park = parked_pass ? uniform_u32(misc[M_NSCR]) : 0u;
                             if (parked_pass && n_park <= (uint32_t) KREG * nthreads && n_park <= cap) {
 #pragma unroll
@@ -635,7 +652,9 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             if (!ABL(128u)) bucket_scan(bst, wtot);
                             phase(3); // scan
                             const uint32_t n_keys = uniform_u32(bst[NBUCKETS]);
-                            const uint32_t n_scr = parked_pass ? 0u : uniform_u32(misc[M_NSCR]);
+                            // (PLAIN: a single pass keeps every key in registers -- the host checks part_target -- and a
+                            //  partitioned one parks them: the scratch lists are not used)
+                            const uint32_t n_scr = (PLAIN || parked_pass) ? 0u : uniform_u32(misc[M_NSCR]);
                             if (n_keys > cap || n_scr > cap || n_park > (uint32_t) KREG * nthreads || n_park > cap) overflow = true;
                             if (!overflow && !ABL(1024u)) {
                                 // (all bucket starts are requested before the first store: a load behind a store to LDS
@@ -664,7 +683,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             phase(4); // placement
                             // ---- A3: a key with an earlier equal key in its bucket segment hands its weight over ------
                             const bool do_pf = !AA && !BOTTOMK && !a.packed && !overflow && last_round && blk + 1 == nblocks &&
-                                               part + 1 == P && nv_r == r_follow && r_follow < a.n_seq && !ABL(512u) &&
+                                               part + 1 == P && nv_r == r_follow && r_follow < a.n_queue && !ABL(512u) &&
                                                (size_t) a.tile_words * 4 >= (size_t) nthreads * 16;
                             if (do_pf) {
                                 uint32_t n = first_tile_words(nv);
@@ -727,7 +746,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                             __syncthreads();
                             phase(5); // A3
-                            if (!overflow && !last_round) {
+                            if (!PLAIN && !overflow && !last_round) {
                                 // ---- compact the distinct pairs into the carry list (scr_keys / scr_w) ------------------
                                 if (tid == 0) misc[M_NSCR] = 0;
                                 __syncthreads();
@@ -846,13 +865,15 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                         }
                         if (!overflow) part_done = true;
+                        else if (PLAIN) { redo = true; restart_block = true; part_done = true; } // the general kernel's
                         else if (!rounds_mode) rounds_mode = true; // redo this partition round by round
                         else { restart_block = true; part_done = true; }
                     }
                 }
                 if (!restart_block) block_done = true;
+                else if (PLAIN && redo) block_done = true;
                 else if (P >= 65536u) { full = true; block_done = true; }
-                else {
+                else if constexpr (!PLAIN) {
                     // too many distinct keys per partition: start the block over with twice as many partitions
                     P *= 2;
                     for (int t = tid; t < a.m; t += nthreads) { hmin[t] = H_INIT; sig[t] = 0; }
@@ -878,7 +899,16 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                 if (tid == 0) { a.lst_n[r] = misc[M_FLAGS]; misc[M_FLAGS] = 0u; } // the row is written by k_pmh_points
             } else {
                 // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
-                uint64_t row = a.block_rows ? a.block_rows[r] + blk : (uint64_t) r;
+                const uint32_t rs = seq_of(r);
+                uint64_t row = a.block_rows ? a.block_rows[rs] + blk : (uint64_t) rs;
+                if (PLAIN && redo) { // nothing of this sequence is kept: the general kernel sketches it from scratch
+                    __syncthreads(); // (points of earlier partitions may still be in flight)
+                    for (int t = tid; t < a.m; t += nthreads) { hmin[t] = H_INIT; sig[t] = 0; }
+                    if (tid == 0) {
+                        *qmax_sh = H_INIT;
+                        a.redo_list[atomicAdd(a.queue + 56, 1u)] = r;
+                    }
+                } else
                 for (int t = tid; t < a.m; t += nthreads) {
                     if (a.part_h) {
                         a.part_h[row * a.m + t] = hmin[t];
@@ -892,6 +922,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                     sig[t] = 0;
                 }
                 if (tid == 0) *qmax_sh = H_INIT;
+                if (PLAIN && redo) __syncthreads();
             }
             // (no barrier: the row and the slots are touched again only behind the barriers of the next pass)
         }
@@ -1204,6 +1235,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.packed_offsets = ds.packed_offsets;
     a.block_rows = d_block_rows;
     a.n_seq = ds.n_seq;
+    a.n_queue = ds.n_seq;
     a.packed = ds.packed;
     a.total_bytes = ds.total_bytes;
     a.cfg = KmerCfg{p->kmer_type, hashed_bytes ? 1 : p->kmer_size, p->fhash};
@@ -1236,9 +1268,13 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     const bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 && !skip_longer &&
                        (size_t) 4 * (2 * (size_t) p->sketch_size + 200) * 8 <= 146 * 1024 && // four waves' slot arrays fit one workgroup
                        split_env && atoi(split_env) == 1;
+    const char *plain_env = getenv("KMU_PMH_PLAIN"); // diagnostics: 0 = always the general instantiation
+    const bool plain = !bottomk && !aa && !split && !part_h && !d_block_rows && p->block_size == 0 && !ds.packed &&
+                 !(plain_env && atoi(plain_env) == 0) && !getenv("KMU_PMH_THREADS"); // (1024 threads: see part_target below)
     const sketch_kernel_t kern = bottomk ? (aa ? k_sketch_pmh3a<true, true> : k_sketch_pmh3a<false, true>)
                                  : aa    ? k_sketch_pmh3a<true, false>
                                  : split ? k_sketch_pmh3a<false, false, true>
+                                 : plain ? k_sketch_pmh3a<false, false, false, true>
                                          : k_sketch_pmh3a<false, false>;
     const void *fn = (const void *) kern;
     a.counts_out = d_counts;
@@ -1254,6 +1290,10 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         (void) hipGetLastError();
         lds_max = 64 * 1024;
     }
+    const sketch_kernel_t kern_redo = k_sketch_pmh3a<false, false>; // takes what the PLAIN instantiation hands back
+    if (plain && lds_max > 64 * 1024 &&
+        hipFuncSetAttribute((const void *) kern_redo, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) != hipSuccess)
+        return fail(ctx, KMU_E_HIP, "hipFuncSetAttribute failed for the general sketch kernel");
     // LDS budget: dense keys 8 cap | weights 4 cap | slot minima 16 m | buckets 4 (NB+1) | misc | staged words
     // (bottom-k re-uses the staged-word area for its per-bucket distinct counts: NBUCKETS + 1 words)
     a.tile_words = (aa && !bottomk) ? 4 : (lds_max > 64 * 1024 || bottomk ? 4096 + 2 : 1024 + 2);
@@ -1268,6 +1308,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.cap = cap;
     a.part_target = cap - cap / 10;
     a.inv_part_target = 1.0 / (double) a.part_target;
+    if (plain && a.part_target > (uint32_t) KREG * 1024u)
+        return fail(ctx, KMU_E_HIP, "internal: a single pass (%u k-mers) must fit the register keys of the PLAIN kernel", a.part_target);
     {
         const uint32_t tp = (a.tile_words - 2) * 16; // 4096 or 1024 words of 16 bases
         a.tile_shift = 0;
@@ -1321,11 +1363,30 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         a.lst_n = (uint32_t *) ln;
         a.queue2 = a.queue + 48;
     }
+    if (plain) {
+        void *rl;
+        KMU_TRY(dev_buf(ctx, "pmh.redo", (size_t) ds.n_seq * 4 + 64, &rl));
+        a.redo_list = (uint32_t *) rl;
+    }
     {
         KernelTimer t(ctx, bottomk ? "k_sketch_bottomk" : "k_sketch_pmh3a");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
     KMU_HIP(ctx, hipGetLastError());
+    if (plain) { // sequences whose k-mers overflowed a pass (repetitive ones): the general instantiation redoes them in rounds
+        uint32_t n_redo = 0;
+        KMU_HIP(ctx, hipMemcpyAsync(&n_redo, a.queue + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_redo) {
+            KMU_HIP(ctx, hipMemsetAsync(a.queue, 0, 256, ctx->stream));
+            a.read_list = a.redo_list;
+            a.n_queue = n_redo;
+            const int grid2 = (int) std::min<uint64_t>((uint64_t) n_redo, (uint64_t) cus * blocks_per_cu);
+            KernelTimer t(ctx, "k_sketch_pmh3a_redo");
+            hipLaunchKernelGGL(kern_redo, dim3(grid2), dim3(threads), lds, ctx->stream, a);
+            KMU_HIP(ctx, hipGetLastError());
+        }
+    }
     if (split) {
         const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + 2 + 128 + 64) * 8 + WINV_LUT * 8;
         if (lds2 > 64 * 1024)
