@@ -375,7 +375,6 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     bucket_clear(bst);
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
     if (tid == 0) { misc[M_NSCR] = 0; misc[M_DEF] = 0; misc[M_FLAGS] = 0; misc[M_FLAGS + 1] = 0; *qmax_sh = H_INIT; }
-    uint32_t flag_sel = 0; // uniform
     // reads are taken from the global queue QCHUNK at a time (thread 0 keeps the cursor): one same-address atomic per
     // read would cap the whole grid at the L2's rate for a single address
     // The next chunk is requested while the last read of the current one is still to be handed out, so its latency is
@@ -422,7 +421,9 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     // (free from there on).  A fresh read starts without waiting for HBM.  pf_r = the read whose head sits there.
     SeqView nv;
     nv.base = a.bases; nv.begin = 0; nv.len = 0; nv.total = 0; nv.packed = a.packed;
+    uint32_t flag_sel = 0; // uniform
     uint32_t nv_r = 0xFFFFFFFFu, pf_r = 0xFFFFFFFFu, pf_nw = 0;
+    u32x4 raw_pf = (u32x4) (0u); // PLAIN: this thread's parked chunk of the next read
     // diagnostics (KMU_PMH_ABLATE & 256): thread 0 accumulates the clock spent in every phase of the read loop
     uint64_t ph_acc[10], ph_t = 0;
 #pragma unroll
@@ -554,8 +555,16 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     const bool parked = pf_r == r && tp0 == 0 && (uint32_t) tid < pf_nw;
                                     pf_r = 0xFFFFFFFFu;
                                     u32x4 raw = (u32x4) (0u);
-                                    if (parked) raw = reinterpret_cast<const u32x4 *>(words)[tid];
-                                    lds_barrier(); // the previous user of `words` is done
+                                    if (PLAIN) {
+                                        // the parked chunk was taken to registers behind the last barrier of the previous
+                                        // read; a pass's first tile follows a barrier that every reader of `words` has
+                                        // passed, so only the later tiles wait here
+                                        if (parked) raw = raw_pf;
+                                        if (tile != 0) lds_barrier();
+                                    } else {
+                                        if (parked) raw = reinterpret_cast<const u32x4 *>(words)[tid];
+                                        lds_barrier(); // the previous user of `words` is done
+                                    }
                                     for (uint32_t t = tid; t < nw; t += nthreads) {
                                         uint32_t b;
                                         words[t] = (parked && t == (uint32_t) tid && chunk_is_plain(sv, wfirst + t))
@@ -861,6 +870,10 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             if (overflow || last_round) {
                                 bucket_clear(bst);
                                 if (tid == 0) misc[M_NSCR] = 0;
+                                if (PLAIN && pf_r != 0xFFFFFFFFu) { // requested before A3: long landed
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    if ((uint32_t) tid < pf_nw) raw_pf = reinterpret_cast<const u32x4 *>(words)[tid];
+                                }
                                 lds_barrier(); // the points are final (-> signature row); bst is clean for the next pass
                                 phase(7); // B2 + clear
                             }
