@@ -167,6 +167,8 @@ __device__ __forceinline__ double exp01_rest(const Exp01 &e, Xoshiro &rng) {
 // 1 / w.  Most weights are tiny: with a table of the exact quotients (filled once per workgroup with the same IEEE
 // division) the 25-instruction f64 division only runs for the rare wave that holds a weight beyond the table.
 static constexpr uint32_t WINV_LUT = 256;
+// k_pmh_points, u64 words per wave beside the 2 m slot words: q_max (2), queue of 128 keys, weights (64), state words (256)
+static constexpr size_t PTS_WAVE_WORDS = 2 + 128 + 64 + 256;
 __device__ __forceinline__ double winv_of(const double *lut, uint32_t w) {
     if (lut && w < WINV_LUT) return lut[w];
     return 1.0 / (double) w;
@@ -786,7 +788,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 if (EMIT) {
                                     // ---- the distinct pairs of this pass leave for the points kernel ---------------------
                                     // misc[M_FLAGS] = pairs of this read written so far (all passes; reset with the row)
-                                    const uint64_t lbase = a.offsets[r];
+                                    const uint64_t lbase = a.offsets[r] - a.offsets[0]; // (a range of a larger read set)
                                     for (uint32_t base = 0; base < n_keys; base += nthreads) { // uniform trip count (ballot)
                                         const uint32_t i = base + tid;
                                         const uint32_t w = i < n_keys ? dw[i] : 0u;
@@ -910,7 +912,11 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                 }
                 bk_n = 0;
             } else if (EMIT) {
-                if (tid == 0) { a.lst_n[r] = misc[M_FLAGS]; misc[M_FLAGS] = 0u; } // the row is written by k_pmh_points
+                if (tid == 0) { // the row is written by k_pmh_points (PLAIN, overflow: an empty list; the redo launch writes the row)
+                    a.lst_n[r] = (PLAIN && redo) ? 0u : misc[M_FLAGS];
+                    misc[M_FLAGS] = 0u;
+                    if (PLAIN && redo) a.redo_list[atomicAdd(a.queue + 56, 1u)] = r;
+                }
             } else {
                 // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
                 const uint32_t rs = seq_of(r);
@@ -957,13 +963,41 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
 // the cheap half of pmh3a_first_point: can the first point of this key lie below q_max (bits `qb`)?  Needs two of the four
 // SplitMix64 words and one f64 product; the rare keys whose first Exp01 draw falls in the sampler's rejection branch pass.
 __device__ __forceinline__ bool pmh3a_first_point_may_matter(const SketchArgs &a, bool sig32, uint64_t qb, uint64_t key,
-                                                             uint32_t w, const double *winv_lut) {
+                                                             uint32_t w, const double *winv_lut, uint64_t &s0, uint64_t &s3) {
     const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, sig32);
-    const uint64_t s0 = splitmix_at(seed, 1), s3 = splitmix_at(seed, 4);
+    s0 = splitmix_at(seed, 1);
+    s3 = splitmix_at(seed, 4);
     const uint64_t r1 = rotl64(s0 + s3, 23) + s0;
     const double u1 = __longlong_as_double((long long) ((r1 >> 12) | 0x3FF0000000000000ull)) - 1.0;
     const double x = a.e01.c1 * u1;
     return !(x < 1.0) || winv_of(winv_lut, w) * x < __longlong_as_double((long long) qb);
+}
+
+// the other half, for a key that passed pmh3a_first_point_may_matter: s0 / s3 are the two state words it computed
+__device__ __forceinline__ void pmh3a_first_point_rest(const SketchArgs &a, bool sig32, uint64_t *hmin, uint64_t *sig,
+                                                       const uint64_t *qmax_sh, bool have, uint64_t key, uint32_t w,
+                                                       uint64_t s0, uint64_t s3, const double *winv_lut) {
+    const uint64_t qb = __hip_atomic_load(qmax_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (have) {
+        const double winv = winv_of(winv_lut, w);
+        const uint64_t r1 = rotl64(s0 + s3, 23) + s0;
+        const double u1 = __longlong_as_double((long long) ((r1 >> 12) | 0x3FF0000000000000ull)) - 1.0;
+        double x = a.e01.c1 * u1;
+        const double qmax = __longlong_as_double((long long) qb);
+        const bool slow = !(x < 1.0);
+        if (slow || winv * x < qmax) { // (q_max may have fallen since the key was queued)
+            const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, sig32);
+            Xoshiro rng;
+            rng.s0 = s0;
+            rng.s3 = s3;
+            rng.s1 = splitmix_at(seed, 2);
+            rng.s2 = splitmix_at(seed, 3);
+            (void) rng.next(); // the draw already used
+            if (slow) x = exp01_rest(a.e01, rng);
+            const double h = winv * x;
+            if (h < qmax) slot_update(hmin, sig, draw_slot(a, rng), h, key);
+        }
+    }
 }
 
 // ProbMinHash3a points from the (key, weight) lists of k_sketch_pmh3a<.., EMIT>: one WAVE per read, so there is no
@@ -977,12 +1011,13 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     const bool sig32 = a.sig_bytes == 4;
     // per wave: slot minima, arg-min keys, q_max word, and a queue of 128 (key, weight) pairs that passed the cheap test:
     // they are worked off 64 at a time, so the expensive half of a first point always runs with all lanes busy
-    uint64_t *hmin = reinterpret_cast<uint64_t *>(smem) + (size_t) wave * (2 * (size_t) a.m + 2 + 128 + 64);
+    uint64_t *hmin = reinterpret_cast<uint64_t *>(smem) + (size_t) wave * (2 * (size_t) a.m + PTS_WAVE_WORDS);
     uint64_t *sig = hmin + a.m;
     uint64_t *qmax_sh = sig + a.m;
     uint64_t *qk = qmax_sh + 2;
     uint32_t *qw = reinterpret_cast<uint32_t *>(qk + 128);
-    double *winv_lut = reinterpret_cast<double *>(reinterpret_cast<uint64_t *>(smem) + (size_t) 4 * (2 * (size_t) a.m + 2 + 128 + 64));
+    uint64_t *qs0 = qk + 128 + 64, *qs3 = qs0 + 128; // the two xoshiro state words the cheap test computed
+    double *winv_lut = reinterpret_cast<double *>(reinterpret_cast<uint64_t *>(smem) + (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS));
     for (uint32_t t = threadIdx.x; t < WINV_LUT; t += blockDim.x) winv_lut[t] = t ? 1.0 / (double) t : 0.0;
     __syncthreads();
     uint32_t q_next = 0, q_end = 0; // lane 0: reads are taken QCHUNK at a time
@@ -997,12 +1032,13 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         }
         r = uniform_u32(r);
         if (r >= a.n_seq) break;
-        const uint64_t base = a.offsets[r];
+        const uint64_t base = a.offsets[r] - a.offsets[0];
         const uint32_t n = a.lst_n[r];
         for (int t = lane; t < a.m; t += 64) { hmin[t] = H_INIT; sig[t] = 0; }
         if (lane == 0) *qmax_sh = H_INIT;
         // ---- pass 1 ----
         uint32_t chunk = 0, qn = 0; // qn: queued pairs (uniform)
+        uint32_t wmax = 0;          // largest weight this lane saw
         uint64_t qb = H_INIT;
         uint64_t key_nx = 0; // the next chunk's pair is requested one iteration ahead
         uint32_t w_nx = 1;
@@ -1012,32 +1048,40 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
             const bool have = i < n;
             const uint64_t key = key_nx;
             const uint32_t w = w_nx;
+            if (have) wmax = w > wmax ? w : wmax;
             if (i + 64u < n) { key_nx = a.lst_keys[base + i + 64u]; w_nx = a.lst_w[base + i + 64u]; }
             if ((chunk & 3u) == 0u) {
                 qb = wave_qmax(hmin, a.m);
                 if (lane == 0) *qmax_sh = qb;
             }
-            const bool pass = have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut);
+            uint64_t s0 = 0, s3 = 0;
+            const bool pass = have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
             const uint64_t pm = __ballot(pass);
             if (pass) {
                 const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));
                 qk[pos] = key;
                 qw[pos] = w;
+                qs0[pos] = s0;
+                qs3[pos] = s3;
             }
             qn += (uint32_t) __popcll(pm);
             if (qn >= 64u) { // the newest 64
                 qn -= 64u;
-                (void) pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, false, true, qk[qn + lane], qw[qn + lane], winv_lut);
+                pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane],
+                                       qs3[qn + lane], winv_lut);
             }
         }
         if (qn) {
             const bool have = (uint32_t) lane < qn;
-            (void) pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, false, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u,
-                                     winv_lut);
+            pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u,
+                                   have ? qs0[lane] : 0ull, have ? qs3[lane] : 0ull, winv_lut);
         }
         // ---- pass 2 ----
+        // (only a key with 1 / w < q_max draws again: with the largest weight of the read at hand the lists are read a
+        //  second time only where that can happen at all)
         qb = wave_qmax(hmin, a.m);
-        if (n && __longlong_as_double((long long) qb) > 0.0) {
+        wmax = (uint32_t) wave_max_u64((uint64_t) wmax);
+        if (n && wmax && winv_of(winv_lut, wmax) < __longlong_as_double((long long) qb)) {
             for (uint32_t c = 0; c < n; c += 64) {
                 const uint32_t i = c + (uint32_t) lane;
                 double winv = 0.0;
@@ -1275,19 +1319,51 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
     const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
     typedef void (*sketch_kernel_t)(SketchArgs);
-    // KMU_PMH_SPLIT=1: whole DNA sequences go through two kernels -- the multiset kernel leaves (key, weight) lists in
-    // HBM, k_pmh_points (one wave per read, full occupancy) generates the points.  3 % faster on the ONT workload
-    // (100.4 vs 103.1 ms) for ~100 GB of extra HBM traffic and 12 bytes of scratch per base, so it is not the default.
+    // Whole DNA sequences in numbers go through two kernels: the multiset kernel leaves the distinct (key, weight) pairs
+    // of every read in HBM, k_pmh_points (one wave per read, no workgroup barrier, 5-7 waves per SIMD) generates the
+    // points.  ONT workload: 56.7 + 21.7 ms against 88.7 ms in one kernel, for 12 bytes of scratch per base.  With few
+    // sequences the single kernel keeps all 1024 threads of a workgroup on one read.  KMU_PMH_SPLIT = 0 / 1: never / always.
     const char *split_env = getenv("KMU_PMH_SPLIT");
-    const bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 && !skip_longer &&
-                       (size_t) 4 * (2 * (size_t) p->sketch_size + 200) * 8 <= 146 * 1024 && // four waves' slot arrays fit one workgroup
-                       split_env && atoi(split_env) == 1;
+    const int split_mode = split_env ? atoi(split_env) : -1;
+    bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 && !skip_longer &&
+                 (size_t) 4 * (2 * (size_t) p->sketch_size + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8 <= 150 * 1024 && // four waves' arrays fit one workgroup
+                 split_mode != 0 && (split_mode == 1 || ds.n_seq >= 4096);
+    if (split) {
+        uint64_t total = 0; // number of bases = capacity of the (key, weight) lists
+        if (!ds.h_offsets.empty()) total = ds.h_offsets[ds.n_seq] - ds.h_offsets[0];
+        else {
+            uint64_t ends[2] = {0, 0};
+            KMU_HIP(ctx, hipMemcpyAsync(&ends[0], ds.offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KMU_HIP(ctx, hipMemcpyAsync(&ends[1], ds.offsets + ds.n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            total = ends[1] - ends[0];
+        }
+        // 8 bytes per base: the same scratch the count build uses for its first partition level ("cnt.partA"); a
+        // context never runs the two at the same time, and at 4.4 Gbases per GPU a second copy would not fit next to
+        // the count table and the exchange buffers
+        const size_t need_k = total * 8 + 64, need_w = total * 4 + 64;
+        size_t grow = 0;
+        if (ctx->bufs["cnt.partA"].bytes < need_k) grow += need_k + need_k / 8;
+        if (ctx->bufs["pmh.lst_w"].bytes < need_w) grow += need_w + need_w / 8;
+        size_t free_b = 0, total_b = 0;
+        if (grow && split_mode != 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < grow + total_b / 8)
+            split = false; // the lists would crowd out what comes after this call: one kernel, no lists
+        if (split) {
+            void *lk, *lw, *ln;
+            KMU_TRY(dev_buf(ctx, "cnt.partA", need_k, &lk));
+            KMU_TRY(dev_buf(ctx, "pmh.lst_w", need_w, &lw));
+            KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 4 + 64, &ln));
+            a.lst_keys = (uint64_t *) lk;
+            a.lst_w = (uint32_t *) lw;
+            a.lst_n = (uint32_t *) ln;
+        }
+    }
     const char *plain_env = getenv("KMU_PMH_PLAIN"); // diagnostics: 0 = always the general instantiation
-    const bool plain = !bottomk && !aa && !split && !part_h && !d_block_rows && p->block_size == 0 && !ds.packed &&
+    const bool plain = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 && !ds.packed &&
                  !(plain_env && atoi(plain_env) == 0) && !getenv("KMU_PMH_THREADS"); // (1024 threads: see part_target below)
     const sketch_kernel_t kern = bottomk ? (aa ? k_sketch_pmh3a<true, true> : k_sketch_pmh3a<false, true>)
                                  : aa    ? k_sketch_pmh3a<true, false>
-                                 : split ? k_sketch_pmh3a<false, false, true>
+                                 : split ? (plain ? k_sketch_pmh3a<false, false, true, true> : k_sketch_pmh3a<false, false, true>)
                                  : plain ? k_sketch_pmh3a<false, false, false, true>
                                          : k_sketch_pmh3a<false, false>;
     const void *fn = (const void *) kern;
@@ -1358,25 +1434,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         a.bk_keys = (uint64_t *) bk;
         a.bk_cnt = (uint32_t *) bc;
     }
-    if (split) {
-        uint64_t total = 0; // number of bases = capacity of the (key, weight) lists
-        if (!ds.h_offsets.empty()) total = ds.h_offsets[ds.n_seq];
-        else {
-            KMU_HIP(ctx, hipMemcpyAsync(&total, ds.offsets + ds.n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
-            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        void *lk, *lw, *ln;
-        // 8 bytes per base: the same scratch the count build uses for its first partition level ("cnt.partA"); a
-        // context never runs the two at the same time, and at 4.4 Gbases per GPU a second copy would not fit next to
-        // the count table and the exchange buffers
-        KMU_TRY(dev_buf(ctx, "cnt.partA", total * 8 + 64, &lk));
-        KMU_TRY(dev_buf(ctx, "pmh.lst_w", total * 4 + 64, &lw));
-        KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 4 + 64, &ln));
-        a.lst_keys = (uint64_t *) lk;
-        a.lst_w = (uint32_t *) lw;
-        a.lst_n = (uint32_t *) ln;
-        a.queue2 = a.queue + 48;
-    }
+    if (split) a.queue2 = a.queue + 48;
     if (plain) {
         void *rl;
         KMU_TRY(dev_buf(ctx, "pmh.redo", (size_t) ds.n_seq * 4 + 64, &rl));
@@ -1387,7 +1445,18 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
     KMU_HIP(ctx, hipGetLastError());
-    if (plain) { // sequences whose k-mers overflowed a pass (repetitive ones): the general instantiation redoes them in rounds
+    if (split) {
+        const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
+        if (lds2 > 64 * 1024)
+            KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_pmh_points, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
+        const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) ctx->num_cus * per_cu));
+        KernelTimer t(ctx, "k_pmh_points");
+        hipLaunchKernelGGL(k_pmh_points, dim3(grid2), dim3(256), lds2, ctx->stream, a);
+        KMU_HIP(ctx, hipGetLastError());
+    }
+    if (plain) { // (after the points kernel, whose row for such a sequence is empty)
+        // sequences whose k-mers overflowed a pass (repetitive ones): the general instantiation redoes them in rounds
         uint32_t n_redo = 0;
         KMU_HIP(ctx, hipMemcpyAsync(&n_redo, a.queue + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
         KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1400,16 +1469,6 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             hipLaunchKernelGGL(kern_redo, dim3(grid2), dim3(threads), lds, ctx->stream, a);
             KMU_HIP(ctx, hipGetLastError());
         }
-    }
-    if (split) {
-        const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + 2 + 128 + 64) * 8 + WINV_LUT * 8;
-        if (lds2 > 64 * 1024)
-            KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_pmh_points, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
-        const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) ctx->num_cus * per_cu));
-        KernelTimer t(ctx, "k_pmh_points");
-        hipLaunchKernelGGL(k_pmh_points, dim3(grid2), dim3(256), lds2, ctx->stream, a);
-        KMU_HIP(ctx, hipGetLastError());
     }
     if (ABL(256u)) { // diagnostics: mean clocks per workgroup and phase
         unsigned long long ph[10];

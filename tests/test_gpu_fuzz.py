@@ -57,7 +57,7 @@ def _kmer_choice(rng):
 
 
 @pytest.mark.parametrize("seed", range(64 * SCALE))
-def test_sketch_sweep(ctx, oracle, seed):
+def test_sketch_sweep(ctx, oracle, seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     kmer_type, k = _kmer_choice(rng)
     w32 = kmer_type != A.KMER64BIT
@@ -101,6 +101,11 @@ def test_sketch_sweep(ctx, oracle, seed):
     else:
         a, b = np.asarray(got), np.asarray(want)
         assert a.shape == b.shape and a.tobytes() == b.tobytes(), (kmer_type, k, algo, m, fhash, kind, block, mode)
+    if algo == A.ALGO_PROB3A and block == 0 and mode == A.MODE_PER_SEQ:
+        # the route big batches take by default (multiset kernel -> (key, weight) lists -> k_pmh_points), forced
+        monkeypatch.setenv("KMU_PMH_SPLIT", "1")
+        a = np.asarray(ctx.sketch(bases, off, p))
+        assert a.tobytes() == np.asarray(want).tobytes(), ("split", kmer_type, k, m, fhash, kind)
 
 
 @pytest.mark.parametrize("seed", range(16 * SCALE))

@@ -909,9 +909,12 @@ def test_ranges_of_a_larger_read_set(ctx, oracle, monkeypatch):
         c.close()
         want = oracle.sketch(sub_b, sub_o, p)
         assert np.array_equal(np.asarray(ctx.sketch(bases, off[first:last + 1].copy(), p)), want)
-        g = ctx.sketch(db, do[first:last + 1], p)
-        ctx.synchronize()
-        assert np.array_equal(g.cpu().numpy().view(np.uint64), want)
+        for split in ("0", "1"):  # one kernel / the two-kernel route of big batches (its lists are indexed from the range's start)
+            monkeypatch.setenv("KMU_PMH_SPLIT", split)
+            g = ctx.sketch(db, do[first:last + 1], p)
+            ctx.synchronize()
+            assert np.array_equal(g.cpu().numpy().view(np.uint64), want)
+        monkeypatch.delenv("KMU_PMH_SPLIT")
         for algo, sig, mode in ((A.ALGO_SUPER, A.SIG_F64, A.MODE_PER_SEQ), (A.ALGO_OPTDENS, A.SIG_F64, A.MODE_PER_SEQ),
                                 (A.ALGO_REVOPTDENS, A.SIG_F32, A.MODE_ALL_SEQS), (A.ALGO_PROB3A, A.SIG_U64, A.MODE_ALL_SEQS),
                                 (A.ALGO_SUPER2, A.SIG_U64, A.MODE_ALL_SEQS), (A.ALGO_BOTTOMK, A.SIG_U64, A.MODE_PER_SEQ)):
@@ -1035,3 +1038,33 @@ def test_partial_sketches_merge_to_the_all_sequences_sketch(ctx, oracle):
         # and splitting by SEQUENCES instead is (as it must be) not the same thing: weights would be partial
         naive = np.stack([np.asarray(ctx.sketch_partial(bases, off[a:b + 1].copy(), p)) for a, b in shares])
         assert not np.array_equal(np.asarray(ctx.sketch_merge_partials(naive, p)), want)
+
+
+@pytest.mark.gpu
+def test_probminhash_many_reads_default_route(ctx, oracle):
+    """A batch of thousands of reads takes the two-kernel route by itself (multiset kernel -> (key, weight) lists ->
+    k_pmh_points, one wave per read): rows equal to the oracle's, for u64 and u32 signatures, with reads shorter than k,
+    repetitive reads (weights > 1, later ProbMinHash rounds) and a few long ones in the batch."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs = []
+    for i in range(5000):
+        if i % 97 == 0:
+            seqs.append(rng.choice(acgt, size=int(rng.integers(12_000, 30_000))).tobytes())  # several partition passes
+        elif i % 13 == 0:
+            unit = rng.choice(acgt, size=int(rng.integers(1, 40))).tobytes()
+            seqs.append((unit * 40)[:int(rng.integers(5, 600))])
+        else:
+            seqs.append(rng.choice(acgt, size=int(rng.integers(1, 400))).tobytes())
+    bases, off = oracle.concat(seqs)
+    for kmer_type, k, sig in ((A.KMER64BIT, 31, A.SIG_U64), (A.KMER32BIT, 8, A.SIG_U32)):
+        p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, 200, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, A.MODE_PER_SEQ,
+                           A.INPUT_ASCII, A.MEM_HOST, 0)
+        want = oracle.sketch(bases, off, p)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        got = np.asarray(ctx.sketch(bases, off, p))
+        names = set(ctx.profile_get())
+        ctx.profile_enable(False)
+        assert "k_pmh_points" in names, names
+        assert got.tobytes() == np.asarray(want).tobytes()
