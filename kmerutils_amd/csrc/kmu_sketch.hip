@@ -116,6 +116,20 @@ __device__ __forceinline__ void slot_update(uint64_t *hmin, uint64_t *sig, uint3
     }
 }
 
+// the same for slot arrays that belong to ONE wave (k_pmh_points): the lanes of a call run in lock step, so the minimum
+// is taken by one LDS atomic and the winner is whoever finds its own value there afterwards; no lock word, no loop.
+// Lanes of a call that meet in a slot with the same h (and therefore the same `cur`) take the same branch below.
+__device__ __forceinline__ void slot_update_wave(uint64_t *hmin, uint64_t *sig, uint32_t k, double h, uint64_t key) {
+    const uint64_t hb = (uint64_t) __double_as_longlong(h);
+    const uint64_t cur = __hip_atomic_load(&hmin[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool cand = hb <= cur;
+    if (cand) __hip_atomic_fetch_min(&hmin[k], hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cand && __hip_atomic_load(&hmin[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == hb) {
+        if (hb < cur) __hip_atomic_store(&sig[k], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // the old key is obsolete
+        __hip_atomic_fetch_min(&sig[k], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // exact ties: smaller key
+    }
+}
+
 // q_max = max over slots of the current minima (MaxValueTracker root); a slot in flight counts as "unknown" = MAX
 __device__ __forceinline__ uint64_t wave_qmax(const uint64_t *hmin, int m) {
     uint64_t q = 0;
@@ -130,9 +144,12 @@ __device__ __forceinline__ uint64_t wave_qmax(const uint64_t *hmin, int m) {
 __device__ __forceinline__ uint32_t draw_slot(const SketchArgs &a, Xoshiro &rng) {
     if (a.rand08) {
         for (;;) {
-            uint64_t v = rng.next();
-            uint64_t hi = __umul64hi(v, (uint64_t) a.m), lo = v * (uint64_t) a.m;
-            if (lo <= a.idx_zone) return (uint32_t) hi;
+            // v * m as 96 bits (m < 2^32): two 32 x 32 -> 64 multiply-adds instead of a full 64 x 64 high product
+            const uint64_t v = rng.next();
+            const uint64_t p0 = (uint64_t) (uint32_t) v * (uint32_t) a.m;
+            const uint64_t p1 = (uint64_t) (uint32_t) (v >> 32) * (uint32_t) a.m + (p0 >> 32);
+            const uint64_t lo = (p1 << 32) | (uint32_t) p0;
+            if (lo <= a.idx_zone) return (uint32_t) (p1 >> 32);
         }
     }
     for (;;) {
@@ -222,6 +239,7 @@ __device__ __forceinline__ bool pmh3a_first_point(const SketchArgs &a, bool sig3
 // pass B2: further points (rounds i >= 2) of the remembered keys, against the q_max reached after all first points.
 // The RNG stream of a key is replayed from its seed: round 1 consumed the Exp01 draws and one slot draw.
 // `qb` (bits of a q_max upper bound) is carried by the wave across calls and refreshed after every round.
+template <bool WAVE_PRIVATE = false>
 __device__ __forceinline__ void pmh3a_more_points(const SketchArgs &a, bool sig32, uint64_t *hmin, uint64_t *sig,
                                                   uint64_t &qb, bool alive, uint64_t key, double winv) {
     Xoshiro rng;
@@ -241,7 +259,10 @@ __device__ __forceinline__ void pmh3a_more_points(const SketchArgs &a, bool sig3
                 double x = exp01_sample(a.e01, rng);
                 double h = hbase + winv * x;
                 uint32_t k = draw_slot(a, rng); // rounds >= 2 always draw the slot
-                if (h < qmax) slot_update(hmin, sig, k, h, key);
+                if (h < qmax) {
+                    if (WAVE_PRIVATE) slot_update_wave(hmin, sig, k, h, key);
+                    else slot_update(hmin, sig, k, h, key);
+                }
                 if (!(winv * (double) i < qmax)) alive = false;
                 i++;
             }
@@ -995,7 +1016,7 @@ __device__ __forceinline__ void pmh3a_first_point_rest(const SketchArgs &a, bool
             (void) rng.next(); // the draw already used
             if (slow) x = exp01_rest(a.e01, rng);
             const double h = winv * x;
-            if (h < qmax) slot_update(hmin, sig, draw_slot(a, rng), h, key);
+            if (h < qmax) slot_update_wave(hmin, sig, draw_slot(a, rng), h, key);
         }
     }
 }
@@ -1091,7 +1112,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
                     winv = winv_of(winv_lut, w);
                     alive = winv < __longlong_as_double((long long) qb);
                 }
-                if (__any(alive)) pmh3a_more_points(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
+                if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
             }
         }
         // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
