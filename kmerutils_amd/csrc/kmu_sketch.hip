@@ -682,6 +682,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                 }
 
                             }
+                            phase(9); // next read's header, parked keys -> registers
                             if (!ABL(128u)) bucket_scan(bst, wtot);
                             phase(3); // scan
                             const uint32_t n_keys = uniform_u32(bst[NBUCKETS]);
@@ -1495,11 +1496,11 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         unsigned long long ph[10];
         KMU_HIP(ctx, hipMemcpyAsync(ph, (const uint64_t *) a.queue + 8, sizeof ph, hipMemcpyDeviceToHost, ctx->stream));
         KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        static const char *nm[10] = {"header", "stage", "A1", "scan", "place", "A3", "B1", "B2+clear", "row", "-"};
+        static const char *nm[10] = {"header", "stage", "A1", "scan", "place", "A3", "B1", "B2+clear", "row", "next+parked"};
         double tot = 0;
         for (int i = 0; i < 10; i++) tot += (double) ph[i];
         fprintf(stderr, "[kmu phases] grid %d:", grid);
-        for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double) ph[i] / (tot > 0 ? tot : 1));
+        for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double) ph[i] / (tot > 0 ? tot : 1));
         fprintf(stderr, "  (clocks/wg %.3g)\n", tot / grid);
     }
     return KMU_OK;
