@@ -394,6 +394,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     uint64_t *bk_keys = hmin;
     uint32_t *bk_cnt = reinterpret_cast<uint32_t *>(sig);
     uint32_t bk_n = 0; // entries of the bottom-k running list (uniform)
+    uint32_t emit_n = 0; // EMIT: list entries of the current read written by earlier passes (uniform)
 
     bucket_clear(bst);
     for (int s = tid; s < a.m; s += nthreads) { hmin[s] = H_INIT; sig[s] = 0; }
@@ -808,25 +809,16 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                             }
                             if (!overflow && last_round) {
                                 if (EMIT) {
-                                    // ---- the distinct pairs of this pass leave for the points kernel ---------------------
-                                    // misc[M_FLAGS] = pairs of this read written so far (all passes; reset with the row)
-                                    const uint64_t lbase = a.offsets[r] - a.offsets[0]; // (a range of a larger read set)
-                                    for (uint32_t base = 0; base < n_keys; base += nthreads) { // uniform trip count (ballot)
-                                        const uint32_t i = base + tid;
-                                        const uint32_t w = i < n_keys ? dw[i] : 0u;
-                                        const uint64_t cm = __ballot(w != 0u);
-                                        if (cm) {
-                                            const int leader = __ffsll((unsigned long long) cm) - 1;
-                                            uint32_t basepos = 0;
-                                            if (lane_id() == leader) basepos = atomicAdd(&misc[M_FLAGS], (uint32_t) __popcll(cm));
-                                            basepos = bcast_u32(basepos, leader);
-                                            if (w != 0u) {
-                                                const uint64_t pos = lbase + basepos + (uint32_t) __popcll(cm & ((1ull << lane_id()) - 1ull));
-                                                a.lst_keys[pos] = dk[i];
-                                                a.lst_w[pos] = w;
-                                            }
-                                        }
+                                    // ---- the pairs of this pass leave for the points kernel -------------------------------
+                                    // a straight copy of the dense arrays, duplicates included with weight 0 (k_pmh_points
+                                    // skips them): no compaction, no atomics.  emit_n = entries of this read so far (all
+                                    // passes; at most one per k-mer, so the list of a read fits its bases' index range)
+                                    const uint64_t lbase = a.offsets[r] - a.offsets[0] + emit_n; // (a range of a larger read set)
+                                    for (uint32_t i = tid; i < n_keys; i += nthreads) {
+                                        a.lst_keys[lbase + i] = dk[i];
+                                        a.lst_w[lbase + i] = dw[i];
                                     }
+                                    emit_n += n_keys;
                                 } else if (!BOTTOMK) {
                                     // ---- B1: the first point of every distinct key -------------------------------------
                                     uint32_t chunk = 0;
@@ -916,7 +908,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                     P *= 2;
                     for (int t = tid; t < a.m; t += nthreads) { hmin[t] = H_INIT; sig[t] = 0; }
                     if (tid == 0) *qmax_sh = H_INIT;
-                    if (EMIT && tid == 0) misc[M_FLAGS] = 0u; // the list of this read starts over
+                    emit_n = 0; // (EMIT) the list of this read starts over
                     bk_n = 0;
                     __syncthreads();
                 }
@@ -935,10 +927,10 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                 bk_n = 0;
             } else if (EMIT) {
                 if (tid == 0) { // the row is written by k_pmh_points (PLAIN, overflow: an empty list; the redo launch writes the row)
-                    a.lst_n[r] = (PLAIN && redo) ? 0u : misc[M_FLAGS];
-                    misc[M_FLAGS] = 0u;
+                    a.lst_n[r] = (PLAIN && redo) ? 0u : emit_n;
                     if (PLAIN && redo) a.redo_list[atomicAdd(a.queue + 56, 1u)] = r;
                 }
+                emit_n = 0;
             } else {
                 // ---- signature of this block: arg-min key per slot, initobj (0) for an empty multiset -----------
                 const uint32_t rs = seq_of(r);
@@ -1067,9 +1059,9 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         if ((uint32_t) lane < n) { key_nx = a.lst_keys[base + lane]; w_nx = a.lst_w[base + lane]; }
         for (uint32_t c = 0; c < n; c += 64, chunk++) { // uniform trip count
             const uint32_t i = c + (uint32_t) lane;
-            const bool have = i < n;
             const uint64_t key = key_nx;
             const uint32_t w = w_nx;
+            const bool have = i < n && w != 0u; // weight 0: a repeat of an earlier entry
             if (have) wmax = w > wmax ? w : wmax;
             if (i + 64u < n) { key_nx = a.lst_keys[base + i + 64u]; w_nx = a.lst_w[base + i + 64u]; }
             if ((chunk & 3u) == 0u) {
@@ -1111,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
                 if (i < n) {
                     const uint32_t w = a.lst_w[base + i];
                     winv = winv_of(winv_lut, w);
-                    alive = winv < __longlong_as_double((long long) qb);
+                    alive = w != 0u && winv < __longlong_as_double((long long) qb);
                 }
                 if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
             }
@@ -1472,7 +1464,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         if (lds2 > 64 * 1024)
             KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_pmh_points, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
-        const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) ctx->num_cus * per_cu));
+        const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) cus * per_cu)); // (cus: see KMU_PMH_RESERVE_CUS)
         KernelTimer t(ctx, "k_pmh_points");
         hipLaunchKernelGGL(k_pmh_points, dim3(grid2), dim3(256), lds2, ctx->stream, a);
         KMU_HIP(ctx, hipGetLastError());
