@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__(256) k_pmh_reduce(const uint64_t *part_h, cons
     }
 }
 
-// longest sequence: out[0] = max_i (offsets[i + 1] - offsets[i]); out[0] must be 0 on entry
+// longest sequence: out[0] = max_i (offsets[i + 1] - offsets[i]); out[0] must be 0 on entry.  out[1] = sum of the lengths
 __global__ void __launch_bounds__(1024) k_max_len(const uint64_t *offsets, uint32_t n_seq, uint64_t *out) {
     uint64_t mx = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_seq; i += gridDim.x * blockDim.x) {
@@ -1162,6 +1162,7 @@ __global__ void __launch_bounds__(1024) k_max_len(const uint64_t *offsets, uint3
     }
     mx = wave_max_u64(mx);
     if (lane_id() == 0 && mx) atomicMax((unsigned long long *) out, (unsigned long long) mx);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[1] = offsets[n_seq] - offsets[0]; // all bases of the call
 }
 
 // exclusive scan of the k-mer counts max(0, L_i - k + 1) of all sequences (single workgroup); koff[n] = total
@@ -1293,7 +1294,7 @@ static bool algo_is_dens(int algo) { return algo == KMU_ALGO_OPTDENS || algo == 
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
                         void *d_sig, uint32_t *d_counts, uint32_t *d_err, const void *hashed = nullptr,
                         int hashed_bytes = 0, uint64_t *part_h = nullptr, uint64_t *part_k = nullptr,
-                        uint32_t skip_longer = 0) {
+                        uint32_t skip_longer = 0, const uint64_t *len_stats = nullptr /* longest sequence, all bases */) {
     const bool bottomk = p->algo == KMU_ALGO_BOTTOMK;
     SketchArgs a;
     memset(&a, 0, sizeof a);
@@ -1333,18 +1334,23 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
     const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
     typedef void (*sketch_kernel_t)(SketchArgs);
-    // Whole DNA sequences in numbers go through two kernels: the multiset kernel leaves the distinct (key, weight) pairs
-    // of every read in HBM, k_pmh_points (one wave per read, no workgroup barrier, 5-7 waves per SIMD) generates the
-    // points.  ONT workload: 56.7 + 21.7 ms against 88.7 ms in one kernel, for 12 bytes of scratch per base.  With few
-    // sequences the single kernel keeps all 1024 threads of a workgroup on one read.  KMU_PMH_SPLIT = 0 / 1: never / always.
+    // Big batches of whole DNA sequences go through two kernels: the multiset kernel leaves the (key, weight) pairs of
+    // every read in HBM, k_pmh_points (one wave per read, no workgroup barrier, 5 waves per SIMD) generates the points.
+    // ONT workload: 53.3 + 21.2 ms against 88.7 ms in one kernel, for 12 bytes of scratch per base.  One wave per read
+    // has a tail: the longest read keeps its wave busy while the others have run out of reads.  The route is taken
+    // when the gain (16 % of the single kernel's time) exceeds the expected overhang of that read; figures of an MI355X
+    // (a wave of k_pmh_points does 4.0e4 k-mers per ms, the single kernel 4.9e7 per ms with 256 CUs).
+    // KMU_PMH_SPLIT = 0 / 1: never / always.
     const char *split_env = getenv("KMU_PMH_SPLIT");
     const int split_mode = split_env ? atoi(split_env) : -1;
     bool split = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 && !skip_longer &&
                  (size_t) 4 * (2 * (size_t) p->sketch_size + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8 <= 150 * 1024 && // four waves' arrays fit one workgroup
-                 split_mode != 0 && (split_mode == 1 || ds.n_seq >= 4096);
+                 split_mode != 0 && (split_mode == 1 || len_stats);
+    uint64_t list_total = 0; // number of bases = capacity of the (key, weight) lists
     if (split) {
-        uint64_t total = 0; // number of bases = capacity of the (key, weight) lists
-        if (!ds.h_offsets.empty()) total = ds.h_offsets[ds.n_seq] - ds.h_offsets[0];
+        uint64_t &total = list_total;
+        if (len_stats) total = len_stats[1];
+        else if (!ds.h_offsets.empty()) total = ds.h_offsets[ds.n_seq] - ds.h_offsets[0];
         else {
             uint64_t ends[2] = {0, 0};
             KMU_HIP(ctx, hipMemcpyAsync(&ends[0], ds.offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1352,6 +1358,16 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
             total = ends[1] - ends[0];
         }
+        if (split_mode != 1) {
+            const double cu_share = (double) ctx->num_cus / 256.0;
+            const double t_ideal = (double) total / (2.05e8 * cu_share), t_tail = (double) len_stats[0] / 4.0e4; // ms
+            const double overhang = t_tail >= t_ideal ? t_tail - 0.5 * t_ideal : t_tail * t_tail / (2.0 * t_ideal);
+            const double gain = 0.16 * (double) total / (4.9e7 * cu_share);
+            if (gain <= overhang + 0.02) split = false; // (0.02 ms: the second launch)
+        }
+    }
+    if (split) {
+        const uint64_t total = list_total;
         // 8 bytes per base: the same scratch the count build uses for its first partition level ("cnt.partA"); a
         // context never runs the two at the same time, and at 4.4 Gbases per GPU a second copy would not fit next to
         // the count table and the exchange buffers
@@ -1643,6 +1659,7 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
             // kernel.  They go through the same global route as a sketch over all sequences -- hashes, radix partition
             // into leaves, per-leaf slot minima, merge -- one sequence at a time, which is linear in L.
             uint32_t skip_longer = 0;
+            uint64_t len_stats[2] = {0, 0}; // longest sequence, all bases (whole sequences only)
             std::vector<uint32_t> long_seqs;
             if (p->block_size == 0) {
                 void *mx;
@@ -1650,9 +1667,9 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
                 KMU_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
                 const uint32_t mgrid = (uint32_t) std::min<uint64_t>(((uint64_t) n_seq + 1023) / 1024, (uint64_t) ctx->num_cus);
                 hipLaunchKernelGGL(k_max_len, dim3(mgrid ? mgrid : 1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, (uint64_t *) mx);
-                uint64_t max_len = 0;
-                KMU_HIP(ctx, hipMemcpyAsync(&max_len, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KMU_HIP(ctx, hipMemcpyAsync(len_stats, mx, 16, hipMemcpyDeviceToHost, ctx->stream));
                 KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                const uint64_t max_len = len_stats[0];
                 if (max_len > (uint64_t) LONG_SEQ_KMERS + (uint64_t) p->kmer_size) {
                     std::vector<uint64_t> h_off((size_t) n_seq + 1);
                     KMU_HIP(ctx, hipMemcpyAsync(h_off.data(), ds.offsets, ((size_t) n_seq + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1664,7 +1681,7 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
                     skip_longer = LONG_SEQ_KMERS;
                 }
             }
-            KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err, nullptr, 0, nullptr, nullptr, skip_longer));
+            KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err, nullptr, 0, nullptr, nullptr, skip_longer, len_stats));
             for (uint32_t i : long_seqs) {
                 DevSeqs one = ds;
                 one.offsets = ds.offsets + i;

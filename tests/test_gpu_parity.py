@@ -1041,30 +1041,43 @@ def test_partial_sketches_merge_to_the_all_sequences_sketch(ctx, oracle):
 
 
 @pytest.mark.gpu
-def test_probminhash_many_reads_default_route(ctx, oracle):
-    """A batch of thousands of reads takes the two-kernel route by itself (multiset kernel -> (key, weight) lists ->
-    k_pmh_points, one wave per read): rows equal to the oracle's, for u64 and u32 signatures, with reads shorter than k,
-    repetitive reads (weights > 1, later ProbMinHash rounds) and a few long ones in the batch."""
+def test_probminhash_many_reads_default_route(ctx, oracle, monkeypatch):
+    """A big batch of reads takes the two-kernel route by itself (multiset kernel -> (key, weight) lists -> k_pmh_points,
+    one wave per read): rows equal to the oracle's, for u64 and u32 signatures, with reads shorter than k and repetitive
+    reads (weights > 1, later ProbMinHash rounds) in the batch.  A batch whose longest read would keep one wave busy long
+    after the others have finished stays on the single kernel."""
     rng = np.random.default_rng(77)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     seqs = []
-    for i in range(5000):
-        if i % 97 == 0:
-            seqs.append(rng.choice(acgt, size=int(rng.integers(12_000, 30_000))).tobytes())  # several partition passes
-        elif i % 13 == 0:
+    for i in range(60000):
+        if i % 13 == 0:
             unit = rng.choice(acgt, size=int(rng.integers(1, 40))).tobytes()
             seqs.append((unit * 40)[:int(rng.integers(5, 600))])
         else:
-            seqs.append(rng.choice(acgt, size=int(rng.integers(1, 400))).tobytes())
+            seqs.append(rng.choice(acgt, size=int(rng.integers(1, 450))).tobytes())
     bases, off = oracle.concat(seqs)
+
+    def kernels_of(call):
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        out = call()
+        names = set(ctx.profile_get())
+        ctx.profile_enable(False)
+        return out, names
+
     for kmer_type, k, sig in ((A.KMER64BIT, 31, A.SIG_U64), (A.KMER32BIT, 8, A.SIG_U32)):
         p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, 200, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, A.MODE_PER_SEQ,
                            A.INPUT_ASCII, A.MEM_HOST, 0)
         want = oracle.sketch(bases, off, p)
-        ctx.profile_reset()
-        ctx.profile_enable(True)
-        got = np.asarray(ctx.sketch(bases, off, p))
-        names = set(ctx.profile_get())
-        ctx.profile_enable(False)
+        got, names = kernels_of(lambda: np.asarray(ctx.sketch(bases, off, p)))
         assert "k_pmh_points" in names, names
         assert got.tobytes() == np.asarray(want).tobytes()
+    # the same batch with one 300 kb read in it: the single kernel, same rows for the reads they share
+    seqs2 = seqs[:20000] + [rng.choice(acgt, size=300_000).tobytes()]
+    b2, o2 = oracle.concat(seqs2)
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 200, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, A.MODE_PER_SEQ,
+                       A.INPUT_ASCII, A.MEM_HOST, 0)
+    got2, names2 = kernels_of(lambda: np.asarray(ctx.sketch(b2, o2, p)))
+    assert "k_pmh_points" not in names2, names2
+    want2 = oracle.sketch(b2, o2, p)
+    assert got2.tobytes() == np.asarray(want2).tobytes()
