@@ -114,6 +114,7 @@ def main():
     total_bases = int(offsets[-1].item())
     nk = int(np.maximum(lens - cfg["k"] + 1, 0).sum())
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()  # the generator's temporaries go back to the device: the library allocates with hipMalloc
     t_gen = time.time() - t_gen
 
     stream = torch.cuda.Stream(device=dev)
