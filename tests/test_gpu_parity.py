@@ -398,9 +398,10 @@ def test_count_reference_kat(ctx, oracle):
     assert (got[:32] == 0).all() and (got[32:] == 255).all()
 
 
-def test_full_size_properties(ctx):
-    """size-independent checks at a larger scale than the oracle is run at: determinism, strand invariance of the
-    canonical sketch, and count conservation (sum of counts == number of k-mers)."""
+def test_full_size_properties(ctx, monkeypatch):
+    """size-independent checks at a larger scale than the oracle is run at: determinism, independence of the route (one
+    kernel / multiset + points kernels / general instantiation), strand invariance of the canonical sketch, and count
+    conservation (sum of counts == number of k-mers)."""
     import torch
     dev = torch.device("cuda:0")
     bases, off, lens = synth.ont_reads_device(20000, 20000 * 6000, 5_000_000, 0xC3, dev)
@@ -408,6 +409,13 @@ def test_full_size_properties(ctx):
     s1 = ctx.sketch(bases, off, p)
     s2 = ctx.sketch(bases, off, p)
     assert torch.equal(s1, s2)
+    for env in ({"KMU_PMH_SPLIT": "1"}, {"KMU_PMH_SPLIT": "0"}, {"KMU_PMH_SPLIT": "0", "KMU_PMH_PLAIN": "0"},
+                {"KMU_PMH_SPLIT": "1", "KMU_PMH_PLAIN": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        assert torch.equal(ctx.sketch(bases, off, p), s1), env
+        for k_ in env:
+            monkeypatch.delenv(k_)
     # reverse-complement every read (on the device): canonical hashing => identical signatures
     comp = torch.zeros(256, dtype=torch.uint8, device=dev)
     for a, b in zip(b"ACGT", b"TGCA"):
