@@ -186,6 +186,9 @@ __device__ __forceinline__ double exp01_rest(const Exp01 &e, Xoshiro &rng) {
 static constexpr uint32_t WINV_LUT = 256;
 // k_pmh_points, u64 words per wave beside the 2 m slot words: q_max (2), queue of 128 keys, weights (64), state words (256)
 static constexpr size_t PTS_WAVE_WORDS = 2 + 128 + 64 + 256;
+// q_max of the wave's slots is recomputed every 16 chunks of 64 keys (every 4: 21.0 ms, 8: 20.0, 16: 19.8 on the ONT
+// workload; a stale bound only lets a few more keys into the expensive half)
+static constexpr uint32_t PTS_REFRESH_MASK = 15u;
 __device__ __forceinline__ double winv_of(const double *lut, uint32_t w) {
     if (lut && w < WINV_LUT) return lut[w];
     return 1.0 / (double) w;
@@ -1064,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
             const bool have = i < n && w != 0u; // weight 0: a repeat of an earlier entry
             if (have) wmax = w > wmax ? w : wmax;
             if (i + 64u < n) { key_nx = a.lst_keys[base + i + 64u]; w_nx = a.lst_w[base + i + 64u]; }
-            if ((chunk & 3u) == 0u) {
+            if ((chunk & PTS_REFRESH_MASK) == 0u) {
                 qb = wave_qmax(hmin, a.m);
                 if (lane == 0) *qmax_sh = qb;
             }
