@@ -189,6 +189,9 @@ static constexpr size_t PTS_WAVE_WORDS = 2 + 128 + 64 + 256;
 // q_max of the wave's slots is recomputed every 16 chunks of 64 keys (every 4: 21.0 ms, 8: 20.0, 16: 19.8 on the ONT
 // workload; a stale bound only lets a few more keys into the expensive half)
 static constexpr uint32_t PTS_REFRESH_MASK = 15u;
+// the single kernel: wave w recomputes the workgroup's q_max when (chunk + w) % 16 == 0, i.e. one of the sixteen waves per
+// chunk of 1024 keys, and posts it for the others (every 4: 88.7 ms, 8: 87.3, 16: 87.0 on the ONT workload)
+static constexpr uint32_t B1_REFRESH_MASK = 15u;
 __device__ __forceinline__ double winv_of(const double *lut, uint32_t w) {
     if (lut && w < WINV_LUT) return lut[w];
     return 1.0 / (double) w;
@@ -833,7 +836,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                         if (i < n_keys) { key = dk[i]; w = dw[i]; }
                                         const bool have = w != 0u;
                                         if (__any(have) && !ABL(1u)) {
-                                            const bool deferred = pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, ((chunk + wave) & 3u) == 0u, have, key, w);
+                                            const bool deferred = pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, ((chunk + wave) & B1_REFRESH_MASK) == 0u, have, key, w);
                                             if (deferred && !ABL(16u)) { dw[i] = w | 0x80000000u; any_deferred = true; }
                                         }
                                     }
