@@ -1025,10 +1025,11 @@ __device__ __forceinline__ void pmh3a_first_point_rest(const SketchArgs &a, bool
 // minima (16 m bytes) + the shared q_max word.  Pass 1 = first point of every key; pass 2 = further rounds for the keys
 // with winv < q_max (a key is deferred in pass 1 exactly when winv < q_max then, and q_max only falls: re-testing
 // against the settled q_max selects a subset of the deferred keys, those that can still produce a point below it).
+template <bool SIG32>
 __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const bool sig32 = a.sig_bytes == 4;
+    constexpr bool sig32 = SIG32; // (the host instantiates both widths)
     // per wave: slot minima, arg-min keys, q_max word, and a queue of 128 (key, weight) pairs that passed the cheap test:
     // they are worked off 64 at a time, so the expensive half of a first point always runs with all lanes busy
     uint64_t *hmin = reinterpret_cast<uint64_t *>(smem) + (size_t) wave * (2 * (size_t) a.m + PTS_WAVE_WORDS);
@@ -1482,13 +1483,14 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     }
     KMU_HIP(ctx, hipGetLastError());
     if (split) {
+        const sketch_kernel_t kpts = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
         const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
         if (lds2 > 64 * 1024)
-            KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_pmh_points, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
         const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) cus * per_cu)); // (cus: see KMU_PMH_RESERVE_CUS)
         KernelTimer t(ctx, "k_pmh_points");
-        hipLaunchKernelGGL(k_pmh_points, dim3(grid2), dim3(256), lds2, ctx->stream, a);
+        hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
         KMU_HIP(ctx, hipGetLastError());
     }
     if (plain) { // (after the points kernel, whose row for such a sequence is empty)
