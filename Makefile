@@ -6,7 +6,7 @@ CC       ?= gcc
 HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function
 CSRC     := kmerutils_amd/csrc
 OBJDIR   := kmerutils_amd/build
-SOURCES  := kmu_api kmu_sketch kmu_sketch_super kmu_sketch_dens kmu_count kmu_compare kmu_ingest
+SOURCES  := kmu_api kmu_sketch kmu_sketch_super kmu_sketch_dens kmu_count kmu_compare kmu_ingest kmu_kmergen
 OBJS     := $(SOURCES:%=$(OBJDIR)/%.o)
 LIB      := kmerutils_amd/libkmu.so
 BIN      := kmerutils_amd/bin

@@ -591,6 +591,46 @@ template <class Kmer> class KmerGenerator {
     std::vector<Kmer> generate_kmer(const SequenceAA &seq) const {
         return std::move(detail::device_kmers<Kmer>(ctx_, detail::gather(std::vector<const SequenceAA *>{&seq}), k_)[0]);
     }
+    /// generate_kmer_in_range(&seq, begin, end) (kmergenerator.rs:169-174; kmeraa.rs:667-672): the k-mers inside bases
+    /// [begin, end).  A bad range throws KmuError(KMU_E_BAD_ARG) where the reference unwraps set_range's Err.
+    template <class Seq> std::vector<Kmer> generate_kmer_in_range(const Seq &seq, size_t begin, size_t end) const {
+        if (begin >= end) throw KmuError(KMU_E_BAD_ARG, "KmerGenerationPattern bad range for kmer iteration");  // kmergenerator.rs:284-286
+        const detail::Batch b = detail::gather(std::vector<const Seq *>{&seq});
+        kmu_hash_params hp{};
+        hp.kmer_type = Kmer::kmu_type;
+        hp.kmer_size = int32_t(k_);
+        hp.fhash = KMU_FHASH_IDENTITY_RAW;
+        hp.input_kind = b.input_kind;
+        hp.mem = KMU_MEM_HOST;
+        std::vector<uint64_t> raw(std::max<uint64_t>(b.offsets.back(), 1), 0);
+        const uint64_t rb = begin, re = end;
+        ctx_.check(kmu_kmer_hashes_range(ctx_.raw(), &hp, b.bytes.data(), b.offsets.data(), b.packed_ptr(), 1, &rb, &re, raw.data()));
+        std::vector<Kmer> out;
+        for (uint64_t p = begin; p + k_ <= end; p++) out.push_back(Kmer::from_raw(raw[p], k_));
+        return out;
+    }
+    /// generate_weighted_kmer(&seq) -> FnvHashMap<Kmer, u32> (kmergenerator.rs:176-181): distinct k-mers with multiplicities,
+    /// counted on the device (kmu_kmer_distribution); returned as (k-mer, count) pairs in no particular order
+    template <class Seq> std::vector<std::pair<Kmer, uint32_t>> generate_weighted_kmer(const Seq &seq) const {
+        const detail::Batch b = detail::gather(std::vector<const Seq *>{&seq});
+        kmu_hash_params hp{};
+        hp.kmer_type = Kmer::kmu_type;
+        hp.kmer_size = int32_t(k_);
+        hp.fhash = KMU_FHASH_IDENTITY_RAW;
+        hp.input_kind = b.input_kind;
+        hp.mem = KMU_MEM_HOST;
+        uint64_t n = 0;
+        ctx_.check(kmu_kmer_distribution(ctx_.raw(), &hp, b.bytes.data(), b.offsets.data(), b.packed_ptr(), 1, nullptr, nullptr, 0,
+                                         nullptr, &n));
+        std::vector<uint64_t> kk(std::max<uint64_t>(n, 1));
+        std::vector<uint32_t> cc(std::max<uint64_t>(n, 1));
+        ctx_.check(kmu_kmer_distribution(ctx_.raw(), &hp, b.bytes.data(), b.offsets.data(), b.packed_ptr(), 1, kk.data(), cc.data(), n,
+                                         nullptr, &n));
+        std::vector<std::pair<Kmer, uint32_t>> out;
+        out.reserve(n);
+        for (uint64_t i = 0; i < n; i++) out.emplace_back(Kmer::from_raw(kk[i], k_), cc[i]);
+        return out;
+    }
 
   private:
     uint8_t k_;

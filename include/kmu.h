@@ -14,7 +14,10 @@
  *      KMU_MEM_HOST   : host pointers; the library stages H2D / D2H itself (synchronous call).
  *      KMU_MEM_DEVICE : HIP device pointers (e.g. a torch tensor's data_ptr()); kernels are enqueued on the
  *                       context's stream and the call returns after the stream has been synchronised unless
- *                       the context was created with `async_device = 1`.
+ *                       the context was created with `async_device = 1`.  Such calls cannot report what their kernels
+ *                       find (a non-ACGT byte, an empty sequence, a full table): the device error word is sticky, and
+ *                       the bits of every call since the last synchronising call come back from the next one --
+ *                       kmu_synchronize at the latest.
  *  - sequences are handed over as one concatenated byte array + (n_seq+1) uint64 offsets:
  *      KMU_INPUT_ASCII  : bases[offsets[i] .. offsets[i+1]) are the ASCII letters of sequence i
  *      KMU_INPUT_PACKED2: offsets are in *bases*; sequence i starts at byte `packed_byte_offsets[i]`
@@ -85,10 +88,14 @@ typedef enum kmu_fhash {
 typedef enum kmu_algo {
     KMU_ALGO_PROB3A = 0, /* ProbMinHash3a  (probminhash crate), src/sketching/seqsketchjaccard.rs:211-260 */
     KMU_ALGO_SUPER = 1,  /* SuperMinHash   (probminhash crate), src/sketching/setsketchert.rs:255-297 */
-    KMU_ALGO_SUPER2 = 2, /* SuperMinHash2  (integer sketch),   src/sketching/setsketchert.rs:963-1004 */
+    KMU_ALGO_SUPER2 = 2, /* SuperMinHash2  (integer sketch),   src/sketching/setsketchert.rs:963-1004.
+                          * PROVISIONAL: the crate's fixed-point arithmetic is not in the reference tree; reference parity
+                          * cannot be established in this build environment */
     KMU_ALGO_BOTTOMK = 3, /* MinHashCount / MinInvHashCountKmer, src/sketching/minhash.rs:62-99,219-265 */
     KMU_ALGO_PROB3 = 4,   /* ProbMinHash3 (SeqSketcher::sketch_probminhash3, seqsketchjaccard.rs:272-319): the same point
                            * process as ProbMinHash3a handled key by key; the signature is the same per-slot arg-min */
+    /* PROVISIONAL (5, 6, 7): scheme from the cited papers, inner hash / variant choices of the `probminhash` crate
+     * unknown here; reference parity impossible in this build environment */
     KMU_ALGO_OPTDENS = 5, /* OptDensHashSketch: one-permutation hashing + optimal densification (Shrivastava 2017),
                            * src/sketching/setsketchert.rs:343-463, src/aautils/setsketchert.rs:482-612; sig F32 / F64 */
     KMU_ALGO_REVOPTDENS = 6, /* RevOptDensHashSketch: the same with reverse densification (Mai et al. 2019), meant for
@@ -209,6 +216,53 @@ int kmu_pack2b(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint
  * For KMU_INPUT_PACKED2 `packed_offsets` gives the byte offset of every sequence (may be NULL for ASCII). */
 int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
                     const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out);
+
+/* KmerGenerationPattern::generate_kmer_pattern_in_range (src/base/kmergenerator.rs:126; impls :271-303,368-408,491-526;
+ * amino acids src/aautils/kmeraa.rs:780-812,870-899): the k-mers that lie inside bases [range_begin[i], range_end[i]) of
+ * sequence i -- KmerSeqIterator::set_range (kmergenerator.rs:66-68) on IterSequence::set_range (src/base/sequence.rs:562-585).
+ * out[offsets[i] + p] for p in [range_begin[i], range_end[i] - k]; other entries untouched.  A range with end <= begin or
+ * end > L_i is the reference's `Err(())` (unwrapped by its callers: a panic): KMU_E_BAD_ARG.  (The reference's debug build
+ * also underflows for end < 4, sequence.rs:574; a release build wraps back to the intended byte: ends 1..3 are served.) */
+int kmu_kmer_hashes_range(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                          const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *range_begin,
+                          const uint64_t *range_end, uint64_t *out);
+
+/* KmerGenerationPattern::generate_kmer_distribution / KmerGenerator::generate_weighted_kmer (kmergenerator.rs:130,176; impls
+ * :245-269,339-366,447-489; amino acids kmeraa.rs:752-778,845-868): the DISTINCT values fhash(kmer) of every sequence with
+ * their multiplicities (u32 like the reference's FnvHashMap<T, u32>).  The pairs of sequence i are
+ * kmers_out / mult_out [dist_offsets_out[i] .. dist_offsets_out[i + 1]), in no particular order (a hash map upstream).
+ * Call with kmers_out == NULL for the sizes: *n_out = number of pairs, dist_offsets_out (n_seq + 1 entries, may be NULL).
+ * KMU_FHASH_IDENTITY_RAW gives the k-mers themselves (`.0`), what the reference's map is keyed by. */
+int kmu_kmer_distribution(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                          const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *kmers_out, uint32_t *mult_out,
+                          uint64_t cap, uint64_t *dist_offsets_out, uint64_t *n_out);
+
+/* ntHash per k-mer position (src/base/nthash.rs; NtHash for 2-bit k-mers src/base/kmer.rs:45-145).
+ *   table KMU_NTHASH_TABLE_2B: seeds of BASE_MAPPING_2B (nthash.rs:28-30) -- Kmer32bit / Kmer16b32bit::nthash_init,
+ *                              nthash_canonical_init (kmer.rs:48-95); ASCII or packed input
+ *         KMU_NTHASH_TABLE_8B: the reference's ASCII table BASE_MAPPING_8B bug for bug ('G' and 'T' hit zero entries,
+ *                              nthash.rs:48-57) -- nthash_init_8b :153-161, nthash_rcomp_init_8b :182-189,
+ *                              nthash_canonical_init_8b :214-228; upper-case ASCII input only
+ *   mode  KMU_NTHASH_CANONICAL: min(forward, rcomp) and its strand (0 forward, 1 reverse; forward on ties, :223-227)
+ *         KMU_NTHASH_FORWARD / KMU_NTHASH_RCOMP: one strand only (strand byte 0 / 1)
+ *   n_hashes > 1: from_one_hash_val_to_mult_hash (:63-72) -- nthash_mult_canonical_init_8b :255-269, kmer.rs:123-131.
+ * hashes_out[(offsets[i] + p) * n_hashes + j], strand_out[offsets[i] + p] (may be NULL) for p in [0, L_i - k + 1).
+ * The value at every position is the *_init value of the k-mer starting there = what a correct roll reaches (the property
+ * the reference tests, nthash.rs:333,379).  Not reproduced: the state resets that make the reference's own
+ * nthash_mult_canonical_cycle_8b (:279-280) and the 2-bit nthash_canonical_cycle (kmer.rs:98-99) differ from their init forms.
+ * 1 <= kmer_size <= 32. */
+typedef enum kmu_nthash_mode { KMU_NTHASH_CANONICAL = 0, KMU_NTHASH_FORWARD = 1, KMU_NTHASH_RCOMP = 2 } kmu_nthash_mode;
+typedef enum kmu_nthash_table { KMU_NTHASH_TABLE_2B = 0, KMU_NTHASH_TABLE_8B = 1 } kmu_nthash_table;
+typedef struct kmu_nthash_params {
+    int32_t kmer_size;
+    int32_t table;      /* kmu_nthash_table */
+    int32_t mode;       /* kmu_nthash_mode */
+    int32_t n_hashes;   /* >= 1 */
+    int32_t input_kind; /* kmu_input_kind */
+    int32_t mem;        /* kmu_mem */
+} kmu_nthash_params;
+int kmu_nthash(kmu_ctx *ctx, const kmu_nthash_params *p, const uint8_t *bases, const uint64_t *offsets,
+               const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *hashes_out, uint8_t *strand_out);
 
 /* The same values without the gaps: fhash of every k-mer of sequence 0, then of sequence 1, ... (uint64, zero-extended).
  * Call with out == NULL for the number of values in *n_out.  (What a rank feeds to the owner exchange of a distributed

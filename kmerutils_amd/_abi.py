@@ -73,3 +73,13 @@ SIG_NP = {SIG_U32: "uint32", SIG_U64: "uint64", SIG_F32: "float32", SIG_F64: "fl
 class HllParams(C.Structure):
     """kmu_hll_params: SetSketchParams (b, a, q); m is the sketch size of the call"""
     _fields_ = [("b", C.c_double), ("a", C.c_double), ("q", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+NTHASH_CANONICAL, NTHASH_FORWARD, NTHASH_RCOMP = 0, 1, 2
+NTHASH_TABLE_2B, NTHASH_TABLE_8B = 0, 1
+
+
+class NthashParams(C.Structure):
+    """kmu_nthash_params"""
+    _fields_ = [("kmer_size", C.c_int32), ("table", C.c_int32), ("mode", C.c_int32), ("n_hashes", C.c_int32),
+                ("input_kind", C.c_int32), ("mem", C.c_int32)]

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkmu.so")
 SOURCES = ["kmu_api.hip", "kmu_sketch.hip", "kmu_sketch_super.hip", "kmu_sketch_dens.hip", "kmu_count.hip", "kmu_compare.hip",
-           "kmu_ingest.hip"]
+           "kmu_ingest.hip", "kmu_kmergen.hip"]
 HEADERS = ["kmu_device.h", "kmu_stream.h", "kmu_ctx.hpp", os.path.join("..", "..", "include", "kmu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]

@@ -94,10 +94,17 @@ int stage_sequences(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
     return KMU_OK;
 }
 
+// The device error word is STICKY between two reads by the host: a call clears it only when the previous call's bits
+// have been read.  In `async_device` contexts KMU_MEM_DEVICE calls return without reading it, so the bits of every call
+// since the last read accumulate (kernels only OR into it) and surface at the next call that synchronises --
+// kmu_synchronize at the latest.  (Round 1 cleared the word on every entry: a full table or a non-ACGT byte in any call
+// but the last of an async sequence was lost.)
 int get_err_word(kmu_ctx *ctx, uint32_t **out) {
     void *p;
+    const bool fresh = ctx->bufs.find("errword") == ctx->bufs.end() || !ctx->bufs["errword"].p;
     KMU_TRY(dev_buf(ctx, "errword", 64, &p));
-    KMU_HIP(ctx, hipMemsetAsync(p, 0, 64, ctx->stream));
+    if (fresh || !ctx->err_unread) KMU_HIP(ctx, hipMemsetAsync(p, 0, 64, ctx->stream));
+    ctx->err_unread = true;
     *out = (uint32_t *) p;
     return KMU_OK;
 }
@@ -106,9 +113,11 @@ int check_err_word(kmu_ctx *ctx, uint32_t *d_err) {
     uint32_t h = 0;
     KMU_HIP(ctx, hipMemcpyAsync(&h, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->err_unread = false; // read: the next call starts from a cleared word
     if (h & DERR_NON_ACGT) return fail(ctx, KMU_E_NON_ACGT, "pattern not a code in alphabet_2b (non-ACGT byte in a sequence)");
     if (h & DERR_BAD_AA) return fail(ctx, KMU_E_BAD_ALPHABET, "encode: not a code in alphabet for amino acid");
     if (h & DERR_TABLE_FULL) return fail(ctx, KMU_E_TABLE_FULL, "device hash table full");
+    if (h & DERR_BAD_RANGE) return fail(ctx, KMU_E_BAD_ARG, "bad range for kmer iteration (set_range: end <= begin or end > sequence size)");
     if (h & 8u) return fail(ctx, KMU_E_EMPTY_SEQ, "empty sequence (the reference panics in get_nbkmer_guess: ilog2(0))");
     return KMU_OK;
 }
@@ -189,28 +198,41 @@ __global__ void __launch_bounds__(256) k_pack2b(const uint8_t *bases, const uint
 }
 
 // per-position k-mer -> fhash(kmer): KmerSeqIterator::next (src/base/kmergenerator.rs:75-106) + closure
+// rb / re (both or none): KmerSeqIterator::set_range (kmergenerator.rs:66-68, sequence.rs:562-585) -- only the k-mers that lie
+// inside bases [rb[i], re[i]) of sequence i; `Err(())` of the reference (end <= begin or end > L) sets DERR_BAD_RANGE.
 __global__ void __launch_bounds__(256) k_kmer_hashes(const uint8_t *bases, const uint64_t *offsets,
                                                      const uint64_t *packed_offsets, uint32_t n_seq, int packed,
-                                                     uint64_t total, KmerCfg cfg, uint64_t *out, uint32_t *err) {
+                                                     uint64_t total, KmerCfg cfg, const uint64_t *rb, const uint64_t *re,
+                                                     uint64_t *out, uint32_t *err) {
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const bool aa = cfg.kmer_type == KMU_KMERAA32BIT || cfg.kmer_type == KMU_KMERAA64BIT;
     for (uint32_t i = blockIdx.x; i < n_seq; i += gridDim.x) {
         SeqView s = make_view(bases, offsets, packed_offsets, n_seq, packed, total, i);
         const uint64_t L = s.len;
         const uint64_t nk = L >= (uint64_t) cfg.k ? L - cfg.k + 1 : 0;
+        uint64_t pb = 0, pe = nk; // k-mer start positions [pb, pe)
+        if (rb) {
+            const uint64_t b = rb[i], e = re[i];
+            if (e <= b || e > L) { // sequence.rs:563-565
+                if (threadIdx.x == 0) atomicOr(err, DERR_BAD_RANGE);
+                continue;
+            }
+            pb = b;
+            pe = e - b >= (uint64_t) cfg.k ? e - cfg.k + 1 : b; // the iterator runs dry once fewer than k bases are left
+        }
         uint64_t *o = out + offsets[i];
         uint32_t bad = 0;
+        if (pe <= pb) continue;
         if (aa) {
-            uint64_t nsteps = (L + 63) / 64;
-            for (uint64_t st = wave; st < nsteps; st += nwaves)
-                bad |= wave_step_kmers_aa(s, cfg.k, st, 0, nk, [&](uint64_t p, uint64_t val, uint64_t) {
+            for (uint64_t st = pb / 64 + wave; st <= (pe - 1) / 64; st += nwaves)
+                bad |= wave_step_kmers_aa(s, cfg.k, st, pb, pe, [&](uint64_t p, uint64_t val, uint64_t) {
                     o[p] = apply_fhash(cfg, val, 0);
                 });
             if (bad) atomicOr(err, DERR_BAD_AA);
         } else {
-            uint64_t nsteps = (seq_num_words(s) + 63) / 64;
-            for (uint64_t st = wave; st < nsteps; st += nwaves)
-                bad |= wave_step_kmers(s, cfg.k, st, 0, nk, [&](uint64_t p, uint64_t val, uint64_t rc) {
+            const uint64_t lead = seq_lead(s);
+            for (uint64_t st = (pb + lead) / 1024 + wave; st <= (pe - 1 + lead) / 1024; st += nwaves)
+                bad |= wave_step_kmers(s, cfg.k, st, pb, pe, [&](uint64_t p, uint64_t val, uint64_t rc) {
                     o[p] = apply_fhash(cfg, val, rc);
                 });
             if (bad) atomicOr(err, DERR_NON_ACGT);
@@ -422,14 +444,30 @@ int kmu_pack2b(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint
     return finish_call(ctx, mem);
 }
 
-int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
-                    const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out) {
+static int kmer_hashes_impl(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                            const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *range_begin,
+                            const uint64_t *range_end, uint64_t *out) {
     if (!ctx || !p || !out) return KMU_E_BAD_ARG;
     KMU_TRY(check_kmer(ctx, p->kmer_type, p->kmer_size));
     if (!fhash_valid(p->fhash, p->kmer_type)) return fail(ctx, KMU_E_BAD_ARG, "fhash %d not valid for kmer_type %d", p->fhash, p->kmer_type);
     if (p->input_kind == KMU_INPUT_PACKED2 && (kmer_is_aa(p->kmer_type) || p->fhash == KMU_FHASH_CANON_NTHASH_8B))
         return fail(ctx, KMU_E_BAD_ARG, "packed input not valid for this kmer_type / fhash");
     KMU_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t *d_rb = range_begin, *d_re = range_end;
+    if (range_begin && p->mem == KMU_MEM_HOST) {
+        for (uint32_t i = 0; i < n_seq; i++) // IterSequence::set_range, sequence.rs:563-565
+            if (range_end[i] <= range_begin[i] || range_end[i] > offsets[i + 1] - offsets[i])
+                return fail(ctx, KMU_E_BAD_ARG, "bad range [%llu, %llu) for kmer iteration on sequence %u of %llu bases",
+                            (unsigned long long) range_begin[i], (unsigned long long) range_end[i], i,
+                            (unsigned long long) (offsets[i + 1] - offsets[i]));
+        void *q;
+        KMU_TRY(dev_buf(ctx, "in.range_b", (size_t) n_seq * 8 + 8, &q));
+        KMU_HIP(ctx, hipMemcpyAsync(q, range_begin, (size_t) n_seq * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_rb = (const uint64_t *) q;
+        KMU_TRY(dev_buf(ctx, "in.range_e", (size_t) n_seq * 8 + 8, &q));
+        KMU_HIP(ctx, hipMemcpyAsync(q, range_end, (size_t) n_seq * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_re = (const uint64_t *) q;
+    }
     DevSeqs ds;
     KMU_TRY(stage_sequences(ctx, bases, offsets, packed_offsets, n_seq, p->input_kind, p->mem, &ds));
     uint64_t *d_out = out;
@@ -440,7 +478,8 @@ int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases
         void *q;
         KMU_TRY(dev_buf(ctx, "out.u64", (size_t) total * 8 + 8, &q));
         d_out = (uint64_t *) q;
-        KMU_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t) total * 8, ctx->stream));
+        // (positions that start no k-mer keep what the caller's array holds: it goes up first)
+        KMU_HIP(ctx, hipMemcpyAsync(d_out, out + off0, (size_t) total * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
@@ -449,13 +488,25 @@ int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases
         int grid = (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
         KernelTimer t(ctx, "k_kmer_hashes");
         hipLaunchKernelGGL(k_kmer_hashes, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, ds.packed_offsets,
-                           n_seq, ds.packed, ds.total_bytes, cfg, d_out, d_err);
+                           n_seq, ds.packed, ds.total_bytes, cfg, d_rb, d_re, d_out, d_err);
     }
     KMU_HIP(ctx, hipGetLastError());
     if (p->mem == KMU_MEM_HOST)
         KMU_HIP(ctx, hipMemcpyAsync(out + off0, d_out, (size_t) total * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
     return finish_call(ctx, p->mem);
+}
+
+int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                    const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out) {
+    return kmer_hashes_impl(ctx, p, bases, offsets, packed_offsets, n_seq, nullptr, nullptr, out);
+}
+
+int kmu_kmer_hashes_range(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                          const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *range_begin,
+                          const uint64_t *range_end, uint64_t *out) {
+    if (!range_begin || !range_end) return KMU_E_BAD_ARG;
+    return kmer_hashes_impl(ctx, p, bases, offsets, packed_offsets, n_seq, range_begin, range_end, out);
 }
 
 int kmu_block_layout(const uint64_t *offsets, uint32_t n_seq, uint32_t block_size, uint64_t *out) {

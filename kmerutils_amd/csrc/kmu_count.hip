@@ -965,11 +965,10 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KMU_TRY(dev_buf(ctx, "cnt.tot2", (size_t) n_regions * 8, &tot2));
     }
     const int k = c->p.kmer_size;
-    static bool lds_attr_done = false;
-    if (!lds_attr_done) {
+    if (!(ctx->lds_attr_set & 1u)) { // function attributes are per device: remembered per context, not per process
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_attr_done = true;
+        ctx->lds_attr_set |= 1u;
     }
     {
         KernelTimer tm(ctx, "k_part_hist1");
@@ -1039,12 +1038,11 @@ namespace kmu {
 int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits, const uint64_t **items_out,
                   const uint64_t **bounds_out, bool hashed_out) {
     if (region_bits > 22) return fail(ctx, KMU_E_UNSUPPORTED, "too many partitions (2^%d)", region_bits);
-    static bool lds_attr_done = false;
-    if (!lds_attr_done) {
+    if (!(ctx->lds_attr_set & 2u)) {
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY_TO_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_attr_done = true;
+        ctx->lds_attr_set |= 2u;
     }
     const int b1 = region_bits <= 11 ? region_bits : (region_bits + 1) / 2;
     const int b2 = region_bits - b1;
@@ -1157,10 +1155,9 @@ static int extract_by_owner(kmu_counter *c, const DevSeqs &ds, uint64_t total_ba
     KMU_TRY(dev_buf(ctx, "cnt.offs1", (size_t) units1 * n_parts * 8, &offs1));
     KMU_TRY(dev_buf(ctx, "cnt.tot1", (size_t) n_parts * 8, &tot1));
     KMU_TRY(dev_buf(ctx, "cnt.binstart1", (size_t) (n_parts + 1) * 8, &binstart1));
-    static bool lds_attr_done = false;
-    if (!lds_attr_done) {
+    if (!(ctx->lds_attr_set & 4u)) {
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_attr_done = true;
+        ctx->lds_attr_set |= 4u;
     }
     const int k = c->p.kmer_size;
     {

@@ -21,6 +21,8 @@ struct kmu_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool async_device = false;
+    bool err_unread = false; // the device error word holds bits no host read has seen yet (get_err_word / check_err_word)
+    uint32_t lds_attr_set = 0; // kernels whose MaxDynamicSharedMemorySize was raised on THIS context's device (bit per kernel group)
     std::string err;
     // kmu_sketch_partial / kmu_sketch_hashed_partial: where the all-sequences paths leave their per-slot minima instead of
     // turning them into a signature (device memory; null in every other call)
@@ -176,7 +178,7 @@ int stage_sequences(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
 int finish_call(kmu_ctx *ctx, int mem);
 
 // device error word (bit flags set by kernels)
-enum : uint32_t { DERR_NON_ACGT = 1u, DERR_TABLE_FULL = 2u, DERR_BAD_AA = 4u };
+enum : uint32_t { DERR_NON_ACGT = 1u, DERR_TABLE_FULL = 2u, DERR_BAD_AA = 4u, DERR_EMPTY_SEQ = 8u, DERR_BAD_RANGE = 16u };
 int get_err_word(kmu_ctx *ctx, uint32_t **out); // zeroed on the stream
 int check_err_word(kmu_ctx *ctx, uint32_t *d_err);
 

@@ -11,7 +11,9 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libkmu.so")
+# KMU_LIB names another build of the library (A/B experiments: scripts/ab_libs.sh, scripts/pmc_lib.sh) -- the product file
+# is never overwritten by an experiment
+SO_PATH = os.environ.get("KMU_LIB") or os.path.join(_HERE, "libkmu.so")
 _lib = None
 
 # every symbol include/kmu.h declares (tests check the library exports all of them)
@@ -25,6 +27,7 @@ SYMBOLS = [
     "kmu_minhash_distance_pairs", "kmu_ingest_fastq", "kmu_ingest_fasta", "kmu_ingest_fastx", "kmu_dev_alloc", "kmu_dev_free",
     "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions", "kmu_count_eliminate_once", "kmu_sketch_partial_words",
     "kmu_sketch_partial", "kmu_sketch_hashed_partial", "kmu_sketch_merge_partials", "kmu_kmer_hashes_compact", "kmu_set_hll_params",
+    "kmu_kmer_hashes_range", "kmu_kmer_distribution", "kmu_nthash",
 ]
 
 
@@ -60,6 +63,9 @@ def load():
     L.kmu_count_non_acgt.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp]
     L.kmu_pack2b.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, vp, vp]
     L.kmu_kmer_hashes.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp]
+    L.kmu_kmer_hashes_range.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
+    L.kmu_kmer_distribution.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, u64p]
+    L.kmu_nthash.argtypes = [vp, C.POINTER(A.NthashParams), vp, vp, vp, C.c_uint32, vp, vp]
     L.kmu_sketch.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
     L.kmu_block_layout.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.kmu_sketch_hashed.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, C.c_uint32, vp, vp]
@@ -114,18 +120,49 @@ def _ptr(x):
     return x.ctypes.data_as(C.c_void_p), False
 
 
+class _StreamOrdered:
+    """libkmu's entry points as seen by one Context: every call is first ordered behind torch's current stream.
+
+    The library enqueues on the context's stream.  When that is not torch's current stream (a context that owns its
+    stream), nothing orders it behind work torch has queued on its own stream -- the producers of the input tensors, and
+    the zero-fill of an output tensor allocated a line earlier, which could otherwise land on top of the kernel's results.
+    Doing it here, at the one place every call passes through, covers the buffers of every present and future method."""
+
+    _PLAIN = ("kmu_last_error", "kmu_destroy", "kmu_stream", "kmu_version", "kmu_device_count", "kmu_create",
+              "kmu_block_layout", "kmu_sketch_partial_words", "kmu_count_destroy")
+
+    def __init__(self, lib, ctx):
+        self._lib = lib
+        self._ctx = ctx
+
+    def __getattr__(self, name):
+        f = getattr(self._lib, name)
+        if name in self._PLAIN:
+            return f
+        ctx = self._ctx
+
+        def call(*args):
+            ctx._order_after_torch()
+            return f(*args)
+        setattr(self, name, call)
+        return call
+
+
 class Context:
     """kmu_ctx: one HIP device + stream.  Use from one thread at a time."""
 
     def __init__(self, device_id=0, stream=None, async_device=False):
-        self.L = load()
+        lib = load()
+        self.h = None
+        self.device_id = device_id
+        self.L = _StreamOrdered(lib, self)
         cfg = A.DeviceCfg(device_id, 1 if async_device else 0, stream, 0)
         h = C.c_void_p()
-        rc = self.L.kmu_create(C.byref(cfg), C.byref(h))
+        rc = lib.kmu_create(C.byref(cfg), C.byref(h))
         if rc:
-            raise KmuError(rc, self.L.kmu_last_error(None).decode())
+            raise KmuError(rc, lib.kmu_last_error(None).decode())
         self.h = h
-        self.device_id = device_id
+        self._stream = lib.kmu_stream(h) or 0
 
     def close(self):
         if getattr(self, "h", None):
@@ -147,7 +184,7 @@ class Context:
 
     @property
     def stream(self):
-        return self.L.kmu_stream(self.h)
+        return self._stream
 
     def set_hll_params(self, b=1.001, a=20.0, q=65534):
         """kmu_set_hll_params: SetSketchParams of the following ALGO_HLL sketches on this context"""
@@ -166,16 +203,20 @@ class Context:
         n = self.L.kmu_profile_get(self.h, arr, 32)
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(min(n, 32))}
 
+    def _order_after_torch(self):
+        """Wait for what torch has queued on its current stream of this device, unless that IS the context's stream
+        (then stream order does it).  Only when torch is loaded and has touched the GPU: host-only callers never pay."""
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is None or self.h is None or not torch.cuda.is_initialized():
+            return
+        cur = torch.cuda.current_stream(self.device_id)
+        if cur.cuda_stream != self._stream:
+            cur.synchronize()
+
     def _wait_producers(self, *xs):
-        """Device buffers are consumed on this context's stream: if they were produced on another torch stream,
-        wait for it first (a no-op when the context was created on torch's current stream)."""
-        for x in xs:
-            if x is not None and _is_torch(x) and x.is_cuda:
-                import torch
-                cur = torch.cuda.current_stream(x.device)
-                if cur.cuda_stream != (self.stream or 0):
-                    cur.synchronize()
-                return
+        """Kept for callers of round 1: the ordering now happens inside every library call (_StreamOrdered)."""
+        self._order_after_torch()
 
     # ---- helpers ----
     @staticmethod
@@ -220,6 +261,67 @@ class Context:
         self._check(self.L.kmu_kmer_hashes(self.h, C.byref(hp), _ptr(bases)[0], _ptr(offsets)[0],
                                            _ptr(packed_offsets)[0], n, _ptr(out)[0]))
         return out
+
+    def kmer_hashes_range(self, bases, offsets, kmer_type, k, fhash, range_begin, range_end, input_kind=A.INPUT_ASCII,
+                          packed_offsets=None, out=None):
+        """kmu_kmer_hashes_range: generate_kmer_pattern_in_range -- fhash of the k-mers inside bases [begin_i, end_i) of
+        every sequence, at out[offsets[i] + p]; a bad range raises KMU_E_BAD_ARG (the reference's set_range Err)."""
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets, range_begin, range_end)
+        hp = A.HashParams(kmer_type, k, fhash, input_kind, mem, 0)
+        if out is None:
+            if mem == A.MEM_DEVICE:
+                import torch
+                out = torch.zeros(max(int(offsets[-1].item()), 1), dtype=torch.int64, device=bases.device)
+            else:
+                out = np.zeros(max(int(offsets[-1]), 1), np.uint64)
+        self._check(self.L.kmu_kmer_hashes_range(self.h, C.byref(hp), _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0],
+                                                 n, _ptr(range_begin)[0], _ptr(range_end)[0], _ptr(out)[0]))
+        return out
+
+    def kmer_distribution(self, bases, offsets, kmer_type, k, fhash=A.FHASH_IDENTITY_RAW, input_kind=A.INPUT_ASCII,
+                          packed_offsets=None):
+        """kmu_kmer_distribution: generate_kmer_distribution -- (values, multiplicities, dist_offsets): the distinct fhash
+        values of sequence i and their counts are [dist_offsets[i], dist_offsets[i + 1]) of the first two arrays."""
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets)
+        hp = A.HashParams(kmer_type, k, fhash, input_kind, mem, 0)
+        cnt = C.c_uint64(0)
+        args = (self.h, C.byref(hp), _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0], n)
+        self._check(self.L.kmu_kmer_distribution(*args, None, None, 0, None, C.byref(cnt)))
+        if mem == A.MEM_DEVICE:
+            import torch
+            kk = torch.zeros(max(cnt.value, 1), dtype=torch.int64, device=bases.device)
+            cc = torch.zeros(max(cnt.value, 1), dtype=torch.int32, device=bases.device)
+            do = torch.zeros(n + 1, dtype=torch.int64, device=bases.device)
+        else:
+            kk, cc, do = np.zeros(max(cnt.value, 1), np.uint64), np.zeros(max(cnt.value, 1), np.uint32), np.zeros(n + 1, np.uint64)
+        self._check(self.L.kmu_kmer_distribution(*args, _ptr(kk)[0], _ptr(cc)[0], cnt.value, _ptr(do)[0], C.byref(cnt)))
+        return kk[:cnt.value], cc[:cnt.value], do
+
+    def nthash(self, bases, offsets, k, n_hashes=1, mode=A.NTHASH_CANONICAL, table=A.NTHASH_TABLE_2B,
+               input_kind=A.INPUT_ASCII, packed_offsets=None, want_strand=True, out=None, strand_out=None):
+        """kmu_nthash: (hashes [n_bases, n_hashes] u64, strand [n_bases] u8) -- rows of positions that start no k-mer
+        stay untouched (zero in freshly allocated outputs)."""
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets)
+        np_ = A.NthashParams(k, table, mode, n_hashes, input_kind, mem)
+        if mem == A.MEM_DEVICE:
+            import torch
+            nb = max(int(offsets[-1].item()), 1)
+            if out is None:
+                out = torch.zeros((nb, n_hashes), dtype=torch.int64, device=bases.device)
+            if want_strand and strand_out is None:
+                strand_out = torch.zeros(nb, dtype=torch.uint8, device=bases.device)
+        else:
+            nb = max(int(offsets[-1]), 1)
+            if out is None:
+                out = np.zeros((nb, n_hashes), np.uint64)
+            if want_strand and strand_out is None:
+                strand_out = np.zeros(nb, np.uint8)
+        self._check(self.L.kmu_nthash(self.h, C.byref(np_), _ptr(bases)[0], _ptr(offsets)[0], _ptr(packed_offsets)[0], n,
+                                      _ptr(out)[0], _ptr(strand_out)[0]))
+        return (out, strand_out) if want_strand else out
 
     def kmer_hashes_compact(self, bases, offsets, kmer_type, k, fhash, input_kind=A.INPUT_ASCII, packed_offsets=None):
         """kmu_kmer_hashes_compact: fhash of every k-mer, sequence after sequence, no gaps (uint64 / int64 tensor)"""

@@ -453,6 +453,223 @@ int kmo_kmer_hashes(const kmu_hash_params *p, const uint8_t *bases, const uint64
     return 0;
 }
 
+/* ----------------------------------------------------------------------------------------------------
+ * KmerSeqIterator with a range: generate_kmer_pattern_in_range, src/base/kmergenerator.rs:126 (impls :271-303,
+ * :368-408, :491-526).  IterSequence restated state for state on the packed bytes of Sequence::new(raw, 2):
+ * new sequence.rs:523-556, set_range :562-585, next :605-648.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const uint8_t *seq;   /* packed bytes */
+    uint64_t size;        /* bases */
+    int tail;             /* description[1] = size % 4 */
+    uint64_t byte, last_byte;
+    int bit, last_bit;
+} kmo_iterseq;
+
+static void iterseq_new(kmo_iterseq *it, const uint8_t *packed, uint64_t size) {
+    uint64_t nbytes = (size + 3) / 4;
+    it->seq = packed;
+    it->size = size;
+    it->tail = (int) (size % 4);
+    it->byte = 0;
+    it->bit = 0;
+    it->last_byte = nbytes - 1;                      /* :533 */
+    it->last_bit = it->tail > 0 ? 2 * it->tail : 8;  /* :534-538 */
+}
+/* 0 = Ok(()), -1 = Err(()) */
+static int iterseq_set_range(kmo_iterseq *it, uint64_t begin, uint64_t end) {
+    if (end <= begin || end > it->size) return -1;   /* :563-565 */
+    it->byte = begin / 4;                            /* :570 */
+    it->bit = 2 * (int) (begin % 4);                 /* :572 */
+    it->last_byte = (end / 4) - 1;                   /* :574 (wraps for end < 4 in a release build, then :577 brings it back) */
+    it->last_bit = 8;
+    if (end % 4 > 0) {
+        it->last_byte += 1;
+        it->last_bit = 2 * (int) (end % 4);
+    }
+    return 0;
+}
+/* -1 = None, else the 2-bit code */
+static int iterseq_next(kmo_iterseq *it) {
+    if (it->byte > it->last_byte || (it->byte == it->last_byte && it->bit >= it->last_bit)) return -1; /* :610-614 */
+    int endbit = (it->byte == it->last_byte && it->tail > 0) ? it->last_bit : 8;                       /* :616-621 */
+    if (it->bit >= endbit) return -1;                                                                    /* :623-626 */
+    int base = 3 & (it->seq[it->byte] >> (8 - it->bit - 2));                                             /* :632 */
+    it->bit += 2;
+    if (it->bit == endbit) {
+        it->byte += 1;
+        if (it->byte <= it->last_byte) it->bit = 0;
+    }
+    return base;
+}
+
+int kmo_kmer_hashes_range(const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                          const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *range_begin,
+                          const uint64_t *range_end, uint64_t *out) {
+    int rc = kmer_check_k(p->kmer_type, p->kmer_size);
+    if (rc) return rc;
+    if (!fhash_valid(p->fhash, p->kmer_type)) return KMU_E_BAD_ARG;
+    if (p->input_kind == KMU_INPUT_PACKED2 && (!packed_offsets || p->fhash == KMU_FHASH_CANON_NTHASH_8B)) return KMU_E_BAD_ARG;
+    const int t = p->kmer_type, k = p->kmer_size;
+    for (uint32_t i = 0; i < n_seq; i++) {
+        const uint64_t L = offsets[i + 1] - offsets[i], b = range_begin[i], e = range_end[i];
+        const uint8_t *src = seq_ptr(bases, offsets, packed_offsets, p->input_kind, i);
+        uint64_t *o = out + offsets[i];
+        if (kmer_is_aa(t)) {
+            /* KmerSeqIterator of kmeraa.rs:568-627 on one byte per residue; set_range :548-557: same Err rule */
+            if (e <= b || e > L) return KMU_E_BAD_ARG;
+            uint8_t *codes = (uint8_t *) malloc(L + 1);
+            rc = seq_to_codes(t, src, L, p->input_kind, codes);
+            if (rc) { free(codes); return rc; }
+            uint64_t *tmp = (uint64_t *) malloc((e - b + 1) * 8);
+            int64_t n = seq_hashed_kmers(t, k, p->fhash, codes + b, 0, e - b, tmp);
+            for (int64_t q = 0; q < n; q++) o[b + q] = tmp[q];
+            free(tmp);
+            free(codes);
+            continue;
+        }
+        /* the reference iterates the PACKED sequence: pack ASCII input first (Sequence::new(raw, 2)) */
+        uint8_t *packed = 0;
+        const uint8_t *pk = src;
+        if (p->input_kind == KMU_INPUT_ASCII) {
+            packed = (uint8_t *) malloc(L / 4 + 2);
+            if (kmo_pack2b(src, L, packed) < 0) { free(packed); return KMU_E_NON_ACGT; }
+            pk = packed;
+        }
+        kmo_iterseq it;
+        iterseq_new(&it, pk, L);
+        if (iterseq_set_range(&it, b, e) != 0) { free(packed); return KMU_E_BAD_ARG; } /* `.unwrap()` of the callers */
+        /* KmerSeqIterator::next, kmergenerator.rs:75-106 */
+        int have_prev = 0;
+        uint64_t prev = 0, n = 0;
+        for (;;) {
+            int nb = iterseq_next(&it);
+            if (nb < 0) break;
+            uint64_t raw;
+            if (have_prev) raw = kmo_kmer_push(t, prev, k, (uint8_t) nb);
+            else {
+                int pos = 2 * (k - 1), ok = 1;
+                uint64_t val = (uint64_t) nb << pos;
+                for (int j = 0; j < k - 1; j++) {
+                    int nb2 = iterseq_next(&it);
+                    if (nb2 < 0) { ok = 0; break; }
+                    val |= (uint64_t) nb2 << (pos - 2 - 2 * j);
+                }
+                if (!ok) break;
+                raw = kmo_kmer_build(t, val, k);
+                have_prev = 1;
+            }
+            prev = raw;
+            if (p->fhash == KMU_FHASH_CANON_NTHASH_8B) o[b + n] = kmo_nthash_canonical_init_8b(src + b + n, k, &(uint64_t){0}, &(uint64_t){0}, 0);
+            else o[b + n] = apply_fhash(p->fhash, t, k, raw);
+            n++;
+        }
+        free(packed);
+    }
+    return 0;
+}
+
+/* generate_kmer_distribution, kmergenerator.rs:130 (impls :245-269, :339-366, :447-489; AA kmeraa.rs:752-778, :845-868):
+ * `*kmer_distribution.entry(kmer).or_insert(0) += 1` over the iterator.  The map has no order; pairs are listed by
+ * ascending value here.  kmers_out == NULL: sizes only. */
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *) a, y = *(const uint64_t *) b;
+    return x < y ? -1 : x > y;
+}
+int kmo_kmer_distribution(const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                          const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *kmers_out, uint32_t *mult_out,
+                          uint64_t cap, uint64_t *dist_offsets_out, uint64_t *n_out) {
+    int rc = kmer_check_k(p->kmer_type, p->kmer_size);
+    if (rc) return rc;
+    if (!fhash_valid(p->fhash, p->kmer_type)) return KMU_E_BAD_ARG;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_seq; i++) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        if (dist_offsets_out) dist_offsets_out[i] = total;
+        uint8_t *codes = (uint8_t *) malloc(L + 1);
+        uint64_t *vals = (uint64_t *) malloc((L + 1) * 8);
+        const uint8_t *src = seq_ptr(bases, offsets, packed_offsets, p->input_kind, i);
+        rc = seq_to_codes(p->kmer_type, src, L, p->input_kind, codes);
+        int64_t n = rc ? rc : seq_hashed_kmers(p->kmer_type, p->kmer_size, p->fhash, codes, p->input_kind == KMU_INPUT_ASCII ? src : 0, L, vals);
+        free(codes);
+        if (n < 0) { free(vals); return (int) n; }
+        qsort(vals, (size_t) n, 8, cmp_u64);
+        for (int64_t q = 0; q < n;) {
+            int64_t r = q;
+            while (r < n && vals[r] == vals[q]) r++;
+            if (kmers_out) {
+                if (total >= cap) { free(vals); return KMU_E_BAD_ARG; }
+                kmers_out[total] = vals[q];
+                mult_out[total] = (uint32_t) (r - q);
+            }
+            total++;
+            q = r;
+        }
+        free(vals);
+    }
+    if (dist_offsets_out) dist_offsets_out[n_seq] = total;
+    *n_out = total;
+    return 0;
+}
+
+/* ntHash per k-mer position: same contract as kmu_nthash (include/kmu.h).
+ * 8-bit table: *_init_8b on the first k-mer, then the reference's cycle functions (nthash.rs:172-176, :198-202, :232-246)
+ * along the sequence -- the literal rolling use.  2-bit table: the init form of kmer.rs:48-95 on every k-mer (its
+ * nthash_canonical_cycle zeroes the state first, kmer.rs:98-99, and cannot be rolled). */
+/* nthash_rcomp_init_8b, nthash.rs:182-189 */
+uint64_t kmo_nthash_rcomp_init_8b(const uint8_t *kmer, int k) {
+    uint64_t h = 0;
+    for (int i = 0; i < k; i++) h ^= rotl64(nt8b(24u + kmer[i]), (unsigned) i % 64);
+    return h;
+}
+/* nthash_rcomp_cycle_8b, nthash.rs:198-202 */
+uint64_t kmo_nthash_rcomp_cycle_8b(uint64_t h, int k, uint8_t old_base, uint8_t new_base) {
+    return rotr64(h, 1) ^ rotr64(nt8b(24u + old_base), 1) ^ rotl64(nt8b(24u + new_base), (unsigned) (k - 1) % 64);
+}
+int kmo_nthash(const kmu_nthash_params *p, const uint8_t *bases, const uint64_t *offsets, const uint64_t *packed_offsets,
+               uint32_t n_seq, uint64_t *hashes_out, uint8_t *strand_out) {
+    const int k = p->kmer_size, nh = p->n_hashes;
+    if (k < 1 || k > 32 || nh < 1) return KMU_E_BAD_ARG;
+    if (p->table == KMU_NTHASH_TABLE_8B && p->input_kind != KMU_INPUT_ASCII) return KMU_E_BAD_ARG;
+    for (uint32_t i = 0; i < n_seq; i++) {
+        const uint64_t L = offsets[i + 1] - offsets[i];
+        const uint8_t *src = seq_ptr(bases, offsets, packed_offsets, p->input_kind, i);
+        uint8_t *codes = (uint8_t *) malloc(L + 1);
+        int rc = seq_to_codes(KMU_KMER64BIT, src, L, p->input_kind, codes);
+        if (rc) { free(codes); return rc; }
+        if (L >= (uint64_t) k) {
+            uint64_t fh = 0, rh = 0;
+            for (uint64_t q = 0; q + k <= L; q++) {
+                uint64_t h0;
+                uint8_t sd;
+                if (p->table == KMU_NTHASH_TABLE_8B) {
+                    uint8_t up[32];
+                    for (int j = 0; j < k; j++) up[j] = src[q + j]; /* (upper-case input) */
+                    if (q == 0) { fh = kmo_nthash_init_8b(up, k); rh = kmo_nthash_rcomp_init_8b(up, k); }
+                    else {
+                        fh = kmo_nthash_cycle_8b(fh, k, src[q - 1], src[q - 1 + k]);
+                        rh = kmo_nthash_rcomp_cycle_8b(rh, k, src[q - 1], src[q - 1 + k]);
+                    }
+                } else {
+                    uint64_t val = 0;
+                    for (int j = 0; j < k; j++) val |= (uint64_t) codes[q + j] << (2 * (k - 1 - j));
+                    (void) kmo_nthash_canonical_2b(val, k, &fh, &rh, 0);
+                }
+                if (p->mode == KMU_NTHASH_FORWARD) { h0 = fh; sd = 0; }
+                else if (p->mode == KMU_NTHASH_RCOMP) { h0 = rh; sd = 1; }
+                else if (fh <= rh) { h0 = fh; sd = 0; }
+                else { h0 = rh; sd = 1; }
+                uint64_t *o = hashes_out + (offsets[i] + q) * (uint64_t) nh;
+                o[0] = h0;
+                kmo_nthash_mult((uint64_t) k, o, nh);
+                if (strand_out) strand_out[offsets[i] + q] = sd;
+            }
+        }
+        free(codes);
+    }
+    return 0;
+}
+
 /* ====================================================================================================
  * RNG + distributions (UNPINNED: third-party crates rand 0.9 / rand_xoshiro 0.7 / probminhash 0.1)
  * ==================================================================================================== */

@@ -67,6 +67,17 @@ uint64_t kmo_xoshiro_next(uint64_t s[4]);
 int kmo_kmer_hashes(const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
                     const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out);
 
+int kmo_kmer_hashes_range(const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                          const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *range_begin,
+                          const uint64_t *range_end, uint64_t *out);
+int kmo_kmer_distribution(const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
+                          const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *kmers_out, uint32_t *mult_out,
+                          uint64_t cap, uint64_t *dist_offsets_out, uint64_t *n_out);
+uint64_t kmo_nthash_rcomp_init_8b(const uint8_t *kmer, int k);
+uint64_t kmo_nthash_rcomp_cycle_8b(uint64_t h, int k, uint8_t old_base, uint8_t new_base);
+int kmo_nthash(const kmu_nthash_params *p, const uint8_t *bases, const uint64_t *offsets, const uint64_t *packed_offsets,
+               uint32_t n_seq, uint64_t *hashes_out, uint8_t *strand_out);
+
 /* ---- L3: same contracts as the kmu_* entry points, host memory only ---- */
 int kmo_sketch(const kmu_sketch_params *p, const uint8_t *bases, const uint64_t *offsets,
                const uint64_t *packed_offsets, uint32_t n_seq, const uint64_t *block_row_offsets, void *sig_out,

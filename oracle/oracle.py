@@ -59,6 +59,13 @@ def lib():
         L.kmo_xoshiro_next.argtypes = [vp]; L.kmo_xoshiro_next.restype = C.c_uint64
         L.kmo_kmer_hashes.argtypes = [C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp]
         L.kmo_kmer_hashes.restype = C.c_int
+        L.kmo_kmer_hashes_range.argtypes = [C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
+        L.kmo_kmer_hashes_range.restype = C.c_int
+        L.kmo_kmer_distribution.argtypes = [C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, u64p]
+        L.kmo_kmer_distribution.restype = C.c_int
+        L.kmo_nthash.argtypes = [C.POINTER(A.NthashParams), vp, vp, vp, C.c_uint32, vp, vp]
+        L.kmo_nthash.restype = C.c_int
+        L.kmo_nthash_rcomp_init_8b.argtypes = [vp, C.c_int]; L.kmo_nthash_rcomp_init_8b.restype = C.c_uint64
         L.kmo_sketch.argtypes = [C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
         L.kmo_sketch.restype = C.c_int
         L.kmo_sketch_hashed.argtypes = [C.POINTER(A.SketchParams), vp, vp, C.c_uint32, vp, vp]
@@ -112,6 +119,47 @@ def kmer_hashes(bases, offsets, kmer_type, k, fhash, input_kind=A.INPUT_ASCII, p
     if rc:
         raise OracleError(rc)
     return out
+
+
+def kmer_hashes_range(bases, offsets, kmer_type, k, fhash, range_begin, range_end, input_kind=A.INPUT_ASCII,
+                      packed_offsets=None):
+    hp = A.HashParams(kmer_type, k, fhash, input_kind, A.MEM_HOST, 0)
+    out = np.zeros(max(int(offsets[-1]), 1), dtype=np.uint64)
+    rb, re = np.ascontiguousarray(range_begin, np.uint64), np.ascontiguousarray(range_end, np.uint64)
+    rc = lib().kmo_kmer_hashes_range(C.byref(hp), _p(bases), _p(offsets), _p(packed_offsets), len(offsets) - 1, _p(rb), _p(re),
+                                     _p(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def kmer_distribution(bases, offsets, kmer_type, k, fhash=A.FHASH_IDENTITY_RAW, input_kind=A.INPUT_ASCII,
+                      packed_offsets=None):
+    """(values ascending per sequence, multiplicities, dist_offsets)"""
+    hp = A.HashParams(kmer_type, k, fhash, input_kind, A.MEM_HOST, 0)
+    n = len(offsets) - 1
+    cnt = C.c_uint64(0)
+    rc = lib().kmo_kmer_distribution(C.byref(hp), _p(bases), _p(offsets), _p(packed_offsets), n, None, None, 0, None, C.byref(cnt))
+    if rc:
+        raise OracleError(rc)
+    kk, cc, do = np.zeros(max(cnt.value, 1), np.uint64), np.zeros(max(cnt.value, 1), np.uint32), np.zeros(n + 1, np.uint64)
+    rc = lib().kmo_kmer_distribution(C.byref(hp), _p(bases), _p(offsets), _p(packed_offsets), n, _p(kk), _p(cc), cnt.value, _p(do),
+                                     C.byref(cnt))
+    if rc:
+        raise OracleError(rc)
+    return kk[:cnt.value], cc[:cnt.value], do
+
+
+def nthash(bases, offsets, k, n_hashes=1, mode=A.NTHASH_CANONICAL, table=A.NTHASH_TABLE_2B, input_kind=A.INPUT_ASCII,
+           packed_offsets=None):
+    np_ = A.NthashParams(k, table, mode, n_hashes, input_kind, A.MEM_HOST)
+    nb = max(int(offsets[-1]), 1)
+    out = np.zeros((nb, n_hashes), np.uint64)
+    strand = np.zeros(nb, np.uint8)
+    rc = lib().kmo_nthash(C.byref(np_), _p(bases), _p(offsets), _p(packed_offsets), len(offsets) - 1, _p(out), _p(strand))
+    if rc:
+        raise OracleError(rc)
+    return out, strand
 
 
 def block_layout(offsets, block_size):

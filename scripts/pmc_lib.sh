@@ -2,7 +2,8 @@
 # diagnostics: instruction / wait counters of the sketch kernels for a library variant (kmerutils_amd/libkmu_<x>.so)
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 for x in ${AB_LIBS:-h n}; do
-  [ "$x" != "h" ] && cp $R/kmerutils_amd/libkmu_$x.so $R/kmerutils_amd/libkmu.so
+  # the variant is selected by KMU_LIB (kmerutils_amd/lib.py); the product library is never overwritten
+  if [ "$x" != "h" ]; then export KMU_LIB=$R/kmerutils_amd/libkmu_$x.so; else unset KMU_LIB; fi
   i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
     i=$((i+1))

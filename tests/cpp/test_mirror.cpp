@@ -142,6 +142,42 @@ TEST(test_kmer_generator_32bit) { check_generator<Kmer32bit>(5); check_generator
 TEST(test_kmer_generator_16b32bit) { check_generator<Kmer16b32bit>(16); }
 TEST(test_kmer_generator_64bit) { check_generator<Kmer64bit>(16); check_generator<Kmer64bit>(31); }
 
+// kmergenerator.rs:661-700 (k-mers of a base range), :777-850 (the 31 distinct 3-mers of a 48-base string with their
+// multiplicities), :853-894 (weighted 15-mers of a string whose head is repeated) -- through the device
+TEST(test_generate_kmer_in_range_and_weighted) {
+    const std::string s50 = "TCAAAGGGAAACATTCAAAATCAGTATGCGCCCGTTCAGTTACGTATTGC";
+    Sequence seq(s50);
+    auto vk = KmerGenerator<Kmer16b32bit>(16).generate_kmer_in_range(seq, 3, 25);
+    CHECK(vk.size() == 7);   // :690
+    for (size_t i = 0; i < vk.size(); i++) {
+        auto un = vk[i].get_uncompressed_kmer();
+        CHECK(std::string(un.begin(), un.end()) == s50.substr(3 + i, 16));
+    }
+    for (auto [b, e] : {std::pair<size_t, size_t>{5, 5}, {9, 3}, {0, 51}}) {   // set_range Err (sequence.rs:563-565)
+        bool threw = false;
+        try { (void) KmerGenerator<Kmer32bit>(8).generate_kmer_in_range(seq, b, e); } catch (const KmuError &x) { threw = x.status() == KMU_E_BAD_ARG; }
+        CHECK(threw);
+    }
+    const std::string s48 = s50.substr(0, 48);
+    auto w3 = KmerGenerator<Kmer32bit>(3).generate_weighted_kmer(Sequence(s48));
+    CHECK(w3.size() == 31);   // :822
+    std::map<std::string, uint32_t> got;
+    for (auto &[km, c] : w3) { auto un = km.get_uncompressed_kmer(); got[std::string(un.begin(), un.end())] = c; }
+    CHECK(got["TCA"] == 4 && got["AAA"] == 4 && got["CAA"] == 2 && got["ATT"] == 2 && got["ACG"] == 1 && got["GGG"] == 1);
+    uint32_t total = 0;
+    for (auto &kv : got) total += kv.second;
+    CHECK(total == 46);
+    const std::string s72 = "TCAAAGGGAAACATTCAAAATCAGTATGCGCCCGTTCAGTTACGTATTTCAAAGGGAAACATTCAAAATCAG";
+    auto w15 = KmerGenerator<Kmer64bit>(15).generate_weighted_kmer(Sequence(s72));
+    for (auto &[km, c] : w15) {
+        auto un = km.get_uncompressed_kmer();
+        const std::string sub(un.begin(), un.end());
+        size_t occ = 0;
+        for (size_t p = 0; p + 15 <= s72.size(); p++) occ += s72.compare(p, 15, sub) == 0;
+        CHECK(occ == c && (c == 1 || c == 2));
+    }
+}
+
 // kmer16b32bit.rs:145-157 style known answers for the reverse complement
 TEST(test_reverse_complement_known_answers) {
     // 16 x A <-> 16 x T
