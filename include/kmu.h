@@ -54,7 +54,8 @@ typedef enum kmu_status {
     KMU_E_BAD_ARG = -7,
     KMU_E_TABLE_FULL = -8,
     KMU_E_UNSUPPORTED = -9,
-    KMU_E_NO_DEVICE = -10
+    KMU_E_NO_DEVICE = -10,
+    KMU_E_RCCL = -11         /* RCCL (or the host's transport) reported an error; text in kmu_last_error */
 } kmu_status;
 
 typedef enum kmu_mem { KMU_MEM_HOST = 0, KMU_MEM_DEVICE = 1 } kmu_mem;
@@ -157,7 +158,7 @@ typedef struct kmu_count_params {
     int32_t kmer_type;     /* DNA types only */
     int32_t kmer_size;
     int32_t counter_bits;  /* 8 or 16 (reference default 8: saturates at 255, src/base/kmercount.rs:1615) */
-    int32_t reserved;
+    int32_t flags;         /* 0, or KMU_COUNT_DISTRIBUTED (see "multi-GPU" below) */
     uint64_t capacity_hint; /* expected number of distinct canonical k-mers */
 } kmu_count_params;
 
@@ -350,6 +351,66 @@ int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint6
                                 uint32_t n_parts, uint64_t **dev_kmers_out, uint64_t *part_bounds_out);
 /* drop every entry not owned by `part` (after the exchange each rank keeps only its key range) */
 int kmu_count_retain_part(kmu_counter *c, uint32_t part, uint32_t n_parts);
+
+/* ---- multi-GPU: one rank per GPU, RCCL over xGMI ------------------------------------------------------------------
+ * The reference's parallel drivers are threads of one process: count_kmer_threaded_one_to_many (src/base/kmercount.rs:881-974)
+ * dispatches every canonical k-mer to the thread that owns it (`int64_hash(kmer) % n`, :412-420, :942) over channels, and
+ * KmerCounterPool (:424-565) keeps one counter per thread; sketching is a rayon map over reads
+ * (src/sketching/seqsketchjaccard.rs:245-248).  Here a rank is a GPU with its own kmu_ctx (one process per GPU, or one
+ * thread per GPU), the channel is ONE all-to-all over xGMI inside the library, and sketching shards reads with no
+ * collective.  Rank 0 creates an id and hands its 128 bytes to the other ranks by any means the host has (a file, MPI, a
+ * socket, torch.distributed); every rank then calls kmu_comm_init (collective).  RCCL is bound when the first of these
+ * calls is made, to the copy already mapped into the process if there is one. */
+#define KMU_COMM_ID_BYTES 128
+typedef struct kmu_comm_id { char bytes[KMU_COMM_ID_BYTES]; } kmu_comm_id; /* an ncclUniqueId */
+int kmu_comm_get_id(kmu_comm_id *out);
+int kmu_comm_init(kmu_ctx *ctx, const kmu_comm_id *id, int rank, int nranks);
+/* A transport supplied by the host instead (a host that owns a communicator already; tests with more ranks than GPUs).
+ * alltoallv: device pointers; counts and displacements per peer in elements of elem_bytes; the library has synchronised
+ * `stream` before the call and expects the received data to be visible to the device at return.  allgather: host memory,
+ * `bytes` from every rank, rank order.  Both return 0 on success. */
+typedef int (*kmu_alltoallv_fn)(void *user, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs,
+                                void *recv_dev, const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes,
+                                void *stream);
+typedef int (*kmu_allgather_fn)(void *user, const void *send_host, void *recv_host, uint64_t bytes);
+int kmu_comm_init_custom(kmu_ctx *ctx, int rank, int nranks, kmu_alltoallv_fn alltoallv, kmu_allgather_fn allgather, void *user);
+int kmu_comm_destroy(kmu_ctx *ctx); /* also done by kmu_destroy */
+int kmu_comm_rank(const kmu_ctx *ctx);   /* -1 without a communicator */
+int kmu_comm_nranks(const kmu_ctx *ctx); /* 0 without a communicator */
+int kmu_comm_allgather(kmu_ctx *ctx, const void *send_host, void *recv_host, uint64_t bytes); /* host memory, collective */
+
+/* Distributed counting.  A counter created with KMU_COUNT_DISTRIBUTED on a context that has a communicator is one member of
+ * a KmerCounterPool spread over the ranks: kmu_count_add_reads takes THIS rank's reads (collective: every rank calls it,
+ * with its own shard, possibly empty), kmu_count_finalize (collective) completes the exchange; afterwards rank r's counter
+ * holds exactly the canonical k-mers with owner r -- kmu_kmer_owner, DispatchableT (kmercount.rs:382-420) -- with their
+ * multiplicities over ALL ranks' reads, and every query / dump / statistic of this header sees that partition.
+ * Two routes, chosen per add from the measured duplication (occurrences / distinct k-mers, estimated on a hash sample of
+ * this batch over all ranks) with a cost model of both (kmu_comm_stats; KMU_COUNT_ROUTE=occurrences|merge forces one):
+ *   OCCURRENCES  every k-mer occurrence travels to its owner (8 B each), the owner builds its table from what it receives:
+ *                the reference's own dispatch; best when most k-mers are distinct (long noisy reads).
+ *   MERGE        every rank counts its shard locally; at finalize the (k-mer, count) entries it does not own travel
+ *                (12 B per DISTINCT k-mer) and are added to the owner's table: less traffic once a k-mer occurs more than
+ *                ~1.5 times per rank (deep short-read coverage), at the price of building twice. */
+#define KMU_COUNT_DISTRIBUTED 0x1 /* kmu_count_params.flags */
+typedef enum kmu_count_route { KMU_ROUTE_NONE = 0, KMU_ROUTE_OCCURRENCES = 1, KMU_ROUTE_MERGE = 2 } kmu_count_route;
+typedef struct kmu_comm_stats {
+    int32_t route;                 /* kmu_count_route of the last distributed kmu_count_add_reads */
+    int32_t sample_shift;          /* the duplication was measured on the k-mers whose owner hash has this many zero bits */
+    double dup_ratio;              /* occurrences / distinct over all ranks (sampled); 0 = not measured */
+    uint64_t kmers_local;          /* k-mer occurrences of this rank's shard (last add) */
+    uint64_t bytes_occurrences;    /* what OCCURRENCES moves off this rank for that add: 8 B x occurrences x (N-1)/N */
+    uint64_t bytes_merge;          /* what MERGE moves off this rank: 12 B x distinct x (N-1)/N (from dup_ratio until
+                                      finalize has run, exact afterwards) */
+    uint64_t bytes_sent;           /* bytes that really left this rank / arrived, last add + its finalize */
+    uint64_t bytes_received;
+    double model_ms_occurrences;   /* the cost model's estimates the choice was made from */
+    double model_ms_merge;
+} kmu_comm_stats;
+int kmu_comm_get_stats(const kmu_ctx *ctx, kmu_comm_stats *out);
+int kmu_count_finalize(kmu_counter *c);
+/* owner of canonical k-mer values in an n_parts-way pool: int32_hash / int64_hash(kmer) % n_parts by the width of the
+ * k-mer type (Kmer32bit / Kmer16b32bit: kmercount.rs:386-402; Kmer64bit :412-420).  Host arithmetic, no device needed. */
+int kmu_kmer_owner(int kmer_type, const uint64_t *canon_kmers, uint64_t n, uint32_t n_parts, uint32_t *owners_out);
 
 /* ---- L-1 ingest: the step before the path ----------------------------------------------------
  * FASTQ / FASTA text -> the accepted reads as (bases, offsets), in file order.  kmu_ingest_fastq: 4-line records,

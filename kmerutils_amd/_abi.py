@@ -8,7 +8,8 @@ E_BAD_K, E_BAD_ALPHABET, E_EMPTY_SEQ, E_NON_ACGT, E_OOM, E_HIP, E_BAD_ARG, E_TAB
     -1, -2, -3, -4, -5, -6, -7, -8, -9, -10)
 STATUS_NAMES = {0: "KMU_OK", -1: "KMU_E_BAD_K", -2: "KMU_E_BAD_ALPHABET", -3: "KMU_E_EMPTY_SEQ", -4: "KMU_E_NON_ACGT",
                 -5: "KMU_E_OOM", -6: "KMU_E_HIP", -7: "KMU_E_BAD_ARG", -8: "KMU_E_TABLE_FULL",
-                -9: "KMU_E_UNSUPPORTED", -10: "KMU_E_NO_DEVICE"}
+                -9: "KMU_E_UNSUPPORTED", -10: "KMU_E_NO_DEVICE", -11: "KMU_E_RCCL"}
+E_RCCL = -11
 
 MEM_HOST, MEM_DEVICE = 0, 1
 INPUT_ASCII, INPUT_PACKED2 = 0, 1
@@ -55,7 +56,28 @@ class HashParams(C.Structure):
 
 class CountParams(C.Structure):
     _fields_ = [("kmer_type", C.c_int32), ("kmer_size", C.c_int32), ("counter_bits", C.c_int32),
-                ("reserved", C.c_int32), ("capacity_hint", C.c_uint64)]
+                ("flags", C.c_int32), ("capacity_hint", C.c_uint64)]
+
+
+COUNT_DISTRIBUTED = 0x1
+ROUTE_NONE, ROUTE_OCCURRENCES, ROUTE_MERGE = 0, 1, 2
+COMM_ID_BYTES = 128
+
+
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * COMM_ID_BYTES)]
+
+
+class CommStats(C.Structure):
+    """kmu_comm_stats"""
+    _fields_ = [("route", C.c_int32), ("sample_shift", C.c_int32), ("dup_ratio", C.c_double), ("kmers_local", C.c_uint64),
+                ("bytes_occurrences", C.c_uint64), ("bytes_merge", C.c_uint64), ("bytes_sent", C.c_uint64),
+                ("bytes_received", C.c_uint64), ("model_ms_occurrences", C.c_double), ("model_ms_merge", C.c_double)]
+
+
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p,
+                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
 
 
 class IngestInfo(C.Structure):

@@ -291,6 +291,7 @@ void kmu_destroy(kmu_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
+    comm_free(ctx);
     for (auto &p : ctx->pending) {
         (void) hipEventDestroy(p.a);
         (void) hipEventDestroy(p.b);

@@ -1,0 +1,217 @@
+// kmu_comm.hip -- communicator of a context: RCCL over xGMI (one rank per GPU), or a transport supplied by the host.
+//
+// Reference shape: the reference's "ranks" are threads of one process that talk through crossbeam channels
+// (count_kmer_threaded_one_to_many, src/base/kmercount.rs:881-974: one producer dispatches every canonical k-mer to the
+// thread that owns it; KmerCounterPool :424-565 keeps one counter per thread).  Here a rank is a GPU, the channel is one
+// all-to-all over xGMI, and the calls below are what a Rust host binds: no Python, no torch.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "kmu_comm.hpp"
+
+namespace kmu {
+
+static_assert(sizeof(ncclUniqueId) == KMU_COMM_ID_BYTES, "kmu_comm_id carries an ncclUniqueId");
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+// One RCCL per process: the copy that is already mapped (RTLD_NOLOAD; torch's has the SONAME librccl.so.1 too), else the
+// system's.
+static Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        const char *paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : paths)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.handle) {
+            const char *e = dlerror();
+            r.error = std::string("cannot load librccl.so.1: ") + (e ? e : "?");
+            return;
+        }
+        auto sym = [&](const char *name) -> void * {
+            void *p = dlsym(r.handle, name);
+            if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + name;
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId)) sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank)) sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy)) sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather)) sym("ncclAllGather");
+        r.Send = (decltype(r.Send)) sym("ncclSend");
+        r.Recv = (decltype(r.Recv)) sym("ncclRecv");
+        r.GroupStart = (decltype(r.GroupStart)) sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd)) sym("ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString)) sym("ncclGetErrorString");
+    });
+    return &r;
+}
+
+#define KMU_NCCL(ctx, expr)                                                                                         \
+    do {                                                                                                            \
+        ncclResult_t r_ = (expr);                                                                                   \
+        if (r_ != ncclSuccess)                                                                                      \
+            return kmu::fail((ctx), KMU_E_RCCL, "%s: %s (%s:%d)", #expr, kmu::rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+int comm_allgather_host(kmu_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
+    kmu_comm *c = ctx->comm;
+    if (!c) return fail(ctx, KMU_E_BAD_ARG, "the context has no communicator (kmu_comm_init)");
+    if (c->ag) {
+        const int rc = c->ag(c->user, send, recv, bytes);
+        if (rc) return fail(ctx, KMU_E_RCCL, "the host's all-gather failed (%d)", rc);
+        return KMU_OK;
+    }
+    void *d;
+    KMU_TRY(dev_buf(ctx, "comm.meta", (size_t) bytes * ((size_t) c->nranks + 1) + 64, &d));
+    uint8_t *d_send = (uint8_t *) d, *d_recv = d_send + ((bytes + 15) & ~(uint64_t) 15);
+    KMU_HIP(ctx, hipMemcpyAsync(d_send, send, bytes, hipMemcpyHostToDevice, ctx->stream));
+    KMU_NCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, (ncclComm_t) c->nccl, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(recv, d_recv, bytes * (uint64_t) c->nranks, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMU_OK;
+}
+
+int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
+                   const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s) {
+    kmu_comm *c = ctx->comm;
+    if (!c) return fail(ctx, KMU_E_BAD_ARG, "the context has no communicator (kmu_comm_init)");
+    uint64_t out = 0, in = 0;
+    for (int p = 0; p < c->nranks; p++)
+        if (p != c->rank) { out += send_counts[p] * elem_bytes; in += recv_counts[p] * elem_bytes; }
+    c->stats.bytes_sent += out;
+    c->stats.bytes_received += in;
+    if (c->a2a) {
+        KMU_HIP(ctx, hipStreamSynchronize(s));
+        const int rc = c->a2a(c->user, send_dev, send_counts, send_displs, recv_dev, recv_counts, recv_displs, elem_bytes, (void *) s);
+        if (rc) return fail(ctx, KMU_E_RCCL, "the host's all-to-all failed (%d)", rc);
+        return KMU_OK;
+    }
+    // every pair of ranks exchanges one message: xGMI is point to point, all seven links of a GPU carry traffic at once
+    const uint8_t *sb = (const uint8_t *) send_dev;
+    uint8_t *rb = (uint8_t *) recv_dev;
+    KMU_NCCL(ctx, rccl()->GroupStart());
+    for (int p = 0; p < c->nranks; p++) {
+        if (send_counts[p])
+            KMU_NCCL(ctx, rccl()->Send(sb + send_displs[p] * elem_bytes, (size_t) send_counts[p] * elem_bytes, ncclUint8, p, (ncclComm_t) c->nccl, s));
+        if (recv_counts[p])
+            KMU_NCCL(ctx, rccl()->Recv(rb + recv_displs[p] * elem_bytes, (size_t) recv_counts[p] * elem_bytes, ncclUint8, p, (ncclComm_t) c->nccl, s));
+    }
+    KMU_NCCL(ctx, rccl()->GroupEnd());
+    return KMU_OK;
+}
+
+static int comm_new(kmu_ctx *ctx, int rank, int nranks) {
+    if (ctx->comm) return fail(ctx, KMU_E_BAD_ARG, "the context already has a communicator");
+    if (nranks < 1 || nranks > 2048 || rank < 0 || rank >= nranks) return fail(ctx, KMU_E_BAD_ARG, "bad rank %d of %d", rank, nranks);
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    kmu_comm *c = new kmu_comm();
+    c->rank = rank;
+    c->nranks = nranks;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return fail(ctx, KMU_E_HIP, "cannot create the exchange stream");
+    }
+    ctx->comm = c;
+    return KMU_OK;
+}
+
+void comm_free(kmu_ctx *ctx) {
+    kmu_comm *c = ctx->comm;
+    if (!c) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    if (c->nccl) (void) rccl()->CommDestroy((ncclComm_t) c->nccl);
+    if (c->ev_a) (void) hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void) hipEventDestroy(c->ev_b);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+    ctx->comm = nullptr;
+}
+
+} // namespace kmu
+
+using namespace kmu;
+
+extern "C" {
+
+int kmu_comm_get_id(kmu_comm_id *out) {
+    if (!out) return KMU_E_BAD_ARG;
+    Rccl *r = rccl();
+    if (!r->error.empty()) return fail(nullptr, KMU_E_RCCL, "%s", r->error.c_str());
+    ncclUniqueId id;
+    const ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(nullptr, KMU_E_RCCL, "ncclGetUniqueId: %s", r->GetErrorString(rc));
+    memcpy(out->bytes, &id, KMU_COMM_ID_BYTES);
+    return KMU_OK;
+}
+
+int kmu_comm_init(kmu_ctx *ctx, const kmu_comm_id *id, int rank, int nranks) {
+    if (!ctx || !id) return KMU_E_BAD_ARG;
+    Rccl *r = rccl();
+    if (!r->error.empty()) return fail(ctx, KMU_E_RCCL, "%s", r->error.c_str());
+    KMU_TRY(comm_new(ctx, rank, nranks));
+    ncclUniqueId nid;
+    memcpy(&nid, id->bytes, KMU_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = r->CommInitRank(&comm, nranks, nid, rank);
+    if (rc != ncclSuccess) {
+        comm_free(ctx);
+        return fail(ctx, KMU_E_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, r->GetErrorString(rc));
+    }
+    ctx->comm->nccl = comm;
+    return KMU_OK;
+}
+
+int kmu_comm_init_custom(kmu_ctx *ctx, int rank, int nranks, kmu_alltoallv_fn alltoallv, kmu_allgather_fn allgather, void *user) {
+    if (!ctx || !alltoallv || !allgather) return KMU_E_BAD_ARG;
+    KMU_TRY(comm_new(ctx, rank, nranks));
+    ctx->comm->a2a = alltoallv;
+    ctx->comm->ag = allgather;
+    ctx->comm->user = user;
+    return KMU_OK;
+}
+
+int kmu_comm_destroy(kmu_ctx *ctx) {
+    if (!ctx) return KMU_E_BAD_ARG;
+    comm_free(ctx);
+    return KMU_OK;
+}
+
+int kmu_comm_rank(const kmu_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->rank : -1; }
+int kmu_comm_nranks(const kmu_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->nranks : 0; }
+
+int kmu_comm_get_stats(const kmu_ctx *ctx, kmu_comm_stats *out) {
+    if (!ctx || !out || !ctx->comm) return KMU_E_BAD_ARG;
+    *out = ctx->comm->stats;
+    return KMU_OK;
+}
+
+// every rank hands in `bytes` of host memory and gets all ranks' contributions in rank order (what a host needs to agree
+// on sizes before it hands buffers to the library; also the smallest complete test of a communicator)
+int kmu_comm_allgather(kmu_ctx *ctx, const void *send_host, void *recv_host, uint64_t bytes) {
+    if (!ctx || !send_host || !recv_host) return KMU_E_BAD_ARG;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    return comm_allgather_host(ctx, send_host, recv_host, bytes);
+}
+
+} // extern "C"

@@ -1,0 +1,31 @@
+// kmu_comm.hpp -- the communicator a kmu_ctx may carry: one rank per GPU (process or thread), RCCL over xGMI.
+//
+// RCCL is bound at run time (dlopen): a host that already carries an RCCL in its process -- PyTorch ships its own copy with
+// the same SONAME -- must end up with ONE copy, the one already mapped; linking librccl.so.1 at build time would map a
+// second one next to torch's (two sets of the same global symbols in one process).  A host-supplied transport (two function
+// pointers) serves hosts that own a communicator already and the tests that run more ranks than the box has GPUs.
+#pragma once
+
+#include "kmu_ctx.hpp"
+
+struct kmu_comm {
+    int rank = 0, nranks = 1;
+    void *nccl = nullptr; // ncclComm_t
+    kmu_alltoallv_fn a2a = nullptr;
+    kmu_allgather_fn ag = nullptr;
+    void *user = nullptr;
+    hipStream_t stream = nullptr; // the exchange runs here, so that kernels on the context's stream can run under it
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    kmu_comm_stats stats{};
+};
+
+namespace kmu {
+
+// every rank contributes `bytes` of host memory; recv gets nranks * bytes in rank order.  Synchronous.
+int comm_allgather_host(kmu_ctx *ctx, const void *send, void *recv, uint64_t bytes);
+// variable all-to-all of device memory in units of elem_bytes; counts / displacements per peer (elements).
+// Enqueued on `s` (RCCL) or completed at return (host transport; `s` is synchronised first).
+int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
+                   const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s);
+
+} // namespace kmu

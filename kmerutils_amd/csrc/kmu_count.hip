@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "kmu_comm.hpp"
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
@@ -30,6 +31,12 @@ struct kmu_counter {
     uint32_t *counts = nullptr;
     uint64_t *scalars = nullptr; // device: [0] distinct, [1] unique, [2] cursor
     bool empty = true;           // table content not materialised yet (every slot is logically free)
+    // distributed counters (KMU_COUNT_DISTRIBUTED): one member of a KmerCounterPool spread over the ranks
+    bool dist = false;
+    bool unmerged = false;       // holds entries this rank does not own (MERGE route adds): finalize moves them
+    // an exchange in flight between dist_add_begin and dist_add_end
+    uint64_t pend_recv = 0;      // k-mers arriving in "cnt.recv"
+    bool pending = false;
 };
 
 namespace kmu {
@@ -62,12 +69,24 @@ __device__ __forceinline__ uint64_t khash_inv(uint64_t h) {
 }
 
 // owner of a k-mer in an n-way key partition: DispatchableT, kmercount.rs:382-420
-__device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_parts) {
-    const uint64_t h = w32 ? (uint64_t) int32_hash((uint32_t) v) : int64_hash(v);
+__device__ __forceinline__ uint64_t owner_hash(uint64_t v, int w32) { return w32 ? (uint64_t) int32_hash((uint32_t) v) : int64_hash(v); }
+__device__ __forceinline__ uint32_t owner_of_hash(uint64_t h, int w32, uint32_t n_parts) {
     // 2 / 4 / 8 GPUs: the remainder is a mask (a 64-bit division per k-mer would dominate the grouping kernels)
     if ((n_parts & (n_parts - 1u)) == 0u) return (uint32_t) h & (n_parts - 1u);
     return w32 ? (uint32_t) h % n_parts : (uint32_t) (h % (uint64_t) n_parts);
 }
+__device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_parts) { return owner_of_hash(owner_hash(v, w32), w32, n_parts); }
+
+// Duplication sample of a batch: the k-mers whose owner hash has `shift` zero bits above bit 8 (a sample by KEY: every
+// occurrence of a sampled k-mer is in it, so occurrences / distinct of the sample estimates the ratio of the batch).
+// Collected per workgroup in LDS and flushed with one global atomic per workgroup.
+static constexpr uint32_t SAMPLE_LDS = 4096; // entries per workgroup
+struct SampleArgs {
+    uint64_t *list;   // null: no sampling
+    uint32_t *n;      // [0] entries written, [1] overflow flag
+    uint32_t cap;
+    uint32_t shift;
+};
 
 struct CountTable {
     uint64_t *keys;
@@ -348,8 +367,9 @@ __global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslo
     uint64_t d = 0, u = 0;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         if (t.keys[i] != CKEY_EMPTY) {
-            d++;
-            u += t.counts[i] == 1u;
+            const uint32_t c = t.counts[i]; // 0: an entry that left for its owner (distributed counters)
+            d += c != 0u;
+            u += c == 1u;
         }
     }
     for (int o = 32; o >= 1; o >>= 1) {
@@ -420,25 +440,123 @@ __device__ __forceinline__ uint32_t region_of(uint64_t canon, int region_bits) {
 
 // level 1, pass 1: per-unit histogram of the level-1 digit (also validates the bases)
 __global__ void __launch_bounds__(256) k_part_hist1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
-                                                    PartPlan pl, uint32_t *hist1, uint32_t *err) {
+                                                    PartPlan pl, uint32_t *hist1, uint32_t *err, SampleArgs sa) {
     extern __shared__ uint32_t lh[];
     const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1;
+    // sampling (owner grouping only): list and counter behind the histogram, 8-byte aligned
+    uint32_t *ls_n = lh + ((bins1 + 1u) & ~1u);
+    uint64_t *ls = reinterpret_cast<uint64_t *>(ls_n + 2);
     for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) lh[b] = 0;
+    if (sa.list && threadIdx.x == 0) ls_n[0] = 0;
     __syncthreads();
     const uint64_t total = offsets[n_seq], start = offsets[0];
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
     const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint64_t smask = sa.shift >= 32 ? 0xFFFFFFFFull : ((1ull << sa.shift) - 1ull);
     uint32_t bad = 0, r_hint = 0xFFFFFFFFu;
     for (uint64_t st = s0 + wave; st < s1; st += nwaves)
         bad |= flat_step_canon(bases, offsets, n_seq, total, start, k, st, r_hint, [&](uint64_t canon) {
-            atomicAdd(&lh[pl.owner_parts ? kmer_owner(canon, pl.owner_w32, pl.owner_parts)
-                                         : region_of(canon, pl.region_bits) >> pl.b2], 1u);
+            if (pl.owner_parts) {
+                const uint64_t h = owner_hash(canon, pl.owner_w32);
+                atomicAdd(&lh[owner_of_hash(h, pl.owner_w32, pl.owner_parts)], 1u);
+                if (sa.list && ((h >> 8) & smask) == 0ull) {
+                    const uint32_t at = atomicAdd(&ls_n[0], 1u);
+                    if (at < SAMPLE_LDS) ls[at] = canon;
+                }
+            } else {
+                atomicAdd(&lh[region_of(canon, pl.region_bits) >> pl.b2], 1u);
+            }
         });
     if (bad) atomicOr(err, DERR_NON_ACGT);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) hist1[(uint64_t) blockIdx.x * bins1 + b] = lh[b];
+    if (sa.list) {
+        __shared__ uint32_t gbase;
+        const uint32_t cnt = ls_n[0], keep = cnt < SAMPLE_LDS ? cnt : SAMPLE_LDS;
+        if (threadIdx.x == 0) {
+            gbase = atomicAdd(&sa.n[0], keep);
+            if (cnt > SAMPLE_LDS) sa.n[1] = 1u; // the sample of this workgroup is truncated: the estimate is void
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < keep; i += blockDim.x)
+            if (gbase + i < sa.cap) sa.list[gbase + i] = ls[i];
+            else sa.n[1] = 1u;
+    }
+}
+
+// distinct k-mers of the sample: every key is inserted into a scratch table (all-ones = free); a successful claim counts
+__global__ void __launch_bounds__(256) k_sample_distinct(const uint64_t *list, uint32_t n, uint64_t *table, uint32_t mask,
+                                                         uint32_t *n_distinct) {
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t key = list[i];
+        uint32_t off = (uint32_t) (khash(key) >> 32) & mask;
+        for (uint32_t probes = 0; probes <= mask; probes++) {
+            const unsigned long long old = atomicCAS((unsigned long long *) &table[off], (unsigned long long) CKEY_EMPTY, (unsigned long long) key);
+            if (old == CKEY_EMPTY) { mine++; break; }
+            if (old == key) break;
+            off = (off + 1) & mask;
+        }
+    }
+    if (mine) atomicAdd(n_distinct, mine);
+}
+
+// ---- finalize of the MERGE route: the entries this rank does not own leave the table ---------------------------------------
+// pass 1: entries per owner; pass 2: (key, count) appended to the owner's range of the send lists, the slot's count zeroed
+// (a zero count is "never seen" for every reader of the table; the key stays as a tombstone of the probe chain)
+__global__ void __launch_bounds__(256) k_owner_census(CountTable t, uint64_t nslots, int w32, uint32_t me, uint32_t n_parts,
+                                                      unsigned long long *per_owner) {
+    extern __shared__ uint32_t lo[];
+    for (uint32_t b = threadIdx.x; b < n_parts; b += blockDim.x) lo[b] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t key = t.keys[i];
+        if (key != CKEY_EMPTY && t.counts[i] != 0u) {
+            const uint32_t o = kmer_owner(key, w32, n_parts);
+            if (o != me) atomicAdd(&lo[o], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_parts; b += blockDim.x)
+        if (lo[b]) atomicAdd(&per_owner[b], (unsigned long long) lo[b]);
+}
+__global__ void __launch_bounds__(256) k_owner_emit(CountTable t, uint64_t nslots, int w32, uint32_t me, uint32_t n_parts,
+                                                    unsigned long long *cursor /* starts of the owners' ranges */,
+                                                    uint64_t *out_k, uint32_t *out_c) {
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    const uint64_t rounds = (nslots + stride - 1) / stride; // wave-uniform trip count (ballots inside)
+    for (uint64_t it = 0; it < rounds; it++) {
+        const uint64_t i = it * stride + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+        uint64_t key = CKEY_EMPTY;
+        uint32_t cnt = 0, o = me;
+        if (i < nslots) {
+            key = t.keys[i];
+            if (key != CKEY_EMPTY) {
+                cnt = t.counts[i];
+                if (cnt) o = kmer_owner(key, w32, n_parts);
+            }
+        }
+        bool send = o != me;
+        // one global atomic per wave and owner present in the wave
+        uint64_t todo = __ballot(send);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long) todo) - 1;
+            const uint32_t ow = bcast_u32(o, leader);
+            const uint64_t grp = __ballot(send && o == ow);
+            uint64_t base = 0;
+            if (lane_id() == leader) base = atomicAdd(&cursor[ow], (unsigned long long) __popcll(grp));
+            base = ((uint64_t) bcast_u32((uint32_t) (base >> 32), leader) << 32) | bcast_u32((uint32_t) base, leader);
+            if (send && o == ow) {
+                const uint64_t pos = base + (uint64_t) __popcll(grp & ((1ull << lane_id()) - 1ull));
+                out_k[pos] = key;
+                out_c[pos] = cnt;
+                t.counts[i] = 0u;
+            }
+            todo &= ~grp;
+        }
+    }
 }
 
 // level 1 scan, step a: one workgroup per bin -> exclusive prefix over the units + bin total
@@ -973,7 +1091,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     {
         KernelTimer tm(ctx, "k_part_hist1");
         hipLaunchKernelGGL(k_part_hist1, dim3(units1), dim3(256), bins1 * 4, ctx->stream, ds.bases, ds.offsets, ds.n_seq, k,
-                           pl, (uint32_t *) hist1, d_err);
+                           pl, (uint32_t *) hist1, d_err, SampleArgs{nullptr, nullptr, 0u, 0u});
     }
     {
         KernelTimer tm(ctx, "k_part_scan1");
@@ -1135,12 +1253,18 @@ static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64
     return KMU_OK;
 }
 
-// canonical k-mers of the reads, grouped by owner rank (one level of the partition machinery with digit = owner)
-static int extract_by_owner(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t n_parts, uint64_t **dev_out,
-                            uint64_t *bounds_host, uint32_t *d_err) {
+// canonical k-mers of the reads, grouped by owner rank (one level of the partition machinery with digit = owner).
+// Two halves, so that a distributed add can look at the duplication sample between them: the census (per-unit histogram of
+// the owners + the sample), then the scatter.
+struct OwnerPlan {
+    PartPlan pl;
+    void *hist1, *offs1, *tot1, *binstart1;
+};
+static int owner_census(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t n_parts, uint32_t *d_err, OwnerPlan *op,
+                        const SampleArgs &sa) {
     kmu_ctx *ctx = c->ctx;
     if (n_parts == 0 || n_parts > 2048) return fail(ctx, KMU_E_BAD_ARG, "n_parts must be in 1..2048");
-    PartPlan pl;
+    PartPlan &pl = op->pl;
     memset(&pl, 0, sizeof pl);
     pl.owner_parts = n_parts;
     pl.owner_w32 = kmer_val_bytes(c->p.kmer_type) == 4;
@@ -1149,40 +1273,221 @@ static int extract_by_owner(kmu_counter *c, const DevSeqs &ds, uint64_t total_ba
     pl.steps_per_unit = (uint32_t) ((std::max<uint64_t>(nsteps, 1) + units1 - 1) / units1);
     units1 = (uint32_t) ((std::max<uint64_t>(nsteps, 1) + pl.steps_per_unit - 1) / pl.steps_per_unit);
     pl.units1 = units1;
-    void *out, *hist1, *offs1, *tot1, *binstart1;
+    KMU_TRY(dev_buf(ctx, "cnt.hist1", (size_t) units1 * n_parts * 4, &op->hist1));
+    KMU_TRY(dev_buf(ctx, "cnt.offs1", (size_t) units1 * n_parts * 8, &op->offs1));
+    KMU_TRY(dev_buf(ctx, "cnt.tot1", (size_t) n_parts * 8, &op->tot1));
+    KMU_TRY(dev_buf(ctx, "cnt.binstart1", (size_t) (n_parts + 1) * 8, &op->binstart1));
+    const int k = c->p.kmer_size;
+    const size_t lds = ((size_t) n_parts + 2) * 4 + (sa.list ? 16 + (size_t) SAMPLE_LDS * 8 : 0);
+    {
+        KernelTimer tm(ctx, "k_part_hist1");
+        hipLaunchKernelGGL(k_part_hist1, dim3(units1), dim3(256), lds, ctx->stream, ds.bases, ds.offsets, ds.n_seq, k, pl,
+                           (uint32_t *) op->hist1, d_err, sa);
+    }
+    {
+        KernelTimer tm(ctx, "k_part_scan1");
+        hipLaunchKernelGGL(k_part_scan1a, dim3(n_parts), dim3(256), 0, ctx->stream, (const uint32_t *) op->hist1, pl,
+                           (uint64_t *) op->offs1, (uint64_t *) op->tot1);
+        hipLaunchKernelGGL(k_part_scan1b, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *) op->tot1, pl,
+                           (uint64_t *) op->binstart1);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+static int owner_scatter(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, const OwnerPlan &op, uint64_t **dev_out) {
+    kmu_ctx *ctx = c->ctx;
+    void *out;
     KMU_TRY(dev_buf(ctx, "cnt.partB", total_bases * 8 + 64, &out));
-    KMU_TRY(dev_buf(ctx, "cnt.hist1", (size_t) units1 * n_parts * 4, &hist1));
-    KMU_TRY(dev_buf(ctx, "cnt.offs1", (size_t) units1 * n_parts * 8, &offs1));
-    KMU_TRY(dev_buf(ctx, "cnt.tot1", (size_t) n_parts * 8, &tot1));
-    KMU_TRY(dev_buf(ctx, "cnt.binstart1", (size_t) (n_parts + 1) * 8, &binstart1));
     if (!(ctx->lds_attr_set & 4u)) {
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->lds_attr_set |= 4u;
     }
-    const int k = c->p.kmer_size;
-    {
-        KernelTimer tm(ctx, "k_part_hist1");
-        hipLaunchKernelGGL(k_part_hist1, dim3(units1), dim3(256), n_parts * 4, ctx->stream, ds.bases, ds.offsets, ds.n_seq, k,
-                           pl, (uint32_t *) hist1, d_err);
-    }
-    {
-        KernelTimer tm(ctx, "k_part_scan1");
-        hipLaunchKernelGGL(k_part_scan1a, dim3(n_parts), dim3(256), 0, ctx->stream, (const uint32_t *) hist1, pl,
-                           (uint64_t *) offs1, (uint64_t *) tot1);
-        hipLaunchKernelGGL(k_part_scan1b, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *) tot1, pl,
-                           (uint64_t *) binstart1);
-    }
     {
         KernelTimer tm(ctx, "k_part_scatter1");
-        hipLaunchKernelGGL(k_part_scatter1, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(n_parts), ctx->stream,
-                           ds.bases, ds.offsets, ds.n_seq, k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1,
-                           (uint64_t *) out);
+        hipLaunchKernelGGL(k_part_scatter1, dim3(op.pl.units1), dim3(SCATTER_THREADS), scatter_lds_bytes(op.pl.owner_parts), ctx->stream,
+                           ds.bases, ds.offsets, ds.n_seq, c->p.kmer_size, op.pl, (const uint64_t *) op.offs1,
+                           (const uint64_t *) op.binstart1, (uint64_t *) out);
     }
     KMU_HIP(ctx, hipGetLastError());
-    KMU_HIP(ctx, hipMemcpyAsync(bounds_host, binstart1, (size_t) (n_parts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *dev_out = (uint64_t *) out;
     return KMU_OK;
+}
+static int extract_by_owner(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t n_parts, uint64_t **dev_out,
+                            uint64_t *bounds_host, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    OwnerPlan op;
+    KMU_TRY(owner_census(c, ds, total_bases, n_parts, d_err, &op, SampleArgs{nullptr, nullptr, 0u, 0u}));
+    KMU_TRY(owner_scatter(c, ds, total_bases, op, dev_out));
+    KMU_HIP(ctx, hipMemcpyAsync(bounds_host, op.binstart1, (size_t) (n_parts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMU_OK;
+}
+
+static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *counts, uint64_t n, int mem);
+static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err);
+
+// the canonical k-mers of device-resident reads into THIS table: the streaming build for big batches of unpacked reads,
+// direct insertion otherwise (total_bases: extent of the flat stream, 0 for packed input)
+static int local_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    bool partitioned = false;
+    const char *force = getenv("KMU_COUNT_PATH"); // "direct" / "partitioned": diagnostics
+    if (!ds.packed) {
+        // the streaming build pays off once the batch is a sizeable fraction of the table
+        partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
+        if (force && !strcmp(force, "direct")) partitioned = false;
+        if (force && !strcmp(force, "partitioned")) partitioned = total_bases > 0;
+    }
+    if (partitioned) return partitioned_add(c, ds, total_bases, d_err);
+    KMU_TRY(materialize(c));
+    CountTable t = table_of(c);
+    if (!ds.packed) {
+        int grid = ctx->num_cus * 8;
+        KernelTimer tm(ctx, "k_count_add_flat");
+        hipLaunchKernelGGL(k_count_add_flat, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, ds.n_seq, c->p.kmer_size, t,
+                           d_err);
+    } else {
+        int grid = (int) std::min<uint64_t>(ds.n_seq, (uint64_t) ctx->num_cus * 8);
+        KernelTimer tm(ctx, "k_count_add_reads");
+        hipLaunchKernelGGL(k_count_add_reads, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, ds.packed_offsets, ds.n_seq,
+                           ds.packed, ds.total_bytes, c->p.kmer_size, t, d_err);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+
+// ---- distributed counting (KMU_COUNT_DISTRIBUTED; kmu.h "multi-GPU") ---------------------------------------------------------
+// Cost model of the two routes, per k-mer occurrence n / distinct k-mer d of a rank's batch, in picoseconds (one MI355X,
+// measured on the single-GPU kernels: profiles/r02*_routes.json): grouping by owner 7.5 / occurrence (census + scatter),
+// building a table from received keys 19.7 / key (two partition levels + region build), the local build from reads 20.3 /
+// occurrence, two passes over the table image for the export, adding a received (k-mer, count) entry by direct insertion
+// ~60 / entry; the links: KMU_XGMI_GBPS per GPU and direction, all peers at once (default 350: seven links of 153 GB/s at
+// ~1/3 efficiency until a multi-GPU measurement says otherwise).
+static void route_model(const kmu_counter *c, double n, double d, int nranks, double *ms_occ, double *ms_merge) {
+    const char *e = getenv("KMU_XGMI_GBPS");
+    const double gbps = e && atof(e) > 0 ? atof(e) : 350.0;
+    const double f = nranks > 1 ? (double) (nranks - 1) / nranks : 0.0;
+    const double ps = 1e-9; // ps -> ms
+    *ms_occ = n * (7.5 + 19.7) * ps + 8.0 * n * f / (gbps * 1e6);
+    *ms_merge = n * 20.3 * ps + 2.0 * (double) c->nslots * 12.0 / 5.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
+}
+
+// first half of a distributed add: census of the owners + duplication sample, agreement on the route over all ranks, then
+// OCCURRENCES: scatter by owner and the all-to-all (on the communicator's stream; the context's stream is free for other
+// work until dist_add_end), MERGE: the local build.
+static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    kmu_comm *cm = ctx->comm;
+    const uint32_t N = (uint32_t) cm->nranks;
+    cm->stats = kmu_comm_stats{};
+    // ---- census + sample ----
+    void *slist, *sn, *stab;
+    const uint64_t nsteps = std::max<uint64_t>(1, ((total_bases + 15) / 16 + 63) / 64);
+    const uint64_t units = std::min<uint64_t>(nsteps, (uint64_t) ctx->num_cus * 8);
+    const uint64_t kmers_per_unit = (nsteps + units - 1) / units * 1024;
+    uint32_t shift = 0; // ~1024 sampled k-mers per workgroup (its LDS list holds 4096)
+    while (shift < 24 && (kmers_per_unit >> shift) > 1024) shift++;
+    const uint32_t cap = (uint32_t) std::min<uint64_t>(units * SAMPLE_LDS, 1u << 26);
+    KMU_TRY(dev_buf(ctx, "cnt.sample", (size_t) cap * 8 + 64, &slist));
+    KMU_TRY(dev_buf(ctx, "cnt.sample_n", 64, &sn));
+    KMU_HIP(ctx, hipMemsetAsync(sn, 0, 64, ctx->stream));
+    OwnerPlan op;
+    KMU_TRY(owner_census(c, ds, total_bases, N, d_err, &op, SampleArgs{(uint64_t *) slist, (uint32_t *) sn, cap, shift}));
+    uint32_t h_sn[4] = {0, 0, 0, 0};
+    KMU_HIP(ctx, hipMemcpyAsync(h_sn, sn, 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint64_t> bounds(N + 1);
+    KMU_HIP(ctx, hipMemcpyAsync(bounds.data(), op.binstart1, (size_t) (N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t n_s = std::min(h_sn[0], cap);
+    uint32_t d_s = 0;
+    if (n_s && !h_sn[1]) {
+        uint32_t tbits = 10;
+        while ((1ull << tbits) < 2ull * n_s) tbits++;
+        KMU_TRY(dev_buf(ctx, "cnt.sample_tab", ((size_t) 8 << tbits) + 64, &stab));
+        KMU_HIP(ctx, hipMemsetAsync(stab, 0xFF, (size_t) 8 << tbits, ctx->stream));
+        KMU_HIP(ctx, hipMemsetAsync((uint32_t *) sn + 2, 0, 4, ctx->stream));
+        {
+            KernelTimer tm(ctx, "k_sample_distinct");
+            hipLaunchKernelGGL(k_sample_distinct, dim3(grid_for(ctx, n_s, 256)), dim3(256), 0, ctx->stream, (const uint64_t *) slist, n_s,
+                               (uint64_t *) stab, (uint32_t) ((1u << tbits) - 1u), (uint32_t *) sn + 2);
+        }
+        KMU_HIP(ctx, hipMemcpyAsync(&d_s, (uint32_t *) sn + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // ---- the ranks agree: sampled occurrences / distinct, local k-mers, and the send counts of every rank ----
+    // (a k-mer's occurrences on different ranks are in different samples: the global distinct count of the sample is not
+    //  known; the per-rank ratio is what decides how much MERGE saves on each rank, and the sum of both sides is used)
+    std::vector<uint64_t> mine(4 + N), all((size_t) (4 + N) * N);
+    mine[0] = n_s;
+    mine[1] = h_sn[1] ? 0 : d_s;
+    mine[2] = bounds[N];
+    mine[3] = c->unmerged ? 1 : 0;
+    for (uint32_t p = 0; p < N; p++) mine[4 + p] = bounds[p + 1] - bounds[p];
+    KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), (4 + N) * 8));
+    double sum_ns = 0, sum_ds = 0, sum_n = 0;
+    bool valid = true;
+    for (uint32_t r = 0; r < N; r++) {
+        const uint64_t *row = &all[(size_t) r * (4 + N)];
+        sum_ns += (double) row[0];
+        sum_ds += (double) row[1];
+        sum_n += (double) row[2];
+        if (row[0] && !row[1]) valid = false; // a truncated sample somewhere
+    }
+    const double ratio = valid && sum_ds > 0 ? sum_ns / sum_ds : 0.0;
+    const double n_loc = sum_n / N, d_loc = ratio > 0 ? n_loc / ratio : n_loc;
+    double ms_occ, ms_merge;
+    route_model(c, n_loc, d_loc, (int) N, &ms_occ, &ms_merge);
+    int route = ms_merge < ms_occ ? KMU_ROUTE_MERGE : KMU_ROUTE_OCCURRENCES;
+    if (const char *e = getenv("KMU_COUNT_ROUTE")) { // (must be the same on every rank)
+        if (!strcmp(e, "occurrences")) route = KMU_ROUTE_OCCURRENCES;
+        if (!strcmp(e, "merge")) route = KMU_ROUTE_MERGE;
+    }
+    const double f = N > 1 ? (double) (N - 1) / N : 0.0;
+    cm->stats.route = route;
+    cm->stats.sample_shift = (int32_t) shift;
+    cm->stats.dup_ratio = ratio;
+    cm->stats.kmers_local = bounds[N];
+    cm->stats.bytes_occurrences = (uint64_t) (8.0 * (double) (bounds[N] - mine[4 + cm->rank]));
+    cm->stats.bytes_merge = (uint64_t) (12.0 * f * (ratio > 0 ? (double) bounds[N] / ratio : (double) bounds[N]));
+    cm->stats.model_ms_occurrences = ms_occ;
+    cm->stats.model_ms_merge = ms_merge;
+    c->pending = false;
+    if (route == KMU_ROUTE_MERGE) {
+        if (total_bases && ds.n_seq) KMU_TRY(local_add(c, ds, total_bases, d_err));
+        c->unmerged = true;
+        return KMU_OK;
+    }
+    // ---- OCCURRENCES: group, exchange ----
+    uint64_t *grouped = nullptr;
+    KMU_TRY(owner_scatter(c, ds, total_bases, op, &grouped));
+    std::vector<uint64_t> scnt(N), sdis(N), rcnt(N), rdis(N);
+    uint64_t n_recv = 0;
+    for (uint32_t p = 0; p < N; p++) {
+        scnt[p] = bounds[p + 1] - bounds[p];
+        sdis[p] = bounds[p];
+        rcnt[p] = all[(size_t) p * (4 + N) + 4 + cm->rank];
+        rdis[p] = n_recv;
+        n_recv += rcnt[p];
+    }
+    void *recv;
+    KMU_TRY(dev_buf(ctx, "cnt.recv", n_recv * 8 + 64, &recv));
+    KMU_HIP(ctx, hipEventRecord(cm->ev_a, ctx->stream));
+    KMU_HIP(ctx, hipStreamWaitEvent(cm->stream, cm->ev_a, 0));
+    KMU_TRY(comm_alltoallv(ctx, grouped, scnt.data(), sdis.data(), recv, rcnt.data(), rdis.data(), 8, cm->stream));
+    KMU_HIP(ctx, hipEventRecord(cm->ev_b, cm->stream));
+    c->pend_recv = n_recv;
+    c->pending = true;
+    return KMU_OK;
+}
+
+// second half: the owner builds its table from what arrived
+static int dist_add_end(kmu_counter *c) {
+    kmu_ctx *ctx = c->ctx;
+    if (!c->pending) return KMU_OK;
+    c->pending = false;
+    KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm->ev_b, 0));
+    if (c->pend_recv == 0) return KMU_OK;
+    return add_entries(c, (const uint64_t *) ctx->bufs["cnt.recv"].p, nullptr, c->pend_recv, KMU_MEM_DEVICE);
 }
 
 extern "C" {
@@ -1220,6 +1525,13 @@ int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out)
         return fail(ctx, KMU_E_OOM, "cannot allocate a %llu-slot count table", ns);
     }
     c->empty = true;
+    if (p->flags & KMU_COUNT_DISTRIBUTED) {
+        if (!ctx->comm) {
+            kmu_count_destroy(c);
+            return fail(ctx, KMU_E_BAD_ARG, "KMU_COUNT_DISTRIBUTED needs a communicator on the context (kmu_comm_init)");
+        }
+        c->dist = true;
+    }
     *out = c;
     return KMU_OK;
 }
@@ -1275,35 +1587,20 @@ int kmu_count_add_reads(kmu_counter *c, const uint8_t *bases, const uint64_t *of
     KMU_TRY(stage_sequences(ctx, bases, offsets, packed_offsets, n_seq, input_kind, mem, &ds));
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
-    if (n_seq) {
-        bool partitioned = false;
+    if (c->dist) { // collective: every rank passes here, also with an empty shard
+        if (ds.packed) return fail(ctx, KMU_E_UNSUPPORTED, "distributed counting takes unpacked (ASCII) reads");
+        if (c->pending) KMU_TRY(dist_add_end(c)); // (an exchange left open by kmu_sketch_count)
         uint64_t total_bases = 0;
-        const char *force = getenv("KMU_COUNT_PATH"); // "direct" / "partitioned": diagnostics
-        if (!ds.packed) {
-            KMU_TRY(flat_stream_extent(ctx, offsets, n_seq, mem, ds, &total_bases));
-            // the streaming build pays off once the batch is a sizeable fraction of the table
-            partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
-            if (force && !strcmp(force, "direct")) partitioned = false;
-            if (force && !strcmp(force, "partitioned")) partitioned = total_bases > 0;
-        }
-        if (partitioned) {
-            KMU_TRY(partitioned_add(c, ds, total_bases, d_err));
-        } else {
-            KMU_TRY(materialize(c));
-            CountTable t = table_of(c);
-            if (!ds.packed) {
-                int grid = ctx->num_cus * 8;
-                KernelTimer tm(ctx, "k_count_add_flat");
-                hipLaunchKernelGGL(k_count_add_flat, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets, n_seq,
-                                   c->p.kmer_size, t, d_err);
-            } else {
-                int grid = (int) std::min<uint64_t>(n_seq, (uint64_t) ctx->num_cus * 8);
-                KernelTimer tm(ctx, "k_count_add_reads");
-                hipLaunchKernelGGL(k_count_add_reads, dim3(grid), dim3(256), 0, ctx->stream, ds.bases, ds.offsets,
-                                   ds.packed_offsets, n_seq, ds.packed, ds.total_bytes, c->p.kmer_size, t, d_err);
-            }
-            KMU_HIP(ctx, hipGetLastError());
-        }
+        if (n_seq) KMU_TRY(flat_stream_extent(ctx, offsets, n_seq, mem, ds, &total_bases));
+        KMU_TRY(dist_add_begin(c, ds, total_bases, d_err));
+        KMU_TRY(dist_add_end(c));
+        if (!(mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
+        return finish_call(ctx, mem);
+    }
+    if (n_seq) {
+        uint64_t total_bases = 0;
+        if (!ds.packed) KMU_TRY(flat_stream_extent(ctx, offsets, n_seq, mem, ds, &total_bases));
+        KMU_TRY(local_add(c, ds, total_bases, d_err));
     }
     if (!(mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
     return finish_call(ctx, mem);
@@ -1576,6 +1873,101 @@ int kmu_count_once_positions(kmu_counter *c, const uint8_t *bases, const uint64_
         KMU_HIP(ctx, hipMemcpyAsync(numkmer_out, d_p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     return finish_call(ctx, mem);
+}
+
+// Collective.  After it the counter of rank r holds the k-mers with owner r and their multiplicities over all ranks.
+int kmu_count_finalize(kmu_counter *c) {
+    if (!c) return KMU_E_BAD_ARG;
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (!c->dist) return KMU_OK; // a counter of one rank is its own pool
+    kmu_comm *cm = ctx->comm;
+    if (!cm) return fail(ctx, KMU_E_BAD_ARG, "the communicator of this counter's context is gone");
+    KMU_TRY(dist_add_end(c));
+    const uint32_t N = (uint32_t) cm->nranks, me = (uint32_t) cm->rank;
+    const int w32 = kmer_val_bytes(c->p.kmer_type) == 4;
+    // who has entries of other owners, and how many for whom
+    void *po;
+    KMU_TRY(dev_buf(ctx, "cnt.per_owner", ((size_t) N + 1) * 8 * 2 + 64, &po));
+    KMU_HIP(ctx, hipMemsetAsync(po, 0, ((size_t) N + 1) * 8 * 2, ctx->stream));
+    const bool have = c->unmerged && !c->empty;
+    if (have) {
+        KernelTimer tm(ctx, "k_owner_census");
+        hipLaunchKernelGGL(k_owner_census, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), (size_t) N * 4, ctx->stream, table_of(c),
+                           c->nslots, w32, me, N, (unsigned long long *) po);
+    }
+    std::vector<uint64_t> mine(N + 1), all((size_t) (N + 1) * N);
+    KMU_HIP(ctx, hipMemcpyAsync(mine.data(), po, (size_t) N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    mine[N] = c->unmerged ? 1 : 0;
+    KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), ((uint64_t) N + 1) * 8));
+    bool any = false;
+    for (uint32_t r = 0; r < N; r++) any |= all[(size_t) r * (N + 1) + N] != 0;
+    c->unmerged = false;
+    if (!any) return KMU_OK;
+    std::vector<uint64_t> scnt(N), sdis(N), rcnt(N), rdis(N);
+    uint64_t n_send = 0, n_recv = 0;
+    for (uint32_t p = 0; p < N; p++) {
+        scnt[p] = mine[p];
+        sdis[p] = n_send;
+        n_send += scnt[p];
+        rcnt[p] = all[(size_t) p * (N + 1) + me];
+        rdis[p] = n_recv;
+        n_recv += rcnt[p];
+    }
+    void *sk, *sc, *rk, *rc;
+    KMU_TRY(dev_buf(ctx, "cnt.send_k", n_send * 8 + 64, &sk));
+    KMU_TRY(dev_buf(ctx, "cnt.send_c", n_send * 4 + 64, &sc));
+    KMU_TRY(dev_buf(ctx, "cnt.recv", n_recv * 8 + 64, &rk));
+    KMU_TRY(dev_buf(ctx, "cnt.recv_c", n_recv * 4 + 64, &rc));
+    if (n_send) {
+        unsigned long long *cursor = (unsigned long long *) po + (N + 1);
+        KMU_HIP(ctx, hipMemcpyAsync(cursor, sdis.data(), (size_t) N * 8, hipMemcpyHostToDevice, ctx->stream));
+        KernelTimer tm(ctx, "k_owner_emit");
+        hipLaunchKernelGGL(k_owner_emit, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), 0, ctx->stream, table_of(c), c->nslots, w32, me,
+                           N, cursor, (uint64_t *) sk, (uint32_t *) sc);
+        KMU_HIP(ctx, hipGetLastError());
+    }
+    const uint64_t sent0 = cm->stats.bytes_sent;
+    KMU_HIP(ctx, hipEventRecord(cm->ev_a, ctx->stream));
+    KMU_HIP(ctx, hipStreamWaitEvent(cm->stream, cm->ev_a, 0));
+    KMU_TRY(comm_alltoallv(ctx, sk, scnt.data(), sdis.data(), rk, rcnt.data(), rdis.data(), 8, cm->stream));
+    KMU_TRY(comm_alltoallv(ctx, sc, scnt.data(), sdis.data(), rc, rcnt.data(), rdis.data(), 4, cm->stream));
+    KMU_HIP(ctx, hipEventRecord(cm->ev_b, cm->stream));
+    KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, cm->ev_b, 0));
+    cm->stats.bytes_merge = cm->stats.bytes_sent - sent0; // exact now
+    if (n_recv) KMU_TRY(add_entries(c, (const uint64_t *) rk, (const uint32_t *) rc, n_recv, KMU_MEM_DEVICE));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // sdis / scnt are locals the copies above read
+    return KMU_OK;
+}
+
+// host copies of the Wang hashes (kmu_device.h): DispatchableT::dispatch, kmercount.rs:382-420
+static uint32_t host_int32_hash(uint32_t key) {
+    key = ~key + (key << 15);
+    key = key ^ (key >> 12);
+    key = key + (key << 2);
+    key = key ^ (key >> 4);
+    key = key * 2057u;
+    key = key ^ (key >> 16);
+    return key;
+}
+static uint64_t host_int64_hash(uint64_t key) {
+    key = ~key + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+int kmu_kmer_owner(int kmer_type, const uint64_t *canon_kmers, uint64_t n, uint32_t n_parts, uint32_t *owners_out) {
+    if ((!canon_kmers || !owners_out) && n) return KMU_E_BAD_ARG;
+    if (n_parts == 0) return KMU_E_BAD_ARG;
+    const bool w32 = kmer_val_bytes(kmer_type) == 4;
+    for (uint64_t i = 0; i < n; i++)
+        owners_out[i] = w32 ? host_int32_hash((uint32_t) canon_kmers[i]) % n_parts : (uint32_t) (host_int64_hash(canon_kmers[i]) % n_parts);
+    return KMU_OK;
 }
 
 int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,

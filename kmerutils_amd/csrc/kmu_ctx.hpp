@@ -16,8 +16,10 @@
 #define KMU_DIAG 0 // diagnostic builds only (KMU_BUILD_DEFS=-DKMU_DIAG=1): phase ablations / clocks, partition experiments
 #endif
 
+struct kmu_comm;
 struct kmu_ctx {
     int device = 0;
+    kmu_comm *comm = nullptr; // kmu_comm_init / kmu_comm_init_custom (kmu_comm.hip)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool async_device = false;
@@ -181,6 +183,8 @@ int finish_call(kmu_ctx *ctx, int mem);
 enum : uint32_t { DERR_NON_ACGT = 1u, DERR_TABLE_FULL = 2u, DERR_BAD_AA = 4u, DERR_EMPTY_SEQ = 8u, DERR_BAD_RANGE = 16u };
 int get_err_word(kmu_ctx *ctx, uint32_t **out); // zeroed on the stream
 int check_err_word(kmu_ctx *ctx, uint32_t *d_err);
+
+void comm_free(kmu_ctx *ctx); // kmu_comm.hip
 
 int check_kmer(kmu_ctx *ctx, int kmer_type, int k);
 inline bool kmer_is_aa(int t) { return t == KMU_KMERAA32BIT || t == KMU_KMERAA64BIT; }

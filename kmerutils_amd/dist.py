@@ -236,3 +236,109 @@ def sketch_seqs_distributed(ctx, bases, offsets, params, group=None):
     sig = ctx.sketch_merge_partials(allp.contiguous(), p)
     ctx.synchronize()
     return sig
+
+
+# ---- the library's own communicator (kmu_comm_*, include/kmu.h "multi-GPU") ---------------------------------------------------
+class TorchTransport:
+    """The two functions kmu_comm_init_custom needs, carried by a torch process group: what a host that already owns a
+    communicator hands to the library, and how the multi-rank paths are rehearsed on a box with fewer GPUs than ranks
+    (gloo: staged through host memory).  `device` None: the pointers are host addresses (CPU tests of this class)."""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+        self.group = group
+        self.device = device
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.nccl = dist.get_backend(group) == "nccl"
+
+    def _view(self, ptr, nbytes):
+        import torch
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device or "cpu")
+        if self.device is None:
+            import ctypes as C
+            return torch.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Dev(), device=self.device)
+
+    def alltoallv(self, sp, sc, sd, rp, rc, rd, eb):
+        import torch
+        import torch.distributed as dist
+        W = self.world
+        send = self._view(sp, max((sd[p] + sc[p]) * eb for p in range(W)))
+        recv = self._view(rp, max((rd[p] + rc[p]) * eb for p in range(W)))
+        if self.nccl:
+            contiguous = all(sd[p] == sum(sc[:p]) for p in range(W)) and all(rd[p] == sum(rc[:p]) for p in range(W))
+            assert contiguous, "the library sends and receives contiguous groups in peer order"
+            dist.all_to_all_single(recv[:sum(rc) * eb], send[:sum(sc) * eb], [n * eb for n in rc], [n * eb for n in sc],
+                                   group=self.group)
+            torch.cuda.synchronize(self.device)
+            return
+        reqs, staged = [], []
+        for p in range(W):
+            s = send[sd[p] * eb:(sd[p] + sc[p]) * eb]
+            if p == self.rank:
+                recv[rd[p] * eb:(rd[p] + rc[p]) * eb].copy_(s)
+                continue
+            if sc[p]:
+                reqs.append(dist.isend(s.cpu().contiguous(), p, group=self.group))
+            if rc[p]:
+                t = torch.empty(rc[p] * eb, dtype=torch.uint8)
+                staged.append((p, t))
+                reqs.append(dist.irecv(t, p, group=self.group))
+        for r in reqs:
+            r.wait()
+        for p, t in staged:
+            recv[rd[p] * eb:(rd[p] + rc[p]) * eb].copy_(t)
+        if self.device is not None:
+            torch.cuda.synchronize(self.device)
+
+    def allgather(self, payload):
+        import torch
+        import torch.distributed as dist
+        dev = self.device if self.nccl else "cpu"
+        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(outs, mine, group=self.group)
+        return b"".join(bytes(o.cpu().numpy().tobytes()) for o in outs)
+
+
+def init_comm(ctx, group=None, transport=None):
+    """Give `ctx` (kmerutils_amd.lib.Context) a communicator over the ranks of a torch process group.
+
+    transport "rccl" (the default whenever the group's backend is nccl, or there is no group): the library's own RCCL
+    communicator -- rank 0 makes the id (kmu_comm_get_id), the 128 bytes travel over the process group, every rank calls
+    kmu_comm_init; from then on the exchanges of distributed counters run inside libkmu.so, which is what a Rust host
+    gets.  transport "torch": the process group carries the exchanges (TorchTransport; gloo rehearsals)."""
+    import torch
+    import torch.distributed as dist
+    from . import lib
+    if not dist.is_initialized():
+        ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
+        return "rccl"
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if transport is None:
+        transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
+    if transport == "rccl":
+        box = [lib.Context.comm_get_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctx.comm_init(box[0], rank, world)
+    else:
+        tt = TorchTransport(group, torch.device("cuda", ctx.device_id))
+        ctx._transport = tt
+        ctx.comm_init_custom(rank, world, tt.alltoallv, tt.allgather)
+    return transport
+
+
+def count_reads_distributed(counter, bases, offsets):
+    """One collective step of distributed counting on a counter created with `distributed=True` on a context that has a
+    communicator: this rank's shard in (kmu_count_add_reads picks OCCURRENCES or MERGE from the measured duplication),
+    kmu_count_finalize, and the counter holds the k-mers this rank owns with their global multiplicities.  Returns the
+    communicator's statistics of the step."""
+    counter.add_reads(bases, offsets)
+    counter.finalize()
+    return counter.ctx.comm_stats()

@@ -28,6 +28,8 @@ SYMBOLS = [
     "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions", "kmu_count_eliminate_once", "kmu_sketch_partial_words",
     "kmu_sketch_partial", "kmu_sketch_hashed_partial", "kmu_sketch_merge_partials", "kmu_kmer_hashes_compact", "kmu_set_hll_params",
     "kmu_kmer_hashes_range", "kmu_kmer_distribution", "kmu_nthash",
+    "kmu_comm_get_id", "kmu_comm_init", "kmu_comm_init_custom", "kmu_comm_destroy", "kmu_comm_rank", "kmu_comm_nranks",
+    "kmu_comm_allgather", "kmu_comm_get_stats", "kmu_count_finalize", "kmu_kmer_owner",
 ]
 
 
@@ -66,6 +68,16 @@ def load():
     L.kmu_kmer_hashes_range.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
     L.kmu_kmer_distribution.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, u64p]
     L.kmu_nthash.argtypes = [vp, C.POINTER(A.NthashParams), vp, vp, vp, C.c_uint32, vp, vp]
+    L.kmu_comm_get_id.argtypes = [C.POINTER(A.CommId)]
+    L.kmu_comm_init.argtypes = [vp, C.POINTER(A.CommId), C.c_int, C.c_int]
+    L.kmu_comm_init_custom.argtypes = [vp, C.c_int, C.c_int, A.ALLTOALLV_FN, A.ALLGATHER_FN, vp]
+    L.kmu_comm_destroy.argtypes = [vp]
+    L.kmu_comm_rank.argtypes = [vp]
+    L.kmu_comm_nranks.argtypes = [vp]
+    L.kmu_comm_allgather.argtypes = [vp, vp, vp, C.c_uint64]
+    L.kmu_comm_get_stats.argtypes = [vp, C.POINTER(A.CommStats)]
+    L.kmu_count_finalize.argtypes = [vp]
+    L.kmu_kmer_owner.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
     L.kmu_sketch.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
     L.kmu_block_layout.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.kmu_sketch_hashed.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, C.c_uint32, vp, vp]
@@ -129,7 +141,8 @@ class _StreamOrdered:
     Doing it here, at the one place every call passes through, covers the buffers of every present and future method."""
 
     _PLAIN = ("kmu_last_error", "kmu_destroy", "kmu_stream", "kmu_version", "kmu_device_count", "kmu_create",
-              "kmu_block_layout", "kmu_sketch_partial_words", "kmu_count_destroy")
+              "kmu_block_layout", "kmu_sketch_partial_words", "kmu_count_destroy", "kmu_comm_get_id", "kmu_comm_rank",
+              "kmu_comm_nranks", "kmu_comm_get_stats", "kmu_kmer_owner", "kmu_comm_destroy")
 
     def __init__(self, lib, ctx):
         self._lib = lib
@@ -190,6 +203,75 @@ class Context:
         """kmu_set_hll_params: SetSketchParams of the following ALGO_HLL sketches on this context"""
         hp = A.HllParams(b, a, q, 0)
         self._check(self.L.kmu_set_hll_params(self.h, C.byref(hp)))
+
+    # ---- communicator (one rank per GPU; kmu.h "multi-GPU") ----
+    @staticmethod
+    def comm_get_id():
+        """kmu_comm_get_id: 128 bytes that rank 0 creates and hands to every other rank"""
+        L = load()
+        cid = A.CommId()
+        rc = L.kmu_comm_get_id(C.byref(cid))
+        if rc:
+            raise KmuError(rc, L.kmu_last_error(None).decode())
+        return bytes(C.string_at(C.byref(cid), A.COMM_ID_BYTES))
+
+    def comm_init(self, comm_id, rank, nranks):
+        """kmu_comm_init: RCCL communicator over the ranks' GPUs (collective)"""
+        cid = A.CommId()
+        C.memmove(C.byref(cid), comm_id, A.COMM_ID_BYTES)
+        self._check(self.L.kmu_comm_init(self.h, C.byref(cid), rank, nranks))
+
+    def comm_init_custom(self, rank, nranks, alltoallv, allgather):
+        """kmu_comm_init_custom: `alltoallv(send_ptr, send_counts, send_displs, recv_ptr, recv_counts, recv_displs,
+        elem_bytes)` (device pointers as ints, counts as lists) and `allgather(bytes) -> bytes of all ranks` supplied by
+        the caller; exceptions inside them are reported as KMU_E_RCCL."""
+        def a2a(_user, sp, sc, sd, rp, rc_, rd, eb, _stream):
+            try:
+                alltoallv(sp or 0, [sc[i] for i in range(nranks)], [sd[i] for i in range(nranks)], rp or 0,
+                          [rc_[i] for i in range(nranks)], [rd[i] for i in range(nranks)], eb)
+                return 0
+            except Exception:  # noqa: BLE001 -- must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def ag(_user, sp, rp, nbytes):
+            try:
+                out = allgather(C.string_at(sp, nbytes))
+                assert len(out) == nbytes * nranks
+                C.memmove(rp, out, len(out))
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._comm_cbs = (A.ALLTOALLV_FN(a2a), A.ALLGATHER_FN(ag))  # keep the trampolines alive
+        self._check(self.L.kmu_comm_init_custom(self.h, rank, nranks, self._comm_cbs[0], self._comm_cbs[1], None))
+
+    def comm_destroy(self):
+        self._check(self.L.kmu_comm_destroy(self.h))
+
+    @property
+    def comm_rank(self):
+        return self.L.kmu_comm_rank(self.h)
+
+    @property
+    def comm_nranks(self):
+        return self.L.kmu_comm_nranks(self.h)
+
+    def comm_allgather(self, payload):
+        """kmu_comm_allgather: bytes from every rank, in rank order"""
+        n = self.comm_nranks
+        src = C.create_string_buffer(bytes(payload), len(payload))
+        dst = C.create_string_buffer(len(payload) * n)
+        self._check(self.L.kmu_comm_allgather(self.h, src, dst, len(payload)))
+        return dst.raw
+
+    def comm_stats(self):
+        st = A.CommStats()
+        self._check(self.L.kmu_comm_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in A.CommStats._fields_}
 
     # ---- profiling ----
     def profile_enable(self, on=True):
@@ -537,17 +619,17 @@ class Context:
                                                       mem, _ptr(out)[0]))
         return out[:n]
 
-    def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20):
-        return Counter(self, kmer_type, k, counter_bits, capacity_hint)
+    def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False):
+        return Counter(self, kmer_type, k, counter_bits, capacity_hint, distributed)
 
 
 class Counter:
     """kmu_counter: exact canonical k-mer multiplicities on the device (KmerCountT contract)."""
 
-    def __init__(self, ctx, kmer_type, k, counter_bits=8, capacity_hint=1 << 20):
+    def __init__(self, ctx, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False):
         self.ctx = ctx
         self.L = ctx.L
-        self.p = A.CountParams(kmer_type, k, counter_bits, 0, capacity_hint)
+        self.p = A.CountParams(kmer_type, k, counter_bits, A.COUNT_DISTRIBUTED if distributed else 0, capacity_hint)
         h = C.c_void_p()
         ctx._check(self.L.kmu_count_create(ctx.h, C.byref(self.p), C.byref(h)))
         self.h = h
@@ -565,6 +647,10 @@ class Counter:
 
     def reset(self):
         self.ctx._check(self.L.kmu_count_reset(self.h))
+
+    def finalize(self):
+        """kmu_count_finalize (collective): afterwards this rank's counter holds the k-mers it owns, counted over all ranks"""
+        self.ctx._check(self.L.kmu_count_finalize(self.h))
 
     def add_reads(self, bases, offsets, input_kind=A.INPUT_ASCII, packed_offsets=None):
         mem = Context._mem(bases, offsets)
@@ -678,3 +764,14 @@ class Counter:
 
     def retain_part(self, part, n_parts):
         self.ctx._check(self.L.kmu_count_retain_part(self.h, part, n_parts))
+
+
+def kmer_owner(kmer_type, canon_kmers, n_parts):
+    """kmu_kmer_owner: DispatchableT::dispatch of canonical k-mer values (host arithmetic)"""
+    L = load()
+    k = np.ascontiguousarray(canon_kmers, np.uint64)
+    out = np.zeros(max(k.size, 1), np.uint32)
+    rc = L.kmu_kmer_owner(kmer_type, _ptr(k)[0], k.size, n_parts, _ptr(out)[0])
+    if rc:
+        raise KmuError(rc, "kmu_kmer_owner")
+    return out[:k.size]

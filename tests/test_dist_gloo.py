@@ -117,3 +117,60 @@ def test_merge_counters_world2_gloo():
         p.join(300)
         assert p.exitcode == 0
     assert ret.get(0) is True and ret.get(1) is True
+
+
+# ---- the transport handed to kmu_comm_init_custom (dist.TorchTransport) on host buffers, world 2, gloo ------------------------
+def _transport_worker(rank, world, port, ret):
+    import ctypes as C
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tt = kdist.TorchTransport(None, None)
+        ok = tt.allgather(bytes([rank, 7, rank + 1])) == bytes([0, 7, 1, 1, 7, 2])
+        # rank r sends (r + 1) * (p + 1) elements of 8 bytes to peer p, values tagged with (sender, receiver, index)
+        for eb, dt in ((8, np.uint64), (4, np.uint32)):
+            sc = [(rank + 1) * (p + 1) for p in range(world)]
+            sd = [int(x) for x in np.concatenate([[0], np.cumsum(sc)[:-1]])]
+            rc = [(p + 1) * (rank + 1) for p in range(world)]
+            rd = [int(x) for x in np.concatenate([[0], np.cumsum(rc)[:-1]])]
+            send = np.concatenate([np.arange(sc[p], dtype=dt) + 1000 * rank + 100 * p for p in range(world)])
+            recv = np.zeros(sum(rc), dt)
+            tt.alltoallv(send.ctypes.data, sc, sd, recv.ctypes.data, rc, rd, eb)
+            want = np.concatenate([np.arange(rc[p], dtype=dt) + 1000 * p + 100 * rank for p in range(world)])
+            ok = ok and np.array_equal(recv, want)
+        # an empty exchange is legal (a rank without k-mers)
+        tt.alltoallv(0, [0] * world, [0] * world, 0, [0] * world, [0] * world, 8)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_transport_world2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_transport_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(0) is True and ret.get(1) is True
+
+
+def test_kmer_owner_matches_oracle(oracle):
+    """kmu_kmer_owner = DispatchableT::dispatch (kmercount.rs:382-420): int32_hash / int64_hash of the value, mod n"""
+    from kmerutils_amd import lib
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    k64 = rng.integers(0, 1 << 62, 500, dtype=np.uint64)
+    for n in (1, 2, 3, 8, 13):
+        assert list(lib.kmer_owner(A.KMER64BIT, k64, n)) == [L.kmo_int64_hash(int(x)) % n for x in k64]
+        k32 = (k64 & np.uint64(0xFFFFFFFF))
+        assert list(lib.kmer_owner(A.KMER16B32BIT, k32, n)) == [L.kmo_int32_hash(int(x)) % n for x in k32]

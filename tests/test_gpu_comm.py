@@ -1,0 +1,150 @@
+"""The communicator inside libkmu.so and the distributed counter on the test box's one GPU:
+  * RCCL itself at world_size 1 -- ncclCommInitRank, ncclAllGather, the grouped ncclSend / ncclRecv all-to-all (to self), the
+    exchange stream and its events -- with both routes forced and the automatic choice, against the oracle;
+  * two ranks sharing the GPU, the exchange carried by a gloo process group through kmu_comm_init_custom: the real device
+    code of both routes incl. the finalize of MERGE (owner census, emit, tombstones, merge of received entries)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+from kmerutils_amd import dist as kdist
+from kmerutils_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(seed=0xC4, n=3000, fixed=150, genome=40_000):
+    """short reads at ~11x coverage: most k-mers occur several times (the MERGE case)"""
+    return synth.genome_reads(n, np.full(n, fixed, np.int64), genome, seed, sub=0.005, ins=0.0, dele=0.0)
+
+
+def _oracle_counts(oracle, bases, off, k=31):
+    g = oracle.Counter(A.KMER64BIT, k, 16, 1 << 20)
+    g.add_reads(bases, off)
+    return g.dump(1)
+
+
+def test_rccl_world1_distributed_counter(oracle, monkeypatch):
+    import torch
+    from kmerutils_amd import lib
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
+    ctx = lib.Context(0)
+    ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
+    assert (ctx.comm_rank, ctx.comm_nranks) == (0, 1)
+    assert ctx.comm_allgather(b"\x01\x02\x03") == b"\x01\x02\x03"  # ncclAllGather through the library
+    for reads, hint in ((_reads(), "short reads"), (synth.ont_reads(500, 400_000, 0xC3), "ont")):
+        bases, off = reads
+        wk, wc = _oracle_counts(oracle, bases, off)
+        db, do = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        nk = int(np.maximum(np.diff(off.astype(np.int64)) - 30, 0).sum())
+        for route in ("occurrences", "merge", None):
+            if route:
+                monkeypatch.setenv("KMU_COUNT_ROUTE", route)
+            else:
+                monkeypatch.delenv("KMU_COUNT_ROUTE", raising=False)
+            for mem_dev in (True, False):
+                c = ctx.counter(A.KMER64BIT, 31, 16, max(nk, 1 << 16), distributed=True)
+                c.add_reads(db, do) if mem_dev else c.add_reads(bases, off)
+                st = ctx.comm_stats()
+                c.finalize()
+                gk, gc = c.dump(1)
+                assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (hint, route, mem_dev)
+                assert c.nb_distinct() == wk.size and c.nb_unique() == int((wc == 1).sum())
+                assert st["kmers_local"] == nk and st["route"] == {"occurrences": 1, "merge": 2}.get(route, st["route"])
+                # the sampled duplication is an estimate of occurrences / distinct of the batch
+                assert st["dup_ratio"] == 0 or abs(st["dup_ratio"] - nk / wk.size) < 0.15 * nk / wk.size, (st, nk, wk.size)
+                assert st["bytes_sent"] == 0  # nothing leaves a single rank
+                c.close()
+        # two batches into one distributed counter, one per route: owned counts add up
+        c = ctx.counter(A.KMER64BIT, 31, 16, max(2 * nk, 1 << 16), distributed=True)
+        monkeypatch.setenv("KMU_COUNT_ROUTE", "merge")
+        c.add_reads(db, do)
+        monkeypatch.setenv("KMU_COUNT_ROUTE", "occurrences")
+        c.add_reads(db, do)
+        c.finalize()
+        gk, gc = c.dump(1)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+        c.close()
+        monkeypatch.delenv("KMU_COUNT_ROUTE", raising=False)
+    # a distributed counter needs a communicator
+    ctx.comm_destroy()
+    with pytest.raises(lib.KmuError):
+        ctx.counter(A.KMER64BIT, 31, 8, 1 << 16, distributed=True)
+    ctx.close()
+
+
+def _worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    from kmerutils_amd import lib
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = lib.Context(0)
+        assert kdist.init_comm(ctx) == "torch"
+        ok = (ctx.comm_rank, ctx.comm_nranks) == (rank, world)
+        L = O.lib()
+        for reads in (_reads(), synth.ont_reads(400, 300_000, 0xC3)):
+            bases, off = reads  # the same set on both ranks, sharded by bases
+            lens = np.diff(off.astype(np.int64))
+            r0, r1 = kdist.shard_reads_by_bases(lens, world)[rank]
+            sb = torch.from_numpy(bases[int(off[r0]):int(off[r1])].copy()).cuda()
+            so = torch.from_numpy((off[r0:r1 + 1] - off[r0]).astype(np.int64)).cuda()
+            g = O.Counter(A.KMER64BIT, 31, 16, 1 << 20)
+            g.add_reads(bases, off)
+            gk, gc = g.dump(1)
+            own = np.array([L.kmo_int64_hash(int(x)) % world for x in gk], dtype=np.int64) == rank
+            for route in ("occurrences", "merge", None):
+                if route:
+                    os.environ["KMU_COUNT_ROUTE"] = route
+                else:
+                    os.environ.pop("KMU_COUNT_ROUTE", None)
+                c = ctx.counter(A.KMER64BIT, 31, 16, int(off[-1]), distributed=True)
+                st = kdist.count_reads_distributed(c, sb, so)
+                kk, cc = c.dump(1)
+                ok = ok and np.array_equal(kk, gk[own]) and np.array_equal(cc, gc[own])
+                ok = ok and c.nb_distinct() == int(own.sum())
+                ok = ok and st["bytes_sent"] > 0 and st["route"] in (1, 2)
+                if route == "merge":  # 12 bytes per entry that left
+                    ok = ok and st["bytes_merge"] == st["bytes_sent"] and st["bytes_sent"] % 12 == 0
+                if route == "occurrences":
+                    ok = ok and st["bytes_sent"] == st["bytes_occurrences"]
+                c.close()
+            # an empty shard on one rank is a legal participant
+            os.environ["KMU_COUNT_ROUTE"] = "merge"
+            c = ctx.counter(A.KMER64BIT, 31, 16, int(off[-1]), distributed=True)
+            if rank == 0:
+                c.add_reads(torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda())
+            else:
+                c.add_reads(torch.zeros(16, dtype=torch.uint8).cuda(), torch.zeros(1, dtype=torch.int64).cuda())
+            c.finalize()
+            kk, cc = c.dump(1)
+            ok = ok and np.array_equal(kk, gk[own]) and np.array_equal(cc, gc[own])
+            c.close()
+            os.environ.pop("KMU_COUNT_ROUTE", None)
+        ret[rank] = bool(ok)
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_library_exchange():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert ret.get(0) is True and ret.get(1) is True
