@@ -177,6 +177,9 @@ void *kmu_stream(kmu_ctx *ctx); /* the hipStream_t kernels are enqueued on */
  * crossing PCIe again.  kmu_dev_free waits for the context's stream first. */
 int kmu_dev_alloc(kmu_ctx *ctx, uint64_t bytes, void **out);
 int kmu_dev_free(kmu_ctx *ctx, void *p);
+/* pinned host memory (hipHostMalloc): uploads from it and downloads into it are real DMA transfers that overlap kernels */
+int kmu_host_alloc(kmu_ctx *ctx, uint64_t bytes, void **out);
+int kmu_host_free(kmu_ctx *ctx, void *p);
 int kmu_copy_to_device(kmu_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
 int kmu_copy_to_host(kmu_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
 
@@ -288,6 +291,20 @@ int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p, const uint8_t *bases, c
  * offsets in host memory */
 int kmu_block_layout(const uint64_t *offsets, uint32_t n_seq, uint32_t block_size, uint64_t *block_row_offsets_out);
 
+/* The reads ONCE, both results: the per-sequence signatures of kmu_sketch and the k-mer counts of kmu_count_add_reads for
+ * one batch of unpacked reads -- the reference's alternation "read a pack of sequences, sketch it" (src/bin/datasketcher.rs:
+ * 243-260) and its counting pass (src/bin/parsefastq.rs:215-236) as one stream-ordered pipeline.
+ *   p->mem == KMU_MEM_HOST   (bases, offsets, sig_out in host memory, best pinned: kmu_host_alloc): the bases cross PCIe
+ *       once, in chunks of whole reads on an upload stream; the sketch kernels of chunk i run under the upload of chunk
+ *       i + 1, the signature rows of chunk i go down on a download stream under the kernels that follow, and the count
+ *       build runs on the resident reads under the last downloads.  Returns when everything is in host memory.
+ *   p->mem == KMU_MEM_DEVICE: both results from the resident reads; a distributed counter's all-to-all is in flight
+ *       while the reads are sketched.
+ * counter may be NULL (signatures only).  Whole sequences, one signature per sequence (mode PER_SEQ, block_size 0), ASCII.
+ * KMU_PIPE_CHUNK_MB sets the chunk size of the host form (default 512). */
+int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p, kmu_counter *counter, const uint8_t *bases,
+                     const uint64_t *offsets, uint32_t n_seq, void *sig_out);
+
 /* fallback for arbitrary closures: the host evaluates fhash, the device does multiset + sketch only.
  * hashed[offsets[i] .. offsets[i+1]) are the hashed k-mers of sequence i (uint32 or uint64 per p->sig_type /
  * kmer_type width). */
@@ -324,6 +341,8 @@ int kmu_count_add_kmers(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n,
 int kmu_count_query(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int mem, uint32_t *counts_out);
 int kmu_count_nb_distinct(kmu_counter *c, uint64_t *out); /* kmercount.rs:280-282 */
 int kmu_count_nb_unique(kmu_counter *c, uint64_t *out);   /* kmercount.rs:285-287 */
+/* sum of the (unsaturated) multiplicities held = k-mer occurrences inserted: the conservation check of a build */
+int kmu_count_nb_occurrences(kmu_counter *c, uint64_t *out);
 /* dump of (canonical k-mer, count) for count >= min_count (dump_kmer_counter, kmercount.rs:500-525 uses 2).
  * Call with kmers_out == NULL to get the number of records in *n_out; records are sorted by k-mer value. */
 int kmu_count_dump(kmu_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,

@@ -292,6 +292,8 @@ void kmu_destroy(kmu_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     comm_free(ctx);
+    if (ctx->pipe_h2d) (void) hipStreamDestroy(ctx->pipe_h2d);
+    if (ctx->pipe_d2h) (void) hipStreamDestroy(ctx->pipe_d2h);
     for (auto &p : ctx->pending) {
         (void) hipEventDestroy(p.a);
         (void) hipEventDestroy(p.b);
@@ -345,6 +347,28 @@ int kmu_dev_free(kmu_ctx *ctx, void *p) {
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // nothing enqueued by this context may still use it
     KMU_HIP(ctx, hipFree(p));
+    return KMU_OK;
+}
+
+// pinned host memory: what the asynchronous uploads of kmu_sketch_count (and every KMU_MEM_HOST call) want to read from
+int kmu_host_alloc(kmu_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out) return KMU_E_BAD_ARG;
+    *out = nullptr;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void) hipGetLastError();
+        return fail(ctx, KMU_E_OOM, "hipHostMalloc of %llu bytes failed", (unsigned long long) bytes);
+    }
+    *out = p;
+    return KMU_OK;
+}
+int kmu_host_free(kmu_ctx *ctx, void *p) {
+    if (!ctx) return KMU_E_BAD_ARG;
+    if (!p) return KMU_OK;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KMU_HIP(ctx, hipHostFree(p));
     return KMU_OK;
 }
 

@@ -362,23 +362,26 @@ __global__ void __launch_bounds__(256) k_count_query(const uint64_t *kmers, uint
     }
 }
 
-// [0] += occupied slots, [1] += slots with count == 1
+// [0] += occupied slots, [1] += slots with count == 1, [3] += sum of the counts (k-mer occurrences held)
 __global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslots, uint64_t *scalars) {
-    uint64_t d = 0, u = 0;
+    uint64_t d = 0, u = 0, tot = 0;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         if (t.keys[i] != CKEY_EMPTY) {
             const uint32_t c = t.counts[i]; // 0: an entry that left for its owner (distributed counters)
             d += c != 0u;
             u += c == 1u;
+            tot += c;
         }
     }
     for (int o = 32; o >= 1; o >>= 1) {
         d += ((uint64_t) (uint32_t) __shfl_xor((int) (d >> 32), o, 64) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) d, o, 64);
         u += ((uint64_t) (uint32_t) __shfl_xor((int) (u >> 32), o, 64) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) u, o, 64);
+        tot += ((uint64_t) (uint32_t) __shfl_xor((int) (tot >> 32), o, 64) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) tot, o, 64);
     }
     if (lane_id() == 0) {
         if (d) atomicAdd((unsigned long long *) &scalars[0], (unsigned long long) d);
         if (u) atomicAdd((unsigned long long *) &scalars[1], (unsigned long long) u);
+        if (tot) atomicAdd((unsigned long long *) &scalars[3], (unsigned long long) tot);
     }
 }
 
@@ -1578,6 +1581,27 @@ static int flat_stream_extent(kmu_ctx *ctx, const uint64_t *host_offsets, uint32
     return KMU_OK;
 }
 
+} // extern "C"
+
+namespace kmu {
+// What kmu_sketch_count needs of a counter: the canonical k-mers of device-resident unpacked reads go in, in two halves
+// (a distributed counter's exchange is in flight between them: the caller's kernels on the context's stream run under it).
+// host_offsets: the caller's host copy of the offsets (mem == KMU_MEM_HOST: already re-based to the staged stream) or null.
+int count_add_device_begin(kmu_counter *c, DevSeqs &ds, const uint64_t *host_offsets, int mem, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    if (c->dist && c->pending) KMU_TRY(dist_add_end(c));
+    uint64_t total_bases = 0;
+    if (ds.n_seq) KMU_TRY(flat_stream_extent(ctx, host_offsets, ds.n_seq, mem, ds, &total_bases));
+    if (c->dist) return dist_add_begin(c, ds, total_bases, d_err);
+    if (ds.n_seq) return local_add(c, ds, total_bases, d_err);
+    return KMU_OK;
+}
+int count_add_device_end(kmu_counter *c) { return c->dist ? dist_add_end(c) : KMU_OK; }
+kmu_ctx *counter_ctx(kmu_counter *c) { return c->ctx; }
+} // namespace kmu
+
+extern "C" {
+
 int kmu_count_add_reads(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, const uint64_t *packed_offsets,
                         uint32_t n_seq, int input_kind, int mem) {
     if (!c) return KMU_E_BAD_ARG;
@@ -1683,12 +1707,13 @@ int kmu_count_query(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int
     return finish_call(ctx, mem);
 }
 
-static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique) {
+static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique, uint64_t *occurrences = nullptr) {
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     if (c->empty) {
         if (distinct) *distinct = 0;
         if (unique) *unique = 0;
+        if (occurrences) *occurrences = 0;
         return KMU_OK;
     }
     KMU_HIP(ctx, hipMemsetAsync(c->scalars, 0, 64, ctx->stream));
@@ -1698,11 +1723,12 @@ static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique) {
                            c->nslots, c->scalars);
     }
     KMU_HIP(ctx, hipGetLastError());
-    uint64_t h[2];
-    KMU_HIP(ctx, hipMemcpyAsync(h, c->scalars, 16, hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t h[4];
+    KMU_HIP(ctx, hipMemcpyAsync(h, c->scalars, 32, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (distinct) *distinct = h[0];
     if (unique) *unique = h[1];
+    if (occurrences) *occurrences = h[3];
     return KMU_OK;
 }
 
@@ -1713,6 +1739,10 @@ int kmu_count_nb_distinct(kmu_counter *c, uint64_t *out) {
 int kmu_count_nb_unique(kmu_counter *c, uint64_t *out) {
     if (!c || !out) return KMU_E_BAD_ARG;
     return count_stats(c, nullptr, out);
+}
+int kmu_count_nb_occurrences(kmu_counter *c, uint64_t *out) {
+    if (!c || !out) return KMU_E_BAD_ARG;
+    return count_stats(c, nullptr, nullptr, out);
 }
 
 // shared by dump / export: select into device buffers, then hand over

@@ -53,6 +53,8 @@ struct kmu_ctx {
     std::map<std::string, Stat> stats;
     int num_cus = 256;
     size_t lds_per_block = 65536;
+    // kmu_sketch_count on host buffers: uploads and downloads run on streams of their own, next to the kernels
+    hipStream_t pipe_h2d = nullptr, pipe_d2h = nullptr;
 };
 
 namespace kmu {
@@ -185,6 +187,10 @@ int get_err_word(kmu_ctx *ctx, uint32_t **out); // zeroed on the stream
 int check_err_word(kmu_ctx *ctx, uint32_t *d_err);
 
 void comm_free(kmu_ctx *ctx); // kmu_comm.hip
+// kmu_count.hip, for kmu_sketch_count
+int count_add_device_begin(kmu_counter *c, DevSeqs &ds, const uint64_t *host_offsets, int mem, uint32_t *d_err);
+int count_add_device_end(kmu_counter *c);
+kmu_ctx *counter_ctx(kmu_counter *c);
 
 int check_kmer(kmu_ctx *ctx, int kmer_type, int k);
 inline bool kmer_is_aa(int t) { return t == KMU_KMERAA32BIT || t == KMU_KMERAA64BIT; }

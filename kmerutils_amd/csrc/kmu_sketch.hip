@@ -1572,6 +1572,74 @@ static int sketch_all_hashed(kmu_ctx *ctx, const kmu_sketch_params *p, const uin
     return launch_super_reduce(ctx, p, (const uint64_t *) pr, n_chunks, d_sig);
 }
 
+// ProbMinHash3a, one signature per sequence, sequences on the device.  h_offsets: a host copy of ds.offsets[0 .. n_seq] if the
+// caller has one (the lengths are then known without asking the device), else null.
+static int sketch_pmh_per_seq(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows, void *d_sig,
+                              uint32_t *d_err, const uint64_t *h_offsets) {
+    const uint32_t n_seq = ds.n_seq;
+    const size_t sigb = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    // Sequences far longer than one LDS pass (genomes, not reads) would take L / cap passes in the per-sequence
+    // kernel.  They go through the same global route as a sketch over all sequences -- hashes, radix partition
+    // into leaves, per-leaf slot minima, merge -- one sequence at a time, which is linear in L.
+    uint32_t skip_longer = 0;
+    uint64_t len_stats[2] = {0, 0}; // longest sequence, all bases (whole sequences only)
+    std::vector<uint32_t> long_seqs;
+    if (p->block_size == 0) {
+        std::vector<uint64_t> h_off;
+        if (h_offsets) {
+            for (uint32_t i = 0; i < n_seq; i++) len_stats[0] = std::max(len_stats[0], h_offsets[i + 1] - h_offsets[i]);
+            len_stats[1] = h_offsets[n_seq] - h_offsets[0];
+        } else {
+            void *mx;
+            KMU_TRY(dev_buf(ctx, "pmh.maxlen", 64, &mx));
+            KMU_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
+            const uint32_t mgrid = (uint32_t) std::min<uint64_t>(((uint64_t) n_seq + 1023) / 1024, (uint64_t) ctx->num_cus);
+            hipLaunchKernelGGL(k_max_len, dim3(mgrid ? mgrid : 1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, (uint64_t *) mx);
+            KMU_HIP(ctx, hipMemcpyAsync(len_stats, mx, 16, hipMemcpyDeviceToHost, ctx->stream));
+            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        const uint64_t max_len = len_stats[0];
+        if (max_len > (uint64_t) LONG_SEQ_KMERS + (uint64_t) p->kmer_size) {
+            if (!h_offsets) {
+                h_off.resize((size_t) n_seq + 1);
+                KMU_HIP(ctx, hipMemcpyAsync(h_off.data(), ds.offsets, ((size_t) n_seq + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                h_offsets = h_off.data();
+            }
+            for (uint32_t i = 0; i < n_seq; i++) {
+                const uint64_t L = h_offsets[i + 1] - h_offsets[i];
+                if (L >= (uint64_t) p->kmer_size && L - p->kmer_size + 1 > LONG_SEQ_KMERS) long_seqs.push_back(i);
+            }
+            skip_longer = LONG_SEQ_KMERS;
+        }
+    }
+    KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err, nullptr, 0, nullptr, nullptr, skip_longer, len_stats));
+    for (uint32_t i : long_seqs) {
+        DevSeqs one = ds;
+        one.offsets = ds.offsets + i;
+        one.packed_offsets = ds.packed_offsets ? ds.packed_offsets + i : nullptr;
+        one.n_seq = 1;
+        void *koff, *hk;
+        KMU_TRY(dev_buf(ctx, "all.koff", 2 * 8 + 64, &koff));
+        hipLaunchKernelGGL(k_nk_scan, dim3(1), dim3(1024), 0, ctx->stream, one.offsets, 1u, p->kmer_size, (uint64_t *) koff, d_err);
+        uint64_t n_items = 0;
+        KMU_HIP(ctx, hipMemcpyAsync(&n_items, (uint64_t *) koff + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &hk));
+        KmerCfg cfg{p->kmer_type, p->kmer_size, p->fhash};
+        {
+            KernelTimer t(ctx, "k_seq_hashes_compact");
+            hipLaunchKernelGGL(k_seq_hashes_compact, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, one.bases, one.offsets,
+                               one.packed_offsets, 1u, one.packed, one.total_bytes, cfg, (const uint64_t *) koff,
+                               (uint64_t *) hk, d_err, 1);
+        }
+        KMU_HIP(ctx, hipGetLastError());
+        KMU_TRY(sketch_all_hashed(ctx, p, (const uint64_t *) hk, n_items,
+                                  reinterpret_cast<uint8_t *>(d_sig) + (size_t) i * p->sketch_size * sigb, d_err));
+    }
+    return KMU_OK;
+}
+
 // ProbMinHash3 (sketch_probminhash3, seqsketchjaccard.rs:272-319) generates the same points per key as ProbMinHash3a
 // and keeps the same per-slot minimum: it runs on the ProbMinHash3a kernel (whole sequences only, like upstream).
 static int resolve_algo(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu_sketch_params *p) {
@@ -1662,59 +1730,7 @@ extern "C" int kmu_sketch(kmu_ctx *ctx, const kmu_sketch_params *p_in, const uin
         KMU_TRY(sketch_all_hashed(ctx, p, (const uint64_t *) hk, n_items, d_sig, d_err));
     } else if (n_seq) {
         switch (p->algo) {
-        case KMU_ALGO_PROB3A: {
-            // Sequences far longer than one LDS pass (genomes, not reads) would take L / cap passes in the per-sequence
-            // kernel.  They go through the same global route as a sketch over all sequences -- hashes, radix partition
-            // into leaves, per-leaf slot minima, merge -- one sequence at a time, which is linear in L.
-            uint32_t skip_longer = 0;
-            uint64_t len_stats[2] = {0, 0}; // longest sequence, all bases (whole sequences only)
-            std::vector<uint32_t> long_seqs;
-            if (p->block_size == 0) {
-                void *mx;
-                KMU_TRY(dev_buf(ctx, "pmh.maxlen", 64, &mx));
-                KMU_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
-                const uint32_t mgrid = (uint32_t) std::min<uint64_t>(((uint64_t) n_seq + 1023) / 1024, (uint64_t) ctx->num_cus);
-                hipLaunchKernelGGL(k_max_len, dim3(mgrid ? mgrid : 1), dim3(1024), 0, ctx->stream, ds.offsets, n_seq, (uint64_t *) mx);
-                KMU_HIP(ctx, hipMemcpyAsync(len_stats, mx, 16, hipMemcpyDeviceToHost, ctx->stream));
-                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                const uint64_t max_len = len_stats[0];
-                if (max_len > (uint64_t) LONG_SEQ_KMERS + (uint64_t) p->kmer_size) {
-                    std::vector<uint64_t> h_off((size_t) n_seq + 1);
-                    KMU_HIP(ctx, hipMemcpyAsync(h_off.data(), ds.offsets, ((size_t) n_seq + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-                    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    for (uint32_t i = 0; i < n_seq; i++) {
-                        const uint64_t L = h_off[i + 1] - h_off[i];
-                        if (L >= (uint64_t) p->kmer_size && L - p->kmer_size + 1 > LONG_SEQ_KMERS) long_seqs.push_back(i);
-                    }
-                    skip_longer = LONG_SEQ_KMERS;
-                }
-            }
-            KMU_TRY(launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err, nullptr, 0, nullptr, nullptr, skip_longer, len_stats));
-            for (uint32_t i : long_seqs) {
-                DevSeqs one = ds;
-                one.offsets = ds.offsets + i;
-                one.packed_offsets = ds.packed_offsets ? ds.packed_offsets + i : nullptr;
-                one.n_seq = 1;
-                void *koff, *hk;
-                KMU_TRY(dev_buf(ctx, "all.koff", 2 * 8 + 64, &koff));
-                hipLaunchKernelGGL(k_nk_scan, dim3(1), dim3(1024), 0, ctx->stream, one.offsets, 1u, p->kmer_size, (uint64_t *) koff, d_err);
-                uint64_t n_items = 0;
-                KMU_HIP(ctx, hipMemcpyAsync(&n_items, (uint64_t *) koff + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                KMU_TRY(dev_buf(ctx, "all.hashes", n_items * 8 + 64, &hk));
-                KmerCfg cfg{p->kmer_type, p->kmer_size, p->fhash};
-                {
-                    KernelTimer t(ctx, "k_seq_hashes_compact");
-                    hipLaunchKernelGGL(k_seq_hashes_compact, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, one.bases, one.offsets,
-                                       one.packed_offsets, 1u, one.packed, one.total_bytes, cfg, (const uint64_t *) koff,
-                                       (uint64_t *) hk, d_err, 1);
-                }
-                KMU_HIP(ctx, hipGetLastError());
-                KMU_TRY(sketch_all_hashed(ctx, p, (const uint64_t *) hk, n_items,
-                                          reinterpret_cast<uint8_t *>(d_sig) + (size_t) i * p->sketch_size * sigb, d_err));
-            }
-            break;
-        }
+        case KMU_ALGO_PROB3A: KMU_TRY(sketch_pmh_per_seq(ctx, p, ds, d_block_rows, d_sig, d_err, nullptr)); break;
         case KMU_ALGO_SUPER:
         case KMU_ALGO_SUPER2: KMU_TRY(launch_super(ctx, p, ds, d_sig, d_err, nullptr, 0, nullptr)); break;
         case KMU_ALGO_OPTDENS:
@@ -1810,6 +1826,126 @@ extern "C" int kmu_sketch_hashed(kmu_ctx *ctx, const kmu_sketch_params *p_in, co
     }
     if (!(p->mem == KMU_MEM_DEVICE && ctx->async_device)) KMU_TRY(check_err_word(ctx, d_err));
     return finish_call(ctx, p->mem);
+}
+
+// per-sequence signatures of device-resident sequences for any algorithm (the switch of kmu_sketch)
+static int sketch_per_seq_device(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, void *d_sig, uint32_t *d_err,
+                                 const uint64_t *h_offsets) {
+    switch (p->algo) {
+    case KMU_ALGO_PROB3A: return sketch_pmh_per_seq(ctx, p, ds, nullptr, d_sig, d_err, h_offsets);
+    case KMU_ALGO_SUPER:
+    case KMU_ALGO_SUPER2: return launch_super(ctx, p, ds, d_sig, d_err, nullptr, 0, nullptr);
+    case KMU_ALGO_OPTDENS:
+    case KMU_ALGO_REVOPTDENS:
+    case KMU_ALGO_HLL: return launch_dens(ctx, p, ds, d_sig, d_err, nullptr, 0);
+    default: return fail(ctx, KMU_E_UNSUPPORTED, "kmu_sketch_count: no per-sequence kernel for algo %d", p->algo);
+    }
+}
+
+extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu_counter *counter, const uint8_t *bases,
+                                const uint64_t *offsets, uint32_t n_seq, void *sig_out) {
+    if (!ctx || !p_in || !sig_out || !offsets) return KMU_E_BAD_ARG;
+    kmu_sketch_params p_res;
+    KMU_TRY(resolve_algo(ctx, p_in, &p_res));
+    const kmu_sketch_params *p = &p_res;
+    KMU_TRY(check_kmer(ctx, p->kmer_type, p->kmer_size));
+    KMU_TRY(sketch_params_check(ctx, p));
+    if (!fhash_valid(p->fhash, p->kmer_type)) return fail(ctx, KMU_E_BAD_ARG, "fhash %d not valid for kmer_type %d", p->fhash, p->kmer_type);
+    if (p->mode != KMU_MODE_PER_SEQ || p->block_size != 0 || p->input_kind != KMU_INPUT_ASCII || p->algo == KMU_ALGO_BOTTOMK)
+        return fail(ctx, KMU_E_UNSUPPORTED, "kmu_sketch_count: whole unpacked sequences, one signature each");
+    if (counter && counter_ctx(counter) != ctx) return fail(ctx, KMU_E_BAD_ARG, "the counter belongs to another context");
+    if (counter && kmer_is_aa(p->kmer_type)) return fail(ctx, KMU_E_BAD_ARG, "counting is defined on DNA k-mers");
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t sigb = p->sig_type == KMU_SIG_U16 ? 2 : (p->sig_type == KMU_SIG_U32 || p->sig_type == KMU_SIG_F32) ? 4 : 8;
+    const size_t rowb = (size_t) p->sketch_size * sigb;
+    uint32_t *d_err;
+    KMU_TRY(get_err_word(ctx, &d_err));
+    if (p->mem == KMU_MEM_DEVICE) {
+        DevSeqs ds;
+        KMU_TRY(stage_sequences(ctx, bases, offsets, nullptr, n_seq, KMU_INPUT_ASCII, KMU_MEM_DEVICE, &ds));
+        if (counter) { // (a distributed counter: census, route, scatter, and the all-to-all leaves on the exchange stream)
+            DevSeqs dc = ds;
+            KMU_TRY(count_add_device_begin(counter, dc, nullptr, KMU_MEM_DEVICE, d_err));
+        }
+        if (n_seq) KMU_TRY(sketch_per_seq_device(ctx, p, ds, sig_out, d_err, nullptr));
+        if (counter) KMU_TRY(count_add_device_end(counter));
+        if (!ctx->async_device) KMU_TRY(check_err_word(ctx, d_err));
+        return finish_call(ctx, KMU_MEM_DEVICE);
+    }
+    if (p->mem != KMU_MEM_HOST) return fail(ctx, KMU_E_BAD_ARG, "bad mem %d", p->mem);
+    if (!bases && n_seq) return fail(ctx, KMU_E_BAD_ARG, "null sequence buffers");
+    // ---- host buffers: upload | sketch | download | count as a pipeline over chunks of whole reads ----
+    const uint64_t off0 = n_seq ? offsets[0] : 0, total = n_seq ? offsets[n_seq] - off0 : 0;
+    std::vector<uint64_t> h_off((size_t) n_seq + 1);
+    for (uint32_t i = 0; i <= n_seq; i++) h_off[i] = offsets[i] - off0;
+    void *d_b, *d_o, *d_sig;
+    KMU_TRY(dev_buf(ctx, "in.bases", total + 64, &d_b));
+    KMU_TRY(dev_buf(ctx, "in.offsets", ((size_t) n_seq + 1) * 8, &d_o));
+    KMU_TRY(dev_buf(ctx, "out.sig", (size_t) n_seq * rowb + 64, &d_sig));
+    if (!ctx->pipe_h2d) KMU_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_h2d, hipStreamNonBlocking));
+    if (!ctx->pipe_d2h) KMU_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_d2h, hipStreamNonBlocking));
+    KMU_HIP(ctx, hipMemcpyAsync(d_o, h_off.data(), ((size_t) n_seq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t chunk_bytes = 512ull << 20;
+    if (const char *e = getenv("KMU_PIPE_CHUNK_MB")) chunk_bytes = (uint64_t) std::max(1, atoi(e)) << 20;
+    std::vector<uint32_t> cut(1, 0u); // chunk c = reads [cut[c], cut[c + 1])
+    for (uint32_t r = 0; r < n_seq;) {
+        const uint64_t lim = h_off[r] + chunk_bytes;
+        uint32_t e = (uint32_t) (std::upper_bound(h_off.begin() + r + 1, h_off.end(), lim) - h_off.begin()) - 1;
+        if (e <= r) e = r + 1; // a read longer than a chunk travels alone
+        cut.push_back(e);
+        r = e;
+    }
+    const size_t n_chunks = cut.size() - 1;
+    std::vector<hipEvent_t> ev_up(n_chunks), ev_sk(n_chunks);
+    for (size_t c = 0; c < n_chunks; c++) {
+        KMU_HIP(ctx, hipEventCreateWithFlags(&ev_up[c], hipEventDisableTiming));
+        KMU_HIP(ctx, hipEventCreateWithFlags(&ev_sk[c], hipEventDisableTiming));
+    }
+    int rc = KMU_OK;
+    auto upload = [&](size_t c) -> int {
+        const uint64_t b0 = h_off[cut[c]], b1 = h_off[cut[c + 1]];
+        KMU_HIP(ctx, hipMemcpyAsync((uint8_t *) d_b + b0, bases + off0 + b0, b1 - b0, hipMemcpyHostToDevice, ctx->pipe_h2d));
+        KMU_HIP(ctx, hipEventRecord(ev_up[c], ctx->pipe_h2d));
+        return KMU_OK;
+    };
+    DevSeqs all;
+    all.bases = (const uint8_t *) d_b;
+    all.offsets = (const uint64_t *) d_o;
+    all.n_seq = n_seq;
+    all.total_bytes = total;
+    if (n_chunks) rc = upload(0);
+    for (size_t c = 0; c < n_chunks && rc == KMU_OK; c++) {
+        if (c + 1 < n_chunks) rc = upload(c + 1);
+        if (rc != KMU_OK) break;
+        DevSeqs ds = all;
+        ds.offsets = all.offsets + cut[c];
+        ds.n_seq = cut[c + 1] - cut[c];
+        uint8_t *d_rows = (uint8_t *) d_sig + (size_t) cut[c] * rowb;
+        if (hipStreamWaitEvent(ctx->stream, ev_up[c], 0) != hipSuccess) { rc = fail(ctx, KMU_E_HIP, "hipStreamWaitEvent failed"); break; }
+        rc = sketch_per_seq_device(ctx, p, ds, d_rows, d_err, h_off.data() + cut[c]);
+        if (rc != KMU_OK) break;
+        if (hipEventRecord(ev_sk[c], ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->pipe_d2h, ev_sk[c], 0) != hipSuccess ||
+            hipMemcpyAsync((uint8_t *) sig_out + (size_t) cut[c] * rowb, d_rows, (size_t) ds.n_seq * rowb, hipMemcpyDeviceToHost,
+                           ctx->pipe_d2h) != hipSuccess)
+            rc = fail(ctx, KMU_E_HIP, "signature download failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (rc == KMU_OK && counter) { // the whole read set is resident by now: ev_up of the last chunk has been waited for
+        DevSeqs dc = all;
+        rc = count_add_device_begin(counter, dc, h_off.data(), KMU_MEM_HOST, d_err);
+        if (rc == KMU_OK) rc = count_add_device_end(counter);
+    }
+    (void) hipStreamSynchronize(ctx->pipe_h2d);
+    (void) hipStreamSynchronize(ctx->pipe_d2h);
+    for (size_t c = 0; c < n_chunks; c++) {
+        (void) hipEventDestroy(ev_up[c]);
+        (void) hipEventDestroy(ev_sk[c]);
+    }
+    if (rc != KMU_OK) {
+        (void) hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    KMU_TRY(check_err_word(ctx, d_err));
+    return finish_call(ctx, KMU_MEM_HOST);
 }
 
 // ---- one signature for sequences held by several GPUs ------------------------------------------------------------------

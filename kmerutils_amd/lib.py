@@ -30,6 +30,7 @@ SYMBOLS = [
     "kmu_kmer_hashes_range", "kmu_kmer_distribution", "kmu_nthash",
     "kmu_comm_get_id", "kmu_comm_init", "kmu_comm_init_custom", "kmu_comm_destroy", "kmu_comm_rank", "kmu_comm_nranks",
     "kmu_comm_allgather", "kmu_comm_get_stats", "kmu_count_finalize", "kmu_kmer_owner",
+    "kmu_sketch_count", "kmu_host_alloc", "kmu_host_free", "kmu_count_nb_occurrences",
 ]
 
 
@@ -68,6 +69,10 @@ def load():
     L.kmu_kmer_hashes_range.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
     L.kmu_kmer_distribution.argtypes = [vp, C.POINTER(A.HashParams), vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, u64p]
     L.kmu_nthash.argtypes = [vp, C.POINTER(A.NthashParams), vp, vp, vp, C.c_uint32, vp, vp]
+    L.kmu_sketch_count.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp]
+    L.kmu_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.kmu_host_free.argtypes = [vp, vp]
+    L.kmu_count_nb_occurrences.argtypes = [vp, u64p]
     L.kmu_comm_get_id.argtypes = [C.POINTER(A.CommId)]
     L.kmu_comm_init.argtypes = [vp, C.POINTER(A.CommId), C.c_int, C.c_int]
     L.kmu_comm_init_custom.argtypes = [vp, C.c_int, C.c_int, A.ALLTOALLV_FN, A.ALLGATHER_FN, vp]
@@ -466,6 +471,27 @@ class Context:
             return out, counts_out[:rows]
         return out
 
+    def sketch_count(self, bases, offsets, params, counter=None, out=None):
+        """kmu_sketch_count: the reads once, both results -- signature rows (returned) and, if `counter` is given, the
+        k-mer counts of the same reads.  Host buffers (numpy / CPU torch tensors, best pinned): chunked upload overlapped
+        with the kernels, rows downloaded under the count build.  Device buffers: both on the resident reads."""
+        n = len(offsets) - 1
+        mem = self._mem(bases, offsets)
+        p = A.SketchParams.from_buffer_copy(params)
+        p.mem = mem
+        p.mode = A.MODE_PER_SEQ
+        if out is None:
+            if mem == A.MEM_DEVICE:
+                import torch
+                tdt = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
+                       A.SIG_F64: torch.float64, A.SIG_U16: torch.int16}[p.sig_type]
+                out = torch.zeros((max(n, 1), p.sketch_size), dtype=tdt, device=bases.device)
+            else:
+                out = np.zeros((max(n, 1), p.sketch_size), dtype=A.SIG_NP[p.sig_type])
+        self._check(self.L.kmu_sketch_count(self.h, C.byref(p), counter.h if counter is not None else None, _ptr(bases)[0],
+                                            _ptr(offsets)[0], n, _ptr(out)[0]))
+        return out[:n]
+
     def sketch_hashed(self, hashed, offsets, params, want_counts=False):
         """kmu_sketch_hashed: the caller evaluated fhash; `hashed` holds Kmer::Val values (uint32 / uint64) of
         sequence i in hashed[offsets[i]:offsets[i+1]]."""
@@ -685,6 +711,12 @@ class Counter:
     def nb_unique(self):
         v = C.c_uint64(0)
         self.ctx._check(self.L.kmu_count_nb_unique(self.h, C.byref(v)))
+        return v.value
+
+    def nb_occurrences(self):
+        """kmu_count_nb_occurrences: sum of the multiplicities held (= k-mer occurrences inserted)"""
+        v = C.c_uint64(0)
+        self.ctx._check(self.L.kmu_count_nb_occurrences(self.h, C.byref(v)))
         return v.value
 
     def dump(self, min_count=2):

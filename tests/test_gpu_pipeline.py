@@ -1,0 +1,107 @@
+"""kmu_sketch_count: the reads once, both results.  Host form (chunked upload | sketch | download | count pipeline) and
+device form, with plain and distributed counters, against the oracle; the chunking must not show in the results."""
+import os
+
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+from kmerutils_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kmerutils_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def _check_counts(c, oracle, bases, off, k):
+    g = oracle.Counter(A.KMER64BIT, k, 8, 1 << 20)
+    g.add_reads(bases, off)
+    wk, wc = g.dump(1)
+    gk, gc = c.dump(1)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    assert c.nb_occurrences() == int(np.maximum(np.diff(off.astype(np.int64)) - k + 1, 0).sum())
+
+
+@pytest.mark.parametrize("chunk_mb", ["1", "512"])
+def test_sketch_count_host_and_device(ctx, oracle, monkeypatch, chunk_mb):
+    import torch
+    monkeypatch.setenv("KMU_PIPE_CHUNK_MB", chunk_mb)
+    bases, off = synth.ont_reads(900, 600_000, 0xC3)  # ~5 Mbases: five chunks of 1 MB, reads of 200 .. 60 k bases
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 200, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    want = oracle.sketch(bases, off, p)
+    nk = int(np.maximum(np.diff(off.astype(np.int64)) - 30, 0).sum())
+    # host buffers, pinned (torch) and pageable (numpy)
+    for pinned in (True, False):
+        c = ctx.counter(A.KMER64BIT, 31, 8, nk)
+        if pinned:
+            hb = torch.from_numpy(bases).pin_memory()
+            ho = torch.from_numpy(off.astype(np.int64)).pin_memory()
+            out = torch.zeros((len(off) - 1, 200), dtype=torch.int64).pin_memory()
+            got = ctx.sketch_count(hb, ho, p, counter=c, out=out).numpy().view(np.uint64)
+        else:
+            got = ctx.sketch_count(bases, off, p, counter=c)
+        assert np.array_equal(got, want)
+        _check_counts(c, oracle, bases, off, 31)
+        c.close()
+    # a range of a larger read set (offsets[0] != 0), no counter
+    got = ctx.sketch_count(bases, off[100:], p)
+    assert np.array_equal(got, want[100:])
+    # device buffers
+    c = ctx.counter(A.KMER64BIT, 31, 8, nk)
+    got = ctx.sketch_count(torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), p, counter=c)
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+    _check_counts(c, oracle, bases, off, 31)
+    c.close()
+    # other sketchers ride the same pipeline
+    ps = A.SketchParams(A.ALGO_SUPER, A.KMER64BIT, 21, 64, A.SIG_F64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    assert np.array_equal(ctx.sketch_count(bases, off, ps).view(np.uint64), oracle.sketch(bases, off, ps).view(np.uint64))
+
+
+def test_sketch_count_errors_and_empty(ctx, oracle):
+    from kmerutils_amd.lib import KmuError
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    bases = np.frombuffer(b"ACGT" * 20 + b"ACGTN" * 20, np.uint8).copy()
+    off = np.array([0, 80, 180], np.uint64)
+    with pytest.raises(KmuError) as ei:
+        ctx.sketch_count(bases, off, p)
+    assert ei.value.code == A.E_NON_ACGT
+    pb = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 10, 0, 0, 0, 0)
+    with pytest.raises(KmuError) as ei:
+        ctx.sketch_count(bases[:80], off[:2], pb)
+    assert ei.value.code == A.E_UNSUPPORTED
+    # afterwards the context still works
+    got = ctx.sketch_count(bases[:80], off[:2], p)
+    assert np.array_equal(got, oracle.sketch(bases[:80], off[:2], p))
+
+
+def test_sketch_count_distributed_world1(oracle, monkeypatch):
+    """device form with a distributed counter: the all-to-all (RCCL, to self) is in flight while the reads are sketched"""
+    import torch
+    from kmerutils_amd import lib
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
+    ctx = lib.Context(0)
+    ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
+    bases, off = synth.ont_reads(600, 500_000, 0xC3)
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 200, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    want = oracle.sketch(bases, off, p)
+    nk = int(np.maximum(np.diff(off.astype(np.int64)) - 30, 0).sum())
+    for route in ("occurrences", "merge"):
+        monkeypatch.setenv("KMU_COUNT_ROUTE", route)
+        for dev in (True, False):
+            c = ctx.counter(A.KMER64BIT, 31, 8, nk, distributed=True)
+            if dev:
+                got = ctx.sketch_count(torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), p, counter=c)
+                got = got.cpu().numpy().view(np.uint64)
+            else:
+                got = ctx.sketch_count(bases, off, p, counter=c)
+            c.finalize()
+            assert np.array_equal(got, want)
+            _check_counts(c, oracle, bases, off, 31)
+            c.close()
+    ctx.close()
