@@ -31,16 +31,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="ont_k31", choices=["ont_k31", "ont_k31_sketch", "ont_k31_count", "c3_k8",
-                                                                "c2_count", "c1_super", "c5_aa", "ont_k31_optdens"])
+    ap.add_argument("--workload", default="ont_k31", choices=list(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank holds a full-size shard; strong: the workload's reads are split over the ranks")
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU")
     ap.add_argument("--bases", type=float, default=0, help="override total bases per GPU")
-    ap.add_argument("--genome", type=int, default=100_000_000)
+    ap.add_argument("--genome", type=int, default=0)
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads timed on the host oracle (0 = auto)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the oracle baseline (0 = min(16, cores))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the oracle baseline (0 = all the box has)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host leg (pinned host buffers in and out)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed output")
     ap.add_argument("--sketch-size", type=int, default=0)
     return ap.parse_args()
+
+
+WORKLOADS = ("ont_k31", "ont_k31_sketch", "ont_k31_count", "c3_k8", "c2_count", "c2_nthash_count", "c4_count", "c1_super",
+             "c5_aa", "ont_k31_optdens")
 
 
 def workload_cfg(args):
@@ -48,7 +55,7 @@ def workload_cfg(args):
     w = args.workload
     cfg = dict(name=w, n_reads=746_333, total_bases=4.38e9, fixed_len=None, errors=(0.04, 0.02, 0.02), k=31,
                kmer_type=A.KMER64BIT, m=200, algo=A.ALGO_PROB3A, sig=A.SIG_U64, hasher=A.HASHER_NOHASH,
-               fhash=A.FHASH_CANON_INVHASH, sketch=True, count=True, seed=0xC3, genome=args.genome)
+               fhash=A.FHASH_CANON_INVHASH, sketch=True, count=True, nthash=False, seed=0xC3, genome=100_000_000)
     if w == "ont_k31_sketch":
         cfg.update(count=False)
     elif w == "ont_k31_count":
@@ -57,15 +64,21 @@ def workload_cfg(args):
         cfg.update(count=False, algo=A.ALGO_OPTDENS, sig=A.SIG_F64)
     elif w == "c3_k8":
         cfg.update(k=8, kmer_type=A.KMER32BIT, sig=A.SIG_U32, count=False)
-    elif w == "c2_count":
+    elif w in ("c2_count", "c2_nthash_count"):
+        # config 2: 1 M x 150 bp from a 10 Mbp genome, k = 21; as written it is "ntHash + unique-filter count": the canonical
+        # ntHash of every 21-mer (kmu_nthash, 8 bytes per position) and the count of every canonical 21-mer
         cfg.update(n_reads=1_000_000, total_bases=1.5e8, fixed_len=150, errors=(0.005, 0, 0), k=21, sketch=False,
-                   seed=0xC2, genome=10_000_000)
+                   nthash=w == "c2_nthash_count", seed=0xC2, genome=10_000_000)
+    elif w == "c4_count":  # config 4's per-GPU shard: 6.25 M x 150 bp of the 50 M reads, 100 Mbp genome, k = 31, count only
+        cfg.update(n_reads=6_250_000, total_bases=9.375e8, fixed_len=150, errors=(0.005, 0, 0), k=31, sketch=False, seed=0xC4)
     elif w == "c1_super":
         cfg.update(n_reads=10_000, total_bases=1e7, fixed_len=1000, errors=(0, 0, 0), k=16, kmer_type=A.KMER16B32BIT,
                    m=64, algo=A.ALGO_SUPER, sig=A.SIG_F64, count=False, seed=0xC1, genome=20_000_000)
     elif w == "c5_aa":  # config 5, one GPU's share of the 5 M proteins
         cfg.update(n_reads=625_000, total_bases=2.1e8, k=12, kmer_type=A.KMERAA64BIT, m=128, algo=A.ALGO_SUPER,
                    sig=A.SIG_F64, fhash=A.FHASH_VALUE_MASKED, count=False, seed=0xC5, protein=True)
+    if args.genome:
+        cfg["genome"] = args.genome
     if args.reads:
         cfg["total_bases"] = cfg["total_bases"] * args.reads / cfg["n_reads"]
         cfg["n_reads"] = args.reads
@@ -88,7 +101,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # KMU_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (the ranks
-    # then share devices and the exchange is staged through the host); the measured configuration is RCCL ("nccl")
+    # then share devices and the library's exchange is carried by the process group); the measured configuration is
+    # the library's own RCCL communicator
     backend = os.environ.get("KMU_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -105,6 +119,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cfg = workload_cfg(args)
+    if args.scaling == "strong" and world > 1:  # the workload's reads split over the ranks (different reads per rank)
+        cfg["n_reads"] = max(1, cfg["n_reads"] // world)
+        cfg["total_bases"] = cfg["total_bases"] / world
 
     # ---- synthetic reads, generated in HBM (same genome on every rank, rank-specific reads) -----------------
     t_gen = time.time()
@@ -119,35 +136,30 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
     ctx = lib.Context(local_rank, stream=stream.cuda_stream, async_device=True)
+    transport = None
+    if world > 1:  # the library's own communicator: RCCL over xGMI (the id travels over the process group)
+        transport = kdist.init_comm(ctx, transport="rccl" if backend == "nccl" else "torch")
     p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0,
                        A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_DEVICE, 0)
     sig_dtype = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
                  A.SIG_F64: torch.float64}[cfg["sig"]]
     sig = torch.zeros((n_reads, cfg["m"]), dtype=sig_dtype, device=dev) if cfg["sketch"] else None
-    counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024)) if cfg["count"] else None
+    # (weak scaling: every rank ends up owning about one shard's worth of distinct k-mers)
+    counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024), distributed=world > 1) if cfg["count"] else None
+    nth = torch.zeros(total_bases + 64, dtype=torch.int64, device=dev) if cfg["nthash"] else None
 
-    def sketch_step():
-        ctx.sketch(bases, offsets, p, out=sig)
-
-    def step():
-        if cfg["count"] and world > 1:
-            # group the k-mers by owner rank, ONE all-to-all over RCCL, build the owned table; the reads are sketched
-            # while the exchange is on the links (ALU work under xGMI traffic)
-            counter.reset()
-            kdist.count_reads_exchange(counter, bases, offsets, overlap=sketch_step if cfg["sketch"] else None)
-            return
-        if cfg["sketch"]:
-            sketch_step()
+    def step_device():
+        """one pass of the hot path over the reads resident in HBM, results left in HBM"""
+        if cfg["nthash"]:
+            ctx.nthash(bases, offsets, cfg["k"], want_strand=False, out=nth)
         if cfg["count"]:
             counter.reset()
+        if cfg["sketch"]:  # the reads once, both results; N > 1: the all-to-all is in flight under the sketch kernels
+            ctx.sketch_count(bases, offsets, p, counter=counter, out=sig)
+        elif cfg["count"]:
             counter.add_reads(bases, offsets)
-
-    if world > 1 and backend == "nccl":  # bring up the RCCL peer-to-peer connections outside the timed region
-        with torch.cuda.stream(stream):
-            t_in = torch.arange(world, dtype=torch.int64, device=dev)
-            t_out = torch.empty_like(t_in)
-            dist.all_to_all_single(t_out, t_in)
-        stream.synchronize()
+        if cfg["count"] and world > 1:
+            counter.finalize()
 
     def barrier():
         ctx.synchronize()
@@ -155,41 +167,86 @@ def main():
         if world > 1:
             dist.barrier()
 
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        ctx.profile_reset()
-        ctx.profile_enable(True)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for _ in range(args.steps):
-            step()
-        ev1.record(stream)
-        barrier()
-        t1 = time.perf_counter()
-        ctx.profile_enable(False)
-    elapsed = t1 - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    def timed(fn, profile):
+        with torch.cuda.stream(stream):
+            for _ in range(args.warmup):
+                fn()
+            barrier()
+            if profile:
+                ctx.profile_reset()
+                ctx.profile_enable(True)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            for _ in range(args.steps):
+                fn()
+            ev1.record(stream)
+            barrier()
+            t1 = time.perf_counter()
+            if profile:
+                ctx.profile_enable(False)
+        el = t1 - t0
+        if world > 1:
+            cdev = dev if backend == "nccl" else torch.device("cpu")
+            tt = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, ev0.elapsed_time(ev1)
+
+    elapsed, dev_ms = timed(step_device, True)
+    stats = ctx.profile_get()
+    comm_stats = ctx.comm_stats() if world > 1 and cfg["count"] else None
     if world > 1:
         cdev = dev if backend == "nccl" else torch.device("cpu")
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         tb = torch.tensor([total_bases], dtype=torch.float64, device=cdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         job_bases = float(tb.item())
     else:
         job_bases = float(total_bases)
-    stats = ctx.profile_get()
 
-    # ---- sanity of what was computed (not timed) ---------------------------------------------------------
+    # ---- sanity of what was computed in the timed steps (not timed) ----------------------------------------
     checks = {}
     if cfg["sketch"]:
         checks["sig_checksum"] = int(sig.view(torch.int64 if sig.element_size() == 8 else torch.int32).sum().item())
-    if cfg["count"] and world == 1:
-        checks["nb_distinct"] = counter.nb_distinct()
+    if cfg["count"]:
+        occ = counter.nb_occurrences()
+        dis = counter.nb_distinct()
+        if world > 1:
+            cdev = dev if backend == "nccl" else torch.device("cpu")
+            t3 = torch.tensor([occ, dis, nk], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t3, op=dist.ReduceOp.SUM)
+            occ, dis, nk_job = int(t3[0].item()), int(t3[1].item()), int(t3[2].item())
+        else:
+            nk_job = nk
+        checks["nb_distinct"] = dis
+        checks["count_conservation_ok"] = bool(occ == nk_job)  # the counts held add up to the k-mers that went in
+    if not args.no_parity and world == 1:
+        checks.update(parity_check(cfg, ctx, bases, offsets, sig, counter, nth))
+
+    # ---- the same step from pinned host memory to pinned host memory (SURVEY 8d's definition of the metric) ---------
+    host = None
+    if cfg["sketch"] and not args.no_host_leg and not cfg.get("protein"):
+        h_bases = torch.empty(total_bases, dtype=torch.uint8).pin_memory()
+        h_bases.copy_(bases[:total_bases])
+        h_off = offsets.cpu().pin_memory()
+        h_sig = torch.zeros((n_reads, cfg["m"]), dtype=sig_dtype).pin_memory()
+        ph = A.SketchParams.from_buffer_copy(p)
+
+        def step_host():
+            if cfg["count"]:
+                counter.reset()
+            ctx.sketch_count(h_bases, h_off, ph, counter=counter, out=h_sig)
+            if cfg["count"] and world > 1:
+                counter.finalize()
+
+        h_el, _ = timed(step_host, False)
+        host = {"value": job_bases * args.steps / h_el / 1e9, "unit": "Gbases/s", "ms_per_step": h_el / args.steps * 1e3,
+                "what": "bases in pinned host memory -> signatures in pinned host memory + counts on the device: one chunked "
+                        "upload overlapped with the sketch kernels, rows downloaded under the count build (kmu_sketch_count)",
+                "bytes_up": total_bases, "bytes_down": n_reads * cfg["m"] * h_sig.element_size()}
+        if cfg["sketch"]:
+            same = bool(torch.equal(h_sig, sig.cpu()))
+            checks["host_leg_equals_device_leg"] = same
 
     if rank == 0:
         value = job_bases * args.steps / elapsed / 1e9
@@ -203,6 +260,7 @@ def main():
             "k_pmh_points": nk * 12 + n_reads * cfg["m"] * sigw,        # (key, weight) lists in, rows out
             "k_sketch_super": total_bases + n_reads * cfg["m"] * sigw,
             "k_oph_reads": total_bases + n_reads * cfg["m"] * sigw,
+            "k_nthash": total_bases + nk * 8,
             "k_count_add_flat": total_bases + nk * 16,
             "k_part_hist1": total_bases,
             "k_part_scatter1": total_bases + nk * 8,
@@ -247,19 +305,52 @@ def main():
         out = {
             "metric": "Gbases/sec k-mer+sketch throughput, k=31, 200 sketches/read",
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": _describe(cfg, n_reads, total_bases), "workload_name": cfg["name"], "reads_per_gpu": n_reads,
                        "bases_per_gpu": total_bases, "kmers_per_gpu": nk, "k": cfg["k"], "sketch_size": cfg["m"],
-                       "sketch": cfg["sketch"], "count": cfg["count"], "parallelism": "reads sharded x%d" % world},
+                       "sketch": cfg["sketch"], "count": cfg["count"], "parallelism": "reads sharded x%d" % world,
+                       "residency": "value: reads and results resident in HBM; host_to_host: pinned host memory in and out"},
             "roofline": roofline, "alu": pmc_alu(cfg, total_bases, dom, kern[dom]["avg_ms"]) if dom else None,
-            "cpu_baseline": cpu, "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
-            "checks": checks, "gen_seconds": t_gen,
+            "cpu_baseline": cpu, "host_to_host": host, "value_device_resident": value,
+            "value_host_to_host": host["value"] if host else None,
+            "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
+            "checks": checks, "comm": dict(comm_stats, transport=transport) if comm_stats else None, "gen_seconds": t_gen,
         }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000):
+    """SURVEY.md 8(d) parity set: the first 1 000 reads of the workload.  The rows / counts / hashes the TIMED steps left
+    behind are compared with the oracle's on those reads (the oracle is the checker here, nothing it computes is timed)."""
+    import torch
+    from kmerutils_amd import _abi as A
+    from oracle import oracle as O
+    n = min(n_check, len(offsets) - 1)
+    nb = int(offsets[n].item())
+    hb = bases[:nb].cpu().numpy()
+    ho = offsets[:n + 1].cpu().numpy().astype(np.uint64)
+    out = {"parity_reads": n}
+    if cfg["sketch"]:
+        p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0, 0, 0, 0, 0)
+        want = O.sketch(hb, ho, p)
+        got = sig[:n].cpu().numpy()
+        out["parity_rows_ok"] = bool(np.array_equal(got.view(np.uint8), np.ascontiguousarray(want).view(np.uint8)))
+    if cfg["count"]:
+        # every canonical k-mer of those reads: the table's count is at least the oracle's count over the 1 000 reads, and
+        # equal for a k-mer the full read set holds nowhere else -- checked through count conservation + this lower bound
+        oc = O.Counter(cfg["kmer_type"], cfg["k"], 16, 1 << 20)
+        oc.add_reads(hb, ho)
+        wk, wc = oc.dump(1)
+        got = counter.query(torch.from_numpy(wk.view(np.int64)).to(bases.device)).cpu().numpy().astype(np.int64)
+        out["parity_counts_ok"] = bool((got >= np.minimum(wc.astype(np.int64), 255)).all() and (got >= 1).all())
+    if cfg.get("nthash"):
+        wh, _ = O.nthash(hb, ho, cfg["k"])
+        out["parity_nthash_ok"] = bool(np.array_equal(nth[:nb].cpu().numpy().view(np.uint64), wh[:, 0]))
+    return out
 
 
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0  # wave-instructions / s: 256 CUs x 4 SIMDs, one full-rate VALU instruction per 4 cycles at 2.4 GHz
@@ -316,6 +407,8 @@ def _describe(cfg, n_reads, total_bases):
     ops = []
     if cfg["sketch"]:
         ops.append("%s m=%d" % ("ProbMinHash3a" if cfg["algo"] == 0 else "SuperMinHash", cfg["m"]))
+    if cfg.get("nthash"):
+        ops.append("canonical ntHash per position")
     if cfg["count"]:
         ops.append("kmercount 8-bit")
     shape = "%d protein sequences" % n_reads if cfg.get("protein") else \
@@ -333,10 +426,11 @@ def cpu_baseline(cfg, bases, offsets, lens, sample_reads, threads=0):
     from kmerutils_amd import _abi as A
     from oracle import oracle as O
     O.lib()
-    T = threads or max(1, min(16, os.cpu_count() or 1))
+    T = threads or max(1, os.cpu_count() or 1)  # what rayon would use: every hardware thread of the box
     if not sample_reads:
-        # roughly 10-20 s of wall time: ~3e7 bases per thread when both legs run
-        target_bases = T * (3e7 if (cfg["sketch"] and cfg["count"]) else 6e7)
+        # roughly 10-30 s of wall time (measured on the 256-thread host of the GPU box: the count leg, one exact hash
+        # table per thread, takes 22 s per Gbase there; the sketch leg 3 s)
+        target_bases = min(T, 64) * (1.2e7 if cfg["count"] else 6e7)
         csum = np.cumsum(lens)
         sample_reads = int(min(len(lens), max(16, np.searchsorted(csum, target_bases) + 1)))
     T = max(1, min(T, sample_reads))
@@ -384,7 +478,25 @@ def cpu_baseline(cfg, bases, offsets, lens, sample_reads, threads=0):
             "sample": "first %d reads (%d bases) of the same read set, sharded over %d threads; sketch %.2f s + count "
                       "%.2f s wall; oracle C restatement, gcc -O2; one thread alone: %.4f Gbases/s"
                       % (sample_reads, nb, len(parts), t_sk, t_ct, rate1),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "physical_cores": _physical_cores()}
+
+
+def _physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 if __name__ == "__main__":

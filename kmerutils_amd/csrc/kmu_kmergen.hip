@@ -293,6 +293,113 @@ __global__ void __launch_bounds__(256) k_nthash(NtArgs a) {
     }
 }
 
+// The same over the FLAT base stream of unpacked reads (the walk of the count build): a wave step is 62 words of the whole
+// array wherever the reads begin and end -- 150 bp reads fill the lanes like 100 kb reads do -- and a k-mer is emitted
+// when it lies inside one read.  The hash of a k-mer only involves its own k bases (the prefixes cancel outside), so
+// nothing has to be restarted at a read boundary; out is indexed by the absolute base position.
+template <bool T8>
+__global__ void __launch_bounds__(256) k_nthash_flat(NtArgs a) {
+    const int lane = lane_id();
+    const int k = a.k;
+    const uint32_t m = (uint32_t) k & 15u;
+    const int d = k >> 4;
+    const uint64_t mult = (uint64_t) k * 0x90b45d39fb6da1faull;
+    const uint64_t total = a.offsets[a.n_seq], start = a.offsets[0];
+    SeqView s;
+    s.base = a.bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
+    const uint64_t w_first = start / 16, nwords = (total + 15) / 16 - w_first, nsteps = (nwords + 61) / 62;
+    const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    uint32_t bad = 0, r_hint = 0xFFFFFFFFu;
+    for (uint64_t st = wave_global; st < nsteps; st += nwaves_global) {
+        const uint64_t widx = w_first + st * 62 + (uint64_t) lane;
+        uint32_t b;
+        const uint32_t w0 = load_code_word(s, widx, b);
+        const uint64_t g0 = widx * 16;
+        if (g0 < start) b &= ~((1u << (start - g0 > 16 ? 16 : (uint32_t) (start - g0))) - 1u); // bytes before the first read
+        bad |= b;
+        const uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
+        uint64_t pf = 0, pr = 0, xf = 0, xr = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t code = (w0 >> (30 - 2 * j)) & 3u;
+            const unsigned t = (unsigned) (16 * lane + j) & 63u;
+            if ((uint32_t) j == m) { xf = pf; xr = pr; }
+            pf ^= rotr64(nt_fwd<T8>(code), t);
+            pr ^= rotl64(nt_rev<T8>(code), t);
+        }
+        const uint64_t ef = wave_incl_xor_u64(pf) ^ pf, er = wave_incl_xor_u64(pr) ^ pr;
+        const uint64_t kf = shfl_down_u64(ef ^ xf, d), kr = shfl_down_u64(er ^ xr, d);
+        uint64_t F = rotl64(kf ^ ef, (unsigned) (16 * lane + k - 1) & 63u);
+        uint64_t R = rotr64(kr ^ er, (unsigned) (16 * lane) & 63u);
+        // the read of this lane's first base (wave-wide 64-ary search, hinted by the previous step)
+        const uint64_t gw = (w_first + st * 62) * 16;
+        uint32_t r = 0;
+        {
+            const uint64_t probe = gw < start ? start : (gw < total ? gw : total - 1);
+            uint32_t lo = 0;
+            if (r_hint < a.n_seq && a.offsets[r_hint] <= probe) {
+                const uint64_t idx = (uint64_t) r_hint + 1 + (uint32_t) lane;
+                const uint32_t c = (uint32_t) __popcll(__ballot(idx < a.n_seq && a.offsets[idx] <= probe));
+                lo = c < 64u ? r_hint + c : 0xFFFFFFFFu;
+            } else lo = 0xFFFFFFFFu;
+            if (lo == 0xFFFFFFFFu) { // full search
+                uint32_t l = 0, h = a.n_seq;
+                while (h - l > 1) {
+                    const uint32_t stp = (h - l + 63) / 64;
+                    const uint64_t idx = (uint64_t) l + (uint64_t) (lane + 1) * stp;
+                    const uint32_t c = (uint32_t) __popcll(__ballot(idx < h && a.offsets[idx] <= probe));
+                    const uint64_t nh = (uint64_t) l + (uint64_t) (c + 1) * stp;
+                    l = l + c * stp;
+                    h = nh < h ? (uint32_t) nh : h;
+                }
+                lo = l;
+            }
+            r_hint = lo;
+            r = lo;
+        }
+        const bool in = g0 < total && g0 + 16 > start && lane < 62;
+        uint64_t rend = 0;
+        if (in) {
+            rend = a.offsets[r + 1];
+            while (g0 >= rend && r + 1 < a.n_seq) { r++; rend = a.offsets[r + 1]; }
+        }
+        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+        const int sh = 64 - 2 * k;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
+            const uint64_t val = v >> sh;
+            if (j > 0) {
+                const uint32_t oldb = (w0 >> (30 - 2 * (j - 1))) & 3u, newb = (uint32_t) val & 3u;
+                F = rotl64(F, 1) ^ rotl64(nt_fwd<T8>(oldb), (unsigned) k) ^ nt_fwd<T8>(newb);
+                R = rotr64(R, 1) ^ rotr64(nt_rev<T8>(oldb), 1) ^ rotl64(nt_rev<T8>(newb), (unsigned) (k - 1));
+            }
+            if (in) {
+                const uint64_t g = g0 + j;
+                while (g >= rend && r + 1 < a.n_seq) { r++; rend = a.offsets[r + 1]; }
+                if (g >= start && g + k <= rend) {
+                    uint64_t h0;
+                    uint8_t sd;
+                    if (a.mode == KMU_NTHASH_FORWARD) { h0 = F; sd = 0; }
+                    else if (a.mode == KMU_NTHASH_RCOMP) { h0 = R; sd = 1; }
+                    else if (F <= R) { h0 = F; sd = 0; }
+                    else { h0 = R; sd = 1; }
+                    uint64_t *op = a.out + g * (uint64_t) a.n_hashes;
+                    op[0] = h0;
+                    for (int q = 1; q < a.n_hashes; q++) {
+                        uint64_t t = h0 * ((uint64_t) q ^ mult);
+                        t ^= t >> 27;
+                        op[q] = t;
+                    }
+                    if (a.strand) a.strand[g] = sd;
+                }
+            }
+        }
+    }
+    if (bad) atomicOr(a.err, DERR_NON_ACGT);
+}
+
 } // namespace kmu
 
 using namespace kmu;
@@ -330,10 +437,15 @@ extern "C" int kmu_nthash(kmu_ctx *ctx, const kmu_nthash_params *p, const uint8_
     if (n_seq) {
         NtArgs a{ds.bases, ds.offsets, ds.packed_offsets, n_seq, ds.packed, ds.total_bytes, p->kmer_size, p->mode, p->n_hashes,
                  d_out, d_strand, d_err};
-        const int grid = (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
         KernelTimer t(ctx, "k_nthash");
-        if (p->table == KMU_NTHASH_TABLE_8B) hipLaunchKernelGGL(k_nthash<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_nthash<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        if (!ds.packed) { // one flat stream: the lanes are full whatever the read lengths
+            const int grid = ctx->num_cus * 8;
+            if (p->table == KMU_NTHASH_TABLE_8B) hipLaunchKernelGGL(k_nthash_flat<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_nthash_flat<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        } else {
+            const int grid = (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
+            hipLaunchKernelGGL(k_nthash<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        }
     }
     KMU_HIP(ctx, hipGetLastError());
     if (p->mem == KMU_MEM_HOST) {
