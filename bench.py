@@ -137,7 +137,10 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = lib.Context(local_rank, stream=stream.cuda_stream, async_device=True)
     transport = None
-    if world > 1:  # the library's own communicator: RCCL over xGMI (the id travels over the process group)
+    # KMU_BENCH_FORCE_COMM=1: a communicator (RCCL, to self) also on one rank, so that one GPU executes and times the very
+    # path N ranks take -- census, route choice, all-to-all, build from what arrives, finalize
+    use_comm = world > 1 or bool(os.environ.get("KMU_BENCH_FORCE_COMM"))
+    if use_comm:  # the library's own communicator: RCCL over xGMI (the id travels over the process group)
         transport = kdist.init_comm(ctx, transport="rccl" if backend == "nccl" else "torch")
     p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0,
                        A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_DEVICE, 0)
@@ -145,7 +148,7 @@ def main():
                  A.SIG_F64: torch.float64}[cfg["sig"]]
     sig = torch.zeros((n_reads, cfg["m"]), dtype=sig_dtype, device=dev) if cfg["sketch"] else None
     # (weak scaling: every rank ends up owning about one shard's worth of distinct k-mers)
-    counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024), distributed=world > 1) if cfg["count"] else None
+    counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024), distributed=use_comm) if cfg["count"] else None
     nth = torch.zeros(total_bases + 64, dtype=torch.int64, device=dev) if cfg["nthash"] else None
 
     def step_device():
@@ -158,7 +161,7 @@ def main():
             ctx.sketch_count(bases, offsets, p, counter=counter, out=sig)
         elif cfg["count"]:
             counter.add_reads(bases, offsets)
-        if cfg["count"] and world > 1:
+        if cfg["count"] and use_comm:
             counter.finalize()
 
     def barrier():
@@ -195,7 +198,7 @@ def main():
 
     elapsed, dev_ms = timed(step_device, True)
     stats = ctx.profile_get()
-    comm_stats = ctx.comm_stats() if world > 1 and cfg["count"] else None
+    comm_stats = ctx.comm_stats() if use_comm and cfg["count"] else None
     if world > 1:
         cdev = dev if backend == "nccl" else torch.device("cpu")
         tb = torch.tensor([total_bases], dtype=torch.float64, device=cdev)
@@ -236,7 +239,7 @@ def main():
             if cfg["count"]:
                 counter.reset()
             ctx.sketch_count(h_bases, h_off, ph, counter=counter, out=h_sig)
-            if cfg["count"] and world > 1:
+            if cfg["count"] and use_comm:
                 counter.finalize()
 
         h_el, _ = timed(step_host, False)

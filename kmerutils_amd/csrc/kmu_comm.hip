@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "kmu_comm.hpp"
@@ -104,17 +105,27 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
         if (rc) return fail(ctx, KMU_E_RCCL, "the host's all-to-all failed (%d)", rc);
         return KMU_OK;
     }
-    // every pair of ranks exchanges one message: xGMI is point to point, all seven links of a GPU carry traffic at once
+    // every pair of ranks exchanges one message per round: xGMI is point to point, all seven links of a GPU carry traffic at
+    // once.  A message is at most KMU_COMM_CHUNK_MB (default 1024) long: rounds of grouped sends / receives until every
+    // pair is through (sizes are known on both sides, so both sides run the same number of rounds for a pair).
     const uint8_t *sb = (const uint8_t *) send_dev;
     uint8_t *rb = (uint8_t *) recv_dev;
-    KMU_NCCL(ctx, rccl()->GroupStart());
-    for (int p = 0; p < c->nranks; p++) {
-        if (send_counts[p])
-            KMU_NCCL(ctx, rccl()->Send(sb + send_displs[p] * elem_bytes, (size_t) send_counts[p] * elem_bytes, ncclUint8, p, (ncclComm_t) c->nccl, s));
-        if (recv_counts[p])
-            KMU_NCCL(ctx, rccl()->Recv(rb + recv_displs[p] * elem_bytes, (size_t) recv_counts[p] * elem_bytes, ncclUint8, p, (ncclComm_t) c->nccl, s));
+    uint64_t chunk = 1024ull << 20;
+    if (const char *e = getenv("KMU_COMM_CHUNK_MB")) chunk = (uint64_t) std::max(1, atoi(e)) << 20;
+    uint64_t longest = 0;
+    for (int p = 0; p < c->nranks; p++) longest = std::max(longest, std::max(send_counts[p], recv_counts[p]) * elem_bytes);
+    for (uint64_t o = 0; o < longest; o += chunk) {
+        KMU_NCCL(ctx, rccl()->GroupStart());
+        for (int p = 0; p < c->nranks; p++) {
+            const uint64_t sbytes = send_counts[p] * elem_bytes, rbytes = recv_counts[p] * elem_bytes;
+            if (o < sbytes)
+                KMU_NCCL(ctx, rccl()->Send(sb + send_displs[p] * elem_bytes + o, (size_t) std::min(chunk, sbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s));
+            if (o < rbytes)
+                KMU_NCCL(ctx, rccl()->Recv(rb + recv_displs[p] * elem_bytes + o, (size_t) std::min(chunk, rbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s));
+        }
+        KMU_NCCL(ctx, rccl()->GroupEnd());
     }
-    KMU_NCCL(ctx, rccl()->GroupEnd());
+    if (getenv("KMU_COMM_SYNC")) KMU_HIP(ctx, hipStreamSynchronize(s)); // diagnostics
     return KMU_OK;
 }
 
