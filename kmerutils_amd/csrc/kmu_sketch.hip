@@ -1124,6 +1124,297 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     }
 }
 
+// ---- k <= 8: the multiset of a read as a DIRECT-INDEXED histogram ---------------------------------------------------------
+// Config 3 as the README times it (`datasketcher -k 8 -s 200`, src/bin/datasketcher.rs:222-254): 4^8 = 65 536 possible
+// 8-mers, so the FnvHashMap<Kmer32bit::Val, u64> of seqsketchjaccard.rs:226-234 is an array in LDS indexed by the k-mer
+// value itself (the canonical one for the canonical closures): one ds_add per position and nothing else -- no bucket ranks,
+// no scan, no placement, no duplicate walk.  Counters are 16 bits wide, two to an LDS word, while the read has at most
+// 65 535 k-mers (no counter can overflow); longer reads count with 32-bit counters in two passes over their positions, one per
+// half of the index space.  The distinct k-mers are then enumerated -- from a list of first touches for reads of up to
+// the list's capacity in k-mers, by scanning the histogram for longer ones -- and their ProbMinHash points are generated by the same
+// code as everywhere else (pmh3a_first_point / pmh3a_more_points).  One persistent workgroup per CU, one read at a time.
+static constexpr uint32_t SMALLK_WORDS = 32768;  // LDS words of the histogram (128 KiB)
+static constexpr uint32_t SMALLK_TILE = 1024;    // staged code words per tile
+
+__device__ __forceinline__ uint32_t revcomp32(uint32_t val, int k) {
+    uint32_t rc = __brev(~val);
+    rc = ((rc & 0x55555555u) << 1) | ((rc & 0xAAAAAAAAu) >> 1);
+    return rc >> (32 - 2 * k);
+}
+
+// EMIT: the (key, weight) pairs of the distinct k-mers leave for k_pmh_points (one wave per read, 95 % VALU busy) instead of
+// being turned into points here by a workgroup that has to meet at barriers.
+template <bool EMIT>
+__global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);
+    uint64_t *hmin = reinterpret_cast<uint64_t *>(cnt + SMALLK_WORDS);
+    uint64_t *sig = hmin + a.m;
+    uint16_t *list = EMIT ? reinterpret_cast<uint16_t *>(hmin) : reinterpret_cast<uint16_t *>(sig + a.m); // (EMIT keeps no slots: the room goes to the list)
+    const uint32_t list_cap = a.cap;                                         // entries, a multiple of 2048
+    uint32_t *words = reinterpret_cast<uint32_t *>(list + list_cap);
+    uint32_t *misc = words + SMALLK_TILE + 2; // [0] list length, [2..3] q_max, [4] first read, [5] the read after the current one
+    uint64_t *qmax_sh = reinterpret_cast<uint64_t *>(misc + 2);
+    const KmerCfg cfg = a.cfg;
+    const int k = cfg.k, tid = threadIdx.x, nthreads = blockDim.x, wave = tid >> 6, nwaves = nthreads >> 6;
+    const bool sig32 = a.sig_bytes == 4;
+    const bool canonical = cfg.fhash == KMU_FHASH_CANON_RAW || cfg.fhash == KMU_FHASH_CANON_VALUE || cfg.fhash == KMU_FHASH_CANON_INVHASH;
+    for (uint32_t i = tid; i < SMALLK_WORDS; i += nthreads) cnt[i] = 0;
+    if (!EMIT)
+        for (int t = tid; t < a.m; t += nthreads) { hmin[t] = H_INIT; sig[t] = 0; }
+    // Reads are taken from the queue QCHUNK at a time (thread 0 keeps the cursor; the next chunk is requested one read before
+    // it is needed).  While a read is being counted the NEXT read's header is fetched, and its first tile of code words is
+    // requested right after the count phase: a fresh read starts without waiting for HBM.
+    uint32_t q_next = 0, q_end = 0, q_pend = 0;
+    bool q_pending = false;
+    if (tid == 0) {
+        misc[0] = 0; misc[1] = 0; *qmax_sh = H_INIT;
+        q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
+        q_end = q_next + QCHUNK;
+        misc[4] = q_next++;
+    }
+    lds_barrier();
+    // the key of histogram index `idx` (a k-mer value): the closure on that k-mer
+    auto key_of = [&](uint32_t idx) -> uint64_t { return apply_fhash(cfg, (uint64_t) idx, (uint64_t) revcomp32(idx, k)); };
+    auto view_of = [&](uint32_t q) {
+        SeqView v;
+        v.base = a.bases;
+        v.len = uniform_u64(a.offsets[q + 1] - a.offsets[q]);
+        v.packed = a.packed;
+        if (a.packed) {
+            v.begin = uniform_u64(a.packed_offsets[q]);
+            v.total = a.total_bytes ? a.total_bytes : uniform_u64(a.packed_offsets[a.n_seq - 1] + (a.offsets[a.n_seq] - a.offsets[a.n_seq - 1] + 3) / 4);
+        } else {
+            v.begin = uniform_u64(a.offsets[q]);
+            v.total = a.total_bytes ? a.total_bytes : uniform_u64(a.offsets[a.n_seq]);
+        }
+        return v;
+    };
+    // words [0, nw] of a read's first tile (positions from 0): nw as the count loop computes it
+    auto first_tile_nw = [&](const SeqView &v) -> uint32_t {
+        const uint32_t Lv = v.len >= 0x80000000ull ? 0u : (uint32_t) v.len;
+        if (Lv < (uint32_t) k) return 0u;
+        const uint32_t nkv = Lv - (uint32_t) k + 1u, tpos = (SMALLK_TILE - 2) * 16, ld = seq_lead(v);
+        const uint32_t t1 = nkv < tpos ? nkv : tpos;
+        return (uint32_t) (((uint64_t) t1 - 1 + ld + (uint64_t) k - 1) >> 4) - (ld >> 4) + 1;
+    };
+    // (every barrier of this kernel orders LDS traffic only: the list stores and the prefetched loads stay in flight across it)
+    uint32_t r = uniform_u32(misc[4]);
+    SeqView sv = view_of(r < a.n_queue ? r : 0u);
+    const uint64_t off_first = uniform_u64(a.offsets[0]);
+    uint64_t off_r = uniform_u64(a.offsets[r < a.n_queue ? r : 0u]); // offsets[r] of the current read
+    uint32_t pf_w0 = 0, pf_w1 = 0, pf_bad = 0; // this thread's word(s) of the current read's first tile, fetched ahead
+    bool pf_valid = false;                      // uniform
+    while (r < a.n_queue) {
+        if (tid == 0) { // the read after this one
+            if (q_next == q_end) {
+                if (!q_pending) q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
+                q_next = q_pend;
+                q_end = q_pend + QCHUNK;
+                q_pending = false;
+            }
+            misc[5] = q_next++;
+            if (q_next == q_end && !q_pending) { q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK); q_pending = true; }
+        }
+        lds_barrier();
+        const uint32_t r_next = uniform_u32(misc[5]);
+        // the next read's header: requested now, first looked at after the count phase (no wait here)
+        const bool has_next = r_next < a.n_queue;
+        const uint64_t n_o0 = has_next ? a.offsets[r_next] : 0ull, n_o1 = has_next ? a.offsets[r_next + 1] : 0ull;
+        const uint64_t n_po = has_next && a.packed ? a.packed_offsets[r_next] : 0ull;
+        SeqView nv = sv;
+        bool nv_done = false; // uniform
+        auto make_nv = [&]() {
+            nv.len = uniform_u64(n_o1 - n_o0);
+            nv.begin = a.packed ? uniform_u64(n_po) : uniform_u64(n_o0);
+            nv_done = true;
+        };
+        if (sv.len >= 0x80000000ull && tid == 0) atomicOr(a.err, DERR_TABLE_FULL);
+        const uint32_t L = sv.len >= 0x80000000ull ? 0u : (uint32_t) sv.len;
+        const uint32_t nk = L >= (uint32_t) k ? L - (uint32_t) k + 1u : 0u;
+        if (L == 0 && tid == 0) atomicOr(a.err, DERR_EMPTY_SEQ);
+        uint32_t bad = pf_valid ? pf_bad : 0u;
+        if (nk == 0) bad |= wave_validate_seq(sv, wave, nwaves, false);
+        const uint32_t lead = seq_lead(sv);
+        const bool wide = nk > 65535u;         // 32-bit counters, two halves of the index space
+        const bool listed = nk <= list_cap;    // first touches are listed: no histogram scan
+        const uint32_t halves = wide ? 2u : 1u;
+        const uint32_t tile_pos = (SMALLK_TILE - 2) * 16;
+        uint32_t emit_n = 0; // EMIT: list entries of this read so far (uniform)
+        for (uint32_t half = 0; half < halves && nk; half++) {
+            // ---- count ----
+            for (uint32_t tp0 = 0; tp0 < nk; tp0 += tile_pos) {
+                const uint32_t tp1 = nk - tp0 > tile_pos ? tp0 + tile_pos : nk;
+                const uint32_t wfirst = (tp0 + lead) >> 4;
+                const uint32_t wlast = (uint32_t) (((uint64_t) tp1 - 1 + lead + (uint64_t) k - 1) >> 4);
+                const uint32_t nw = wlast - wfirst + 1;
+                lds_barrier(); // the previous tile's readers are done
+                if (pf_valid && tp0 == 0 && half == 0) { // fetched while the previous read was being handed over
+                    if ((uint32_t) tid <= nw) words[tid] = pf_w0;
+                    if ((uint32_t) tid + nthreads <= nw) words[tid + nthreads] = pf_w1;
+                } else
+                for (uint32_t t = tid; t <= nw; t += nthreads) { // (+1: the word after the last, read by the window below)
+                    uint32_t b;
+                    words[t] = load_code_word(sv, (uint64_t) wfirst + t, b);
+                    if (half == 0) bad |= b;
+                }
+                lds_barrier();
+                // four positions per thread and step: the window reads, then the four counter atomics, are requested
+                // together, and the first touches of all four are appended with ONE atomic per wave (the loop is bound by
+                // dependent LDS round trips, not by instructions)
+                for (uint32_t p0 = tp0; p0 < tp1 && !ABL(1u); p0 += 4u * nthreads) { // uniform trip count (ballots)
+                    uint32_t idx[4], old[4];
+                    bool act[4], first[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
+                        act[u] = p < tp1;
+                        const uint32_t qq = (act[u] ? p : tp0) + lead - 16u * wfirst, wi = qq >> 4, sh = (qq & 15u) * 2u;
+                        const uint64_t win = ((uint64_t) words[wi] << 32) | words[wi + 1];
+                        const uint32_t val = (uint32_t) ((win << sh) >> (64 - 2 * k));
+                        idx[u] = val;
+                        if (canonical) { const uint32_t rc = revcomp32(val, k); idx[u] = rc < val ? rc : val; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        old[u] = 0;
+                        if (!wide) { if (act[u]) old[u] = atomicAdd(&cnt[idx[u] >> 1], (idx[u] & 1u) ? 65536u : 1u); }
+                        else if (act[u] && (idx[u] >> 15) == half) atomicAdd(&cnt[idx[u] & 0x7FFFu], 1u);
+                    }
+                    if (listed) {
+                        uint32_t mine = 0, tot = 0, before = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            first[u] = act[u] && ((idx[u] & 1u) ? old[u] >> 16 : old[u] & 0xFFFFu) == 0u;
+                            const uint64_t fm = __ballot(first[u]);
+                            if (first[u]) mine = mine | (1u << u);
+                            // rank of this lane's entry u among the wave's appends of this step: entries of earlier u first
+                            if (first[u]) before = (before & ~(0xFFu << (8 * u))) | ((tot + (uint32_t) __popcll(fm & ((1ull << lane_id()) - 1ull))) << (8 * u));
+                            tot += (uint32_t) __popcll(fm);
+                        }
+                        if (tot) { // wave-uniform
+                            uint32_t base = 0;
+                            if (lane_id() == 0) base = atomicAdd(&misc[0], tot);
+                            base = bcast_u32(base, 0);
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (mine & (1u << u)) list[base + ((before >> (8 * u)) & 0xFFu)] = (uint16_t) idx[u];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            if (half + 1 == halves && has_next) { // the next read's first tile is requested now, used a read later
+                make_nv();
+                const uint32_t nwn = first_tile_nw(nv), wf = seq_lead(nv) >> 4;
+                uint32_t b0 = 0, b1 = 0;
+                pf_w0 = (uint32_t) tid <= nwn && nwn ? load_code_word(nv, (uint64_t) wf + tid, b0) : 0u;
+                pf_w1 = (uint32_t) tid + nthreads <= nwn && nwn ? load_code_word(nv, (uint64_t) wf + tid + nthreads, b1) : 0u;
+                pf_bad = b0 | b1;
+            }
+            // ---- enumerate the distinct k-mers of this half, a list's worth at a time; pass 0 = first points, pass 1 = the
+            //      further points of the keys whose 1 / w lies below the settled q_max (and the counters are wiped) ----
+            const uint32_t wpb = wide ? list_cap : list_cap / 2; // histogram words whose counters fit the list
+            const uint32_t nblocks = listed ? 1u : (SMALLK_WORDS + wpb - 1) / wpb;
+            for (int pass = EMIT ? 1 : 0; pass < 2; pass++) { // (EMIT: one traversal: hand over, wipe)
+                uint64_t qb = (!EMIT && pass) ? wave_qmax(hmin, a.m) : 0ull;
+                for (uint32_t blk = 0; blk < nblocks; blk++) {
+                    if (!listed) { // the occupied counters of this block of the histogram
+                        if (tid == 0) misc[0] = 0;
+                        lds_barrier();
+                        const uint32_t w0 = blk * wpb, w1 = w0 + wpb < SMALLK_WORDS ? w0 + wpb : SMALLK_WORDS;
+                        for (uint32_t wbase = w0; wbase < w1; wbase += nthreads) { // uniform trip count (ballots)
+                            const uint32_t c = wbase + tid < w1 ? cnt[wbase + tid] : 0u;
+                            for (uint32_t h = 0; h < (wide ? 1u : 2u); h++) {
+                                const bool occ = wide ? c != 0u : ((h ? c >> 16 : c & 0xFFFFu) != 0u);
+                                const uint64_t om = __ballot(occ);
+                                if (om) {
+                                    const int leader = __ffsll((unsigned long long) om) - 1;
+                                    uint32_t base = 0;
+                                    if (lane_id() == leader) base = atomicAdd(&misc[0], (uint32_t) __popcll(om));
+                                    base = bcast_u32(base, leader);
+                                    if (occ) {
+                                        const uint32_t idx = wide ? ((half << 15) | (wbase + tid)) : (((wbase + tid) << 1) | h);
+                                        list[base + (uint32_t) __popcll(om & ((1ull << lane_id()) - 1ull))] = (uint16_t) idx;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    lds_barrier();
+                    const uint32_t n_list = uniform_u32(misc[0]);
+                    uint32_t chunk = 0;
+                    if (EMIT) {
+                        const uint64_t lbase = off_r - off_first + emit_n;
+                        for (uint32_t i = tid; i < n_list && !ABL(2u); i += nthreads) {
+                            const uint32_t idx = list[i];
+                            const uint32_t c = wide ? cnt[idx & 0x7FFFu] : cnt[idx >> 1];
+                            a.lst_keys[lbase + i] = key_of(idx);
+                            a.lst_w[lbase + i] = wide ? c : ((idx & 1u) ? c >> 16 : c & 0xFFFFu);
+                        }
+                        emit_n += n_list;
+                    } else
+                    for (uint32_t base = 0; base < n_list; base += nthreads, chunk++) {
+                        const uint32_t i = base + tid;
+                        uint32_t idx = 0, w = 0;
+                        if (i < n_list) {
+                            idx = list[i];
+                            const uint32_t c = wide ? cnt[idx & 0x7FFFu] : cnt[idx >> 1];
+                            w = wide ? c : ((idx & 1u) ? c >> 16 : c & 0xFFFFu);
+                        }
+                        const bool have = w != 0u;
+                        if (pass == 0) {
+                            if (__any(have))
+                                (void) pmh3a_first_point(a, sig32, hmin, sig, qmax_sh, ((chunk + wave) & B1_REFRESH_MASK) == 0u, have,
+                                                         have ? key_of(idx) : 0ull, w);
+                        } else {
+                            double winv = 0.0;
+                            bool alive = false;
+                            if (have) {
+                                winv = 1.0 / (double) w;
+                                alive = winv < __longlong_as_double((long long) qb);
+                            }
+                            if (__any(alive)) pmh3a_more_points(a, sig32, hmin, sig, qb, alive, alive ? key_of(idx) : 0ull, winv);
+                        }
+                    }
+                    lds_barrier(); // every reader of the list and of the counters is through
+                    if (pass == 1) { // wipe what this block enumerated
+                        if (listed) {
+                            for (uint32_t i = tid; i < n_list; i += nthreads) cnt[wide ? (list[i] & 0x7FFFu) : (list[i] >> 1)] = 0u;
+                        } else {
+                            const uint32_t w0 = blk * wpb, w1 = w0 + wpb < SMALLK_WORDS ? w0 + wpb : SMALLK_WORDS;
+                            for (uint32_t i = w0 + tid; i < w1; i += nthreads) cnt[i] = 0u;
+                        }
+                    }
+                }
+                lds_barrier(); // (pass 0 -> 1: all first points are in before q_max is read)
+            }
+            if (tid == 0) misc[0] = 0;
+            lds_barrier();
+        }
+        if (bad) atomicOr(a.err, DERR_NON_ACGT);
+        // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
+        if (EMIT) {
+            if (tid == 0) a.lst_n[r] = emit_n; // the row is written by k_pmh_points
+        } else
+        for (int t = tid; t < a.m; t += nthreads) {
+            const uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
+            if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * a.m + t] = (uint32_t) v;
+            else reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = v;
+            hmin[t] = H_INIT;
+            sig[t] = 0;
+        }
+        if (tid == 0) *qmax_sh = H_INIT;
+        // (a read without k-mers never reached the prefetch: its successor loads its own words)
+        if (has_next && !nv_done) make_nv();
+        pf_valid = nk != 0 && has_next && first_tile_nw(nv) != 0;
+        r = r_next;
+        sv = nv;
+        off_r = uniform_u64(n_o0);
+        lds_barrier();
+    }
+}
+
 // merge the slot minima of disjoint key sets (leaves): per slot the smallest (h, key); one workgroup per slot
 // (stride: words between the rows of consecutive parts; part_out: write (h, key) to part_out[t], part_out[m + t] instead)
 __global__ void __launch_bounds__(256) k_pmh_reduce(const uint64_t *part_h, const uint64_t *part_k, uint64_t n_parts, int m,
@@ -1298,6 +1589,21 @@ int launch_dens_merge(kmu_ctx *ctx, const kmu_sketch_params *p, const uint64_t *
 // the sketches kept as m bins / registers with one independent update per k-mer occurrence (kmu_sketch_dens.hip)
 static bool algo_is_dens(int algo) { return algo == KMU_ALGO_OPTDENS || algo == KMU_ALGO_REVOPTDENS || algo == KMU_ALGO_HLL; }
 
+// ProbMinHash3a of whole DNA sequences with k <= 8 (Kmer32bit) and a closure that is injective on the (canonical) k-mer:
+// the histogram route of k_sketch_smallk.  KMU_PMH_SMALLK=0 keeps the general kernels (diagnostics, A/B).
+static bool smallk_route(const kmu_sketch_params *p, int hashed_bytes, bool partial, bool blocks) {
+    if (p->algo != KMU_ALGO_PROB3A || p->kmer_type != KMU_KMER32BIT || p->kmer_size > 8 || hashed_bytes || partial || blocks ||
+        p->block_size != 0 || p->sketch_size > 512)
+        return false;
+    switch (p->fhash) {
+    case KMU_FHASH_IDENTITY_RAW: case KMU_FHASH_VALUE_MASKED: case KMU_FHASH_CANON_RAW: case KMU_FHASH_CANON_INVHASH:
+    case KMU_FHASH_INVHASH_RAW: case KMU_FHASH_CANON_VALUE: break;
+    default: return false; // (ntHash is not injective in principle)
+    }
+    const char *e = getenv("KMU_PMH_SMALLK");
+    return !(e && atoi(e) == 0);
+}
+
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
                         void *d_sig, uint32_t *d_counts, uint32_t *d_err, const void *hashed = nullptr,
                         int hashed_bytes = 0, uint64_t *part_h = nullptr, uint64_t *part_k = nullptr,
@@ -1341,6 +1647,70 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
     const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
     typedef void (*sketch_kernel_t)(SketchArgs);
+    if (smallk_route(p, hashed_bytes, part_h != nullptr, d_block_rows != nullptr)) { // k <= 8: direct-indexed histogram
+        // the distinct (key, weight) pairs go to k_pmh_points through lists in HBM (12 bytes per base of scratch, the lists
+        // of the two-kernel route) unless that memory is not to be had: then the histogram kernel makes the points itself
+        bool emit = (size_t) 4 * (2 * (size_t) p->sketch_size + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8 <= 150 * 1024;
+        if (const char *e = getenv("KMU_PMH_SPLIT")) emit = emit && atoi(e) != 0;
+        uint64_t total = 0;
+        if (emit) {
+            if (len_stats) total = len_stats[1];
+            else if (!ds.h_offsets.empty()) total = ds.h_offsets[ds.n_seq] - ds.h_offsets[0];
+            else {
+                uint64_t ends[2] = {0, 0};
+                KMU_HIP(ctx, hipMemcpyAsync(&ends[0], ds.offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KMU_HIP(ctx, hipMemcpyAsync(&ends[1], ds.offsets + ds.n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                total = ends[1] - ends[0];
+            }
+            const size_t need_k = total * 8 + 64, need_w = total * 4 + 64;
+            size_t grow = 0, free_b = 0, total_b = 0;
+            if (ctx->bufs["cnt.partA"].bytes < need_k) grow += need_k + need_k / 8;
+            if (ctx->bufs["pmh.lst_w"].bytes < need_w) grow += need_w + need_w / 8;
+            if (grow && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < grow + total_b / 8) emit = false;
+            if (emit) {
+                void *lk, *lw, *ln;
+                KMU_TRY(dev_buf(ctx, "cnt.partA", need_k, &lk));
+                KMU_TRY(dev_buf(ctx, "pmh.lst_w", need_w, &lw));
+                KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 4 + 64, &ln));
+                a.lst_keys = (uint64_t *) lk;
+                a.lst_w = (uint32_t *) lw;
+                a.lst_n = (uint32_t *) ln;
+            }
+        }
+        const sketch_kernel_t kern = emit ? k_sketch_smallk<true> : k_sketch_smallk<false>;
+        // LDS: histogram | slot minima (only when the kernel makes the points itself) | list of u16 indices | staged words
+        const size_t lds_fixed = (size_t) SMALLK_WORDS * 4 + (emit ? 0 : (size_t) 16 * a.m) + ((size_t) SMALLK_TILE + 2) * 4 + 64;
+        a.cap = (uint32_t) ((160 * 1024 - lds_fixed) / 2) & ~2047u;
+        if (a.cap > 32768u) a.cap = 32768u;
+        const size_t lds = lds_fixed + (size_t) a.cap * 2;
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        void *q;
+        KMU_TRY(dev_buf(ctx, "queue", 256, &q));
+        KMU_HIP(ctx, hipMemsetAsync(q, 0, 256, ctx->stream));
+        a.queue = (uint32_t *) q;
+        a.queue2 = a.queue + 48;
+        int cus = ctx->num_cus;
+        if (const char *rs = getenv("KMU_PMH_RESERVE_CUS")) cus = std::max(cus / 2, cus - std::max(0, atoi(rs)));
+        const int grid = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) ds.n_seq, (uint64_t) cus));
+        {
+            KernelTimer t(ctx, "k_sketch_smallk");
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, a);
+        }
+        KMU_HIP(ctx, hipGetLastError());
+        if (emit) {
+            const sketch_kernel_t kpts = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
+            const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
+            if (lds2 > 64 * 1024)
+                KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
+            const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) cus * per_cu));
+            KernelTimer t(ctx, "k_pmh_points");
+            hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
+            KMU_HIP(ctx, hipGetLastError());
+        }
+        return KMU_OK;
+    }
     // Big batches of whole DNA sequences go through two kernels: the multiset kernel leaves the (key, weight) pairs of
     // every read in HBM, k_pmh_points (one wave per read, no workgroup barrier, 5 waves per SIMD) generates the points.
     // ONT workload: 53.3 + 21.2 ms against 88.7 ms in one kernel, for 12 bytes of scratch per base.  One wave per read
@@ -1584,6 +1954,8 @@ static int sketch_pmh_per_seq(kmu_ctx *ctx, const kmu_sketch_params *p, const De
     uint32_t skip_longer = 0;
     uint64_t len_stats[2] = {0, 0}; // longest sequence, all bases (whole sequences only)
     std::vector<uint32_t> long_seqs;
+    if (p->block_size == 0 && smallk_route(p, 0, false, d_block_rows != nullptr)) // any length fits the histogram
+        return launch_pmh3a(ctx, p, ds, d_block_rows, d_sig, nullptr, d_err);
     if (p->block_size == 0) {
         std::vector<uint64_t> h_off;
         if (h_offsets) {

@@ -690,6 +690,7 @@ def test_two_kernel_probminhash_path(ctx, oracle, monkeypatch):
     """KMU_PMH_SPLIT=1: multiset kernel -> (key, weight) lists -> k_pmh_points; same rows as the oracle, including
     reads that need several partition passes, tandem repeats and a read shorter than k."""
     monkeypatch.setenv("KMU_PMH_SPLIT", "1")
+    monkeypatch.setenv("KMU_PMH_SMALLK", "0")  # (k = 8 has a route of its own: test_smallk_histogram_route)
     rng = np.random.default_rng(21)
     seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in (12, 300, 7000, 45000, 9000)]
     seqs.append(b"ACGGT" * 3000)
@@ -1089,3 +1090,33 @@ def test_probminhash_many_reads_default_route(ctx, oracle, monkeypatch):
     assert "k_pmh_points" not in names2, names2
     want2 = oracle.sketch(b2, o2, p)
     assert got2.tobytes() == np.asarray(want2).tobytes()
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_smallk_histogram_route(ctx, oracle, monkeypatch, split):
+    """k <= 8: the multiset as a direct-indexed histogram in LDS (k_sketch_smallk), with the points made by k_pmh_points
+    (KMU_PMH_SPLIT=1) or by the histogram kernel itself (=0).  Reads of every regime: shorter than k, listed first touches
+    (<= 8192 k-mers), scanned histogram, 32-bit counters in two halves (> 65535 k-mers), poly-A (one counter takes it all),
+    tandem repeats; every closure the route accepts; packed input; against the oracle and against the general kernels."""
+    monkeypatch.setenv("KMU_PMH_SPLIT", split)
+    rng = np.random.default_rng(88)
+    seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in (5, 8, 9, 300, 8199, 8200, 30000, 65542, 65543, 150000)]
+    seqs += [b"A" * 70000, b"ACGGT" * 2000, b"AC" * 40000, b"T" * 9]
+    bases, off = oracle.concat(seqs)
+    packed, poff = ctx.pack2b(bases, off)
+    for k, fh, m in ((8, A.FHASH_CANON_INVHASH, 200), (8, A.FHASH_IDENTITY_RAW, 64), (5, A.FHASH_CANON_VALUE, 33), (3, A.FHASH_INVHASH_RAW, 16),
+                     (7, A.FHASH_CANON_RAW, 500), (8, A.FHASH_VALUE_MASKED, 2)):
+        p = A.SketchParams(A.ALGO_PROB3A, A.KMER32BIT, k, m, A.SIG_U32, A.HASHER_NOHASH, fh, 0, 0, 0, 0, 0)
+        want = oracle.sketch(bases, off, p)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        got = np.asarray(ctx.sketch(bases, off, p))
+        ctx.profile_enable(False)
+        prof = ctx.profile_get()
+        assert "k_sketch_smallk" in prof and ("k_pmh_points" in prof) == (split == "1")
+        assert np.array_equal(got, want), (k, fh, m)
+        pp = A.SketchParams.from_buffer_copy(p)
+        pp.input_kind = A.INPUT_PACKED2
+        assert np.array_equal(np.asarray(ctx.sketch(packed, off, pp, packed_offsets=poff)), want)
+    monkeypatch.setenv("KMU_PMH_SMALLK", "0")
+    assert np.array_equal(np.asarray(ctx.sketch(bases, off, p)), want)
