@@ -340,6 +340,7 @@ def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000):
     if cfg["sketch"]:
         p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0, 0, 0, 0, 0)
         want = O.sketch(hb, ho, p)
+        ctx.synchronize()
         got = sig[:n].cpu().numpy()
         out["parity_rows_ok"] = bool(np.array_equal(got.view(np.uint8), np.ascontiguousarray(want).view(np.uint8)))
     if cfg["count"]:
@@ -348,9 +349,12 @@ def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000):
         oc = O.Counter(cfg["kmer_type"], cfg["k"], 16, 1 << 20)
         oc.add_reads(hb, ho)
         wk, wc = oc.dump(1)
-        got = counter.query(torch.from_numpy(wk.view(np.int64)).to(bases.device)).cpu().numpy().astype(np.int64)
+        got_d = counter.query(torch.from_numpy(wk.view(np.int64)).to(bases.device))
+        ctx.synchronize()  # (an asynchronous context: the query runs on the library's stream, not on torch's current one)
+        got = got_d.cpu().numpy().astype(np.int64)
         out["parity_counts_ok"] = bool((got >= np.minimum(wc.astype(np.int64), 255)).all() and (got >= 1).all())
     if cfg.get("nthash"):
+        ctx.synchronize()
         wh, _ = O.nthash(hb, ho, cfg["k"])
         out["parity_nthash_ok"] = bool(np.array_equal(nth[:nb].cpu().numpy().view(np.uint64), wh[:, 0]))
     return out

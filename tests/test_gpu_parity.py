@@ -1120,3 +1120,33 @@ def test_smallk_histogram_route(ctx, oracle, monkeypatch, split):
         assert np.array_equal(np.asarray(ctx.sketch(packed, off, pp, packed_offsets=poff)), want)
     monkeypatch.setenv("KMU_PMH_SMALLK", "0")
     assert np.array_equal(np.asarray(ctx.sketch(bases, off, p)), want)
+
+
+def test_count_compact_state(ctx, oracle, monkeypatch):
+    """KMU_COUNT_COMPACT=1: the partitioned build leaves every region as its (key, count) pairs + a per-region length; the
+    statistics come from the build, a second batch re-inserts the pairs, and whatever probes slots expands the table first"""
+    monkeypatch.setenv("KMU_COUNT_COMPACT", "1")
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    bases, off = synth.ont_reads(500, 300_000, 0xC3)
+    half = 250
+    o = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 20)
+    c = ctx.counter(A.KMER64BIT, 31, 8, int(off[-1]))
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    c.add_reads(bases[:int(off[half])], off[:half + 1])            # fresh -> compact
+    o.add_reads(bases[:int(off[half])], off[:half + 1])
+    assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())  # (cached by the build: no table pass)
+    assert "k_count_stats" not in ctx.profile_get()
+    c.add_reads(bases[int(off[half]):], off[half:] - off[half])    # compact -> compact: the pairs are re-inserted
+    o.add_reads(bases[int(off[half]):], off[half:] - off[half])
+    assert (c.nb_distinct(), c.nb_unique(), c.nb_occurrences()) == (o.nb_distinct(), o.nb_unique(), int(np.maximum(np.diff(off.astype(np.int64)) - 30, 0).sum()))
+    wk, wc = o.dump(1)
+    assert np.array_equal(c.query(wk), wc)                         # expands (k_part_expand), then probes
+    ctx.profile_enable(False)
+    assert "k_part_expand" in ctx.profile_get()
+    gk, gc = c.dump(1)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    monkeypatch.setenv("KMU_COUNT_PATH", "direct")
+    c.add_kmers(wk[:100])                                          # direct insertion on the open image
+    assert np.array_equal(c.query(wk[:200]), np.minimum(wc[:200].astype(np.int64) + (np.arange(200) < 100), 255))
+    c.close()
