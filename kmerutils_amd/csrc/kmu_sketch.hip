@@ -819,7 +819,8 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                     // a straight copy of the dense arrays, duplicates included with weight 0 (k_pmh_points
                                     // skips them): no compaction, no atomics.  emit_n = entries of this read so far (all
                                     // passes; at most one per k-mer, so the list of a read fits its bases' index range)
-                                    const uint64_t lbase = a.offsets[r] - a.offsets[0] + emit_n; // (a range of a larger read set)
+                                    const uint32_t rsq = seq_of(r); // (the general instantiation may be walking a list of reads)
+                                    const uint64_t lbase = a.offsets[rsq] - a.offsets[0] + emit_n; // (a range of a larger read set)
                                     for (uint32_t i = tid; i < n_keys; i += nthreads) {
                                         a.lst_keys[lbase + i] = dk[i];
                                         a.lst_w[lbase + i] = dw[i];
@@ -933,7 +934,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                 bk_n = 0;
             } else if (EMIT) {
                 if (tid == 0) { // the row is written by k_pmh_points (PLAIN, overflow: an empty list; the redo launch writes the row)
-                    a.lst_n[r] = (PLAIN && redo) ? 0u : emit_n;
+                    a.lst_n[seq_of(r)] = (PLAIN && redo) ? 0u : emit_n;
                     if (PLAIN && redo) a.redo_list[atomicAdd(a.queue + 56, 1u)] = r;
                 }
                 emit_n = 0;
@@ -1121,6 +1122,295 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
             if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * a.m + t] = (uint32_t) v;
             else reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = v;
         }
+    }
+}
+
+// ---- reads that fit the registers of one workgroup: the multiset without a counting sort ------------------------------------
+// In a noisy long read almost every 31-mer occurs once.  k_multiset_uq does not sort what does not need sorting: every key
+// sets its bit in an occupancy bitmap A of 2^16 bits (a second hash of the key; `ds_or_rtn`), a key that finds its bit set also
+// sets it in B.  After one barrier a key whose B bit is clear has PROVABLY met no equal key -- weight 1, final -- and leaves
+// for the (key, weight) lists straight from the registers (nine keys in ten of an ONT read at k = 31).  The others, a few
+// hundred per read, are collected in LDS and merged exactly by a miniature of the general kernel's counting sort (1 024
+// buckets, rank / scan / place / walk).  No partitions, blocks, rounds, parked keys: the kernel is small, a workgroup is 512
+// threads with 20 keys per thread, and TWO workgroups share a CU, so one read's barriers hide under the other's work.
+// Reads with more than UQ_KEYS k-mers (or more than UQ_COLL keys in collision groups) are appended to `redo_list` and taken
+// by the general list-emitting kernel in a second launch.  Output: the lists k_pmh_points reads, as k_sketch_pmh3a<EMIT>.
+// Two shapes: <512 threads, 2^16-bit bitmaps, 2 048 collected keys> for reads of up to 10 240 k-mers, two workgroups per CU;
+// <1024, 2^17, 4 096> for up to 20 480 k-mers, one workgroup per CU, run on the list the first shape leaves behind.
+static constexpr int UQ_KREG = 20;
+template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL>
+struct UqShape {
+    static constexpr uint32_t KEYS = (uint32_t) UQ_THREADS * UQ_KREG;
+    static constexpr uint32_t BM_WORDS = (1u << UQ_BM_BITS) / 32;
+    static constexpr uint32_t BUCKETS = 2u * UQ_THREADS; // of the collision groups' counting sort: two per thread
+    static constexpr uint32_t TILE = (KEYS + 32 + 15) / 16 + 3; // staged code words of a read
+    static constexpr size_t LDS = (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64;
+};
+
+template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, int MINW>
+__global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) {
+    typedef UqShape<UQ_THREADS, UQ_BM_BITS, UQ_COLL> SH;
+    constexpr uint32_t UQ_KEYS = SH::KEYS, UQ_BM_WORDS = SH::BM_WORDS, UQ_BUCKETS = SH::BUCKETS, UQ_TILE = SH::TILE;
+    static_assert(UQ_BM_WORDS / 4 == (uint32_t) UQ_THREADS, "one 16-byte store per thread wipes a bitmap");
+    static_assert(UQ_COLL % UQ_THREADS == 0 && UQ_COLL / UQ_THREADS <= 4, "collected keys per thread");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *bmA = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *bmB = bmA + UQ_BM_WORDS;
+    uint64_t *ck = reinterpret_cast<uint64_t *>(bmB + UQ_BM_WORDS); // keys of the collision groups, as collected
+    uint64_t *dk = ck + UQ_COLL;                                     // ... grouped by bucket
+    uint32_t *dw = reinterpret_cast<uint32_t *>(dk + UQ_COLL);
+    uint32_t *bst = dw + UQ_COLL;          // UQ_BUCKETS + 1
+    uint32_t *words = bst + UQ_BUCKETS + 1; // UQ_TILE
+    uint32_t *wtot = words + UQ_TILE;       // one per wave
+    uint32_t *misc = wtot + UQ_THREADS / 64; // [0] unique entries, [1] collected keys, [4] first read, [5] the read after the current one
+    const KmerCfg cfg = a.cfg;
+    const int k = cfg.k, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    for (uint32_t i = tid; i < UQ_BUCKETS + 1; i += UQ_THREADS) bst[i] = 0;
+    uint32_t q_next = 0, q_end = 0, q_pend = 0;
+    bool q_pending = false;
+    if (tid == 0) {
+        q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
+        q_end = q_next + QCHUNK;
+        misc[4] = q_next++;
+    }
+    __syncthreads();
+    const uint64_t off_first = uniform_u64(a.offsets[0]);
+    const uint64_t total = a.total_bytes ? a.total_bytes : uniform_u64(a.offsets[a.n_seq]);
+    // queue entry q stands for sequence read_list[q] when a list is given (the second shape's launch), else for sequence q
+    auto seq_of = [&](uint32_t q) -> uint32_t { return a.read_list ? a.read_list[q] : q; };
+    uint32_t r = uniform_u32(misc[4]);
+    uint32_t rs = r < a.n_queue ? uniform_u32(seq_of(r)) : 0u; // the sequence
+    SeqView sv;
+    sv.base = a.bases; sv.packed = 0; sv.total = total; sv.begin = 0; sv.len = 0;
+    if (r < a.n_queue) { sv.begin = uniform_u64(a.offsets[rs]); sv.len = uniform_u64(a.offsets[rs + 1]) - sv.begin; }
+    uint32_t pf_w[3] = {0, 0, 0}, pf_bad = 0; // this thread's words of the current read, fetched a read ahead
+    bool pf_valid = false;                    // uniform
+    auto n_words = [&](const SeqView &v) -> uint32_t { // staged words of a read of 1 .. UQ_KEYS k-mers (its k-mers' windows + 1)
+        const uint32_t Lv = (uint32_t) v.len, ld = seq_lead(v);
+        return (uint32_t) ((Lv - 1 + ld) >> 4) + 2;
+    };
+    while (r < a.n_queue) {
+        if (tid == 0) { // the read after this one (the queue is asked a read before the chunk runs out)
+            if (q_next == q_end) {
+                if (!q_pending) q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
+                q_next = q_pend;
+                q_end = q_pend + QCHUNK;
+                q_pending = false;
+            }
+            misc[5] = q_next++;
+            if (q_next == q_end && !q_pending) { q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK); q_pending = true; }
+            misc[0] = 0;
+            misc[1] = 0;
+        }
+        const uint32_t L = sv.len >= 0x80000000ull ? 0xFFFFFFFFu : (uint32_t) sv.len;
+        const uint32_t nk = L >= (uint32_t) k ? L - (uint32_t) k + 1u : 0u;
+        const bool mine = nk >= 1u && nk <= UQ_KEYS; // else: no k-mer at all (row of zeros), or the general kernel's
+        uint32_t bad = 0;
+        if (L == 0 && tid == 0) atomicOr(a.err, DERR_EMPTY_SEQ);
+        if (nk == 0) bad |= wave_validate_seq(sv, wave, UQ_THREADS / 64, false);
+        const uint32_t lead = seq_lead(sv), wfirst = lead >> 4;
+        if (mine) { // stage the read's code words (prefetched ones first), wipe the bitmaps
+            const uint32_t nw = n_words(sv);
+            if (pf_valid) {
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+                    if ((uint32_t) tid + (uint32_t) u * UQ_THREADS < nw) words[tid + u * UQ_THREADS] = pf_w[u];
+                bad |= pf_bad;
+            } else {
+                for (uint32_t t = tid; t < nw; t += UQ_THREADS) {
+                    uint32_t b;
+                    words[t] = load_code_word(sv, (uint64_t) wfirst + t, b);
+                    bad |= b;
+                }
+            }
+            uint4 *za = reinterpret_cast<uint4 *>(bmA), *zb = reinterpret_cast<uint4 *>(bmB);
+            za[tid] = make_uint4(0u, 0u, 0u, 0u); // 2 048 words = 512 x 16 bytes each
+            zb[tid] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        lds_barrier();
+        const uint32_t r_next = uniform_u32(misc[5]);
+        const bool has_next = r_next < a.n_queue;
+        // the next read's header: requested now, looked at after the key phase
+        const uint32_t rs_next = has_next ? seq_of(r_next) : 0u;
+        const uint64_t n_o0 = has_next ? a.offsets[rs_next] : 0ull, n_o1 = has_next ? a.offsets[rs_next + 1] : 0ull;
+        uint64_t rk[UQ_KREG];
+        uint32_t rbi[UQ_KREG];
+        bool over = false; // uniform: too many keys in collision groups
+        if (mine) {
+            // ---- keys: extract, closure, bitmaps; four positions' LDS round trips in flight at a time ----
+#pragma unroll
+            for (int q0 = 0; q0 < UQ_KREG; q0 += 4) {
+                uint32_t bit[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u;
+                    const uint32_t p = (uint32_t) q * UQ_THREADS + tid;
+                    rbi[q] = 0xFFFFFFFFu;
+                    rk[q] = 0;
+                    if (p < nk) {
+                        const uint32_t qq = p + lead - 16u * wfirst, idx = qq >> 4, sh = (qq & 15u) * 2u;
+                        const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
+                        const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
+                        const uint64_t val = v >> (64 - 2 * k);
+                        const uint64_t key = apply_fhash(cfg, val, revcomp_val(val, k));
+                        const uint32_t h = mix32(key);
+                        rk[q] = key;
+                        rbi[q] = ((h ^ (h >> 13)) * 0x85EBCA6Bu) >> (32 - UQ_BM_BITS);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u;
+                    bit[u] = 0;
+                    if (rbi[q] != 0xFFFFFFFFu) {
+                        const uint32_t b = 1u << (rbi[q] & 31u);
+                        bit[u] = atomicOr(&bmA[rbi[q] >> 5], b) & b;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (bit[u]) atomicOr(&bmB[rbi[q0 + u] >> 5], bit[u]);
+            }
+            lds_barrier();
+        }
+        // ---- the next read's words are requested now and land while this read is sorted out and handed over ----
+        SeqView nv = sv;
+        bool nv_mine = false;
+        if (has_next) {
+            nv.begin = uniform_u64(n_o0);
+            nv.len = uniform_u64(n_o1) - nv.begin;
+            const uint32_t Ln = nv.len >= 0x80000000ull ? 0xFFFFFFFFu : (uint32_t) nv.len;
+            nv_mine = Ln >= (uint32_t) k && Ln - (uint32_t) k + 1u <= UQ_KEYS;
+            if (nv_mine) {
+                const uint32_t nwn = n_words(nv), wf = seq_lead(nv) >> 4;
+                pf_bad = 0;
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    uint32_t b = 0;
+                    pf_w[u] = (uint32_t) tid + (uint32_t) u * UQ_THREADS < nwn ? load_code_word(nv, (uint64_t) wf + tid + (uint32_t) u * UQ_THREADS, b) : 0u;
+                    pf_bad |= b;
+                }
+            }
+        }
+        const uint64_t lb = sv.begin - off_first; // list entries of read r start here
+        if (mine) {
+            // ---- sort out: B bit clear = occurs once = list entry (key, 1) from the register; else collect ----
+#pragma unroll
+            for (int q0 = 0; q0 < UQ_KREG; q0 += 4) {
+                bool uq[4], co[4];
+                uint64_t um[4], cm[4];
+                uint32_t ut = 0, ct = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u;
+                    const bool have = rbi[q] != 0xFFFFFFFFu;
+                    co[u] = have && (bmB[rbi[q] >> 5] & (1u << (rbi[q] & 31u))) != 0u;
+                    uq[u] = have && !co[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    um[u] = __ballot(uq[u]);
+                    cm[u] = __ballot(co[u]);
+                    ut += (uint32_t) __popcll(um[u]);
+                    ct += (uint32_t) __popcll(cm[u]);
+                }
+                uint32_t ub = 0, cb = 0; // one atomic per wave, list and group of four register slots
+                if (lane == 0) {
+                    if (ut) ub = atomicAdd(&misc[0], ut);
+                    if (ct) cb = atomicAdd(&misc[1], ct);
+                }
+                ub = bcast_u32(ub, 0);
+                cb = bcast_u32(cb, 0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint64_t below = (1ull << lane) - 1ull;
+                    if (uq[u]) {
+                        const uint64_t at = lb + ub + (uint32_t) __popcll(um[u] & below);
+                        a.lst_keys[at] = rk[q0 + u];
+                        a.lst_w[at] = 1u;
+                    }
+                    if (co[u]) {
+                        const uint32_t at = cb + (uint32_t) __popcll(cm[u] & below);
+                        if (at < UQ_COLL) ck[at] = rk[q0 + u];
+                    }
+                    ub += (uint32_t) __popcll(um[u]);
+                    cb += (uint32_t) __popcll(cm[u]);
+                }
+            }
+            lds_barrier();
+            const uint32_t n_u = uniform_u32(misc[0]), n_c = uniform_u32(misc[1]);
+            over = n_c > UQ_COLL;
+            if (!over && n_c) {
+                // ---- the collision groups: counting sort on 10 hash bits, equal keys hand their weight to the first ----
+                uint64_t key[UQ_COLL / UQ_THREADS];
+                uint32_t rb[UQ_COLL / UQ_THREADS];
+#pragma unroll
+                for (int j = 0; j < (int) (UQ_COLL / UQ_THREADS); j++) {
+                    const uint32_t i = (uint32_t) j * UQ_THREADS + tid;
+                    rb[j] = 0xFFFFFFFFu;
+                    key[j] = 0;
+                    if (i < n_c) {
+                        key[j] = ck[i];
+                        const uint32_t b = mix32(key[j]) / (0x80000000u / (UQ_BUCKETS / 2)); // the top log2(UQ_BUCKETS) bits
+                        rb[j] = (b << 16) | atomicAdd(&bst[b], 1u);
+                    }
+                }
+                lds_barrier();
+                { // exclusive scan of the 1 024 bucket counts, two per thread
+                    const uint32_t c0 = bst[2 * tid], c1 = bst[2 * tid + 1];
+                    const uint32_t incl = wave_incl_scan_u32(c0 + c1);
+                    if (lane == 63) wtot[wave] = incl;
+                    lds_barrier();
+                    uint32_t pre = incl - (c0 + c1);
+#pragma unroll
+                    for (int w = 0; w < UQ_THREADS / 64; w++) pre += w < wave ? wtot[w] : 0u;
+                    bst[2 * tid] = pre;
+                    bst[2 * tid + 1] = pre + c0;
+                }
+                lds_barrier();
+#pragma unroll
+                for (int j = 0; j < (int) (UQ_COLL / UQ_THREADS); j++)
+                    if (rb[j] != 0xFFFFFFFFu) {
+                        const uint32_t pos = bst[rb[j] >> 16] + (rb[j] & 0xFFFFu);
+                        rb[j] = (rb[j] & 0xFFFF0000u) | pos;
+                        dk[pos] = key[j];
+                        dw[pos] = 1u;
+                    }
+                lds_barrier();
+#pragma unroll
+                for (int j = 0; j < (int) (UQ_COLL / UQ_THREADS); j++)
+                    if (rb[j] != 0xFFFFFFFFu) {
+                        const uint32_t pos = rb[j] & 0xFFFFu;
+                        for (uint32_t t = bst[rb[j] >> 16]; t < pos; t++)
+                            if (dk[t] == key[j]) { // the first equal key of the bucket takes this one's weight
+                                dw[pos] = 0u;
+                                atomicAdd(&dw[t], 1u);
+                                break;
+                            }
+                    }
+                lds_barrier();
+                for (uint32_t i = tid; i < n_c; i += UQ_THREADS) {
+                    a.lst_keys[lb + n_u + i] = dk[i];
+                    a.lst_w[lb + n_u + i] = dw[i];
+                }
+                bst[2 * tid] = 0;
+                bst[2 * tid + 1] = 0;
+            }
+            if (tid == 0 && !over) a.lst_n[rs] = n_u + n_c;
+        }
+        if (tid == 0) {
+            if (nk == 0) a.lst_n[rs] = 0u; // no k-mer: k_pmh_points writes the row of an empty multiset
+            else if (!mine || over) {       // the next kernel's: longer than the registers, or too repetitive
+                a.lst_n[rs] = 0u;
+                a.redo_list[atomicAdd(a.queue + 56, 1u)] = rs;
+            }
+        }
+        if (bad) atomicOr(a.err, DERR_NON_ACGT);
+        pf_valid = nv_mine;
+        r = r_next;
+        rs = uniform_u32(rs_next);
+        sv = nv;
+        lds_barrier();
     }
 }
 
@@ -1847,7 +2137,65 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         KMU_TRY(dev_buf(ctx, "pmh.redo", (size_t) ds.n_seq * 4 + 64, &rl));
         a.redo_list = (uint32_t *) rl;
     }
-    {
+    // Whole unpacked DNA reads on the two-kernel route: the reads that fit one workgroup's registers (<= 10 240 k-mers: 87 % of
+    // the reads, 64 % of the bases of the ONT workload) go through k_multiset_uq, which does not sort what occurs once; the
+    // longer ones (and the rare read with too many repeated keys) are handed to the general list-emitting kernel.
+    const char *uq_env = getenv("KMU_PMH_UQ"); // 0: every read through the counting-sort kernel (A/B)
+    const bool uq = split && plain && !(uq_env && atoi(uq_env) == 0);
+    bool main_launched = false;
+    if (uq) {
+        {
+            typedef UqShape<512, 16, 2048> SA;
+            const auto ka = k_multiset_uq<512, 16, 2048, 4>;
+            KMU_HIP(ctx, hipFuncSetAttribute((const void *) ka, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            KernelTimer t(ctx, "k_multiset_uq");
+            hipLaunchKernelGGL(ka, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(ds.n_seq, (uint64_t) cus * 2))), dim3(512), SA::LDS,
+                               ctx->stream, a);
+        }
+        KMU_HIP(ctx, hipGetLastError());
+        uint32_t n_long = 0;
+        KMU_HIP(ctx, hipMemcpyAsync(&n_long, a.queue + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const char *uq2_env = getenv("KMU_PMH_UQ2"); // 0: no second shape (A/B)
+        if (n_long && !(uq2_env && atoi(uq2_env) == 0)) { // the second shape: reads of up to 20 480 k-mers, from the first one's list
+            typedef UqShape<1024, 17, 4096> SB;
+            const auto kb = k_multiset_uq<1024, 17, 4096, 4>;
+            void *rl2;
+            KMU_TRY(dev_buf(ctx, "pmh.redo2", (size_t) ds.n_seq * 4 + 64, &rl2));
+            KMU_HIP(ctx, hipFuncSetAttribute((const void *) kb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            KMU_HIP(ctx, hipMemsetAsync(a.queue, 0, 256, ctx->stream));
+            uint32_t *list1 = a.redo_list;
+            a.read_list = list1;
+            a.redo_list = (uint32_t *) rl2;
+            a.n_queue = n_long;
+            {
+                KernelTimer t(ctx, "k_multiset_uq");
+                hipLaunchKernelGGL(kb, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(n_long, (uint64_t) cus))), dim3(1024), SB::LDS, ctx->stream, a);
+            }
+            KMU_HIP(ctx, hipGetLastError());
+            KMU_HIP(ctx, hipMemcpyAsync(&n_long, a.queue + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
+            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            a.read_list = nullptr;
+            a.n_queue = ds.n_seq;
+        }
+        if (n_long) {
+            const sketch_kernel_t kgen = k_sketch_pmh3a<false, false, true>; // reads its reads from a list; repetitive reads in rounds
+            if (lds_max > 64 * 1024 && hipFuncSetAttribute((const void *) kgen, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_max) != hipSuccess)
+                return fail(ctx, KMU_E_HIP, "hipFuncSetAttribute failed for the general list-emitting kernel");
+            KMU_HIP(ctx, hipMemsetAsync(a.queue, 0, 256, ctx->stream));
+            a.read_list = a.redo_list;
+            a.n_queue = n_long;
+            const int gridl = (int) std::min<uint64_t>((uint64_t) n_long, (uint64_t) cus * blocks_per_cu);
+            KernelTimer t(ctx, "k_sketch_pmh3a");
+            hipLaunchKernelGGL(kgen, dim3(gridl), dim3(threads), lds, ctx->stream, a);
+            KMU_HIP(ctx, hipGetLastError());
+            a.read_list = nullptr;
+            a.n_queue = ds.n_seq;
+        }
+        KMU_HIP(ctx, hipMemsetAsync(a.queue, 0, 256, ctx->stream)); // (the points kernel's cursor; nothing is left to redo)
+        main_launched = true;
+    }
+    if (!main_launched) {
         KernelTimer t(ctx, bottomk ? "k_sketch_bottomk" : "k_sketch_pmh3a");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
@@ -1863,7 +2211,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
         KMU_HIP(ctx, hipGetLastError());
     }
-    if (plain) { // (after the points kernel, whose row for such a sequence is empty)
+    if (plain && !uq) { // (after the points kernel, whose row for such a sequence is empty)
         // sequences whose k-mers overflowed a pass (repetitive ones): the general instantiation redoes them in rounds
         uint32_t n_redo = 0;
         KMU_HIP(ctx, hipMemcpyAsync(&n_redo, a.queue + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
