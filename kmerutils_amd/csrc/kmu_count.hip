@@ -644,10 +644,18 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t item, int region_bits, int
     return (region_of_hash(IT == IT_HASH ? item : khash(item), region_bits) >> shift) & mask;
 }
 
+// Segmented output (the single-pass partition, see partitioned_add): bin b of this unit owns the fixed range
+// [(bin_base + b) * bincap + end_rel - cap, (bin_base + b) * bincap + end_rel) of `out`, sized from the expected number of
+// items with a margin; an item beyond its range is dropped and reported in *ovf (the caller then takes the exact route).
+struct SegOut {
+    uint64_t bin_base, bincap, end_rel, cap;
+    uint32_t *ovf;
+};
+
 // it[j] == CKEY_EMPTY marks "no k-mer".  All 1024 threads call this together.
-template <int IT>
+template <int IT, bool SEG = false>
 __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLds &l, uint32_t nbins, int region_bits,
-                                             int shift, uint32_t mask, uint64_t *out) {
+                                             int shift, uint32_t mask, uint64_t *out, const SegOut *sg = nullptr) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t br[16];
 #pragma unroll
@@ -693,16 +701,21 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
             v[u] = p < total ? l.stage[p] : CKEY_EMPTY;
         }
+        uint64_t lim[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
             const uint32_t bin = p < total ? digit_of<IT>(v[u], region_bits, shift, mask) : 0u;
             dst[u] = l.gbase[bin] + (uint64_t) (p - l.lstart[bin]);
+            lim[u] = SEG ? (sg->bin_base + bin) * sg->bincap + sg->end_rel : ~0ull;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
-            if (p < total) out[dst[u]] = v[u];
+            if (p < total) {
+                if (!SEG || dst[u] < lim[u]) out[dst[u]] = v[u];
+                else *sg->ovf = 1u;
+            }
         }
     }
     lds_barrier();
@@ -722,9 +735,21 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
     lds_barrier();
 }
 
+// the unused tail of every segment of this unit is filled with "no k-mer" marks (the readers of the next level skip them):
+// wave w takes bins w, w + 16, ...; its lanes store consecutive items
+__device__ __forceinline__ void seg_fill_tails(const ScatterLds &l, uint32_t nbins, const SegOut &sg, uint64_t *out) {
+    const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, lane = (uint32_t) lane_id();
+    for (uint32_t b = wave; b < nbins; b += nwaves) {
+        const uint64_t end = (sg.bin_base + b) * sg.bincap + sg.end_rel;
+        uint64_t cur = l.gbase[b];
+        cur = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (cur >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) cur);
+        for (uint64_t i = cur + lane; i < end; i += 64) out[i] = CKEY_EMPTY;
+    }
+}
+
 // the code words of wave step `st`: this lane's word and (lanes 0/1) the two words after the wave's last
 __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t total, uint64_t st, bool active, uint32_t &w0,
-                                               uint32_t &ex) {
+                                               uint32_t &ex, uint32_t *bad_acc = nullptr) {
     w0 = 0;
     ex = 0;
     if (!active) return; // wave-uniform
@@ -733,6 +758,7 @@ __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t to
     uint32_t bad, bad2;
     w0 = load_code_word(s, st * 64 + (uint64_t) lane_id(), bad);
     ex = load_code_word(s, st * 64 + 64 + (uint64_t) (lane_id() & 1), bad2);
+    if (bad_acc) *bad_acc |= bad; // (every word is some step's own word: the halo words need no second look)
 }
 
 // up to 16 canonical k-mers of this lane for wave step `st` (CKEY_EMPTY where a k-mer would straddle a read end)
@@ -785,37 +811,52 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
 }
 
 // level 1, pass 2: scatter the canonical k-mers into their level-1 partitions (private ranges per unit)
+// seg.cap != 0: the single-pass form -- no histogram ran; unit u (= seg.unit_base + blockIdx.x) writes bin b into its own
+// segment [b * seg.bincap + u * seg.cap, + seg.cap) of `out` (offs1 / binstart1 are not read), and validates the bases.
+struct SegPlan1 {
+    uint64_t cap, bincap, unit_base, step_base; // step_base: first wave step of blockIdx.x == 0 (chunked calls)
+    uint32_t *ovf;
+    uint32_t *err;
+};
 __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
                                                         int k, PartPlan pl, const uint64_t *offs1,
-                                                        const uint64_t *binstart1, uint64_t *out) {
+                                                        const uint64_t *binstart1, uint64_t *out, SegPlan1 seg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1;
     ScatterLds l = scatter_lds(smem, bins1);
+    const bool SEGM = seg.cap != 0;
+    const uint64_t unit = seg.unit_base + blockIdx.x;
+    SegOut sg{0, seg.bincap, (unit + 1) * seg.cap, seg.cap, seg.ovf};
     for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) {
-        l.gbase[b] = binstart1[b] + offs1[(uint64_t) blockIdx.x * bins1 + b];
+        l.gbase[b] = SEGM ? (uint64_t) b * seg.bincap + unit * seg.cap : binstart1[b] + offs1[(uint64_t) blockIdx.x * bins1 + b];
         l.lstart[b] = 0;
     }
     if (threadIdx.x == 0) l.lstart[bins1] = 0;
     lds_barrier();
     const uint64_t total = offsets[n_seq], start = offsets[0];
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
-    const uint64_t s0 = (uint64_t) blockIdx.x * pl.steps_per_unit;
+    const uint64_t s0 = seg.step_base + (uint64_t) blockIdx.x * pl.steps_per_unit;
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    uint32_t r_hint = 0xFFFFFFFFu, w0, ex;
-    flat_step_load(bases, total, s0 + wave, s0 + wave < s1, w0, ex);
+    uint32_t r_hint = 0xFFFFFFFFu, w0, ex, bad = 0;
+    flat_step_load(bases, total, s0 + wave, s0 + wave < s1, w0, ex, &bad);
     for (uint64_t t0 = s0; t0 < s1; t0 += nwaves) {
         uint64_t it[16];
         flat_step_items(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
         // the next step's words are requested now; their latency hides under the tile sort
-        flat_step_load(bases, total, t0 + nwaves + wave, t0 + nwaves + wave < s1, w0, ex);
+        flat_step_load(bases, total, t0 + nwaves + wave, t0 + nwaves + wave < s1, w0, ex, &bad);
         if (pl.owner_parts) tile_scatter<IT_OWNER>(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
         else { // from here on the k-mers travel as their table hash
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
-            tile_scatter<IT_HASH>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
+            if (SEGM) tile_scatter<IT_HASH, true>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out, &sg);
+            else tile_scatter<IT_HASH>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
         }
+    }
+    if (SEGM) {
+        seg_fill_tails(l, bins1, sg, out);
+        if (bad) atomicOr(seg.err, DERR_NON_ACGT); // (the histogram pass that used to validate the bases did not run)
     }
 }
 
@@ -913,13 +954,21 @@ __global__ void __launch_bounds__(256) k_arr_scan_b(const uint64_t *tot, const u
     }
 }
 
+// seg_cap != 0: the single-pass form -- no histogram ran; unit (partition p, chunk c) writes bin b into its own segment
+// [((p * bins + b) * chunks + c) * seg_cap, + seg_cap) of `out` (offs_rel / outbounds are not read); "no k-mer" marks in the
+// input (the tails of the previous level's segments) are skipped like everywhere else.
 template <int IT>
 __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
-                                                      const uint64_t *offs_rel, const uint64_t *outbounds, uint64_t *out) {
+                                                      const uint64_t *offs_rel, const uint64_t *outbounds, uint64_t *out,
+                                                      uint64_t seg_cap, uint32_t *seg_ovf) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds l = scatter_lds(smem, pl.bins);
+    const bool SEGM = seg_cap != 0;
+    const uint64_t sp = blockIdx.x / pl.chunks, sc = blockIdx.x % pl.chunks;
+    SegOut sg{sp * pl.bins, (uint64_t) pl.chunks * seg_cap, (sc + 1) * seg_cap, seg_cap, seg_ovf};
     for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) {
-        l.gbase[b] = outbounds[(uint64_t) (blockIdx.x / pl.chunks) * pl.bins + b] + offs_rel[(uint64_t) blockIdx.x * pl.bins + b];
+        l.gbase[b] = SEGM ? ((sp * pl.bins + b) * pl.chunks + sc) * seg_cap
+                          : outbounds[(uint64_t) (blockIdx.x / pl.chunks) * pl.bins + b] + offs_rel[(uint64_t) blockIdx.x * pl.bins + b];
         l.lstart[b] = 0;
     }
     if (threadIdx.x == 0) l.lstart[pl.bins] = 0;
@@ -947,10 +996,18 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
             tile_scatter<IT_HASH>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
+        } else if (IT == IT_HASH && SEGM) {
+            tile_scatter<IT_HASH, true>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out, &sg);
         } else {
             tile_scatter<IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
         }
     }
+    if (IT == IT_HASH && SEGM) seg_fill_tails(l, pl.bins, sg, out);
+}
+
+// bounds[i] = i * stride (the input partitions of the single-pass level 2: level 1's fixed-size bins)
+__global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, uint64_t stride) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = i * stride;
 }
 
 // build: one workgroup per region.  The region (keys + counts) lives in LDS while its k-mers are inserted, then it
@@ -967,7 +1024,8 @@ static constexpr int BUILD_PRE = 6;
 template <int IT>
 __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *items, const uint64_t *leafstart,
                                                               uint32_t n_regions, CountTable t, int in_mode, int out_compact,
-                                                              uint32_t *rcount, unsigned long long *stats, uint32_t *err) {
+                                                              uint32_t *rcount, unsigned long long *stats, uint32_t *err,
+                                                              uint64_t leaf_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t R = t.rmask + 1; // >= 1024
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
@@ -980,7 +1038,10 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *it
     uint64_t st_d = 0, st_u = 0, st_o = 0;
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
         const uint64_t gbase = (uint64_t) r * R;
-        const uint64_t i0 = leafstart ? leafstart[r] : 0, i1 = leafstart ? leafstart[r + 1] : 0;
+        // the items of region r: [leafstart[r], leafstart[r + 1]), or a fixed-size range that may hold "no k-mer" marks (the
+        // leaves of the single-pass partition), or none (the expansion of a compact table)
+        const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
+        const uint64_t i1 = leaf_stride ? i0 + leaf_stride : leafstart ? leafstart[r + 1] : 0;
         uint64_t pre_it[BUILD_PRE];
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++) {
@@ -1025,7 +1086,10 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *it
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++)
             if (pre_it[q] != CKEY_EMPTY) insert(pre_it[q]);
-        for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) insert(items[i]);
+        for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) {
+            const uint64_t item = items[i];
+            if (item != CKEY_EMPTY) insert(item);
+        }
         lds_barrier();
         if (!out_compact) {
             for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
@@ -1118,7 +1182,8 @@ static int grid_for(const kmu_ctx *ctx, uint64_t n, int per_block) {
 // `to_compact`: leave the table compact (the partitioned builds) or as the open-addressing image.
 static size_t build_lds(const kmu_counter *c) { return ((size_t) 12 << c->rbits) + 64 * 8 + 65 * 4 + 16; }
 template <int IT>
-static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, bool to_compact, uint32_t *d_err) {
+static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, bool to_compact, uint32_t *d_err,
+                        uint64_t leaf_stride = 0) {
     kmu_ctx *ctx = c->ctx;
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
@@ -1127,7 +1192,7 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     {
         KernelTimer tm(ctx, items ? "k_part_build" : "k_part_expand");
         hipLaunchKernelGGL(k_part_build<IT>, dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
-                           table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err);
+                           table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride);
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;
@@ -1162,6 +1227,140 @@ static int materialize(kmu_counter *c) {
     }
     c->stats_cached = false; // whoever asked for the image may change it
     return KMU_OK;
+}
+
+// ---- the single-pass partition -------------------------------------------------------------------------------------------
+// The exact route reads everything twice per level: a histogram pass gives every unit exact private output ranges, then the
+// scatter.  The k-mers travel as khash(k-mer), so the digits are uniform: a unit's share of a bin is its item count / bins
+// with a standard deviation of sqrt(that).  Here every (unit, bin) gets a FIXED segment of mean + 7 sigma + 64 items (16 % over
+// the mean at the bench size), the scatters run without their histogram passes (-7.6 and -6.0 ms), the unused tail of every
+// segment is filled with "no k-mer" marks that the next level skips (+16 % traffic on three streams), and the region build
+// takes fixed-size leaves.  A segment that overflows (k-mers that are not spread by the hash: a genome of one repeated
+// k-mer) raises a flag that is read before the build touches the table: the call then takes the exact route from scratch.
+// Level 1 without a global histogram is also what lets kmu_sketch_count partition a chunk while the next one is uploaded.
+static bool seg_partition_wanted(uint64_t total_bases) {
+    const char *e = getenv("KMU_COUNT_SEG"); // 0: always the exact two-pass levels (A/B); 2: also for small batches (tests)
+    if (e && atoi(e) == 0) return false;
+    if (e && atoi(e) == 2) return true;
+    return total_bases >= (1ull << 27); // (the margins are a small share of the mean only for big batches)
+}
+static uint64_t seg_cap_for(double mean) {
+    double pct = 1.0;
+    if (const char *e = getenv("KMU_COUNT_SEG_PCT")) pct = std::max(0.01, atof(e) / 100.0); // tests: force overflows
+    const double cap = (mean + 7.0 * std::sqrt(mean) + 64.0) * pct;
+    return ((uint64_t) cap + 15) & ~(uint64_t) 15; // whole 128-byte lines
+}
+struct SegPlan {
+    uint32_t units1, steps_per_unit;
+    uint64_t cap1, bincap1, cap2, leafcap;
+    uint32_t chunks2;
+};
+static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan &pl) {
+    SegPlan sp;
+    const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
+    const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
+    // units of level 1: enough to fill the chip, few enough that a unit's share of a bin stays around 2 048 items
+    const uint64_t by_size = total_bases / ((uint64_t) bins1 * 2048) + 1;
+    sp.units1 = (uint32_t) std::min<uint64_t>(nsteps, std::min<uint64_t>(std::max<uint64_t>(by_size, (uint64_t) ctx->num_cus), (uint64_t) ctx->num_cus * 4));
+    sp.steps_per_unit = (uint32_t) ((nsteps + sp.units1 - 1) / sp.units1);
+    sp.units1 = (uint32_t) ((nsteps + sp.steps_per_unit - 1) / sp.steps_per_unit);
+    sp.cap1 = seg_cap_for((double) sp.steps_per_unit * 1024.0 / bins1);
+    sp.bincap1 = (uint64_t) sp.units1 * sp.cap1;
+    sp.chunks2 = 1; // a level-2 unit is a whole level-1 bin: the biggest segments, the smallest margins
+    sp.cap2 = seg_cap_for((double) total_bases / bins1 / sp.chunks2 / bins2);
+    sp.leafcap = (uint64_t) sp.chunks2 * sp.cap2;
+    return sp;
+}
+// state of a single-pass partition between its level-1 launches (kmu_sketch_count runs them chunk by chunk under the upload)
+struct SegRun {
+    PartPlan pl;
+    SegPlan sp;
+    DevSeqs ds;
+    uint64_t total_bases = 0;
+    uint32_t units_done = 0;
+    void *A = nullptr, *B = nullptr, *ovf = nullptr, *bnd = nullptr;
+    uint32_t *d_err = nullptr;
+};
+// own_buffer: the level-1 output must survive other users of the shared scratch "cnt.partA" (kmu_sketch_count's chunked form:
+// the sketch of the next chunk writes its (key, weight) lists there while this partition is still being filled)
+static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, const PartPlan &pl_in, uint32_t *d_err, SegRun *run,
+                     bool own_buffer = false) {
+    kmu_ctx *ctx = c->ctx;
+    run->pl = pl_in;
+    run->sp = seg_plan(ctx, total_bases, pl_in);
+    run->ds = ds;
+    run->total_bases = total_bases;
+    run->units_done = 0;
+    run->d_err = d_err;
+    const uint32_t bins1 = 1u << pl_in.b1;
+    const uint64_t n_regions = 1ull << pl_in.region_bits;
+    run->pl.units1 = run->sp.units1;
+    run->pl.steps_per_unit = run->sp.steps_per_unit;
+    KMU_TRY(dev_buf(ctx, own_buffer ? "cnt.segA" : "cnt.partA", (size_t) bins1 * run->sp.bincap1 * 8 + 64, &run->A));
+    KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * run->sp.leafcap * 8 + 64, &run->B));
+    KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &run->ovf));
+    KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &run->bnd));
+    KMU_HIP(ctx, hipMemsetAsync(run->ovf, 0, 64, ctx->stream));
+    if (!(ctx->lds_attr_set & 1u)) {
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->lds_attr_set |= 1u;
+    }
+    return KMU_OK;
+}
+// level 1 for the units whose wave steps (and their 32-base halo) lie inside the first `bases_ready` bases of the stream
+static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
+    kmu_ctx *ctx = c->ctx;
+    const uint64_t steps_ready = bases_ready >= run->total_bases ? ((run->total_bases + 15) / 16 + 63) / 64
+                                                                 : (bases_ready >= 32 ? (bases_ready - 32) / 1024 : 0);
+    uint32_t upto = bases_ready >= run->total_bases ? run->sp.units1
+                                                    : (uint32_t) std::min<uint64_t>(steps_ready / run->sp.steps_per_unit, run->sp.units1);
+    if (bases_ready < run->total_bases) { // partial launches in whole rounds of one workgroup per CU: a launch of fewer leaves CUs idle
+        const uint32_t round = (uint32_t) ctx->num_cus;
+        if (upto < run->units_done + round) return KMU_OK;
+        upto = run->units_done + (upto - run->units_done) / round * round;
+    }
+    if (upto <= run->units_done) return KMU_OK;
+    const uint32_t bins1 = 1u << run->pl.b1;
+    {
+        KernelTimer tm(ctx, "k_part_scatter1");
+        hipLaunchKernelGGL(k_part_scatter1, dim3(upto - run->units_done), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
+                           run->ds.bases, run->ds.offsets, run->ds.n_seq, c->p.kmer_size, run->pl, (const uint64_t *) nullptr,
+                           (const uint64_t *) nullptr, (uint64_t *) run->A,
+                           SegPlan1{run->sp.cap1, run->sp.bincap1, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
+                                    (uint32_t *) run->ovf, run->d_err});
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    run->units_done = upto;
+    return KMU_OK;
+}
+// the rest of level 1, level 2, the overflow flag, the build.  *taken = 0: a segment overflowed, the table is untouched.
+static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
+    kmu_ctx *ctx = c->ctx;
+    *taken = 0;
+    KMU_TRY(seg_level1(c, run, run->total_bases));
+    const uint32_t bins1 = 1u << run->pl.b1, bins2 = 1u << run->pl.b2;
+    hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) run->bnd, (uint64_t) bins1 + 1, run->sp.bincap1);
+    {
+        ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2};
+        KernelTimer tm(ctx, "k_part_scatter2");
+        hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
+                           (const uint64_t *) run->A, (const uint64_t *) run->bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
+                           (uint64_t *) run->B, run->sp.cap2, (uint32_t *) run->ovf);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    uint32_t h_ovf = 0; // read before the table is touched: an overflow leaves the call to the exact route
+    KMU_HIP(ctx, hipMemcpyAsync(&h_ovf, run->ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_ovf) return KMU_OK;
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(), run->d_err, run->sp.leafcap));
+    *taken = 1;
+    return KMU_OK;
+}
+static int seg_partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, const PartPlan &pl_in, uint32_t *d_err, int *taken) {
+    SegRun run;
+    KMU_TRY(seg_begin(c, ds, total_bases, pl_in, d_err, &run));
+    return seg_finish(c, &run, taken);
 }
 
 // the radix-partitioned build over device-resident ASCII reads
@@ -1209,6 +1408,11 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KMU_TRY(dev_buf(ctx, "cnt.tot2", (size_t) n_regions * 8, &tot2));
     }
     const int k = c->p.kmer_size;
+    if (pl.b2 && !dbg_split && seg_partition_wanted(total_bases)) {
+        int taken = 0;
+        KMU_TRY(seg_partitioned_add(c, ds, total_bases, pl, d_err, &taken));
+        if (taken) return KMU_OK; // (else a segment overflowed -- very skewed k-mers -- and nothing was touched: the exact route)
+    }
     if (!(ctx->lds_attr_set & 1u)) { // function attributes are per device: remembered per context, not per process
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1230,7 +1434,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1,
-                           (uint64_t *) A);
+                           (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr});
     }
     const uint64_t *items = (const uint64_t *) A;
     const uint64_t *leaves = (const uint64_t *) binstart1;
@@ -1254,7 +1458,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
             hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
                                (const uint64_t *) A, (const uint64_t *) binstart1, ap, (const uint64_t *) offs2,
                                (const uint64_t *) leafstart,
-                               (uint64_t *) B);
+                               (uint64_t *) B, 0ull, (uint32_t *) nullptr);
         }
         items = (const uint64_t *) B;
         leaves = (const uint64_t *) leafstart;
@@ -1323,13 +1527,13 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
             const size_t slds = scatter_lds_bytes(bins);
             if (!hashed_out)
                 hipLaunchKernelGGL(k_arr_scatter<IT_KEY>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
-                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
+                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr);
             else if (!first_done)
                 hipLaunchKernelGGL(k_arr_scatter<IT_KEY_TO_HASH>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds,
-                                   ap, (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
+                                   ap, (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr);
             else
                 hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
-                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf);
+                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr);
             first_done = true;
         }
         KMU_HIP(ctx, hipGetLastError());
@@ -1409,7 +1613,7 @@ static int owner_scatter(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1, dim3(op.pl.units1), dim3(SCATTER_THREADS), scatter_lds_bytes(op.pl.owner_parts), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, c->p.kmer_size, op.pl, (const uint64_t *) op.offs1,
-                           (const uint64_t *) op.binstart1, (uint64_t *) out);
+                           (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr});
     }
     KMU_HIP(ctx, hipGetLastError());
     *dev_out = (uint64_t *) out;
@@ -1689,7 +1893,49 @@ static int flat_stream_extent(kmu_ctx *ctx, const uint64_t *host_offsets, uint32
 
 } // extern "C"
 
+// the partition plan of a table (levels and their fan-out); false: more than two levels would be needed
+static bool part_plan_for(const kmu_counter *c, PartPlan *pl) {
+    memset(pl, 0, sizeof *pl);
+    pl->region_bits = c->lg - c->rbits;
+    if (pl->region_bits <= 11) { pl->b1 = pl->region_bits; pl->b2 = 0; }
+    else { pl->b1 = (pl->region_bits + 1) / 2; pl->b2 = pl->region_bits - pl->b1; }
+    return pl->b1 <= 11 && pl->b2 <= 11;
+}
+
 namespace kmu {
+// kmu_sketch_count on host buffers: the count's level-1 partition runs chunk by chunk under the upload (the single-pass
+// partition needs no histogram of the whole batch).  count_chunked_begin returns *on = 0 when that route does not apply
+// (a distributed counter, a small batch, a one-level table): the caller then adds the reads in one go at the end.
+struct CountChunked {
+    SegRun run;
+};
+int count_chunked_begin(kmu_counter *c, DevSeqs &all, const uint64_t *host_offsets, uint32_t *d_err, void **handle, int *on) {
+    *on = 0;
+    *handle = nullptr;
+    if (c->dist || all.n_seq == 0) return KMU_OK;
+    uint64_t total_bases = 0;
+    KMU_TRY(flat_stream_extent(c->ctx, host_offsets, all.n_seq, KMU_MEM_HOST, all, &total_bases));
+    PartPlan pl;
+    const bool partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
+    if (!partitioned || !part_plan_for(c, &pl) || !pl.b2 || !seg_partition_wanted(total_bases)) return KMU_OK;
+    CountChunked *h = new CountChunked();
+    const int rc = seg_begin(c, all, total_bases, pl, d_err, &h->run, true);
+    if (rc != KMU_OK) { delete h; return rc; }
+    *handle = h;
+    *on = 1;
+    return KMU_OK;
+}
+int count_chunked_level1(kmu_counter *c, void *handle, uint64_t bases_ready) { return seg_level1(c, &((CountChunked *) handle)->run, bases_ready); }
+int count_chunked_finish(kmu_counter *c, void *handle) {
+    CountChunked *h = (CountChunked *) handle;
+    int taken = 0;
+    int rc = seg_finish(c, &h->run, &taken);
+    if (rc == KMU_OK && !taken) rc = local_add(c, h->run.ds, h->run.total_bases, h->run.d_err); // a segment overflowed: the exact route
+    delete h;
+    return rc;
+}
+void count_chunked_abort(void *handle) { delete (CountChunked *) handle; }
+
 // What kmu_sketch_count needs of a counter: the canonical k-mers of device-resident unpacked reads go in, in two halves
 // (a distributed counter's exchange is in flight between them: the caller's kernels on the context's stream run under it).
 // host_offsets: the caller's host copy of the offsets (mem == KMU_MEM_HOST: already re-based to the staged stream) or null.

@@ -191,6 +191,10 @@ void comm_free(kmu_ctx *ctx); // kmu_comm.hip
 int count_add_device_begin(kmu_counter *c, DevSeqs &ds, const uint64_t *host_offsets, int mem, uint32_t *d_err);
 int count_add_device_end(kmu_counter *c);
 kmu_ctx *counter_ctx(kmu_counter *c);
+int count_chunked_begin(kmu_counter *c, DevSeqs &all, const uint64_t *host_offsets, uint32_t *d_err, void **handle, int *on);
+int count_chunked_level1(kmu_counter *c, void *handle, uint64_t bases_ready);
+int count_chunked_finish(kmu_counter *c, void *handle);
+void count_chunked_abort(void *handle);
 
 int check_kmer(kmu_ctx *ctx, int kmer_type, int k);
 inline bool kmer_is_aa(int t) { return t == KMU_KMERAA32BIT || t == KMU_KMERAA64BIT; }

@@ -2029,7 +2029,9 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             const double cu_share = (double) ctx->num_cus / 256.0;
             const double t_ideal = (double) total / (2.05e8 * cu_share), t_tail = (double) len_stats[0] / 4.0e4; // ms
             const double overhang = t_tail >= t_ideal ? t_tail - 0.5 * t_ideal : t_tail * t_tail / (2.0 * t_ideal);
-            const double gain = 0.16 * (double) total / (4.9e7 * cu_share);
+            // (r02: with the reads that fit a workgroup's registers on k_multiset_uq the two-kernel route takes 53 ms where the
+            //  single kernel takes 87 on the ONT workload: 39 % of the single kernel's time, 16 % before)
+            const double gain = 0.39 * (double) total / (4.9e7 * cu_share);
             if (gain <= overhang + 0.02) split = false; // (0.02 ms: the second launch)
         }
     }
@@ -2633,7 +2635,14 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     all.offsets = (const uint64_t *) d_o;
     all.n_seq = n_seq;
     all.total_bytes = total;
-    if (n_chunks) rc = upload(0);
+    // the count's level-1 partition runs under the upload too, for the part of the stream that has arrived
+    void *cc = nullptr;
+    int cc_on = 0;
+    if (counter && n_seq) {
+        DevSeqs dc = all;
+        rc = count_chunked_begin(counter, dc, h_off.data(), d_err, &cc, &cc_on);
+    }
+    if (n_chunks && rc == KMU_OK) rc = upload(0);
     for (size_t c = 0; c < n_chunks && rc == KMU_OK; c++) {
         if (c + 1 < n_chunks) rc = upload(c + 1);
         if (rc != KMU_OK) break;
@@ -2648,12 +2657,19 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
             hipMemcpyAsync((uint8_t *) sig_out + (size_t) cut[c] * rowb, d_rows, (size_t) ds.n_seq * rowb, hipMemcpyDeviceToHost,
                            ctx->pipe_d2h) != hipSuccess)
             rc = fail(ctx, KMU_E_HIP, "signature download failed: %s", hipGetErrorString(hipGetLastError()));
+        if (rc == KMU_OK && cc_on) rc = count_chunked_level1(counter, cc, h_off[cut[c + 1]]);
     }
     if (rc == KMU_OK && counter) { // the whole read set is resident by now: ev_up of the last chunk has been waited for
-        DevSeqs dc = all;
-        rc = count_add_device_begin(counter, dc, h_off.data(), KMU_MEM_HOST, d_err);
-        if (rc == KMU_OK) rc = count_add_device_end(counter);
+        if (cc_on) {
+            rc = count_chunked_finish(counter, cc);
+            cc = nullptr;
+        } else {
+            DevSeqs dc = all;
+            rc = count_add_device_begin(counter, dc, h_off.data(), KMU_MEM_HOST, d_err);
+            if (rc == KMU_OK) rc = count_add_device_end(counter);
+        }
     }
+    if (cc) count_chunked_abort(cc);
     (void) hipStreamSynchronize(ctx->pipe_h2d);
     (void) hipStreamSynchronize(ctx->pipe_d2h);
     for (size_t c = 0; c < n_chunks; c++) {

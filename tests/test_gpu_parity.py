@@ -1150,3 +1150,43 @@ def test_count_compact_state(ctx, oracle, monkeypatch):
     c.add_kmers(wk[:100])                                          # direct insertion on the open image
     assert np.array_equal(c.query(wk[:200]), np.minimum(wc[:200].astype(np.int64) + (np.arange(200) < 100), 255))
     c.close()
+
+
+@pytest.mark.parametrize("pct", ["100", "60"])
+def test_count_single_pass_partition(ctx, oracle, monkeypatch, pct):
+    """KMU_COUNT_SEG=2: the partitioned build with fixed-size segments and no histogram passes (what big batches take by
+    themselves), forced on a batch the oracle can count; pct 60: segments smaller than their expected fill overflow, the
+    flag is read before the table is touched and the exact route takes over.  Same table either way, also for a second
+    batch into the same counter and with a non-ACGT byte in the reads."""
+    import torch
+    from kmerutils_amd.lib import KmuError
+    monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    monkeypatch.setenv("KMU_COUNT_SEG_PCT", pct)
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    dev = torch.device("cuda", 0)
+    bases, off, lens = synth.ont_reads_device(1500, 9_000_000, 2_000_000, 0xC7, dev)
+    hb, ho = bases[:int(off[-1])].cpu().numpy(), off.cpu().numpy().astype(np.uint64)
+    nk = int(np.maximum(lens - 30, 0).sum())
+    c = ctx.counter(A.KMER64BIT, 31, 8, 16_000_000)  # 2^25 slots: 8 192 regions, two partition levels
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    c.add_reads(bases, off)
+    ctx.profile_enable(False)
+    prof = ctx.profile_get()
+    assert ("k_part_hist1" in prof) == (pct == "60")  # the histogram passes only run on the exact route
+    o = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 22)
+    o.add_reads(hb, ho)
+    assert (c.nb_distinct(), c.nb_unique(), c.nb_occurrences()) == (o.nb_distinct(), o.nb_unique(), nk)
+    wk, wc = o.dump(2)
+    gk, gc = c.dump(2)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    c.add_reads(bases, off)  # onto a table that holds something
+    assert c.nb_occurrences() == 2 * nk and c.nb_distinct() == o.nb_distinct()
+    c.close()
+    bad = bases.clone()
+    bad[12345] = ord("N")
+    c = ctx.counter(A.KMER64BIT, 31, 8, 16_000_000)
+    with pytest.raises(KmuError) as ei:
+        c.add_reads(bad, off)
+    assert ei.value.code == A.E_NON_ACGT
+    c.close()

@@ -105,3 +105,36 @@ def test_sketch_count_distributed_world1(oracle, monkeypatch):
             _check_counts(c, oracle, bases, off, 31)
             c.close()
     ctx.close()
+
+
+def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
+    """host form with the count's level-1 partition running chunk by chunk under the upload (the single-pass partition,
+    forced on a batch the oracle can count: KMU_COUNT_SEG=2), nine 1 MB chunks; also with segments that overflow (the
+    exact route redoes the whole batch at the end)"""
+    import torch
+    monkeypatch.setenv("KMU_PIPE_CHUNK_MB", "1")
+    monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    dev = torch.device("cuda", 0)
+    bases, off, lens = synth.ont_reads_device(1500, 9_000_000, 2_000_000, 0xC8, dev)
+    hb, ho = bases[:int(off[-1])].cpu().numpy(), off.cpu().numpy().astype(np.uint64)
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    want = oracle.sketch(hb, ho, p)
+    o = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 22)
+    o.add_reads(hb, ho)
+    wk, wc = o.dump(2)
+    for pct in ("100", "60"):
+        monkeypatch.setenv("KMU_COUNT_SEG_PCT", pct)
+        c = ctx.counter(A.KMER64BIT, 31, 8, 16_000_000)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        got = ctx.sketch_count(hb, ho, p, counter=c)
+        ctx.profile_enable(False)
+        prof = ctx.profile_get()
+        assert ("k_part_hist1" in prof) == (pct == "60")  # the histogram passes only run when the exact route takes over
+        # (overflowing segments: the chunked attempt, the one-go attempt of the exact route's entry, then the exact levels)
+        assert prof["k_part_scatter2"][0] == (1 if pct == "100" else 3)
+        assert np.array_equal(got, want)
+        assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())
+        gk, gc = c.dump(2)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        c.close()
