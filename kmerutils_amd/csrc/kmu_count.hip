@@ -995,14 +995,15 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
-            tile_scatter<IT_HASH>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
+            if (SEGM) tile_scatter<IT_HASH, true>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out, &sg);
+            else tile_scatter<IT_HASH>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
         } else if (IT == IT_HASH && SEGM) {
             tile_scatter<IT_HASH, true>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out, &sg);
         } else {
             tile_scatter<IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
         }
     }
-    if (IT == IT_HASH && SEGM) seg_fill_tails(l, pl.bins, sg, out);
+    if ((IT == IT_HASH || IT == IT_KEY_TO_HASH) && SEGM) seg_fill_tails(l, pl.bins, sg, out);
 }
 
 // bounds[i] = i * stride (the input partitions of the single-pass level 2: level 1's fixed-size bins)
@@ -1238,6 +1239,15 @@ static int materialize(kmu_counter *c) {
 // takes fixed-size leaves.  A segment that overflows (k-mers that are not spread by the hash: a genome of one repeated
 // k-mer) raises a flag that is read before the build touches the table: the call then takes the exact route from scratch.
 // Level 1 without a global histogram is also what lets kmu_sketch_count partition a chunk while the next one is uploaded.
+// the partition plan of a table (levels and their fan-out); false: more than two levels would be needed
+static bool part_plan_for(const kmu_counter *c, PartPlan *pl) {
+    memset(pl, 0, sizeof *pl);
+    pl->region_bits = c->lg - c->rbits;
+    if (pl->region_bits <= 11) { pl->b1 = pl->region_bits; pl->b2 = 0; }
+    else { pl->b1 = (pl->region_bits + 1) / 2; pl->b2 = pl->region_bits - pl->b1; }
+    return pl->b1 <= 11 && pl->b2 <= 11;
+}
+
 static bool seg_partition_wanted(uint64_t total_bases) {
     const char *e = getenv("KMU_COUNT_SEG"); // 0: always the exact two-pass levels (A/B); 2: also for small batches (tests)
     if (e && atoi(e) == 0) return false;
@@ -1548,9 +1558,65 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
 
 } // namespace kmu
 
+// the single-pass partition for an ARRAY of canonical k-mers (what the owner of a key range receives in the OCCURRENCES
+// route of a distributed add): level 1 cuts the array into chunks, every (chunk, bin) a fixed segment, no histograms
+static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64_t n, const PartPlan &pl, uint32_t *d_err, int *taken) {
+    kmu_ctx *ctx = c->ctx;
+    *taken = 0;
+    const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
+    const uint64_t n_regions = 1ull << pl.region_bits;
+    const uint64_t by_size = n / ((uint64_t) bins1 * 2048) + 1;
+    const uint32_t chunks1 = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(by_size, (uint64_t) ctx->num_cus), (uint64_t) ctx->num_cus * 4);
+    const uint64_t cap1 = seg_cap_for((double) n / chunks1 / bins1), bincap1 = (uint64_t) chunks1 * cap1;
+    const uint64_t cap2 = seg_cap_for((double) n / bins1 / bins2);
+    void *A, *B, *ovf, *bnd, *b0;
+    KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + 64, &A));
+    KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * cap2 * 8 + 64, &B));
+    KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &ovf));
+    KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &bnd));
+    KMU_TRY(dev_buf(ctx, "arr.bounds0", 16, &b0));
+    KMU_HIP(ctx, hipMemsetAsync(ovf, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_fill_linear, dim3(1), dim3(256), 0, ctx->stream, (uint64_t *) b0, (uint64_t) 2, n);
+    if (!(ctx->lds_attr_set & 2u)) {
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY_TO_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->lds_attr_set |= 2u;
+    }
+    {
+        ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1};
+        KernelTimer tm(ctx, "k_arr_scatter");
+        hipLaunchKernelGGL(k_arr_scatter<IT_KEY_TO_HASH>, dim3(chunks1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream, d_kmers,
+                           (const uint64_t *) b0, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) A, cap1, (uint32_t *) ovf);
+    }
+    hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) bnd, (uint64_t) bins1 + 1, bincap1);
+    {
+        ArrPlan ap{pl.region_bits, 0, bins2, bins1, 1u};
+        KernelTimer tm(ctx, "k_arr_scatter");
+        hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(bins1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream, (const uint64_t *) A,
+                           (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf);
+    }
+    KMU_HIP(ctx, hipGetLastError());
+    uint32_t h_ovf = 0;
+    KMU_HIP(ctx, hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_ovf) return KMU_OK; // the table is untouched: the exact levels take over
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(), d_err, cap2));
+    *taken = 1;
+    return KMU_OK;
+}
+
 // big batches of explicit canonical k-mers (device arrays): partition by region, then the LDS build
 static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64_t n, uint32_t *d_err) {
     kmu_ctx *ctx = c->ctx;
+    {
+        PartPlan pl;
+        if (part_plan_for(c, &pl) && pl.b2 && seg_partition_wanted(n)) {
+            int taken = 0;
+            KMU_TRY(seg_partitioned_add_kmers(c, d_kmers, n, pl, d_err, &taken));
+            if (taken) return KMU_OK;
+        }
+    }
     const uint64_t *items, *bounds;
     const int region_bits = c->lg - c->rbits;
     // (a table of a single region is not partitioned at all: the items stay keys)
@@ -1892,15 +1958,6 @@ static int flat_stream_extent(kmu_ctx *ctx, const uint64_t *host_offsets, uint32
 }
 
 } // extern "C"
-
-// the partition plan of a table (levels and their fan-out); false: more than two levels would be needed
-static bool part_plan_for(const kmu_counter *c, PartPlan *pl) {
-    memset(pl, 0, sizeof *pl);
-    pl->region_bits = c->lg - c->rbits;
-    if (pl->region_bits <= 11) { pl->b1 = pl->region_bits; pl->b2 = 0; }
-    else { pl->b1 = (pl->region_bits + 1) / 2; pl->b2 = pl->region_bits - pl->b1; }
-    return pl->b1 <= 11 && pl->b2 <= 11;
-}
 
 namespace kmu {
 // kmu_sketch_count on host buffers: the count's level-1 partition runs chunk by chunk under the upload (the single-pass

@@ -2611,7 +2611,8 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     if (const char *e = getenv("KMU_PIPE_CHUNK_MB")) chunk_bytes = (uint64_t) std::max(1, atoi(e)) << 20;
     std::vector<uint32_t> cut(1, 0u); // chunk c = reads [cut[c], cut[c + 1])
     for (uint32_t r = 0; r < n_seq;) {
-        const uint64_t lim = h_off[r] + chunk_bytes;
+        // (the first chunk is an eighth of the others: the kernels start after 1 ms of upload instead of 9)
+        const uint64_t lim = h_off[r] + (r == 0 ? std::max<uint64_t>(chunk_bytes / 8, 1) : chunk_bytes);
         uint32_t e = (uint32_t) (std::upper_bound(h_off.begin() + r + 1, h_off.end(), lim) - h_off.begin()) - 1;
         if (e <= r) e = r + 1; // a read longer than a chunk travels alone
         cut.push_back(e);
