@@ -615,6 +615,7 @@ __global__ void __launch_bounds__(256) k_part_scan1b(const uint64_t *tot1, PartP
 // exclusive scan, 8-byte staging writes) and copies the sorted tile out, so that the k-mers of one bin leave as one
 // contiguous run (full sectors) instead of isolated 8-byte stores (which cost a 32-byte HBM write each: measured
 // 3.7x write amplification).  The bin of a staged k-mer is recomputed from the k-mer on the way out.
+__device__ __forceinline__ void vm_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); } // vmcnt(0), expcnt / lgkmcnt untouched
 static constexpr uint32_t TILE_ITEMS = 16384;
 static constexpr int SCATTER_THREADS = 1024;
 
@@ -747,6 +748,159 @@ __device__ __forceinline__ void seg_fill_tails(const ScatterLds &l, uint32_t nbi
     }
 }
 
+// ---- the tile sort of the single-pass partition (round 2) -------------------------------------------------------------
+// Same tile, same runs, fewer phases: four LDS barriers per tile instead of seven and one table look-up per item on the way
+// out instead of two.  The running fill of a bin's segment lives in the REGISTERS of the thread that owns the bin (thread t:
+// bins 2t, 2t + 1); what the write-out needs is one 32-bit word per bin, grel = fill - start of the bin inside the tile
+// (mod 2^32), so that an item at tile position p goes to slot grel[bin] + p of its segment.  The rank counters are a
+// separate array that the owner zeroes while it scans them, so the ranks of the next tile are taken by the waves that are
+// through with this tile's write-out while the others still store (no barrier behind the write-out).
+struct SegLds {
+    uint64_t *stage;  // TILE_ITEMS
+    uint32_t *cnt;    // nbins + 1 (+ 1 pad): ranks handed out in this tile; [nbins]: the "no k-mer" marks
+    uint32_t *lstart; // nbins + 1 (+ 1 pad): exclusive starts inside the tile
+    uint32_t *grel;   // nbins
+    uint32_t *wtot;   // 16 wave totals
+};
+__device__ __forceinline__ SegLds seg_lds(uint8_t *smem, uint32_t nbins) {
+    SegLds l;
+    l.stage = reinterpret_cast<uint64_t *>(smem);
+    l.cnt = reinterpret_cast<uint32_t *>(l.stage + TILE_ITEMS);
+    l.lstart = l.cnt + nbins + 2;
+    l.grel = l.lstart + nbins + 2;
+    l.wtot = l.grel + nbins;
+    return l;
+}
+static size_t seg_lds_bytes(uint32_t nbins) { return (size_t) TILE_ITEMS * 8 + ((size_t) nbins * 3 + 4) * 4 + 64; }
+
+#if KMU_DIAG
+__device__ unsigned long long g_diag_seg[2][8]; // [level][phase]: thread-0 clocks of the tile sort (diagnostic builds)
+#endif
+struct SegClk {
+#if KMU_DIAG
+    uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t = 0;
+    __device__ __forceinline__ void start() { if (threadIdx.x == 0) t = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark(int i) { if (threadIdx.x == 0) { const uint64_t n = __builtin_readcyclecounter(); acc[i] += n - t; t = n; } }
+    __device__ __forceinline__ void flush(int level) { if (threadIdx.x == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_diag_seg[level][i], (unsigned long long) acc[i]); }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int) {}
+#endif
+};
+
+// items are khash values (IT_HASH); nbins a multiple of 4, <= 2048; all 1024 threads call this together; cnt[] zero on the
+// first call.  The digit is a bit field of the item's high word; a destination is one v_mad_u64_u32.  (A form without the
+// per-item branches -- "no k-mer" marks as items of a bin of their own behind the others -- needs 40 more registers than
+// the 128 a thread has: the compiler keeps both tiles' items and all sixteen addresses live.)
+// VMWAIT: the caller prefetches the next tile with unconditional loads (see flat_step_fetch)
+template <bool VMWAIT>
+__device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLds &l, uint32_t nbins, int region_bits, int shift,
+                                                 uint64_t *out, const SegOut &sg, uint32_t (&run)[2], SegClk &clk) {
+    const uint32_t tid = threadIdx.x, nthreads = SCATTER_THREADS, mask = nbins - 1;
+    const uint32_t sh32 = (uint32_t) (32 - region_bits + shift); // digit = (high word >> sh32) & mask  (region_bits <= 22)
+    auto bin_of = [&](uint64_t item) -> uint32_t { return ((uint32_t) (item >> 32) >> sh32) & mask; };
+    clk.mark(0); // everything between two tiles: the loads, the front end of level 1
+    uint32_t rk[8]; // ranks (< 16384), two to a register
+#pragma unroll
+    for (int j = 0; j < 8; j++) rk[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (it[j] != CKEY_EMPTY) rk[j >> 1] |= atomicAdd(&l.cnt[bin_of(it[j])], 1u) << (16 * (j & 1));
+    lds_barrier(); // (also: every wave is through with the last tile's write-out: stage / lstart / grel are free)
+    clk.mark(1);
+    const uint32_t b0 = 2u * tid;
+    uint32_t c0 = 0, c1 = 0;
+    if (b0 < nbins) {
+        const uint2 c = *reinterpret_cast<const uint2 *>(&l.cnt[b0]);
+        c0 = c.x;
+        c1 = c.y;
+        *reinterpret_cast<uint2 *>(&l.cnt[b0]) = make_uint2(0u, 0u);
+    }
+    const uint32_t incl = wave_incl_scan_u32(c0 + c1);
+    if (lane_id() == 63) l.wtot[tid >> 6] = incl;
+    lds_barrier();
+    uint32_t wpre = 0, total = 0; // total: the k-mers of the tile
+    {
+        const uint4 *w4 = reinterpret_cast<const uint4 *>(l.wtot);
+        const uint32_t wave = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = w4[q];
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                wpre += (uint32_t) (q * 4 + z) < wave ? e[z] : 0u;
+                total += e[z];
+            }
+        }
+    }
+    if (b0 < nbins) {
+        const uint32_t excl = wpre + incl - (c0 + c1);
+        *reinterpret_cast<uint2 *>(&l.lstart[b0]) = make_uint2(excl, excl + c0);
+        *reinterpret_cast<uint2 *>(&l.grel[b0]) = make_uint2(run[0] - excl, run[1] - (excl + c0));
+        run[0] += c0;
+        run[1] += c1;
+    }
+    lds_barrier();
+    clk.mark(2);
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (it[j] != CKEY_EMPTY) l.stage[l.lstart[bin_of(it[j])] + ((rk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu)] = it[j];
+    lds_barrier();
+    clk.mark(3);
+    if (VMWAIT) vm_wait_all(); // the next tile's requests (in flight since before the ranks) and the last tile's stores: nothing younger
+    const uint64_t seg0 = sg.end_rel - sg.cap; // start of this unit's segment inside a bin's range
+    const uint32_t bb = (uint32_t) sg.bin_base, bc = (uint32_t) sg.bincap, cap = (uint32_t) sg.cap;
+    for (uint32_t p0 = 0; p0 < total; p0 += 8u * nthreads) {
+        uint64_t v[8];
+        uint32_t rel[8], bin[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
+            v[u] = l.stage[p < total ? p : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
+            bin[u] = ((uint32_t) (v[u] >> 32) >> sh32) & mask;
+            rel[u] = l.grel[bin[u]] + p;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
+            if (p < total) {
+                if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
+                else *sg.ovf = 1u;
+            }
+        }
+    }
+    clk.mark(4);
+}
+
+// after the last tile.  fill = true: the unused tail of every segment of this unit gets "no k-mer" marks (the next level
+// reads whole bins); wave w takes bins w, w + 16, ..., its lanes store consecutive items.  fill = false: the fills go to
+// counts[bin_base + b] instead (a leaf has one writer: the build reads exactly the items that are there).
+__device__ __forceinline__ void seg_finish_unit(const SegLds &l, uint32_t nbins, const SegOut &sg, const uint32_t (&run)[2], uint64_t *out,
+                                                bool fill, uint32_t *counts) {
+    const uint32_t tid = threadIdx.x, b0 = 2u * tid;
+    const uint32_t f0 = (uint64_t) run[0] < sg.cap ? run[0] : (uint32_t) sg.cap, f1 = (uint64_t) run[1] < sg.cap ? run[1] : (uint32_t) sg.cap;
+    if (!fill) {
+        if (b0 < nbins) *reinterpret_cast<uint2 *>(&counts[sg.bin_base + b0]) = make_uint2(f0, f1);
+        return;
+    }
+    lds_barrier(); // (the last write-out has read grel / stage; lstart is free in any case)
+    if (b0 < nbins) *reinterpret_cast<uint2 *>(&l.lstart[b0]) = make_uint2(f0, f1);
+    lds_barrier();
+    const uint32_t wave = tid >> 6, nwaves = SCATTER_THREADS >> 6, lane = (uint32_t) lane_id();
+    const uint64_t seg0 = sg.end_rel - sg.cap;
+    for (uint32_t b = wave; b < nbins; b += nwaves) {
+        const uint64_t base = (sg.bin_base + b) * sg.bincap + seg0;
+        const uint32_t cur = (uint32_t) __builtin_amdgcn_readfirstlane((int) l.lstart[b]);
+        for (uint64_t i = cur + lane; i < sg.cap; i += 64) out[base + i] = CKEY_EMPTY;
+    }
+}
+
 // the code words of wave step `st`: this lane's word and (lanes 0/1) the two words after the wave's last
 __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t total, uint64_t st, bool active, uint32_t &w0,
                                                uint32_t &ex, uint32_t *bad_acc = nullptr) {
@@ -759,6 +913,44 @@ __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t to
     w0 = load_code_word(s, st * 64 + (uint64_t) lane_id(), bad);
     ex = load_code_word(s, st * 64 + 64 + (uint64_t) (lane_id() & 1), bad2);
     if (bad_acc) *bad_acc |= bad; // (every word is some step's own word: the halo words need no second look)
+}
+
+// The same in two halves, for prefetching: flat_step_fetch requests the two aligned 16-byte chunks (this lane's word, the
+// halo word of lane & 1) and nothing looks at them until flat_step_words turns them into code words one tile later -- the
+// requests are UNCONDITIONAL loads from clamped addresses (needs total >= 16), so that their number in flight is a constant
+// for the compiler's s_waitcnt placement (a load under a branch makes it wait for everything at the first use of anything).
+// All vector-memory waits of the scatter loops are the explicit vmcnt(0) of vm_wait_all(): once before the loop, once per
+// tile just before the write-out, when the requests of the next tile have had the whole tile sort to arrive and the stores
+// of the last tile are long gone.
+struct FlatRaw {
+    uint4 c0, cx;
+};
+__device__ __forceinline__ void flat_step_fetch(const uint8_t *bases, uint64_t total, uint64_t st, FlatRaw &r) {
+    r.c0 = make_uint4(0u, 0u, 0u, 0u);
+    r.cx = r.c0;
+    if (total < 16) return; // (wave-uniform; flat_step_words then reads the ragged chunk itself)
+    const uint64_t lastc = (total - 16) & ~15ull;
+    const uint64_t a0 = (st * 64 + (uint64_t) lane_id()) * 16, ax = (st * 64 + 64 + (uint64_t) (lane_id() & 1)) * 16;
+    r.c0 = *reinterpret_cast<const uint4 *>(bases + (a0 < lastc ? a0 : lastc));
+    r.cx = *reinterpret_cast<const uint4 *>(bases + (ax < lastc ? ax : lastc));
+}
+__device__ __forceinline__ void flat_step_words(const uint8_t *bases, uint64_t total, uint64_t st, bool active, const FlatRaw &r,
+                                                uint32_t &w0, uint32_t &ex, uint32_t &bad_acc) {
+    w0 = 0;
+    ex = 0;
+    if (!active) return; // wave-uniform
+    const uint64_t i0 = st * 64 + (uint64_t) lane_id(), ix = st * 64 + 64 + (uint64_t) (lane_id() & 1);
+    uint32_t bad = 0, bad2 = 0;
+    if (__all(ix * 16 + 16 <= total)) { // (every chunk of the step whole: all but the last step of the stream)
+        w0 = pack16_ascii(r.c0, bad);
+        ex = pack16_ascii(r.cx, bad2);
+    } else {
+        SeqView s;
+        s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
+        w0 = load_code_word(s, i0, bad);
+        ex = load_code_word(s, ix, bad2);
+    }
+    bad_acc |= bad; // (every word is some step's own word: the halo words need no second look)
 }
 
 // up to 16 canonical k-mers of this lane for wave step `st` (CKEY_EMPTY where a k-mer would straddle a read end)
@@ -818,20 +1010,27 @@ struct SegPlan1 {
     uint32_t *ovf;
     uint32_t *err;
 };
+template <bool SEGM>
 __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
                                                         int k, PartPlan pl, const uint64_t *offs1,
                                                         const uint64_t *binstart1, uint64_t *out, SegPlan1 seg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t bins1 = pl.owner_parts ? pl.owner_parts : 1u << pl.b1;
     ScatterLds l = scatter_lds(smem, bins1);
-    const bool SEGM = seg.cap != 0;
+    SegLds ls = seg_lds(smem, bins1);
     const uint64_t unit = seg.unit_base + blockIdx.x;
     SegOut sg{0, seg.bincap, (unit + 1) * seg.cap, seg.cap, seg.ovf};
-    for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) {
-        l.gbase[b] = SEGM ? (uint64_t) b * seg.bincap + unit * seg.cap : binstart1[b] + offs1[(uint64_t) blockIdx.x * bins1 + b];
-        l.lstart[b] = 0;
+    uint32_t run[2] = {0u, 0u};
+    SegClk clk;
+    if (SEGM) {
+        for (uint32_t b = threadIdx.x; b <= bins1; b += blockDim.x) ls.cnt[b] = 0;
+    } else {
+        for (uint32_t b = threadIdx.x; b < bins1; b += blockDim.x) {
+            l.gbase[b] = binstart1[b] + offs1[(uint64_t) blockIdx.x * bins1 + b];
+            l.lstart[b] = 0;
+        }
+        if (threadIdx.x == 0) l.lstart[bins1] = 0;
     }
-    if (threadIdx.x == 0) l.lstart[bins1] = 0;
     lds_barrier();
     const uint64_t total = offsets[n_seq], start = offsets[0];
     const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
@@ -839,23 +1038,29 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t r_hint = 0xFFFFFFFFu, w0, ex, bad = 0;
-    flat_step_load(bases, total, s0 + wave, s0 + wave < s1, w0, ex, &bad);
+    FlatRaw raw;
+    flat_step_fetch(bases, total, s0 + wave, raw);
+    vm_wait_all();
+    clk.start();
     for (uint64_t t0 = s0; t0 < s1; t0 += nwaves) {
         uint64_t it[16];
+        flat_step_words(bases, total, t0 + wave, t0 + wave < s1, raw, w0, ex, bad);
         flat_step_items(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
-        // the next step's words are requested now; their latency hides under the tile sort
-        flat_step_load(bases, total, t0 + nwaves + wave, t0 + nwaves + wave < s1, w0, ex, &bad);
-        if (pl.owner_parts) tile_scatter<IT_OWNER>(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
+        // the next step's chunks are requested now (behind the read-bound look-ups of this step, which are waited for in
+        // order); they arrive under the tile sort, which waits for them before its write-out
+        flat_step_fetch(bases, total, t0 + nwaves + wave, raw);
+        if (!SEGM && pl.owner_parts) tile_scatter<IT_OWNER>(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
         else { // from here on the k-mers travel as their table hash
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
-            if (SEGM) tile_scatter<IT_HASH, true>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out, &sg);
+            for (int j = 0; j < 16; j++) it[j] = khash(it[j]); // (khash keeps the "no k-mer" mark)
+            if (SEGM) tile_scatter_seg<true>(it, ls, bins1, pl.region_bits, pl.b2, out, sg, run, clk);
             else tile_scatter<IT_HASH>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
         }
     }
     if (SEGM) {
-        seg_fill_tails(l, bins1, sg, out);
+        seg_finish_unit(ls, bins1, sg, run, out, true, nullptr);
+        clk.mark(5);
+        clk.flush(0);
         if (bad) atomicOr(seg.err, DERR_NON_ACGT); // (the histogram pass that used to validate the bases did not run)
     }
 }
@@ -957,53 +1162,89 @@ __global__ void __launch_bounds__(256) k_arr_scan_b(const uint64_t *tot, const u
 // seg_cap != 0: the single-pass form -- no histogram ran; unit (partition p, chunk c) writes bin b into its own segment
 // [((p * bins + b) * chunks + c) * seg_cap, + seg_cap) of `out` (offs_rel / outbounds are not read); "no k-mer" marks in the
 // input (the tails of the previous level's segments) are skipped like everywhere else.
-template <int IT>
+template <int IT, bool SEGM>
 __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
                                                       const uint64_t *offs_rel, const uint64_t *outbounds, uint64_t *out,
-                                                      uint64_t seg_cap, uint32_t *seg_ovf) {
+                                                      uint64_t seg_cap, uint32_t *seg_ovf, uint32_t *leafcnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds l = scatter_lds(smem, pl.bins);
-    const bool SEGM = seg_cap != 0;
+    SegLds ls = seg_lds(smem, pl.bins);
     const uint64_t sp = blockIdx.x / pl.chunks, sc = blockIdx.x % pl.chunks;
     SegOut sg{sp * pl.bins, (uint64_t) pl.chunks * seg_cap, (sc + 1) * seg_cap, seg_cap, seg_ovf};
-    for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) {
-        l.gbase[b] = SEGM ? ((sp * pl.bins + b) * pl.chunks + sc) * seg_cap
-                          : outbounds[(uint64_t) (blockIdx.x / pl.chunks) * pl.bins + b] + offs_rel[(uint64_t) blockIdx.x * pl.bins + b];
-        l.lstart[b] = 0;
+    uint32_t run[2] = {0u, 0u};
+    SegClk clk;
+    if (SEGM) {
+        for (uint32_t b = threadIdx.x; b <= pl.bins; b += blockDim.x) ls.cnt[b] = 0;
+    } else {
+        for (uint32_t b = threadIdx.x; b < pl.bins; b += blockDim.x) {
+            l.gbase[b] = outbounds[(uint64_t) (blockIdx.x / pl.chunks) * pl.bins + b] + offs_rel[(uint64_t) blockIdx.x * pl.bins + b];
+            l.lstart[b] = 0;
+        }
+        if (threadIdx.x == 0) l.lstart[pl.bins] = 0;
     }
-    if (threadIdx.x == 0) l.lstart[pl.bins] = 0;
     lds_barrier();
     uint64_t i0, i1;
     arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
+    // PADDED: the input is a partition buffer of the library with a tile's worth of readable bytes behind its end -- a tile is
+    // requested whole by unconditional loads, what lies beyond the unit is not looked at, and the waits are explicit (see
+    // flat_step_fetch); otherwise (arrays of the caller) the loads stay under their bounds tests and the compiler's waits.
+    constexpr bool PADDED = IT == IT_HASH && SEGM;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     uint64_t nxt[16];
+    // PADDED: 16 bytes per lane and request -- item 2 j2 + e of a thread is element j2 * 2048 + 2 tid + e of the tile (the
+    // unit starts on a multiple of 16 items: segment sizes are multiples of 16)
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint64_t i = i0 + (uint64_t) j * blockDim.x + threadIdx.x;
-        nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
+        if (!PADDED) nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
     }
+    if (PADDED) {
+#pragma unroll
+        for (int j2 = 0; j2 < 8; j2++) {
+            u64x2 q = {CKEY_EMPTY, CKEY_EMPTY};
+            if (i0 < i1) q = *reinterpret_cast<const u64x2 *>(in + i0 + (uint64_t) j2 * 2048 + 2u * threadIdx.x);
+            nxt[2 * j2] = q.x;
+            nxt[2 * j2 + 1] = q.y;
+        }
+        vm_wait_all();
+    }
+    clk.start();
     for (uint64_t t0 = i0; t0 < i1; t0 += TILE_ITEMS) {
         uint64_t it[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) it[j] = nxt[j];
-        // the next tile is requested before this one is sorted: its HBM latency hides under the LDS work
-#pragma unroll
         for (int j = 0; j < 16; j++) {
-            const uint64_t i = t0 + TILE_ITEMS + (uint64_t) j * blockDim.x + threadIdx.x;
-            nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
+            if (PADDED) it[j] = t0 + (uint64_t) (j >> 1) * 2048 + 2u * threadIdx.x + (j & 1) < i1 ? nxt[j] : CKEY_EMPTY;
+            else it[j] = nxt[j];
+        }
+        // the next tile is requested before this one is sorted: its HBM latency hides under the LDS work
+        if (PADDED) {
+#pragma unroll
+            for (int j2 = 0; j2 < 8; j2++) {
+                const u64x2 q = *reinterpret_cast<const u64x2 *>(in + t0 + TILE_ITEMS + (uint64_t) j2 * 2048 + 2u * threadIdx.x);
+                nxt[2 * j2] = q.x;
+                nxt[2 * j2 + 1] = q.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint64_t i = t0 + TILE_ITEMS + (uint64_t) j * blockDim.x + threadIdx.x;
+                nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
+            }
         }
         if (IT == IT_KEY_TO_HASH) { // from here on the k-mers travel as their table hash (no further evaluations)
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
-            if (SEGM) tile_scatter<IT_HASH, true>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out, &sg);
-            else tile_scatter<IT_HASH>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
-        } else if (IT == IT_HASH && SEGM) {
-            tile_scatter<IT_HASH, true>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out, &sg);
-        } else {
-            tile_scatter<IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
         }
+        if (SEGM) tile_scatter_seg<PADDED>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk);
+        else tile_scatter<IT == IT_KEY_TO_HASH ? IT_HASH : IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
-    if ((IT == IT_HASH || IT == IT_KEY_TO_HASH) && SEGM) seg_fill_tails(l, pl.bins, sg, out);
+    if (SEGM) {
+        // a level with one unit per input partition writes leaves: their fills go to leafcnt, no tail marks
+        seg_finish_unit(ls, pl.bins, sg, run, out, leafcnt == nullptr, leafcnt);
+        clk.mark(5);
+        clk.flush(1);
+    }
 }
 
 // bounds[i] = i * stride (the input partitions of the single-pass level 2: level 1's fixed-size bins)
@@ -1026,7 +1267,7 @@ template <int IT>
 __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *items, const uint64_t *leafstart,
                                                               uint32_t n_regions, CountTable t, int in_mode, int out_compact,
                                                               uint32_t *rcount, unsigned long long *stats, uint32_t *err,
-                                                              uint64_t leaf_stride) {
+                                                              uint64_t leaf_stride, const uint32_t *leafcnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t R = t.rmask + 1; // >= 1024
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
@@ -1042,7 +1283,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *it
         // the items of region r: [leafstart[r], leafstart[r + 1]), or a fixed-size range that may hold "no k-mer" marks (the
         // leaves of the single-pass partition), or none (the expansion of a compact table)
         const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
-        const uint64_t i1 = leaf_stride ? i0 + leaf_stride : leafstart ? leafstart[r + 1] : 0;
+        const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (uint64_t) leafcnt[r] : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
         uint64_t pre_it[BUILD_PRE];
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++) {
@@ -1184,7 +1425,7 @@ static int grid_for(const kmu_ctx *ctx, uint64_t n, int per_block) {
 static size_t build_lds(const kmu_counter *c) { return ((size_t) 12 << c->rbits) + 64 * 8 + 65 * 4 + 16; }
 template <int IT>
 static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, bool to_compact, uint32_t *d_err,
-                        uint64_t leaf_stride = 0) {
+                        uint64_t leaf_stride = 0, const uint32_t *leafcnt = nullptr) {
     kmu_ctx *ctx = c->ctx;
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
@@ -1193,7 +1434,7 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     {
         KernelTimer tm(ctx, items ? "k_part_build" : "k_part_expand");
         hipLaunchKernelGGL(k_part_build<IT>, dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
-                           table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride);
+                           table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt);
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;
@@ -1239,6 +1480,19 @@ static int materialize(kmu_counter *c) {
 // takes fixed-size leaves.  A segment that overflows (k-mers that are not spread by the hash: a genome of one repeated
 // k-mer) raises a flag that is read before the build touches the table: the call then takes the exact route from scratch.
 // Level 1 without a global histogram is also what lets kmu_sketch_count partition a chunk while the next one is uploaded.
+// the LDS-staged scatter kernels ask for more than 64 KiB of dynamic LDS: one attribute call per instantiation and device
+// (function attributes are per device: remembered per context, not per process)
+static int scatter_attrs(kmu_ctx *ctx) {
+    if (ctx->lds_attr_set & 1u) return KMU_OK;
+    const void *fns[] = {(const void *) k_part_scatter1<false>, (const void *) k_part_scatter1<true>,
+                         (const void *) k_arr_scatter<IT_HASH, false>, (const void *) k_arr_scatter<IT_HASH, true>,
+                         (const void *) k_arr_scatter<IT_KEY, false>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, false>,
+                         (const void *) k_arr_scatter<IT_KEY_TO_HASH, true>};
+    for (const void *f : fns) KMU_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->lds_attr_set |= 1u;
+    return KMU_OK;
+}
+
 // the partition plan of a table (levels and their fan-out); false: more than two levels would be needed
 static bool part_plan_for(const kmu_counter *c, PartPlan *pl) {
     memset(pl, 0, sizeof *pl);
@@ -1265,13 +1519,18 @@ struct SegPlan {
     uint64_t cap1, bincap1, cap2, leafcap;
     uint32_t chunks2;
 };
-static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan &pl) {
+static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan &pl, bool chunked) {
     SegPlan sp;
     const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
     const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
-    // units of level 1: enough to fill the chip, few enough that a unit's share of a bin stays around 2 048 items
+    // units of level 1: one per CU (the biggest segments, the smallest margins: 8.6 % of the bench workload's stream); the
+    // chunked form of kmu_sketch_count launches them in rounds under the upload and takes up to four rounds' worth, a unit's
+    // share of a bin staying around 2 048 items (margins of 18 %)
     const uint64_t by_size = total_bases / ((uint64_t) bins1 * 2048) + 1;
-    sp.units1 = (uint32_t) std::min<uint64_t>(nsteps, std::min<uint64_t>(std::max<uint64_t>(by_size, (uint64_t) ctx->num_cus), (uint64_t) ctx->num_cus * 4));
+    uint64_t want = (uint64_t) ctx->num_cus;
+    if (chunked) want = std::min<uint64_t>(std::max<uint64_t>(by_size, want), want * 4);
+    if (const char *e = getenv("KMU_COUNT_SEG_UNITS")) want = (uint64_t) std::max(1, atoi(e)); // A/B runs
+    sp.units1 = (uint32_t) std::min<uint64_t>(nsteps, want);
     sp.steps_per_unit = (uint32_t) ((nsteps + sp.units1 - 1) / sp.units1);
     sp.units1 = (uint32_t) ((nsteps + sp.steps_per_unit - 1) / sp.steps_per_unit);
     sp.cap1 = seg_cap_for((double) sp.steps_per_unit * 1024.0 / bins1);
@@ -1288,7 +1547,7 @@ struct SegRun {
     DevSeqs ds;
     uint64_t total_bases = 0;
     uint32_t units_done = 0;
-    void *A = nullptr, *B = nullptr, *ovf = nullptr, *bnd = nullptr;
+    void *A = nullptr, *B = nullptr, *ovf = nullptr, *bnd = nullptr, *leafcnt = nullptr;
     uint32_t *d_err = nullptr;
 };
 // own_buffer: the level-1 output must survive other users of the shared scratch "cnt.partA" (kmu_sketch_count's chunked form:
@@ -1297,7 +1556,7 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
                      bool own_buffer = false) {
     kmu_ctx *ctx = c->ctx;
     run->pl = pl_in;
-    run->sp = seg_plan(ctx, total_bases, pl_in);
+    run->sp = seg_plan(ctx, total_bases, pl_in, own_buffer);
     run->ds = ds;
     run->total_bases = total_bases;
     run->units_done = 0;
@@ -1306,16 +1565,14 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     const uint64_t n_regions = 1ull << pl_in.region_bits;
     run->pl.units1 = run->sp.units1;
     run->pl.steps_per_unit = run->sp.steps_per_unit;
-    KMU_TRY(dev_buf(ctx, own_buffer ? "cnt.segA" : "cnt.partA", (size_t) bins1 * run->sp.bincap1 * 8 + 64, &run->A));
+    // (+ a tile: level 2 requests whole tiles, k_arr_scatter's PADDED form)
+    KMU_TRY(dev_buf(ctx, own_buffer ? "cnt.segA" : "cnt.partA", (size_t) bins1 * run->sp.bincap1 * 8 + (size_t) TILE_ITEMS * 8 + 64, &run->A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * run->sp.leafcap * 8 + 64, &run->B));
+    KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &run->leafcnt));
     KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &run->ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &run->bnd));
     KMU_HIP(ctx, hipMemsetAsync(run->ovf, 0, 64, ctx->stream));
-    if (!(ctx->lds_attr_set & 1u)) {
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->lds_attr_set |= 1u;
-    }
+    KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;
 }
 // level 1 for the units whose wave steps (and their 32-base halo) lie inside the first `bases_ready` bases of the stream
@@ -1334,7 +1591,7 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
     const uint32_t bins1 = 1u << run->pl.b1;
     {
         KernelTimer tm(ctx, "k_part_scatter1");
-        hipLaunchKernelGGL(k_part_scatter1, dim3(upto - run->units_done), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
+        hipLaunchKernelGGL(k_part_scatter1<true>, dim3(upto - run->units_done), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream,
                            run->ds.bases, run->ds.offsets, run->ds.n_seq, c->p.kmer_size, run->pl, (const uint64_t *) nullptr,
                            (const uint64_t *) nullptr, (uint64_t *) run->A,
                            SegPlan1{run->sp.cap1, run->sp.bincap1, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
@@ -1354,16 +1611,31 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     {
         ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2};
         KernelTimer tm(ctx, "k_part_scatter2");
-        hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
+        hipLaunchKernelGGL((k_arr_scatter<IT_HASH, true>), dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream,
                            (const uint64_t *) run->A, (const uint64_t *) run->bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
-                           (uint64_t *) run->B, run->sp.cap2, (uint32_t *) run->ovf);
+                           (uint64_t *) run->B, run->sp.cap2, (uint32_t *) run->ovf, (uint32_t *) run->leafcnt);
     }
     KMU_HIP(ctx, hipGetLastError());
     uint32_t h_ovf = 0; // read before the table is touched: an overflow leaves the call to the exact route
     KMU_HIP(ctx, hipMemcpyAsync(&h_ovf, run->ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_ovf) return KMU_OK;
-    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(), run->d_err, run->sp.leafcap));
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(), run->d_err, run->sp.leafcap, (const uint32_t *) run->leafcnt));
+#if KMU_DIAG
+    if (getenv("KMU_DIAG_SEG")) { // thread-0 clocks of the tile sort, summed over the workgroups: [level] between / rank / scan / place / out / finish
+        unsigned long long h[2][8], z[2][8] = {};
+        KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KMU_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diag_seg), sizeof h));
+        KMU_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_diag_seg), z, sizeof z));
+        for (int lv = 0; lv < 2; lv++) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 6; i++) tot += h[lv][i];
+            fprintf(stderr, "diag seg level %d:", lv + 1);
+            for (int i = 0; i < 6; i++) fprintf(stderr, " %.1f%%", tot ? 100.0 * (double) h[lv][i] / (double) tot : 0.0);
+            fprintf(stderr, "  (between rank scan place out finish; %.3g clocks)\n", (double) tot);
+        }
+    }
+#endif
     *taken = 1;
     return KMU_OK;
 }
@@ -1423,11 +1695,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KMU_TRY(seg_partitioned_add(c, ds, total_bases, pl, d_err, &taken));
         if (taken) return KMU_OK; // (else a segment overflowed -- very skewed k-mers -- and nothing was touched: the exact route)
     }
-    if (!(ctx->lds_attr_set & 1u)) { // function attributes are per device: remembered per context, not per process
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->lds_attr_set |= 1u;
-    }
+    KMU_TRY(scatter_attrs(ctx));
     {
         KernelTimer tm(ctx, "k_part_hist1");
         hipLaunchKernelGGL(k_part_hist1, dim3(units1), dim3(256), bins1 * 4, ctx->stream, ds.bases, ds.offsets, ds.n_seq, k,
@@ -1442,7 +1710,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     }
     {
         KernelTimer tm(ctx, "k_part_scatter1");
-        hipLaunchKernelGGL(k_part_scatter1, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
+        hipLaunchKernelGGL(k_part_scatter1<false>, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1,
                            (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr});
     }
@@ -1465,10 +1733,10 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         }
         {
             KernelTimer tm(ctx, "k_part_scatter2");
-            hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
+            hipLaunchKernelGGL((k_arr_scatter<IT_HASH, false>), dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
                                (const uint64_t *) A, (const uint64_t *) binstart1, ap, (const uint64_t *) offs2,
                                (const uint64_t *) leafstart,
-                               (uint64_t *) B, 0ull, (uint32_t *) nullptr);
+                               (uint64_t *) B, 0ull, (uint32_t *) nullptr, (uint32_t *) nullptr);
         }
         items = (const uint64_t *) B;
         leaves = (const uint64_t *) leafstart;
@@ -1486,12 +1754,7 @@ namespace kmu {
 int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits, const uint64_t **items_out,
                   const uint64_t **bounds_out, bool hashed_out) {
     if (region_bits > 22) return fail(ctx, KMU_E_UNSUPPORTED, "too many partitions (2^%d)", region_bits);
-    if (!(ctx->lds_attr_set & 2u)) {
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY_TO_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->lds_attr_set |= 2u;
-    }
+    KMU_TRY(scatter_attrs(ctx));
     const int b1 = region_bits <= 11 ? region_bits : (region_bits + 1) / 2;
     const int b2 = region_bits - b1;
     void *b0;
@@ -1536,14 +1799,14 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
             KernelTimer tm(ctx, "k_arr_scatter");
             const size_t slds = scatter_lds_bytes(bins);
             if (!hashed_out)
-                hipLaunchKernelGGL(k_arr_scatter<IT_KEY>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
-                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr);
+                hipLaunchKernelGGL((k_arr_scatter<IT_KEY, false>), dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
+                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr, (uint32_t *) nullptr);
             else if (!first_done)
-                hipLaunchKernelGGL(k_arr_scatter<IT_KEY_TO_HASH>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds,
-                                   ap, (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr);
+                hipLaunchKernelGGL((k_arr_scatter<IT_KEY_TO_HASH, false>), dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds,
+                                   ap, (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr, (uint32_t *) nullptr);
             else
-                hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
-                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr);
+                hipLaunchKernelGGL((k_arr_scatter<IT_HASH, false>), dim3(units), dim3(SCATTER_THREADS), slds, ctx->stream, items, bounds, ap,
+                                   (const uint64_t *) offs, (const uint64_t *) outb, (uint64_t *) outbuf, 0ull, (uint32_t *) nullptr, (uint32_t *) nullptr);
             first_done = true;
         }
         KMU_HIP(ctx, hipGetLastError());
@@ -1565,43 +1828,40 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     *taken = 0;
     const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
     const uint64_t n_regions = 1ull << pl.region_bits;
-    const uint64_t by_size = n / ((uint64_t) bins1 * 2048) + 1;
-    const uint32_t chunks1 = (uint32_t) std::min<uint64_t>(std::max<uint64_t>(by_size, (uint64_t) ctx->num_cus), (uint64_t) ctx->num_cus * 4);
+    const uint32_t chunks1 = (uint32_t) ctx->num_cus; // one unit per CU: the biggest segments, the smallest margins
     const uint64_t cap1 = seg_cap_for((double) n / chunks1 / bins1), bincap1 = (uint64_t) chunks1 * cap1;
     const uint64_t cap2 = seg_cap_for((double) n / bins1 / bins2);
-    void *A, *B, *ovf, *bnd, *b0;
-    KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + 64, &A));
+    void *A, *B, *ovf, *bnd, *b0, *leafcnt;
+    KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + (size_t) TILE_ITEMS * 8 + 64, &A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * cap2 * 8 + 64, &B));
+    KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &leafcnt));
     KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &bnd));
     KMU_TRY(dev_buf(ctx, "arr.bounds0", 16, &b0));
     KMU_HIP(ctx, hipMemsetAsync(ovf, 0, 64, ctx->stream));
     hipLaunchKernelGGL(k_fill_linear, dim3(1), dim3(256), 0, ctx->stream, (uint64_t *) b0, (uint64_t) 2, n);
-    if (!(ctx->lds_attr_set & 2u)) {
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_KEY_TO_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_arr_scatter<IT_HASH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->lds_attr_set |= 2u;
-    }
+    KMU_TRY(scatter_attrs(ctx));
     {
         ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1};
         KernelTimer tm(ctx, "k_arr_scatter");
-        hipLaunchKernelGGL(k_arr_scatter<IT_KEY_TO_HASH>, dim3(chunks1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream, d_kmers,
-                           (const uint64_t *) b0, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) A, cap1, (uint32_t *) ovf);
+        hipLaunchKernelGGL((k_arr_scatter<IT_KEY_TO_HASH, true>), dim3(chunks1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, d_kmers,
+                           (const uint64_t *) b0, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) A, cap1, (uint32_t *) ovf,
+                           (uint32_t *) nullptr);
     }
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) bnd, (uint64_t) bins1 + 1, bincap1);
     {
         ArrPlan ap{pl.region_bits, 0, bins2, bins1, 1u};
         KernelTimer tm(ctx, "k_arr_scatter");
-        hipLaunchKernelGGL(k_arr_scatter<IT_HASH>, dim3(bins1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream, (const uint64_t *) A,
-                           (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf);
+        hipLaunchKernelGGL((k_arr_scatter<IT_HASH, true>), dim3(bins1), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream, (const uint64_t *) A,
+                           (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf,
+                           (uint32_t *) leafcnt);
     }
     KMU_HIP(ctx, hipGetLastError());
     uint32_t h_ovf = 0;
     KMU_HIP(ctx, hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_ovf) return KMU_OK; // the table is untouched: the exact levels take over
-    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(), d_err, cap2));
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(), d_err, cap2, (const uint32_t *) leafcnt));
     *taken = 1;
     return KMU_OK;
 }
@@ -1671,13 +1931,10 @@ static int owner_scatter(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases
     kmu_ctx *ctx = c->ctx;
     void *out;
     KMU_TRY(dev_buf(ctx, "cnt.partB", total_bases * 8 + 64, &out));
-    if (!(ctx->lds_attr_set & 4u)) {
-        KMU_HIP(ctx, hipFuncSetAttribute((const void *) k_part_scatter1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->lds_attr_set |= 4u;
-    }
+    KMU_TRY(scatter_attrs(ctx));
     {
         KernelTimer tm(ctx, "k_part_scatter1");
-        hipLaunchKernelGGL(k_part_scatter1, dim3(op.pl.units1), dim3(SCATTER_THREADS), scatter_lds_bytes(op.pl.owner_parts), ctx->stream,
+        hipLaunchKernelGGL(k_part_scatter1<false>, dim3(op.pl.units1), dim3(SCATTER_THREADS), scatter_lds_bytes(op.pl.owner_parts), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, c->p.kmer_size, op.pl, (const uint64_t *) op.offs1,
                            (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr});
     }

@@ -52,7 +52,7 @@ int main() {
             run<0, 1>("ds_read_b64 random", th); run<0, 4>("ds_read_b64 random", th);
             run<1, 1>("cmpst_rtn_b64 (claims)", th); run<4, 1>("cmpst_rtn_b64 (fails)", th); run<4, 4>("cmpst_rtn_b64 (fails)", th);
             run<2, 1>("ds_add_u32 noret", th); run<2, 4>("ds_add_u32 noret", th);
-            run<3, 1>("ds_add_rtn_u32", th); run<3, 4>("ds_add_rtn_u32", th);
+            run<3, 1>("ds_add_rtn_u32", th); run<3, 4>("ds_add_rtn_u32", th); run<3, 16>("ds_add_rtn_u32", th); run<2, 16>("ds_add_u32 noret", th); run<5, 16>("ds_write_b64", th); run<0, 16>("ds_read_b64 random", th);
             run<5, 1>("ds_write_b64", th); run<5, 4>("ds_write_b64", th);
         } else {
             run<0, 1>("ds_read_b64 random", th); run<4, 1>("cmpst_rtn_b64 (fails)", th); run<4, 4>("cmpst_rtn_b64 (fails)", th); run<3, 1>("ds_add_rtn_u32", th);
