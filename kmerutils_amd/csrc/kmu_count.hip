@@ -1039,16 +1039,19 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t r_hint = 0xFFFFFFFFu, w0, ex, bad = 0;
     FlatRaw raw;
-    flat_step_fetch(bases, total, s0 + wave, raw);
-    vm_wait_all();
+    if (SEGM) {
+        flat_step_fetch(bases, total, s0 + wave, raw);
+        vm_wait_all();
+    }
     clk.start();
     for (uint64_t t0 = s0; t0 < s1; t0 += nwaves) {
         uint64_t it[16];
-        flat_step_words(bases, total, t0 + wave, t0 + wave < s1, raw, w0, ex, bad);
+        if (SEGM) flat_step_words(bases, total, t0 + wave, t0 + wave < s1, raw, w0, ex, bad);
+        else flat_step_load(bases, total, t0 + wave, t0 + wave < s1, w0, ex, &bad); // (the exact levels and the owner grouping: the older tile sort leaves no registers for a chunk in flight)
         flat_step_items(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
         // the next step's chunks are requested now (behind the read-bound look-ups of this step, which are waited for in
         // order); they arrive under the tile sort, which waits for them before its write-out
-        flat_step_fetch(bases, total, t0 + nwaves + wave, raw);
+        if (SEGM) flat_step_fetch(bases, total, t0 + nwaves + wave, raw);
         if (!SEGM && pl.owner_parts) tile_scatter<IT_OWNER>(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
         else { // from here on the k-mers travel as their table hash
 #pragma unroll
