@@ -300,10 +300,12 @@ def main():
         cand = [n for n in kern if n in alg_bytes and not (PAIR in kern and n in SK)]
         dom = max(cand, key=lambda n: kern[n]["avg_ms"] * kern[n]["launches"], default=None)
         roofline = None
+        # launches per step of the parts of a composite unit (k_multiset_uq runs in two shapes: two launches a step)
+        per_step = {n: kern[n]["launches"] / kern[dom]["launches"] for n in dom.split("+")} if dom else {}
         if dom:
             ach = kern[dom]["GBps"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cfg, total_bases, dom),
+                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cfg, total_bases, dom, per_step),
                         "avg_launch_ms": kern[dom]["avg_ms"], "alg_bytes_per_launch": kern[dom]["alg_bytes"]}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -317,7 +319,7 @@ def main():
                        "bases_per_gpu": total_bases, "kmers_per_gpu": nk, "k": cfg["k"], "sketch_size": cfg["m"],
                        "sketch": cfg["sketch"], "count": cfg["count"], "parallelism": "reads sharded x%d" % world,
                        "residency": "value: reads and results resident in HBM; host_to_host: pinned host memory in and out"},
-            "roofline": roofline, "alu": pmc_alu(cfg, total_bases, dom, kern[dom]["avg_ms"]) if dom else None,
+            "roofline": roofline, "alu": pmc_alu(cfg, total_bases, dom, kern[dom]["avg_ms"], per_step) if dom else None,
             "cpu_baseline": cpu, "host_to_host": host, "value_device_resident": value,
             "value_host_to_host": host["value"] if host else None,
             "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
@@ -366,27 +368,30 @@ def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000):
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0  # wave-instructions / s: 256 CUs x 4 SIMDs, one full-rate VALU instruction per 4 cycles at 2.4 GHz
 
 
-def pmc_alu(cfg, total_bases, kernel, avg_ms):
+def pmc_alu(cfg, total_bases, kernel, avg_ms, per_step=None):
     """Instruction-issue view of an ALU-bound kernel, next to the HBM roofline the tier asks for: vector wave-instructions
     per launch from the committed PMC pass (SQ_INSTS_VALU) / the launch time measured in this run, against the chip's
-    full-rate VALU issue peak.  null when the committed profile is not of this workload and size."""
+    full-rate VALU issue peak.  null when the committed profile is not of this workload and size.  `per_step`: launches
+    per step of every kernel name of a composite unit (a name's per-launch figure is the mean over its launches)."""
+    per_step = per_step or {}
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         d = json.load(open(path))
         if d.get("workload") == cfg["name"] and abs(d.get("bases_per_gpu", 0) - total_bases) < 1e-3 * total_bases:
             ks = [d["kernels"].get(n, {}) for n in kernel.split("+")]
-            valu = sum(k.get("SQ_INSTS_VALU_per_launch", 0) for k in ks) if all("SQ_INSTS_VALU_per_launch" in k for k in ks) else None
+            mult = [per_step.get(n, 1.0) for n in kernel.split("+")]
+            valu = sum(k.get("SQ_INSTS_VALU_per_launch", 0) * m for k, m in zip(ks, mult)) if all("SQ_INSTS_VALU_per_launch" in k for k in ks) else None
             if valu and avg_ms:
                 ach = valu / (avg_ms * 1e-3)
                 return {"bound": "valu-issue", "valu_wave_insts": valu,
-                        "salu_wave_insts": sum(k.get("SQ_INSTS_SALU_per_launch", 0) for k in ks),
+                        "salu_wave_insts": sum(k.get("SQ_INSTS_SALU_per_launch", 0) * m for k, m in zip(ks, mult)),
                         "achieved": ach, "peak": VALU_ISSUE_PEAK, "unit": "wave-inst/s", "frac": ach / VALU_ISSUE_PEAK}
     except Exception:
         pass
     return None
 
 
-def pmc_traffic(cfg, total_bases, kernel):
+def pmc_traffic(cfg, total_bases, kernel, per_step=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected
     as MI355X_MICROARCH.md prescribes; scripts/summarize_prof.py).  PMC counters cannot be read from inside the timed
     run, so the figure is only reported when the committed profile is of this exact workload and size; else null."""
@@ -395,7 +400,8 @@ def pmc_traffic(cfg, total_bases, kernel):
         d = json.load(open(path))
         if d.get("workload") == cfg["name"] and abs(d.get("bases_per_gpu", 0) - total_bases) < 1e-3 * total_bases:
             ks = [d["kernels"].get(n, {}).get("hbm_bytes_per_launch") for n in kernel.split("+")]
-            return sum(ks) if all(v is not None for v in ks) else None
+            mult = [(per_step or {}).get(n, 1.0) for n in kernel.split("+")]
+            return sum(v * m for v, m in zip(ks, mult)) if all(v is not None for v in ks) else None
     except Exception:
         pass
     return None
