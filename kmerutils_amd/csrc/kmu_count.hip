@@ -1188,7 +1188,7 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     lds_barrier();
     uint64_t i0, i1;
     arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
-    // PADDED: the input is a partition buffer of the library with a tile's worth of readable bytes behind its end -- a tile is
+    // PADDED: the input is a partition buffer of the library with two tiles' worth of readable bytes behind its end -- a tile is
     // requested whole by unconditional loads, what lies beyond the unit is not looked at, and the waits are explicit (see
     // flat_step_fetch); otherwise (arrays of the caller) the loads stay under their bounds tests and the compiler's waits.
     constexpr bool PADDED = IT == IT_HASH && SEGM;
@@ -1568,8 +1568,9 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     const uint64_t n_regions = 1ull << pl_in.region_bits;
     run->pl.units1 = run->sp.units1;
     run->pl.steps_per_unit = run->sp.steps_per_unit;
-    // (+ a tile: level 2 requests whole tiles, k_arr_scatter's PADDED form)
-    KMU_TRY(dev_buf(ctx, own_buffer ? "cnt.segA" : "cnt.partA", (size_t) bins1 * run->sp.bincap1 * 8 + (size_t) TILE_ITEMS * 8 + 64, &run->A));
+    // (+ two tiles: level 2 requests whole tiles a tile ahead, k_arr_scatter's PADDED form: its last request of the last bin
+    // ends less than two tiles behind the bin)
+    KMU_TRY(dev_buf(ctx, own_buffer ? "cnt.segA" : "cnt.partA", (size_t) bins1 * run->sp.bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &run->A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * run->sp.leafcap * 8 + 64, &run->B));
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &run->leafcnt));
     KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &run->ovf));
@@ -1679,6 +1680,13 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     const uint32_t units2 = bins1 * pl.chunks2;
     const uint64_t n_regions = 1ull << pl.region_bits;
 
+    // the single-pass partition first, BEFORE this route takes its buffers: both use "cnt.partA" / "cnt.partB" with different
+    // sizes, and a buffer that grows is freed and allocated anew (pointers taken earlier would dangle)
+    if (pl.b2 && !dbg_split && seg_partition_wanted(total_bases)) {
+        int taken = 0;
+        KMU_TRY(seg_partitioned_add(c, ds, total_bases, pl, d_err, &taken));
+        if (taken) return KMU_OK; // (else a segment overflowed -- very skewed k-mers -- and nothing was touched: the exact route)
+    }
     void *A, *B = nullptr, *hist1, *offs1, *tot1, *binstart1, *hist2 = nullptr, *offs2 = nullptr, *leafstart = nullptr, *tot2 = nullptr;
     KMU_TRY(dev_buf(ctx, "cnt.partA", total_bases * 8 + 64, &A));
     KMU_TRY(dev_buf(ctx, "cnt.hist1", (size_t) units1 * bins1 * 4, &hist1));
@@ -1693,11 +1701,6 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KMU_TRY(dev_buf(ctx, "cnt.tot2", (size_t) n_regions * 8, &tot2));
     }
     const int k = c->p.kmer_size;
-    if (pl.b2 && !dbg_split && seg_partition_wanted(total_bases)) {
-        int taken = 0;
-        KMU_TRY(seg_partitioned_add(c, ds, total_bases, pl, d_err, &taken));
-        if (taken) return KMU_OK; // (else a segment overflowed -- very skewed k-mers -- and nothing was touched: the exact route)
-    }
     KMU_TRY(scatter_attrs(ctx));
     {
         KernelTimer tm(ctx, "k_part_hist1");
@@ -1835,7 +1838,7 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     const uint64_t cap1 = seg_cap_for((double) n / chunks1 / bins1), bincap1 = (uint64_t) chunks1 * cap1;
     const uint64_t cap2 = seg_cap_for((double) n / bins1 / bins2);
     void *A, *B, *ovf, *bnd, *b0, *leafcnt;
-    KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + (size_t) TILE_ITEMS * 8 + 64, &A));
+    KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * cap2 * 8 + 64, &B));
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &leafcnt));
     KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &ovf));

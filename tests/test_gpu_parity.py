@@ -1152,6 +1152,38 @@ def test_count_compact_state(ctx, oracle, monkeypatch):
     c.close()
 
 
+def test_count_single_pass_overflow_on_a_fresh_context(oracle, monkeypatch):
+    """The overflow fall-back of the single-pass partition on a context whose scratch buffers do not exist yet: the attempt
+    allocates "cnt.partA" / "cnt.partB" in its own sizes, the exact levels that take over allocate them anew (a route that
+    kept pointers across the other's allocations wrote into freed memory: found by forcing the route on the whole suite).
+    The reads are skewed -- thousands of copies of one k-mer overflow a segment -- and go in twice."""
+    from kmerutils_amd import lib
+    monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    bases, off = synth.ont_reads(2500, 3_000_000, 0xC8)
+    extra, eoff = oracle.concat([b"A" * 9000, b"ACGT" * 2000, b"T" * 7000])
+    bases = np.concatenate([bases, extra])
+    off = np.concatenate([off, eoff[1:] + off[-1]])
+    o = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 22)
+    o.add_reads(bases, off)
+    fresh = lib.Context(0)
+    try:
+        c = fresh.counter(A.KMER64BIT, 31, 8, 12_000_000)  # 2^25 slots: two partition levels
+        fresh.profile_reset()
+        fresh.profile_enable(True)
+        c.add_reads(bases, off)
+        fresh.profile_enable(False)
+        assert "k_part_hist1" in fresh.profile_get()  # the segments overflowed: the exact route ran
+        wk, wc = o.dump(1)
+        gk, gc = c.dump(1)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        c.add_reads(bases, off)
+        assert c.nb_distinct() == o.nb_distinct()
+        c.close()
+    finally:
+        fresh.close()
+
+
 @pytest.mark.parametrize("pct", ["100", "60"])
 def test_count_single_pass_partition(ctx, oracle, monkeypatch, pct):
     """KMU_COUNT_SEG=2: the partitioned build with fixed-size segments and no histogram passes (what big batches take by
