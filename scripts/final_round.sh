@@ -1,0 +1,23 @@
+#!/bin/bash
+# end-of-round measurement on one GPU box: the full -m gpu suite, the rocprofv3 / PMC passes of the default bench (profiles/<tag>_*),
+# the default bench line with cpu_baseline, the other workloads.  usage: scripts/final_round.sh <tag>
+tag=$1
+cd $GRAFT_REPO_ROOT
+timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/t_final_$tag.log 2>&1; echo rc=$? >> gpurun_out/t_final_$tag.log; tail -3 gpurun_out/t_final_$tag.log
+grep -q "^rc=0" gpurun_out/t_final_$tag.log || exit 1
+bash scripts/pmc_bench.sh $tag > gpurun_out/pmc_bench_$tag.log 2>&1 || { echo "pmc_bench failed"; tail -5 gpurun_out/pmc_bench_$tag.log; exit 1; }
+timeout -k 10 300 python bench.py > gpurun_out/bench_${tag}_default.json 2> gpurun_out/bench_${tag}_default.err || { echo "bench failed"; exit 1; }
+WORKLOADS="c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa" bash scripts/other_workloads.sh
+python3 - <<PY
+import json
+runs = {}
+for w in "c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa".split():
+    try:
+        d = json.loads(open("gpurun_out/wl_%s.json" % w).read().strip().splitlines()[-1])
+    except Exception as e:
+        print("no line for", w, e); continue
+    runs[w] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+               "value_host_to_host": d.get("value_host_to_host"), "kernels": {k: v["avg_ms"] for k, v in d["kernels"].items()},
+               "checks": d["checks"], "cpu_baseline": (d.get("cpu_baseline") or {}).get("value")}
+json.dump({"round": "$tag", "source": "scripts/final_round.sh", "runs": runs}, open("gpurun_out/${tag}_workloads.json", "w"), indent=1, sort_keys=True)
+PY
