@@ -42,6 +42,7 @@ struct kmu_counter {
     // an exchange in flight between dist_add_begin and dist_add_end
     uint64_t pend_recv = 0;      // k-mers arriving in "cnt.recv"
     bool pending = false;
+    bool no_seg = false;         // the single-pass partition of this batch has just overflowed: straight to the exact levels
 };
 
 namespace kmu {
@@ -789,6 +790,16 @@ struct SegClk {
 #endif
 };
 
+// An item that finds its segment full goes to the spill list (k-mers that occur many times -- a genome at coverage c -- make
+// a bin's fill vary sqrt(c) times more than the margin of independent k-mers allows for; the list is added to the finished
+// table by direct insertion, k_count_add_spill); only a full spill list raises the flag that sends the batch to the exact
+// levels.  ovf: [0] flag, [1] items spilled, [2] capacity of the list, [4..5] its address.
+__device__ __forceinline__ void seg_spill(uint32_t *ovf, uint64_t item) {
+    const uint32_t at = atomicAdd(&ovf[1], 1u);
+    if (at < ovf[2]) (*reinterpret_cast<uint64_t *const *>(ovf + 4))[at] = item;
+    else ovf[0] = 1u;
+}
+
 // items are khash values (IT_HASH); nbins a multiple of 4, <= 2048; all 1024 threads call this together; cnt[] zero on the
 // first call.  The digit is a bit field of the item's high word; a destination is one v_mad_u64_u32.  (A form without the
 // per-item branches -- "no k-mer" marks as items of a bin of their own behind the others -- needs 40 more registers than
@@ -871,7 +882,7 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
             if (p < total) {
                 if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
-                else *sg.ovf = 1u;
+                else seg_spill(sg.ovf, v[u]);
             }
         }
     }
@@ -1250,6 +1261,15 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     }
 }
 
+// the spill list of a single-pass partition (khash values) into the finished table, by direct insertion
+__global__ void __launch_bounds__(256) k_count_add_spill(const uint64_t *items, const uint32_t *ovf, CountTable t, uint32_t *err) {
+    const uint32_t n = ovf[1] < ovf[2] ? ovf[1] : ovf[2];
+    bool full = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (!count_insert(t, khash_inv(items[i]), 1u)) full = true;
+    if (full) atomicOr(err, DERR_TABLE_FULL);
+}
+
 // bounds[i] = i * stride (the input partitions of the single-pass level 2: level 1's fixed-size bins)
 __global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, uint64_t stride) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = i * stride;
@@ -1505,6 +1525,32 @@ static bool part_plan_for(const kmu_counter *c, PartPlan *pl) {
     return pl->b1 <= 11 && pl->b2 <= 11;
 }
 
+// the overflow word block of a single-pass partition (see seg_spill) and its spill list: room for 1/32 of the items
+static int seg_spill_setup(kmu_ctx *ctx, uint64_t n_items, bool spill_ok, void **ovf_out) {
+    void *ovf, *sp;
+    const uint64_t cap = spill_ok ? std::min<uint64_t>(n_items / 32 + 4096, 0x7FFFFFFFull) : 0;
+    KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &ovf));
+    KMU_TRY(dev_buf(ctx, "cnt.spill", (size_t) cap * 8 + 64, &sp));
+    uint32_t hdr[16] = {0};
+    hdr[2] = (uint32_t) cap;
+    memcpy(&hdr[4], &sp, sizeof sp);
+    KMU_HIP(ctx, hipMemcpyAsync(ovf, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream)); // (pageable source: copied before the call returns)
+    *ovf_out = ovf;
+    return KMU_OK;
+}
+// after the build: the spilled items, if any (h_ovf: the two words read back before the build)
+static int seg_spill_add(kmu_counter *c, const void *ovf, const uint32_t *h_ovf, uint32_t *d_err) {
+    kmu_ctx *ctx = c->ctx;
+    if (!h_ovf[1]) return KMU_OK;
+    void *sp;
+    KMU_TRY(dev_buf(ctx, "cnt.spill", 64, &sp)); // (the list seg_spill_setup made: same buffer, never smaller)
+    KernelTimer tm(ctx, "k_count_add_spill");
+    hipLaunchKernelGGL(k_count_add_spill, dim3(grid_for(ctx, h_ovf[1], 256)), dim3(256), 0, ctx->stream, (const uint64_t *) sp, (const uint32_t *) ovf,
+                       table_of(c), d_err);
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+
 static bool seg_partition_wanted(uint64_t total_bases) {
     const char *e = getenv("KMU_COUNT_SEG"); // 0: always the exact two-pass levels (A/B); 2: also for small batches (tests)
     if (e && atoi(e) == 0) return false;
@@ -1573,9 +1619,8 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     KMU_TRY(dev_buf(ctx, own_buffer ? "cnt.segA" : "cnt.partA", (size_t) bins1 * run->sp.bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &run->A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * run->sp.leafcap * 8 + 64, &run->B));
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &run->leafcnt));
-    KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &run->ovf));
+    KMU_TRY(seg_spill_setup(ctx, total_bases, !want_compact(), &run->ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &run->bnd));
-    KMU_HIP(ctx, hipMemsetAsync(run->ovf, 0, 64, ctx->stream));
     KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;
 }
@@ -1620,11 +1665,12 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
                            (uint64_t *) run->B, run->sp.cap2, (uint32_t *) run->ovf, (uint32_t *) run->leafcnt);
     }
     KMU_HIP(ctx, hipGetLastError());
-    uint32_t h_ovf = 0; // read before the table is touched: an overflow leaves the call to the exact route
-    KMU_HIP(ctx, hipMemcpyAsync(&h_ovf, run->ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t h_ovf[2] = {0, 0}; // read before the table is touched: a full spill list leaves the call to the exact route
+    KMU_HIP(ctx, hipMemcpyAsync(h_ovf, run->ovf, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_ovf) return KMU_OK;
+    if (h_ovf[0]) return KMU_OK;
     KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(), run->d_err, run->sp.leafcap, (const uint32_t *) run->leafcnt));
+    KMU_TRY(seg_spill_add(c, run->ovf, h_ovf, run->d_err));
 #if KMU_DIAG
     if (getenv("KMU_DIAG_SEG")) { // thread-0 clocks of the tile sort, summed over the workgroups: [level] between / rank / scan / place / out / finish
         unsigned long long h[2][8], z[2][8] = {};
@@ -1682,7 +1728,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
 
     // the single-pass partition first, BEFORE this route takes its buffers: both use "cnt.partA" / "cnt.partB" with different
     // sizes, and a buffer that grows is freed and allocated anew (pointers taken earlier would dangle)
-    if (pl.b2 && !dbg_split && seg_partition_wanted(total_bases)) {
+    if (pl.b2 && !dbg_split && !c->no_seg && seg_partition_wanted(total_bases)) {
         int taken = 0;
         KMU_TRY(seg_partitioned_add(c, ds, total_bases, pl, d_err, &taken));
         if (taken) return KMU_OK; // (else a segment overflowed -- very skewed k-mers -- and nothing was touched: the exact route)
@@ -1841,10 +1887,9 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * cap2 * 8 + 64, &B));
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &leafcnt));
-    KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &ovf));
+    KMU_TRY(seg_spill_setup(ctx, n, !want_compact(), &ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &bnd));
     KMU_TRY(dev_buf(ctx, "arr.bounds0", 16, &b0));
-    KMU_HIP(ctx, hipMemsetAsync(ovf, 0, 64, ctx->stream));
     hipLaunchKernelGGL(k_fill_linear, dim3(1), dim3(256), 0, ctx->stream, (uint64_t *) b0, (uint64_t) 2, n);
     KMU_TRY(scatter_attrs(ctx));
     {
@@ -1863,11 +1908,12 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
                            (uint32_t *) leafcnt);
     }
     KMU_HIP(ctx, hipGetLastError());
-    uint32_t h_ovf = 0;
-    KMU_HIP(ctx, hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t h_ovf[2] = {0, 0};
+    KMU_HIP(ctx, hipMemcpyAsync(h_ovf, ovf, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_ovf) return KMU_OK; // the table is untouched: the exact levels take over
+    if (h_ovf[0]) return KMU_OK; // the table is untouched: the exact levels take over
     KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(), d_err, cap2, (const uint32_t *) leafcnt));
+    KMU_TRY(seg_spill_add(c, ovf, h_ovf, d_err));
     *taken = 1;
     return KMU_OK;
 }
@@ -2250,7 +2296,11 @@ int count_chunked_finish(kmu_counter *c, void *handle) {
     CountChunked *h = (CountChunked *) handle;
     int taken = 0;
     int rc = seg_finish(c, &h->run, &taken);
-    if (rc == KMU_OK && !taken) rc = local_add(c, h->run.ds, h->run.total_bases, h->run.d_err); // a segment overflowed: the exact route
+    if (rc == KMU_OK && !taken) { // a segment overflowed: the exact route (not a second attempt on the same k-mers)
+        c->no_seg = true;
+        rc = local_add(c, h->run.ds, h->run.total_bases, h->run.d_err);
+        c->no_seg = false;
+    }
     delete h;
     return rc;
 }

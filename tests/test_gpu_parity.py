@@ -1153,17 +1153,15 @@ def test_count_compact_state(ctx, oracle, monkeypatch):
 
 
 def test_count_single_pass_overflow_on_a_fresh_context(oracle, monkeypatch):
-    """The overflow fall-back of the single-pass partition on a context whose scratch buffers do not exist yet: the attempt
+    """The fall-back of the single-pass partition on a context whose scratch buffers do not exist yet: the attempt
     allocates "cnt.partA" / "cnt.partB" in its own sizes, the exact levels that take over allocate them anew (a route that
     kept pointers across the other's allocations wrote into freed memory: found by forcing the route on the whole suite).
-    The reads are skewed -- thousands of copies of one k-mer overflow a segment -- and go in twice."""
+    Segments of 60 % of their expected fill: far more items overflow than the spill list takes."""
     from kmerutils_amd import lib
     monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    monkeypatch.setenv("KMU_COUNT_SEG_PCT", "60")
     monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
     bases, off = synth.ont_reads(2500, 3_000_000, 0xC8)
-    extra, eoff = oracle.concat([b"A" * 9000, b"ACGT" * 2000, b"T" * 7000])
-    bases = np.concatenate([bases, extra])
-    off = np.concatenate([off, eoff[1:] + off[-1]])
     o = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 22)
     o.add_reads(bases, off)
     fresh = lib.Context(0)
@@ -1173,7 +1171,7 @@ def test_count_single_pass_overflow_on_a_fresh_context(oracle, monkeypatch):
         fresh.profile_enable(True)
         c.add_reads(bases, off)
         fresh.profile_enable(False)
-        assert "k_part_hist1" in fresh.profile_get()  # the segments overflowed: the exact route ran
+        assert "k_part_hist1" in fresh.profile_get()  # the exact route ran
         wk, wc = o.dump(1)
         gk, gc = c.dump(1)
         assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
@@ -1182,6 +1180,37 @@ def test_count_single_pass_overflow_on_a_fresh_context(oracle, monkeypatch):
         c.close()
     finally:
         fresh.close()
+
+
+def test_count_single_pass_spill_list(ctx, oracle, monkeypatch):
+    """K-mers that occur thousands of times (homopolymer runs, a tandem repeat, the same reads three times over) overflow
+    their segments of the single-pass partition: the items go to the spill list and are inserted into the finished table,
+    the batch is NOT redone by the exact levels.  Counts equal to the oracle's, also for a second batch into the table."""
+    monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    bases, off = synth.ont_reads(1200, 1_500_000, 0xC9)
+    extra, eoff = oracle.concat([b"A" * 9000, b"ACGT" * 2000, b"T" * 7000, b"ACGGT" * 1500])
+    parts, offs = [bases, bases, bases, extra], [off, off[1:] + off[-1], off[1:] + 2 * off[-1], eoff[1:] + 3 * off[-1]]
+    bases = np.concatenate(parts)
+    off = np.concatenate(offs)
+    o = oracle.Counter(A.KMER64BIT, 31, 16, 1 << 22)
+    o.add_reads(bases, off)
+    c = ctx.counter(A.KMER64BIT, 31, 16, 12_000_000)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    c.add_reads(bases, off)
+    ctx.profile_enable(False)
+    prof = ctx.profile_get()
+    assert "k_part_hist1" not in prof and "k_count_add_spill" in prof
+    wk, wc = o.dump(1)
+    gk, gc = c.dump(1)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    c.add_reads(bases, off)
+    o.add_reads(bases, off)
+    wk, wc = o.dump(1)
+    gk, gc = c.dump(1)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    c.close()
 
 
 @pytest.mark.parametrize("pct", ["100", "60"])
