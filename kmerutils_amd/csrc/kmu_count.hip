@@ -1030,7 +1030,12 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     ScatterLds l = scatter_lds(smem, bins1);
     SegLds ls = seg_lds(smem, bins1);
     const uint64_t unit = seg.unit_base + blockIdx.x;
-    SegOut sg{0, seg.bincap, (unit + 1) * seg.cap, seg.cap, seg.ovf};
+    // single-pass form: the segments of a unit lie side by side (block `unit` of bins1 segments): a workgroup's 2^b1 output
+    // streams stay inside bins1 x cap items (148 MB at the bench size) instead of spreading over the whole buffer, one
+    // stream every 18 MB (18.6 against 20.1 ms on the bench workload, same box, alternating processes; the kernel also has
+    // a slow state of the box -- 25 ms with either layout for minutes on end -- that no layout changes)
+    SegOut sg{unit * bins1, seg.cap, seg.cap, seg.cap, seg.ovf};
+    if (seg.bincap) sg = SegOut{0, seg.bincap, (unit + 1) * seg.cap, seg.cap, seg.ovf}; // (A/B: the bins' ranges side by side, KMU_COUNT_SEG_LAYOUT=bin)
     uint32_t run[2] = {0u, 0u};
     SegClk clk;
     if (SEGM) {
@@ -1095,6 +1100,9 @@ struct ArrPlan {
     uint32_t bins;
     uint32_t nparts;
     uint32_t chunks;
+    // != 0: the input partition p is not contiguous but the p-th segment (seg_cap items) of each of seg_units blocks of
+    // seg_bins segments -- what the single-pass level 1 leaves, one block per unit (k_part_scatter1<true>); bounds is not read
+    uint32_t seg_units, seg_cap, seg_bins;
 };
 
 __device__ __forceinline__ void arr_unit_range(const uint64_t *bounds, const ArrPlan &pl, uint32_t unit, uint64_t *i0,
@@ -1184,7 +1192,9 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     ScatterLds l = scatter_lds(smem, pl.bins);
     SegLds ls = seg_lds(smem, pl.bins);
     const uint64_t sp = blockIdx.x / pl.chunks, sc = blockIdx.x % pl.chunks;
-    SegOut sg{sp * pl.bins, (uint64_t) pl.chunks * seg_cap, (sc + 1) * seg_cap, seg_cap, seg_ovf};
+    // segmented output: the bins' segments of a unit side by side, block blockIdx.x of pl.bins segments (level 2, one unit per
+    // input partition: the region leaves in region order)
+    SegOut sg{(uint64_t) blockIdx.x * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
     uint32_t run[2] = {0u, 0u};
     SegClk clk;
     if (SEGM) {
@@ -1198,10 +1208,12 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     }
     lds_barrier();
     uint64_t i0, i1;
-    arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
-    // PADDED: the input is a partition buffer of the library with two tiles' worth of readable bytes behind its end -- a tile is
-    // requested whole by unconditional loads, what lies beyond the unit is not looked at, and the waits are explicit (see
-    // flat_step_fetch); otherwise (arrays of the caller) the loads stay under their bounds tests and the compiler's waits.
+    if (pl.seg_units) { i0 = 0; i1 = (uint64_t) pl.seg_units * pl.seg_cap; } // (positions in the partition's segments, one after the other)
+    else arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
+    // PADDED: the input is the segmented output of a single-pass level 1 (pl.seg_units != 0) -- a tile is requested whole by
+    // unconditional loads (positions beyond the partition are mapped to its last block and not looked at) and the waits are
+    // explicit (see flat_step_fetch); otherwise (arrays of the caller) the loads stay under their bounds tests and the
+    // compiler's waits.
     constexpr bool PADDED = IT == IT_HASH && SEGM;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     uint64_t nxt[16];
@@ -1212,13 +1224,29 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
         const uint64_t i = i0 + (uint64_t) j * blockDim.x + threadIdx.x;
         if (!PADDED) nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
     }
-    if (PADDED) {
+    // the 16 items of this thread of the tile that starts at position t of the partition
+    const uint64_t seg_stride = (uint64_t) pl.seg_bins * pl.seg_cap, seg_base = (uint64_t) sp * pl.seg_cap;
+    auto tile_request = [&](uint64_t t) {
+        { // position -> (block, offset); a pair of items never straddles segments (their sizes are multiples of 16)
+            uint32_t i = (uint32_t) t + 2u * threadIdx.x;
+            uint32_t u = i / pl.seg_cap, o = i - u * pl.seg_cap;
 #pragma unroll
-        for (int j2 = 0; j2 < 8; j2++) {
-            u64x2 q = {CKEY_EMPTY, CKEY_EMPTY};
-            if (i0 < i1) q = *reinterpret_cast<const u64x2 *>(in + i0 + (uint64_t) j2 * 2048 + 2u * threadIdx.x);
-            nxt[2 * j2] = q.x;
-            nxt[2 * j2 + 1] = q.y;
+            for (int j2 = 0; j2 < 8; j2++) {
+                const uint32_t uu = u < pl.seg_units ? u : pl.seg_units - 1; // (beyond the partition: anything readable)
+                const u64x2 q = *reinterpret_cast<const u64x2 *>(in + (uint64_t) uu * seg_stride + seg_base + o);
+                nxt[2 * j2] = q.x;
+                nxt[2 * j2 + 1] = q.y;
+                o += 2048u;
+                if (pl.seg_cap >= 2048u) { if (o >= pl.seg_cap) { o -= pl.seg_cap; u++; } }
+                else { const uint32_t d = o / pl.seg_cap; u += d; o -= d * pl.seg_cap; }
+            }
+        }
+    };
+    if (PADDED) {
+        if (i0 < i1) tile_request(i0);
+        else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) nxt[j] = CKEY_EMPTY;
         }
         vm_wait_all();
     }
@@ -1232,12 +1260,7 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
         }
         // the next tile is requested before this one is sorted: its HBM latency hides under the LDS work
         if (PADDED) {
-#pragma unroll
-            for (int j2 = 0; j2 < 8; j2++) {
-                const u64x2 q = *reinterpret_cast<const u64x2 *>(in + t0 + TILE_ITEMS + (uint64_t) j2 * 2048 + 2u * threadIdx.x);
-                nxt[2 * j2] = q.x;
-                nxt[2 * j2 + 1] = q.y;
-            }
+            tile_request(t0 + TILE_ITEMS);
         } else {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -1555,7 +1578,12 @@ static bool seg_partition_wanted(uint64_t total_bases) {
     const char *e = getenv("KMU_COUNT_SEG"); // 0: always the exact two-pass levels (A/B); 2: also for small batches (tests)
     if (e && atoi(e) == 0) return false;
     if (e && atoi(e) == 2) return true;
+    if (total_bases >> 40) return false; // (positions inside a level-1 bin are 32-bit numbers)
     return total_bases >= (1ull << 27); // (the margins are a small share of the mean only for big batches)
+}
+static bool seg_layout_bin() { // A/B runs: level 1's output with the ranges of the bins side by side instead of the units' blocks
+    const char *e = getenv("KMU_COUNT_SEG_LAYOUT");
+    return e && e[0] == 'b';
 }
 static uint64_t seg_cap_for(double mean) {
     double pct = 1.0;
@@ -1643,7 +1671,7 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
         hipLaunchKernelGGL(k_part_scatter1<true>, dim3(upto - run->units_done), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream,
                            run->ds.bases, run->ds.offsets, run->ds.n_seq, c->p.kmer_size, run->pl, (const uint64_t *) nullptr,
                            (const uint64_t *) nullptr, (uint64_t *) run->A,
-                           SegPlan1{run->sp.cap1, run->sp.bincap1, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
+                           SegPlan1{run->sp.cap1, seg_layout_bin() ? run->sp.bincap1 : 0, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
                                     (uint32_t *) run->ovf, run->d_err});
     }
     KMU_HIP(ctx, hipGetLastError());
@@ -1658,7 +1686,8 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     const uint32_t bins1 = 1u << run->pl.b1, bins2 = 1u << run->pl.b2;
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) run->bnd, (uint64_t) bins1 + 1, run->sp.bincap1);
     {
-        ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2};
+        ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2, run->sp.units1, (uint32_t) run->sp.cap1, bins1};
+        if (seg_layout_bin()) { ap.seg_units = 1; ap.seg_cap = (uint32_t) run->sp.bincap1; }
         KernelTimer tm(ctx, "k_part_scatter2");
         hipLaunchKernelGGL((k_arr_scatter<IT_HASH, true>), dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream,
                            (const uint64_t *) run->A, (const uint64_t *) run->bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
@@ -1901,7 +1930,7 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     }
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) bnd, (uint64_t) bins1 + 1, bincap1);
     {
-        ArrPlan ap{pl.region_bits, 0, bins2, bins1, 1u};
+        ArrPlan ap{pl.region_bits, 0, bins2, bins1, 1u, chunks1, (uint32_t) cap1, bins1};
         KernelTimer tm(ctx, "k_arr_scatter");
         hipLaunchKernelGGL((k_arr_scatter<IT_HASH, true>), dim3(bins1), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream, (const uint64_t *) A,
                            (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf,
