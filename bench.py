@@ -47,7 +47,7 @@ def parse():
 
 
 WORKLOADS = ("ont_k31", "ont_k31_sketch", "ont_k31_count", "c3_k8", "c2_count", "c2_nthash_count", "c4_count", "c1_super",
-             "c5_aa", "ont_k31_optdens")
+             "c5_aa", "ont_k31_optdens", "short_k21_sketch")
 
 
 def workload_cfg(args):
@@ -69,6 +69,9 @@ def workload_cfg(args):
         # ntHash of every 21-mer (kmu_nthash, 8 bytes per position) and the count of every canonical 21-mer
         cfg.update(n_reads=1_000_000, total_bases=1.5e8, fixed_len=150, errors=(0.005, 0, 0), k=21, sketch=False,
                    nthash=w == "c2_nthash_count", seed=0xC2, genome=10_000_000)
+    elif w == "short_k21_sketch":  # config 2's reads (1 M x 150 bp) through ProbMinHash3a: the short-read regime of the sketch kernels
+        cfg.update(n_reads=1_000_000, total_bases=1.5e8, fixed_len=150, errors=(0.005, 0, 0), k=21, count=False, seed=0xC2,
+                   genome=10_000_000)
     elif w == "c4_count":  # config 4's per-GPU shard: 6.25 M x 150 bp of the 50 M reads, 100 Mbp genome, k = 31, count only
         cfg.update(n_reads=6_250_000, total_bases=9.375e8, fixed_len=150, errors=(0.005, 0, 0), k=31, sketch=False, seed=0xC4)
     elif w == "c1_super":

@@ -654,10 +654,11 @@ struct SegOut {
     uint32_t *ovf;
 };
 
-// it[j] == CKEY_EMPTY marks "no k-mer".  All 1024 threads call this together.
-template <int IT, bool SEG = false>
+// it[j] == CKEY_EMPTY marks "no k-mer".  All 1024 threads call this together.  (The exact levels, the owner grouping of a
+// distributed add, the generic array partition; the single-pass partition has its own form, tile_scatter_seg.)
+template <int IT>
 __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLds &l, uint32_t nbins, int region_bits,
-                                             int shift, uint32_t mask, uint64_t *out, const SegOut *sg = nullptr) {
+                                             int shift, uint32_t mask, uint64_t *out) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t br[16];
 #pragma unroll
@@ -703,21 +704,16 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
             v[u] = p < total ? l.stage[p] : CKEY_EMPTY;
         }
-        uint64_t lim[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
             const uint32_t bin = p < total ? digit_of<IT>(v[u], region_bits, shift, mask) : 0u;
             dst[u] = l.gbase[bin] + (uint64_t) (p - l.lstart[bin]);
-            lim[u] = SEG ? (sg->bin_base + bin) * sg->bincap + sg->end_rel : ~0ull;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
-            if (p < total) {
-                if (!SEG || dst[u] < lim[u]) out[dst[u]] = v[u];
-                else *sg->ovf = 1u;
-            }
+            if (p < total) out[dst[u]] = v[u];
         }
     }
     lds_barrier();
@@ -735,18 +731,6 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
     }
     if (tid == 0) l.lstart[nbins] = 0;
     lds_barrier();
-}
-
-// the unused tail of every segment of this unit is filled with "no k-mer" marks (the readers of the next level skip them):
-// wave w takes bins w, w + 16, ...; its lanes store consecutive items
-__device__ __forceinline__ void seg_fill_tails(const ScatterLds &l, uint32_t nbins, const SegOut &sg, uint64_t *out) {
-    const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, lane = (uint32_t) lane_id();
-    for (uint32_t b = wave; b < nbins; b += nwaves) {
-        const uint64_t end = (sg.bin_base + b) * sg.bincap + sg.end_rel;
-        uint64_t cur = l.gbase[b];
-        cur = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (cur >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) cur);
-        for (uint64_t i = cur + lane; i < end; i += 64) out[i] = CKEY_EMPTY;
-    }
 }
 
 // ---- the tile sort of the single-pass partition (round 2) -------------------------------------------------------------
