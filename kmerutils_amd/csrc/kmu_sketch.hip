@@ -1414,6 +1414,119 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     }
 }
 
+// ---- reads of at most 256 k-mers (short-read sequencers): the multiset by ONE WAVE per read ---------------------------------
+// A 150 bp read has ~130 k-mers: a 512-thread workgroup of k_multiset_uq spends ten barriers on a quarter of a key per thread
+// (12.9 ms for a million such reads).  Here a wave takes a read by itself: the lanes stage the read's <= 20 code words in the
+// wave's corner of LDS, every lane makes up to four keys, and equal keys meet in a 512-slot open-addressing table of the wave
+// (`ds_cmpst_rtn_b64` claims a slot, `ds_add` counts) -- exact, no barrier, 20 waves per CU.  The occupied slots leave as the
+// (key, weight) list k_pmh_points reads (its result does not depend on the order of a list).  The all-ones value that marks
+// a free slot can be a key: such keys are counted in a register and listed at the end.
+// Taken by launch_pmh3a when the longest read of the batch has at most SHORT_KEYS k-mers.
+static constexpr uint32_t SHORT_KEYS = 256, SHORT_SLOTS = 512, SHORT_WORDS = 24;
+static constexpr size_t SHORT_WAVE_BYTES = (size_t) SHORT_SLOTS * 12 + SHORT_WORDS * 4;
+__global__ void __launch_bounds__(256) k_multiset_short(SketchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    uint64_t *tk = reinterpret_cast<uint64_t *>(smem + (size_t) wave * SHORT_WAVE_BYTES);
+    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + SHORT_SLOTS);
+    uint32_t *words = tc + SHORT_SLOTS;
+    const KmerCfg cfg = a.cfg;
+    const int k = cfg.k;
+    for (uint32_t t = (uint32_t) lane; t < SHORT_SLOTS; t += 64u) { tk[t] = ~0ull; tc[t] = 0u; }
+    const uint64_t off_first = uniform_u64(a.offsets[0]);
+    const uint64_t total = a.total_bytes ? a.total_bytes : uniform_u64(a.offsets[a.n_seq]);
+    uint32_t q_next = 0, q_end = 0, bad = 0; // lane 0: reads are taken QCHUNK at a time
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) {
+            if (q_next == q_end) {
+                q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
+                q_end = q_next + QCHUNK;
+            }
+            r = q_next++;
+        }
+        r = uniform_u32(r);
+        if (r >= a.n_seq) break;
+        SeqView sv;
+        sv.base = a.bases; sv.packed = 0; sv.total = total;
+        sv.begin = uniform_u64(a.offsets[r]);
+        sv.len = uniform_u64(a.offsets[r + 1]) - sv.begin;
+        const uint32_t L = sv.len >= 0x80000000ull ? 0xFFFFFFFFu : (uint32_t) sv.len;
+        const uint32_t nk = L >= (uint32_t) k ? L - (uint32_t) k + 1u : 0u;
+        if (L == 0 && lane == 0) atomicOr(a.err, DERR_EMPTY_SEQ);
+        if (nk == 0) { // no k-mer: k_pmh_points writes the row of an empty multiset
+            bad |= wave_validate_seq(sv, 0, 1, false);
+            if (lane == 0) a.lst_n[r] = 0u;
+            continue;
+        }
+        if (nk > SHORT_KEYS) { // (the host only sends batches whose longest read fits)
+            if (lane == 0) { a.lst_n[r] = 0u; atomicOr(a.err, DERR_TABLE_FULL); }
+            continue;
+        }
+        const uint32_t lead = seq_lead(sv), wfirst = lead >> 4;
+        const uint32_t nw = (uint32_t) ((L - 1 + lead) >> 4) + 2; // the k-mers' windows + 1 (<= 20 words)
+        if ((uint32_t) lane < nw) {
+            uint32_t b;
+            words[lane] = load_code_word(sv, (uint64_t) wfirst + (uint32_t) lane, b);
+            bad |= b;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the wave's own LDS traffic is in order; this keeps the compiler from moving it
+        __builtin_amdgcn_wave_barrier();
+        uint32_t n_free_key = 0; // occurrences of the key that looks like a free slot (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < (int) (SHORT_KEYS / 64); j++) {
+            const uint32_t p = (uint32_t) lane + 64u * (uint32_t) j;
+            const bool have = p < nk;
+            uint64_t key = 0;
+            if (have) {
+                const uint32_t qq = p + lead - 16u * wfirst, idx = qq >> 4, sh = (qq & 15u) * 2u;
+                const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
+                const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
+                const uint64_t val = v >> (64 - 2 * k);
+                key = apply_fhash(cfg, val, revcomp_val(val, k));
+            }
+            const bool odd = have && key == ~0ull;
+            n_free_key += (uint32_t) __popcll(__ballot(odd));
+            if (have && !odd) {
+                uint32_t slot = mix32(key) & (SHORT_SLOTS - 1);
+                for (;;) { // (256 keys at most in 512 slots: a free slot always turns up)
+                    const uint64_t old = atomicCAS((unsigned long long *) &tk[slot], ~0ull, (unsigned long long) key);
+                    if (old == ~0ull || old == key) { atomicAdd(&tc[slot], 1u); break; }
+                    slot = (slot + 1) & (SHORT_SLOTS - 1);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- the occupied slots leave as the read's list (and the table is free again) ----
+        const uint64_t lb = sv.begin - off_first;
+        uint32_t n_out = 0;
+#pragma unroll
+        for (int s8 = 0; s8 < (int) (SHORT_SLOTS / 64); s8++) {
+            const uint32_t slot = (uint32_t) s8 * 64u + (uint32_t) lane;
+            const uint64_t kq = tk[slot];
+            const bool occ = kq != ~0ull;
+            const uint64_t om = __ballot(occ);
+            if (occ) {
+                const uint64_t at = lb + n_out + (uint32_t) __popcll(om & ((1ull << lane) - 1ull));
+                a.lst_keys[at] = kq;
+                a.lst_w[at] = tc[slot];
+                tk[slot] = ~0ull;
+                tc[slot] = 0u;
+            }
+            n_out += (uint32_t) __popcll(om);
+        }
+        if (n_free_key) {
+            if (lane == 0) { a.lst_keys[lb + n_out] = ~0ull; a.lst_w[lb + n_out] = n_free_key; }
+            n_out++;
+        }
+        if (lane == 0) a.lst_n[r] = n_out;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (bad) atomicOr(a.err, DERR_NON_ACGT);
+}
+
 // ---- k <= 8: the multiset of a read as a DIRECT-INDEXED histogram ---------------------------------------------------------
 // Config 3 as the README times it (`datasketcher -k 8 -s 200`, src/bin/datasketcher.rs:222-254): 4^8 = 65 536 possible
 // 8-mers, so the FnvHashMap<Kmer32bit::Val, u64> of seqsketchjaccard.rs:226-234 is an array in LDS indexed by the k-mer
@@ -2145,7 +2258,18 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     const char *uq_env = getenv("KMU_PMH_UQ"); // 0: every read through the counting-sort kernel (A/B)
     const bool uq = split && plain && !(uq_env && atoi(uq_env) == 0);
     bool main_launched = false;
-    if (uq) {
+    const char *sh_env = getenv("KMU_PMH_SHORT"); // 0: short reads through k_multiset_uq like the others (A/B)
+    if (uq && len_stats && len_stats[0] < (uint64_t) SHORT_KEYS + (uint64_t) p->kmer_size && !(sh_env && atoi(sh_env) == 0)) {
+        // every read of the batch has at most 256 k-mers: one wave per read (k_multiset_short)
+        const size_t lds_s = 4 * SHORT_WAVE_BYTES;
+        const int per_cu = 5; // (88 registers: five waves per SIMD)
+        KernelTimer t(ctx, "k_multiset_short");
+        hipLaunchKernelGGL(k_multiset_short, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) cus * per_cu))),
+                           dim3(256), lds_s, ctx->stream, a);
+        KMU_HIP(ctx, hipGetLastError());
+        KMU_HIP(ctx, hipMemsetAsync(a.queue, 0, 256, ctx->stream)); // (the points kernel's cursor)
+        main_launched = true;
+    } else if (uq) {
         {
             typedef UqShape<512, 16, 2048> SA;
             const auto ka = k_multiset_uq<512, 16, 2048, 4>;

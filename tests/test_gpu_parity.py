@@ -1251,3 +1251,32 @@ def test_count_single_pass_partition(ctx, oracle, monkeypatch, pct):
         c.add_reads(bad, off)
     assert ei.value.code == A.E_NON_ACGT
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,kt,sig", [(21, A.KMER64BIT, A.SIG_U64), (31, A.KMER64BIT, A.SIG_U64), (12, A.KMER32BIT, A.SIG_U32)])
+def test_short_reads_wave_per_read_multiset(ctx, oracle, monkeypatch, k, kt, sig):
+    """A batch whose longest read has at most 256 k-mers takes k_multiset_short (one wave per read, a 512-slot table per wave)
+    in front of k_pmh_points: 100-270 bp reads incl. homopolymers, tandem repeats, a read of exactly 256 k-mers, reads
+    shorter than k; signatures equal to the oracle's, and to the general route's (KMU_PMH_SHORT=0)."""
+    rng = np.random.default_rng(0x5107 + k)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n))) for n in rng.integers(100, 256 + k - 1, size=3000)]
+    seqs += [b"A" * 200, b"AC" * 120, b"ACGTT" * 50, b"T" * (255 + k), b"ACG"[:2] * 5, b"G" * (k - 1), b"C" * k]
+    seqs.append(bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=255 + k)))  # exactly 256 k-mers
+    bases, off = oracle.concat(seqs)
+    p = A.SketchParams(A.ALGO_PROB3A, kt, k, 64, sig, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    want = oracle.sketch(bases, off, p)
+    monkeypatch.setenv("KMU_PMH_SPLIT", "1")
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    got = ctx.sketch(bases, off, p)
+    ctx.profile_enable(False)
+    assert "k_multiset_short" in ctx.profile_get()
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("KMU_PMH_SHORT", "0")
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    got2 = ctx.sketch(bases, off, p)
+    ctx.profile_enable(False)
+    assert "k_multiset_short" not in ctx.profile_get()
+    assert np.array_equal(got2, want)
