@@ -1572,7 +1572,11 @@ static bool seg_layout_bin() { // A/B runs: level 1's output with the ranges of 
 static uint64_t seg_cap_for(double mean) {
     double pct = 1.0;
     if (const char *e = getenv("KMU_COUNT_SEG_PCT")) pct = std::max(0.01, atof(e) / 100.0); // tests: force overflows
-    const double cap = (mean + 7.0 * std::sqrt(mean) + 64.0) * pct;
+    // 5 sigma of independent k-mers: three segments in ten million overflow, by a few items that the spill list takes
+    // (7 sigma + 64 before the spill list existed, when an overflow cost the whole attempt: 17.5 ms either way at level 1)
+    double sig = 5.0, add = 32.0;
+    if (const char *e = getenv("KMU_COUNT_SEG_SIGMA")) sig = atof(e); // A/B runs
+    const double cap = (mean + sig * std::sqrt(mean) + add) * pct;
     return ((uint64_t) cap + 15) & ~(uint64_t) 15; // whole 128-byte lines
 }
 struct SegPlan {

@@ -7,11 +7,11 @@ timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/t_final_$tag.
 grep -q "^rc=0" gpurun_out/t_final_$tag.log || exit 1
 bash scripts/pmc_bench.sh $tag > gpurun_out/pmc_bench_$tag.log 2>&1 || { echo "pmc_bench failed"; tail -5 gpurun_out/pmc_bench_$tag.log; exit 1; }
 timeout -k 10 300 python bench.py > gpurun_out/bench_${tag}_default.json 2> gpurun_out/bench_${tag}_default.err || { echo "bench failed"; exit 1; }
-WORKLOADS="c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa" bash scripts/other_workloads.sh
+WORKLOADS="c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa short_k21_sketch" bash scripts/other_workloads.sh
 python3 - <<PY
 import json
 runs = {}
-for w in "c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa".split():
+for w in "c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa short_k21_sketch".split():
     try:
         d = json.loads(open("gpurun_out/wl_%s.json" % w).read().strip().splitlines()[-1])
     except Exception as e:
@@ -21,3 +21,5 @@ for w in "c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa".split():
                "checks": d["checks"], "cpu_baseline": (d.get("cpu_baseline") or {}).get("value")}
 json.dump({"round": "$tag", "source": "scripts/final_round.sh", "runs": runs}, open("gpurun_out/${tag}_workloads.json", "w"), indent=1, sort_keys=True)
 PY
+# the two routes of a distributed add through a communicator of one rank (profiles/<tag>_routes.json is assembled from these)
+ROUTE_WORKLOADS="c4_count ont_k31_count" bash scripts/routes.sh > gpurun_out/routes_$tag.txt 2>&1; tail -6 gpurun_out/routes_$tag.txt
