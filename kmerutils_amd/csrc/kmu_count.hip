@@ -1504,12 +1504,15 @@ static int materialize(kmu_counter *c) {
 // ---- the single-pass partition -------------------------------------------------------------------------------------------
 // The exact route reads everything twice per level: a histogram pass gives every unit exact private output ranges, then the
 // scatter.  The k-mers travel as khash(k-mer), so the digits are uniform: a unit's share of a bin is its item count / bins
-// with a standard deviation of sqrt(that).  Here every (unit, bin) gets a FIXED segment of mean + 7 sigma + 64 items (16 % over
-// the mean at the bench size), the scatters run without their histogram passes (-7.6 and -6.0 ms), the unused tail of every
-// segment is filled with "no k-mer" marks that the next level skips (+16 % traffic on three streams), and the region build
-// takes fixed-size leaves.  A segment that overflows (k-mers that are not spread by the hash: a genome of one repeated
-// k-mer) raises a flag that is read before the build touches the table: the call then takes the exact route from scratch.
-// Level 1 without a global histogram is also what lets kmu_sketch_count partition a chunk while the next one is uploaded.
+// with a standard deviation of sqrt(that).  Here every (unit, bin) gets a FIXED segment of mean + 5 sigma + 32 items (6 %
+// over the mean at level 1 of the bench size, 13 % per region leaf), the scatters run without their histogram passes (-7.6
+// and -6.0 ms), the unused tail of every level-1 segment is filled with "no k-mer" marks that level 2 skips, the leaves
+// carry their fill in a count of their own.  An item that finds its segment full goes to a spill list that is inserted
+// into the finished table (seg_spill, k_count_add_spill: k-mers that arrive many at a time -- a genome at coverage -- vary
+// a bin's fill more than independent ones); only a full spill list (k-mers that the hash cannot spread: a genome of one
+// repeated k-mer) raises a flag that is read before the build touches the table: the call then takes the exact route from
+// scratch.  Level 1 without a global histogram is also what lets kmu_sketch_count partition a chunk while the next one is
+// uploaded.
 // the LDS-staged scatter kernels ask for more than 64 KiB of dynamic LDS: one attribute call per instantiation and device
 // (function attributes are per device: remembered per context, not per process)
 static int scatter_attrs(kmu_ctx *ctx) {
