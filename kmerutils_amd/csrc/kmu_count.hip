@@ -2060,19 +2060,20 @@ static int local_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, ui
 
 // ---- distributed counting (KMU_COUNT_DISTRIBUTED; kmu.h "multi-GPU") ---------------------------------------------------------
 // Cost model of the two routes for a rank's batch of n k-mer occurrences holding d distinct k-mers, in picoseconds per item,
-// measured on one MI355X with the single-rank communicator (scripts/routes.sh, profiles/r02_routes.json; ONT-shaped 4.36 G
-// k-mers and config 4's 0.75 G agree within 15 %): the owner census + duplication sample 3.5 / occurrence (both routes pay
-// it), the scatter by owner 5.9, building a table from received keys 21.4 / key (two array-partition levels + region
-// build), the local build from reads 20.2 / occurrence, two passes over the table image for the export of MERGE (4.8 TB/s),
-// a received (k-mer, count) entry added by direct insertion ~60 / entry; the links: KMU_XGMI_GBPS per GPU and direction, all
-// peers at once (default 350: seven links of 153 GB/s at ~1/3 efficiency until a multi-GPU measurement replaces it).
+// measured on one MI355X with the single-rank communicator (scripts/routes.sh, profiles/r02_routes.json as of r02e; ONT-shaped
+// 4.36 G k-mers and config 4's 0.75 G agree within 20 %): the owner census + duplication sample 3.5 / occurrence (both routes
+// pay it), the scatter by owner 5.9, building a table from received keys 17.3 / key (two single-pass array-partition levels
+// + region build), the local build from reads 16.4 / occurrence, two passes over the table image for the export of MERGE
+// (4.8 TB/s), a received (k-mer, count) entry added by direct insertion ~60 / entry; the links: KMU_XGMI_GBPS per GPU and
+// direction, all peers at once (default 350: seven links of 153 GB/s at ~1/3 efficiency until a multi-GPU measurement
+// replaces it).
 static void route_model(const kmu_counter *c, double n, double d, int nranks, double *ms_occ, double *ms_merge) {
     const char *e = getenv("KMU_XGMI_GBPS");
     const double gbps = e && atof(e) > 0 ? atof(e) : 350.0;
     const double f = nranks > 1 ? (double) (nranks - 1) / nranks : 0.0;
     const double ps = 1e-9; // ps -> ms
-    *ms_occ = n * (3.5 + 5.9 + 21.4) * ps + 8.0 * n * f / (gbps * 1e6);
-    *ms_merge = n * (3.5 + 20.2) * ps + 2.0 * (double) c->nslots * 12.0 / 4.8e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
+    *ms_occ = n * (3.5 + 5.9 + 17.3) * ps + 8.0 * n * f / (gbps * 1e6);
+    *ms_merge = n * (3.5 + 16.4) * ps + 2.0 * (double) c->nslots * 12.0 / 4.8e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
 }
 
 // first half of a distributed add: census of the owners + duplication sample, agreement on the route over all ranks, then
