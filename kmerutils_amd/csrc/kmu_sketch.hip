@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         //  second time only where that can happen at all)
         qb = wave_qmax(hmin, a.m);
         wmax = (uint32_t) wave_max_u64((uint64_t) wmax);
-        if (n && wmax && winv_of(winv_lut, wmax) < __longlong_as_double((long long) qb)) {
+        if (n && wmax && winv_of(winv_lut, wmax) < __longlong_as_double((long long) qb) && !ABL(512u)) { // (ABL: diagnostic builds, pass 2 left out: wrong rows, its share of the time)
             for (uint32_t c = 0; c < n; c += 64) {
                 const uint32_t i = c + (uint32_t) lane;
                 double winv = 0.0;
@@ -1525,6 +1525,110 @@ __global__ void __launch_bounds__(256) k_multiset_short(SketchArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
     if (bad) atomicOr(a.err, DERR_NON_ACGT);
+}
+
+// ---- the points of a SHORT list (at most 256 pairs: the reads k_multiset_short takes) ------------------------------------------
+// A read with fewer keys than m ln m cannot prune: ~m H_m points (1 200 at m = 200) are drawn before every slot is hit, round
+// after round over all keys.  k_pmh_points walks a list chunk by chunk, each chunk through all of ITS rounds with the
+// generator replayed from the seed, which for three chunks of a 130-key read is three times eighteen chunk-rounds; here the
+// wave keeps its <= 4 pairs per lane AND their generator states in registers and takes all keys through round i before
+// round i + 1 (nine rounds for the same read), q_max refreshed once per round.  Same draws per key in the same order, same
+// slot arithmetic: the rows are those of k_pmh_points (the result of ProbMinHash3a does not depend on the order of the keys).
+template <bool SIG32>
+__global__ void __launch_bounds__(256) k_pmh_points_short(SketchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    constexpr bool sig32 = SIG32;
+    uint64_t *hmin = reinterpret_cast<uint64_t *>(smem) + (size_t) wave * (2 * (size_t) a.m + 2);
+    uint64_t *sig = hmin + a.m;
+    double *winv_lut = reinterpret_cast<double *>(reinterpret_cast<uint64_t *>(smem) + (size_t) 4 * (2 * (size_t) a.m + 2));
+    for (uint32_t t = threadIdx.x; t < WINV_LUT; t += blockDim.x) winv_lut[t] = t ? 1.0 / (double) t : 0.0;
+    __syncthreads();
+    constexpr int NJ = (int) (SHORT_KEYS / 64);
+    uint32_t q_next = 0, q_end = 0; // lane 0: reads are taken QCHUNK at a time
+    for (;;) {
+        uint32_t r = 0;
+        if (lane == 0) {
+            if (q_next == q_end) {
+                q_next = atomicAdd(a.queue2, (uint32_t) QCHUNK);
+                q_end = q_next + QCHUNK;
+            }
+            r = q_next++;
+        }
+        r = uniform_u32(r);
+        if (r >= a.n_seq) break;
+        const uint64_t base = a.offsets[r] - a.offsets[0];
+        const uint32_t n = a.lst_n[r]; // <= SHORT_KEYS + 1 (the all-ones key, if any, sits behind the table's pairs)
+        uint64_t key[NJ + 1];
+        double winv[NJ + 1];
+        Xoshiro rng[NJ + 1];
+        bool alive[NJ + 1];
+#pragma unroll
+        for (int j = 0; j <= NJ; j++) {
+            const uint32_t i = (uint32_t) lane + 64u * (uint32_t) j;
+            alive[j] = false;
+            key[j] = 0;
+            winv[j] = 0.0;
+            if (i < n && (j < NJ || lane == 0)) {
+                key[j] = a.lst_keys[base + i];
+                const uint32_t w = a.lst_w[base + i];
+                winv[j] = winv_of(winv_lut, w);
+                alive[j] = w != 0u;
+            }
+        }
+        for (int t = lane; t < a.m; t += 64) { hmin[t] = H_INIT; sig[t] = 0; }
+        uint64_t qb = H_INIT;
+        // ---- round 1: the first point of every key (pmh3a_first_point, with the generator kept) ----
+#pragma unroll
+        for (int j = 0; j <= NJ; j++) {
+            if (__any(alive[j])) {
+                if (alive[j]) {
+                    rng[j].seed(hasher_finish(KMU_HASHER_NOHASH, key[j], sig32));
+                    const double x = exp01_sample(a.e01, rng[j]);
+                    const double h = winv[j] * x, qmax = __longlong_as_double((long long) qb);
+                    if (h < qmax) {
+                        const uint32_t k = draw_slot(a, rng[j]);
+                        slot_update_wave(hmin, sig, k, h, key[j]);
+                        alive[j] = winv[j] < qmax; // the crate: `if winv < qmax { to_be_processed.push(..) }`
+                    } else {
+                        alive[j] = false;
+                    }
+                }
+                qb = wave_qmax(hmin, a.m);
+            }
+        }
+        // ---- rounds i >= 2, all keys through a round before the next (pmh3a_more_points without the replay) ----
+        for (uint32_t i = 2;; i++) {
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j <= NJ; j++) {
+                if (__any(alive[j])) {
+                    any = true;
+                    if (alive[j]) {
+                        const double qmax = __longlong_as_double((long long) qb);
+                        const double hbase = winv[j] * (double) (i - 1);
+                        if (!(hbase < qmax)) {
+                            alive[j] = false;
+                        } else {
+                            const double x = exp01_sample(a.e01, rng[j]);
+                            const double h = hbase + winv[j] * x;
+                            const uint32_t k = draw_slot(a, rng[j]); // rounds >= 2 always draw the slot
+                            if (h < qmax) slot_update_wave(hmin, sig, k, h, key[j]);
+                            if (!(winv[j] * (double) i < qmax)) alive[j] = false;
+                        }
+                    }
+                }
+            }
+            if (!any) break;
+            qb = wave_qmax(hmin, a.m);
+        }
+        // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
+        for (int t = lane; t < a.m; t += 64) {
+            const uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
+            if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * a.m + t] = (uint32_t) v;
+            else reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = v;
+        }
+    }
 }
 
 // ---- k <= 8: the multiset of a read as a DIRECT-INDEXED histogram ---------------------------------------------------------
@@ -2257,7 +2361,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     // longer ones (and the rare read with too many repeated keys) are handed to the general list-emitting kernel.
     const char *uq_env = getenv("KMU_PMH_UQ"); // 0: every read through the counting-sort kernel (A/B)
     const bool uq = split && plain && !(uq_env && atoi(uq_env) == 0);
-    bool main_launched = false;
+    bool main_launched = false, short_route = false;
     const char *sh_env = getenv("KMU_PMH_SHORT"); // 0: short reads through k_multiset_uq like the others (A/B)
     if (uq && len_stats && len_stats[0] < (uint64_t) SHORT_KEYS + (uint64_t) p->kmer_size && !(sh_env && atoi(sh_env) == 0)) {
         // every read of the batch has at most 256 k-mers: one wave per read (k_multiset_short)
@@ -2269,6 +2373,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         KMU_HIP(ctx, hipGetLastError());
         KMU_HIP(ctx, hipMemsetAsync(a.queue, 0, 256, ctx->stream)); // (the points kernel's cursor)
         main_launched = true;
+        short_route = true;
     } else if (uq) {
         {
             typedef UqShape<512, 16, 2048> SA;
@@ -2326,7 +2431,17 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
     KMU_HIP(ctx, hipGetLastError());
-    if (split) {
+    if (split && short_route) { // lists of at most 256 pairs: all keys of a read in a wave's registers, round by round
+        const sketch_kernel_t kpts = a.sig_bytes == 4 ? k_pmh_points_short<true> : k_pmh_points_short<false>;
+        const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + 2) * 8 + WINV_LUT * 8;
+        if (lds2 > 64 * 1024)
+            KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds2));
+        const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) cus * per_cu));
+        KernelTimer t(ctx, "k_pmh_points_short");
+        hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
+        KMU_HIP(ctx, hipGetLastError());
+    } else if (split) {
         const sketch_kernel_t kpts = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
         const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
         if (lds2 > 64 * 1024)

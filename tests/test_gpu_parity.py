@@ -1271,7 +1271,7 @@ def test_short_reads_wave_per_read_multiset(ctx, oracle, monkeypatch, k, kt, sig
     ctx.profile_enable(True)
     got = ctx.sketch(bases, off, p)
     ctx.profile_enable(False)
-    assert "k_multiset_short" in ctx.profile_get()
+    assert "k_multiset_short" in ctx.profile_get() and "k_pmh_points_short" in ctx.profile_get()
     assert np.array_equal(got, want)
     monkeypatch.setenv("KMU_PMH_SHORT", "0")
     ctx.profile_reset()
