@@ -1268,6 +1268,16 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     }
 }
 
+// the overflow word block of a single-pass partition (seg_spill): flag and count zero, capacity and address of the list
+__global__ void __launch_bounds__(64) k_spill_header(uint32_t *ovf, uint32_t cap, uint64_t *list) {
+    if (threadIdx.x < 16) ovf[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ovf[2] = cap;
+        *reinterpret_cast<uint64_t **>(ovf + 4) = list;
+    }
+}
+
 // the spill list of a single-pass partition (khash values) into the finished table, by direct insertion
 __global__ void __launch_bounds__(256) k_count_add_spill(const uint64_t *items, const uint32_t *ovf, CountTable t, uint32_t *err) {
     const uint32_t n = ovf[1] < ovf[2] ? ovf[1] : ovf[2];
@@ -1541,10 +1551,8 @@ static int seg_spill_setup(kmu_ctx *ctx, uint64_t n_items, bool spill_ok, void *
     const uint64_t cap = spill_ok ? std::min<uint64_t>(n_items / 32 + 4096, 0x7FFFFFFFull) : 0;
     KMU_TRY(dev_buf(ctx, "cnt.seg_ovf", 64, &ovf));
     KMU_TRY(dev_buf(ctx, "cnt.spill", (size_t) cap * 8 + 64, &sp));
-    uint32_t hdr[16] = {0};
-    hdr[2] = (uint32_t) cap;
-    memcpy(&hdr[4], &sp, sizeof sp);
-    KMU_HIP(ctx, hipMemcpyAsync(ovf, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream)); // (pageable source: copied before the call returns)
+    hipLaunchKernelGGL(k_spill_header, dim3(1), dim3(64), 0, ctx->stream, (uint32_t *) ovf, (uint32_t) cap, (uint64_t *) sp);
+    KMU_HIP(ctx, hipGetLastError());
     *ovf_out = ovf;
     return KMU_OK;
 }

@@ -1273,6 +1273,13 @@ def test_short_reads_wave_per_read_multiset(ctx, oracle, monkeypatch, k, kt, sig
     ctx.profile_enable(False)
     assert "k_multiset_short" in ctx.profile_get() and "k_pmh_points_short" in ctx.profile_get()
     assert np.array_equal(got, want)
+    # a base outside ACGT in a short read: the reference panics, here the call fails
+    from kmerutils_amd.lib import KmuError
+    badb = bases.copy()
+    badb[int(off[7]) + 33] = ord("N")
+    with pytest.raises(KmuError) as ei:
+        ctx.sketch(badb, off, p)
+    assert ei.value.code == A.E_NON_ACGT
     monkeypatch.setenv("KMU_PMH_SHORT", "0")
     ctx.profile_reset()
     ctx.profile_enable(True)
