@@ -1755,7 +1755,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
                 const uint32_t wfirst = (tp0 + lead) >> 4;
                 const uint32_t wlast = (uint32_t) (((uint64_t) tp1 - 1 + lead + (uint64_t) k - 1) >> 4);
                 const uint32_t nw = wlast - wfirst + 1;
-                lds_barrier(); // the previous tile's readers are done
+                if (tp0 != 0 || half != 0) lds_barrier(); // the previous tile's readers are done (a read's first tile: the barrier at the top of its turn has seen to that)
                 if (pf_valid && tp0 == 0 && half == 0) { // fetched while the previous read was being handed over
                     if ((uint32_t) tid <= nw) words[tid] = pf_w0;
                     if ((uint32_t) tid + nthreads <= nw) words[tid + nthreads] = pf_w1;
@@ -1823,6 +1823,25 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
             //      further points of the keys whose 1 / w lies below the settled q_max (and the counters are wiped) ----
             const uint32_t wpb = wide ? list_cap : list_cap / 2; // histogram words whose counters fit the list
             const uint32_t nblocks = listed ? 1u : (SMALLK_WORDS + wpb - 1) / wpb;
+            if (EMIT && listed && !wide) {
+                // The common case in one sweep behind the count's barrier: every thread hands its first-touch entries over
+                // and clears the counter it has just read (the two 16-bit counters of a word belong to different entries:
+                // an atomic AND on the own half), one barrier, the list's length is reset -- the barrier at the end of the
+                // read's turn orders that before the next read's appends.  Three barriers less per read than the general form.
+                const uint32_t n_list = uniform_u32(misc[0]);
+                const uint64_t lbase = off_r - off_first;
+                for (uint32_t i = tid; i < n_list && !ABL(2u); i += nthreads) {
+                    const uint32_t idx = list[i];
+                    const uint32_t c = cnt[idx >> 1];
+                    a.lst_keys[lbase + i] = key_of(idx);
+                    a.lst_w[lbase + i] = (idx & 1u) ? c >> 16 : c & 0xFFFFu;
+                    atomicAnd(&cnt[idx >> 1], (idx & 1u) ? 0x0000FFFFu : 0xFFFF0000u);
+                }
+                emit_n = n_list;
+                lds_barrier();
+                if (tid == 0) misc[0] = 0;
+                continue;
+            }
             for (int pass = EMIT ? 1 : 0; pass < 2; pass++) { // (EMIT: one traversal: hand over, wipe)
                 uint64_t qb = (!EMIT && pass) ? wave_qmax(hmin, a.m) : 0ull;
                 for (uint32_t blk = 0; blk < nblocks; blk++) {
@@ -1918,7 +1937,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
         r = r_next;
         sv = nv;
         off_r = uniform_u64(n_o0);
-        lds_barrier();
+        // (no barrier here: the one at the top of the next turn follows at once, and nothing in between reads what this turn wrote)
     }
 }
 
