@@ -1679,8 +1679,25 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
         q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
         q_end = q_next + QCHUNK;
         misc[4] = q_next++;
+        misc[5] = q_next++; // (QCHUNK >= 2: the read after the first comes from the same chunk)
+        if (q_next == q_end) { q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK); q_pending = true; }
     }
+    static_assert(QCHUNK >= 2, "the first two reads of a workgroup come from one chunk");
     lds_barrier();
+    // thread 0: the read after the next one goes to misc[5] (called once per turn, after everybody has read misc[5] and
+    // before the last barrier of the turn)
+    auto q_post_next = [&]() {
+        if (tid == 0) {
+            if (q_next == q_end) {
+                if (!q_pending) q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
+                q_next = q_pend;
+                q_end = q_pend + QCHUNK;
+                q_pending = false;
+            }
+            misc[5] = q_next++;
+            if (q_next == q_end && !q_pending) { q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK); q_pending = true; }
+        }
+    };
     // the key of histogram index `idx` (a k-mer value): the closure on that k-mer
     auto key_of = [&](uint32_t idx) -> uint64_t { return apply_fhash(cfg, (uint64_t) idx, (uint64_t) revcomp32(idx, k)); };
     auto view_of = [&](uint32_t q) {
@@ -1710,20 +1727,10 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
     SeqView sv = view_of(r < a.n_queue ? r : 0u);
     const uint64_t off_first = uniform_u64(a.offsets[0]);
     uint64_t off_r = uniform_u64(a.offsets[r < a.n_queue ? r : 0u]); // offsets[r] of the current read
-    uint32_t pf_w0 = 0, pf_w1 = 0, pf_bad = 0; // this thread's word(s) of the current read's first tile, fetched ahead
-    bool pf_valid = false;                      // uniform
+    uint32_t pf_bad = 0; // non-ACGT bits of the words this thread staged ahead for the current read
+    bool words_staged = false; // uniform: the current read's first tile was staged in LDS during the previous turn
     while (r < a.n_queue) {
-        if (tid == 0) { // the read after this one
-            if (q_next == q_end) {
-                if (!q_pending) q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
-                q_next = q_pend;
-                q_end = q_pend + QCHUNK;
-                q_pending = false;
-            }
-            misc[5] = q_next++;
-            if (q_next == q_end && !q_pending) { q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK); q_pending = true; }
-        }
-        lds_barrier();
+        // (no barrier at the top of a turn: the last barrier of the previous turn made misc[5] and the pre-staged words visible)
         const uint32_t r_next = uniform_u32(misc[5]);
         // the next read's header: requested now, first looked at after the count phase (no wait here)
         const bool has_next = r_next < a.n_queue;
@@ -1740,7 +1747,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
         const uint32_t L = sv.len >= 0x80000000ull ? 0u : (uint32_t) sv.len;
         const uint32_t nk = L >= (uint32_t) k ? L - (uint32_t) k + 1u : 0u;
         if (L == 0 && tid == 0) atomicOr(a.err, DERR_EMPTY_SEQ);
-        uint32_t bad = pf_valid ? pf_bad : 0u;
+        uint32_t bad = words_staged ? pf_bad : 0u;
         if (nk == 0) bad |= wave_validate_seq(sv, wave, nwaves, false);
         const uint32_t lead = seq_lead(sv);
         const bool wide = nk > 65535u;         // 32-bit counters, two halves of the index space
@@ -1755,17 +1762,18 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
                 const uint32_t wfirst = (tp0 + lead) >> 4;
                 const uint32_t wlast = (uint32_t) (((uint64_t) tp1 - 1 + lead + (uint64_t) k - 1) >> 4);
                 const uint32_t nw = wlast - wfirst + 1;
-                if (tp0 != 0 || half != 0) lds_barrier(); // the previous tile's readers are done (a read's first tile: the barrier at the top of its turn has seen to that)
-                if (pf_valid && tp0 == 0 && half == 0) { // fetched while the previous read was being handed over
-                    if ((uint32_t) tid <= nw) words[tid] = pf_w0;
-                    if ((uint32_t) tid + nthreads <= nw) words[tid + nthreads] = pf_w1;
-                } else
-                for (uint32_t t = tid; t <= nw; t += nthreads) { // (+1: the word after the last, read by the window below)
-                    uint32_t b;
-                    words[t] = load_code_word(sv, (uint64_t) wfirst + t, b);
-                    if (half == 0) bad |= b;
+                if (words_staged && tp0 == 0 && half == 0) {
+                    // the words were fetched and put into LDS while the previous read was handed over: its last barrier has
+                    // made them visible -- a read's first tile starts counting at once
+                } else {
+                    if (tp0 != 0 || half != 0) lds_barrier(); // the previous tile's readers are done
+                    for (uint32_t t = tid; t <= nw; t += nthreads) { // (+1: the word after the last, read by the window below)
+                        uint32_t b;
+                        words[t] = load_code_word(sv, (uint64_t) wfirst + t, b);
+                        if (half == 0) bad |= b;
+                    }
+                    lds_barrier();
                 }
-                lds_barrier();
                 // four positions per thread and step: the window reads, then the four counter atomics, are requested
                 // together, and the first touches of all four are appended with ONE atomic per wave (the loop is bound by
                 // dependent LDS round trips, not by instructions)
@@ -1811,13 +1819,19 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
                 }
             }
             lds_barrier();
-            if (half + 1 == halves && has_next) { // the next read's first tile is requested now, used a read later
-                make_nv();
-                const uint32_t nwn = first_tile_nw(nv), wf = seq_lead(nv) >> 4;
-                uint32_t b0 = 0, b1 = 0;
-                pf_w0 = (uint32_t) tid <= nwn && nwn ? load_code_word(nv, (uint64_t) wf + tid, b0) : 0u;
-                pf_w1 = (uint32_t) tid + nthreads <= nwn && nwn ? load_code_word(nv, (uint64_t) wf + tid + nthreads, b1) : 0u;
-                pf_bad = b0 | b1;
+            if (half + 1 == halves) {
+                q_post_next(); // (everybody has read misc[5]; a barrier follows on every path below)
+                if (has_next) { // the next read's first tile: fetched now and put into LDS (the staged words are free: this
+                                // read is counted), the last barrier of this turn hands them to the next
+                    make_nv();
+                    const uint32_t nwn = first_tile_nw(nv), wf = seq_lead(nv) >> 4;
+                    uint32_t b0 = 0, b1 = 0;
+                    if (nwn) {
+                        if ((uint32_t) tid <= nwn) words[tid] = load_code_word(nv, (uint64_t) wf + tid, b0);
+                        if ((uint32_t) tid + nthreads <= nwn) words[tid + nthreads] = load_code_word(nv, (uint64_t) wf + tid + nthreads, b1);
+                    }
+                    pf_bad = b0 | b1;
+                }
             }
             // ---- enumerate the distinct k-mers of this half, a list's worth at a time; pass 0 = first points, pass 1 = the
             //      further points of the keys whose 1 / w lies below the settled q_max (and the counters are wiped) ----
@@ -1931,13 +1945,17 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
             sig[t] = 0;
         }
         if (tid == 0) *qmax_sh = H_INIT;
-        // (a read without k-mers never reached the prefetch: its successor loads its own words)
+        // (a read without k-mers never reached the prefetch: its successor loads its own words; its turn has no barrier of
+        //  its own either, so the queue is advanced behind one here)
+        if (nk == 0) {
+            q_post_next();
+            lds_barrier();
+        }
         if (has_next && !nv_done) make_nv();
-        pf_valid = nk != 0 && has_next && first_tile_nw(nv) != 0;
+        words_staged = nk != 0 && has_next && first_tile_nw(nv) != 0;
         r = r_next;
         sv = nv;
         off_r = uniform_u64(n_o0);
-        // (no barrier here: the one at the top of the next turn follows at once, and nothing in between reads what this turn wrote)
     }
 }
 
