@@ -1304,10 +1304,10 @@ static constexpr int BUILD_THREADS = 512;
 static constexpr int BUILD_PRE = 6;
 
 template <int IT>
-__global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *items, const uint64_t *leafstart,
+__global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
                                                               uint32_t n_regions, CountTable t, int in_mode, int out_compact,
                                                               uint32_t *rcount, unsigned long long *stats, uint32_t *err,
-                                                              uint64_t leaf_stride, const uint32_t *leafcnt) {
+                                                              uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t R = t.rmask + 1; // >= 1024
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
