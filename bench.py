@@ -2,7 +2,8 @@
 """bench.py -- headline metric of BASELINE.json on MI355X: Gbases/s of the k-mer + sketch (+ count) hot path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or plain
+     `python bench.py --gpus N`, which starts the same N ranks as a child process)
 
 A "step" is one pass of the hot path over the whole synthetic read set resident in HBM:
     default workload `ont_k31`: 746 333 ONT-shaped reads / 4.38 Gbases per GPU (BASELINE config 3's read set) at the
@@ -92,8 +93,28 @@ def workload_cfg(args):
     return cfg
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks as a CHILD `torch.distributed.run`
+    (one process per GPU, rendezvous on 127.0.0.1), relay its output and exit code.  Nothing in this process has touched
+    the GPU (no torch import yet), and the child is a child -- never an exec of a process that holds the device."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
     from kmerutils_amd import _abi as A
@@ -226,8 +247,19 @@ def main():
             nk_job = nk
         checks["nb_distinct"] = dis
         checks["count_conservation_ok"] = bool(occ == nk_job)  # the counts held add up to the k-mers that went in
-    if not args.no_parity and world == 1:
-        checks.update(parity_check(cfg, ctx, bases, offsets, sig, counter, nth))
+    if not args.no_parity:
+        # every rank checks what ITS timed steps left behind against the oracle (rows of its first 1 000 reads; counts of
+        # their k-mers, filtered by owner at N > 1); the booleans are AND-ed over the ranks
+        mine = parity_check(cfg, ctx, bases, offsets, sig, counter, nth, rank=rank, world=world if use_comm else 1)
+        if world > 1:
+            cdev = dev if backend == "nccl" else torch.device("cpu")
+            keys = sorted(k for k, v in mine.items() if isinstance(v, bool))
+            tb = torch.tensor([1.0 if mine[k] else 0.0 for k in keys], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tb, op=dist.ReduceOp.MIN)
+            for k, v in zip(keys, tb.tolist()):
+                mine[k] = bool(v == 1.0)
+            mine["parity_ranks"] = world
+        checks.update(mine)
 
     # ---- the same step from pinned host memory to pinned host memory (SURVEY 8d's definition of the metric) ---------
     host = None
@@ -256,60 +288,22 @@ def main():
 
     if rank == 0:
         value = job_bases * args.steps / elapsed / 1e9
-        # ---- roofline of the dominant kernel (HBM-bound integer path) -------------------------------------
+        # ---- roofline of the dominant unit (HBM-bound integer path) ------------------------------------------
         sigw = 8 if cfg["sig"] in (A.SIG_U64, A.SIG_F64) else 4
-        nslots = 1 << max(10, int(np.ceil(np.log2(max(1.5 * nk, 1024)))))
-        # algorithmic bytes per launch: sketch = bases in + signatures out; the partitioned count is a
-        # pipeline of streaming kernels: bases (+ 8 B per k-mer per scatter level), then the 12-byte-per-slot table image
-        alg_bytes = {
-            "k_sketch_pmh3a": total_bases + n_reads * cfg["m"] * sigw,   # the sketch path's bytes
-            "k_pmh_points": nk * 12 + n_reads * cfg["m"] * sigw,        # (key, weight) lists in, rows out
-            "k_sketch_super": total_bases + n_reads * cfg["m"] * sigw,
-            "k_sketch_smallk": total_bases + n_reads * cfg["m"] * sigw,
-            "k_multiset_uq": total_bases + n_reads * cfg["m"] * sigw,
-            "k_oph_reads": total_bases + n_reads * cfg["m"] * sigw,
-            "k_nthash": total_bases + nk * 8,
-            "k_count_add_flat": total_bases + nk * 16,
-            "k_part_hist1": total_bases,
-            "k_part_scatter1": total_bases + nk * 8,
-            "k_part_hist2": nk * 8,
-            "k_part_scatter2": nk * 16,
-            "k_arr_hist": nk * 8,
-            "k_arr_scatter": nk * 16,
-            "k_part_build": nk * 8 + nslots * 12,
-        }
-        kern = {}
-        for name, (launches, ms) in stats.items():
-            if launches:
-                avg = ms / launches
-                ent = {"launches": launches, "avg_ms": avg}
-                if name in alg_bytes:
-                    ent["alg_bytes"] = alg_bytes[name]
-                    ent["GBps"] = alg_bytes[name] / (avg * 1e-3) / 1e9
-                kern[name] = ent
-        # big batches are sketched by a pair of kernels (multiset -> (key, weight) lists in HBM -> points): SURVEY 8d's
-        # bytes of the sketch (bases in, signature rows out) belong to the pair, priced against the sum of both launches;
-        # taken alone the first kernel writes lists, not rows
-        SK = [n for n in ("k_multiset_uq", "k_sketch_smallk", "k_sketch_pmh3a", "k_pmh_points") if n in kern]
-        PAIR = "+".join(SK)
-        if "k_pmh_points" in kern and len(SK) >= 2:
-            ms = sum(kern[n]["avg_ms"] * kern[n]["launches"] for n in SK) / kern["k_pmh_points"]["launches"]
-            kern[PAIR] = {"launches": kern["k_pmh_points"]["launches"], "avg_ms": ms, "alg_bytes": alg_bytes["k_sketch_pmh3a"],
-                          "GBps": alg_bytes["k_sketch_pmh3a"] / (ms * 1e-3) / 1e9}
-            for n in SK[:-1]:  # bases in, lists out (upper bound: every k-mer distinct); with two multiset kernels each does a share
-                kern[n].pop("alg_bytes", None)
-                kern[n].pop("GBps", None)
-            alg_bytes[PAIR] = alg_bytes["k_sketch_pmh3a"]
-        cand = [n for n in kern if n in alg_bytes and not (PAIR in kern and n in SK)]
-        dom = max(cand, key=lambda n: kern[n]["avg_ms"] * kern[n]["launches"], default=None)
+        kern, dom, per_step = kernel_units(stats, args.steps, total_bases, nk, n_reads, cfg["m"], sigw,
+                                           counter.table_bytes() if counter is not None else 0)
         roofline = None
-        # launches per step of the parts of a composite unit (k_multiset_uq runs in two shapes: two launches a step)
-        per_step = {n: kern[n]["launches"] / kern[dom]["launches"] for n in dom.split("+")} if dom else {}
         if dom:
             ach = kern[dom]["GBps"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cfg, total_bases, dom, per_step),
-                        "avg_launch_ms": kern[dom]["avg_ms"], "alg_bytes_per_launch": kern[dom]["alg_bytes"]}
+                        "avg_launch_ms": kern[dom]["avg_ms"], "alg_bytes_per_launch": kern[dom]["alg_bytes"],
+                        "what": "SURVEY 8(d) bytes of the unit (sketch: bases in + signature rows out; count: bases in + 16 B per "
+                                "k-mer occurrence) / the summed launch time of the unit's kernels in one step"}
+            # the other units of the step, priced the same way
+            roofline["units"] = {n: {"frac": e["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": e["avg_ms"], "alg_bytes_per_launch": e["alg_bytes"],
+                                     "traffic": pmc_traffic(cfg, total_bases, n, e.get("per_step"))}
+                                 for n, e in kern.items() if "alg_bytes" in e}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(cfg, bases, offsets, lens, args.cpu_sample_reads, args.cpu_threads)
@@ -334,9 +328,89 @@ def main():
         dist.destroy_process_group()
 
 
-def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000):
+# the kernels of the two units of a step, by the names the library's timers carry (= the kernels' function names, the
+# names rocprofv3 prints)
+SKETCH_UNIT = ("k_multiset_uq", "k_multiset_short", "k_sketch_smallk", "k_sketch_pmh3a", "k_sketch_pmh3a_redo", "k_pmh_points",
+               "k_pmh_points_short")
+COUNT_UNIT = ("k_part_hist1", "k_part_scan1", "k_part_scatter1", "k_arr_hist", "k_arr_scan", "k_arr_scatter", "k_part_build",
+              "k_count_add_spill", "k_count_add_flat")
+
+
+def kernel_units(stats, steps, total_bases, nk, n_reads, m, sigw, table_bytes):
+    """Per-kernel launch statistics of the timed steps -> (kernels, dominant unit, launches per step of its parts).
+
+    `alg_bytes` are SURVEY.md 8(d)'s ALGORITHMIC bytes and exist for whole units only: the sketch unit (every kernel between
+    bases and signature rows: bases in + rows out) and the count unit (every kernel between bases and the table: bases in +
+    16 B per k-mer occurrence).  A unit's time is the sum of its kernels' launches in one step.  Single kernels of a unit
+    carry `design_bytes` instead -- what THIS design makes the kernel move (partition streams, the table image): a
+    bandwidth figure of the kernel, not a roofline figure of the path."""
+    sketch_alg = total_bases + n_reads * m * sigw
+    count_alg = total_bases + nk * 16
+    design = {
+        "k_pmh_points": nk * 12 + n_reads * m * sigw,         # (key, weight) lists in, rows out
+        "k_part_hist1": total_bases,
+        "k_part_scatter1": total_bases + nk * 8,
+        "k_arr_hist": nk * 8,
+        "k_arr_scatter": nk * 16,
+        "k_part_build": nk * 8 + table_bytes,                  # leaves in, the table image out
+    }
+    single = {"k_sketch_super": sketch_alg, "k_oph_reads": sketch_alg, "k_nthash": total_bases + nk * 8}
+    kern = {}
+    for name, (launches, ms) in stats.items():
+        if launches:
+            avg = ms / launches
+            ent = {"launches": launches, "avg_ms": avg}
+            if name in design:
+                ent["design_bytes"] = design[name]
+                ent["design_GBps"] = design[name] / (avg * 1e-3) / 1e9
+            if name in single:
+                ent["alg_bytes"] = single[name]
+                ent["GBps"] = single[name] / (avg * 1e-3) / 1e9
+            kern[name] = ent
+    for unit, alg in ((SKETCH_UNIT, sketch_alg), (COUNT_UNIT, count_alg)):
+        parts = [n for n in unit if n in kern]
+        if not parts:
+            continue
+        ms = sum(kern[n]["avg_ms"] * kern[n]["launches"] for n in parts) / steps  # the unit's kernel time in one step
+        kern["+".join(parts)] = {"launches": steps, "avg_ms": ms, "alg_bytes": alg, "GBps": alg / (ms * 1e-3) / 1e9,
+                                 "per_step": {n: kern[n]["launches"] / steps for n in parts}}
+    cand = [n for n in kern if "alg_bytes" in kern[n]]
+    dom = max(cand, key=lambda n: kern[n]["avg_ms"] * kern[n]["launches"], default=None)
+    return kern, dom, (kern[dom].get("per_step") or {dom: kern[dom]["launches"] / steps}) if dom else {}
+
+
+def _np_int64_hash(key):
+    """Thomas Wang's hash64shift on a numpy uint64 array: DispatchableT::dispatch of Kmer64bit, kmercount.rs:412-420"""
+    with np.errstate(over="ignore"):
+        key = key.astype(np.uint64)
+        key = ~key + (key << np.uint64(21))
+        key = key ^ (key >> np.uint64(24))
+        key = (key + (key << np.uint64(3))) + (key << np.uint64(8))
+        key = key ^ (key >> np.uint64(14))
+        key = (key + (key << np.uint64(2))) + (key << np.uint64(4))
+        key = key ^ (key >> np.uint64(28))
+        key = key + (key << np.uint64(31))
+    return key
+
+
+def _np_int32_hash(key):
+    with np.errstate(over="ignore"):
+        key = key.astype(np.uint32)
+        key = ~key + (key << np.uint32(15))
+        key = key ^ (key >> np.uint32(12))
+        key = key + (key << np.uint32(2))
+        key = key ^ (key >> np.uint32(4))
+        key = key * np.uint32(2057)
+        key = key ^ (key >> np.uint32(16))
+    return key
+
+
+def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000, rank=0, world=1):
     """SURVEY.md 8(d) parity set: the first 1 000 reads of the workload.  The rows / counts / hashes the TIMED steps left
-    behind are compared with the oracle's on those reads (the oracle is the checker here, nothing it computes is timed)."""
+    behind are compared with the oracle's on those reads (the oracle is the checker here, nothing it computes is timed).
+    world > 1 (a distributed counter): after kmu_count_finalize this rank holds exactly the k-mers with owner == rank
+    (int64_hash(kmer) % world, kmercount.rs:412-420): the k-mers of its 1 000 reads that it owns must be there with at
+    least the oracle's count, the ones it does not own must be absent."""
     import torch
     from kmerutils_amd import _abi as A
     from oracle import oracle as O
@@ -360,7 +434,14 @@ def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000):
         got_d = counter.query(torch.from_numpy(wk.view(np.int64)).to(bases.device))
         ctx.synchronize()  # (an asynchronous context: the query runs on the library's stream, not on torch's current one)
         got = got_d.cpu().numpy().astype(np.int64)
-        out["parity_counts_ok"] = bool((got >= np.minimum(wc.astype(np.int64), 255)).all() and (got >= 1).all())
+        if world > 1:
+            w32 = A.kmer_val_bytes(cfg["kmer_type"]) == 4
+            own = ((_np_int32_hash(wk).astype(np.uint64) if w32 else _np_int64_hash(wk)) % np.uint64(world)) == np.uint64(rank)
+            out["parity_counts_ok"] = bool((got[own] >= np.minimum(wc[own].astype(np.int64), 255)).all() and (got[own] >= 1).all()
+                                           and (got[~own] == 0).all())
+            out["parity_kmers_owned"] = int(own.sum())
+        else:
+            out["parity_counts_ok"] = bool((got >= np.minimum(wc.astype(np.int64), 255)).all() and (got >= 1).all())
     if cfg.get("nthash"):
         ctx.synchronize()
         wh, _ = O.nthash(hb, ho, cfg["k"])
@@ -495,7 +576,11 @@ def cpu_baseline(cfg, bases, offsets, lens, sample_reads, threads=0):
     rate1 = float(np.mean([parts[i][0].size / per_thread[i] for i in range(len(parts))])) / 1e9
     return {"value": nb / tot / 1e9, "unit": "Gbases/s", "cores": len(parts), "kind": "port",
             "sample": "first %d reads (%d bases) of the same read set, sharded over %d threads; sketch %.2f s + count "
-                      "%.2f s wall; oracle C restatement, gcc -O2; one thread alone: %.4f Gbases/s"
+                      "%.2f s wall; oracle C restatement, gcc -O2; one thread alone: %.4f Gbases/s; sketch: reads sharded like "
+                      "the reference's rayon map (seqsketchjaccard.rs:245-248); count: one private exact table per thread "
+                      "over its own shard, not merged -- cheaper than the reference's count_kmer_thread_independant "
+                      "(kmercount.rs:797-867, where every thread scans ALL reads and keeps its key range), so this "
+                      "baseline flatters the CPU"
                       % (sample_reads, nb, len(parts), t_sk, t_ct, rate1),
             "host_cpus": os.cpu_count(), "physical_cores": _physical_cores()}
 

@@ -216,7 +216,8 @@ int kmu_pack2b(kmu_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint
 
 /* ---- L1/L2: k-mer generation + canonicalise + hash, one value per k-mer start position -------------
  * KmerSeqIterator::next (src/base/kmergenerator.rs:75-106) followed by the fhash closure.
- * out[offsets[i] + p] (uint64, zero-extended for u32 types) for p in [0, L_i-k+1); other entries untouched.
+ * out[offsets[i] + p] (uint64, zero-extended for u32 types) for p in [0, L_i-k+1); other entries (the last k-1 positions
+ * of a sequence) untouched in KMU_MEM_DEVICE arrays, zero in KMU_MEM_HOST arrays (the array comes back whole).
  * For KMU_INPUT_PACKED2 `packed_offsets` gives the byte offset of every sequence (may be NULL for ASCII). */
 int kmu_kmer_hashes(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_t *bases, const uint64_t *offsets,
                     const uint64_t *packed_offsets, uint32_t n_seq, uint64_t *out);
@@ -343,6 +344,19 @@ int kmu_count_nb_distinct(kmu_counter *c, uint64_t *out); /* kmercount.rs:280-28
 int kmu_count_nb_unique(kmu_counter *c, uint64_t *out);   /* kmercount.rs:285-287 */
 /* sum of the (unsaturated) multiplicities held = k-mer occurrences inserted: the conservation check of a build */
 int kmu_count_nb_occurrences(kmu_counter *c, uint64_t *out);
+/* The table in HBM (no counterpart upstream: the reference's filters size themselves, kmercount.rs:70-123).  Slots are a power
+ * of two >= 1.5 x capacity_hint.  Big tables (>= 2^23 slots with 8-bit counters, >= 2^29 with 16-bit ones) keep ONE 8-byte
+ * word per slot -- the bits of the table hash that the slot's position does not already say, and a count field of
+ * count_field_bits that stops a little below its maximum (every reader saturates at 2^counter_bits - 1 like
+ * kmercount.rs:1615; kmu_count_nb_occurrences is exact while no k-mer occurs 2^count_field_bits - 1024 times) --, small ones
+ * a 64-bit key + a 32-bit count. */
+typedef struct kmu_count_table_info_t {
+    uint64_t nslots;
+    uint64_t table_bytes;
+    uint32_t bytes_per_slot;   /* 8 or 12 */
+    uint32_t count_field_bits; /* width of the in-table count */
+} kmu_count_table_info_t;
+int kmu_count_table_info(const kmu_counter *c, kmu_count_table_info_t *out);
 /* dump of (canonical k-mer, count) for count >= min_count (dump_kmer_counter, kmercount.rs:500-525 uses 2).
  * Call with kmers_out == NULL to get the number of records in *n_out; records are sorted by k-mer value. */
 int kmu_count_dump(kmu_counter *c, uint32_t min_count, uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap,

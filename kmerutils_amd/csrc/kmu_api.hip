@@ -114,6 +114,7 @@ int check_err_word(kmu_ctx *ctx, uint32_t *d_err) {
     KMU_HIP(ctx, hipMemcpyAsync(&h, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->err_unread = false; // read: the next call starts from a cleared word
+    if (h) KMU_HIP(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream)); // ... and a second read (kmu_synchronize) does not report it again
     if (h & DERR_NON_ACGT) return fail(ctx, KMU_E_NON_ACGT, "pattern not a code in alphabet_2b (non-ACGT byte in a sequence)");
     if (h & DERR_BAD_AA) return fail(ctx, KMU_E_BAD_ALPHABET, "encode: not a code in alphabet for amino acid");
     if (h & DERR_TABLE_FULL) return fail(ctx, KMU_E_TABLE_FULL, "device hash table full");
@@ -503,8 +504,11 @@ static int kmer_hashes_impl(kmu_ctx *ctx, const kmu_hash_params *p, const uint8_
         void *q;
         KMU_TRY(dev_buf(ctx, "out.u64", (size_t) total * 8 + 8, &q));
         d_out = (uint64_t *) q;
-        // (positions that start no k-mer keep what the caller's array holds: it goes up first)
-        KMU_HIP(ctx, hipMemcpyAsync(d_out, out + off0, (size_t) total * 8, hipMemcpyHostToDevice, ctx->stream));
+        // host arrays come back whole.  Range form: positions outside the ranges keep what the caller's array holds, so it
+        // goes up first; plain form: the only positions that start no k-mer are the last k - 1 of every sequence -- they
+        // come back as zeros (no upload of 8 bytes per base of possibly uninitialised caller memory for their sake)
+        if (range_begin) KMU_HIP(ctx, hipMemcpyAsync(d_out, out + off0, (size_t) total * 8, hipMemcpyHostToDevice, ctx->stream));
+        else KMU_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t) total * 8, ctx->stream));
     }
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));

@@ -116,14 +116,19 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
     for (int p = 0; p < c->nranks; p++) longest = std::max(longest, std::max(send_counts[p], recv_counts[p]) * elem_bytes);
     for (uint64_t o = 0; o < longest; o += chunk) {
         KMU_NCCL(ctx, rccl()->GroupStart());
-        for (int p = 0; p < c->nranks; p++) {
+        // a failing send / receive must not leave the group open (every later RCCL call of this thread would queue into it and
+        // the peers that have posted their side would wait): the first error is kept, the group is always closed
+        ncclResult_t first = ncclSuccess;
+        for (int p = 0; p < c->nranks && first == ncclSuccess; p++) {
             const uint64_t sbytes = send_counts[p] * elem_bytes, rbytes = recv_counts[p] * elem_bytes;
             if (o < sbytes)
-                KMU_NCCL(ctx, rccl()->Send(sb + send_displs[p] * elem_bytes + o, (size_t) std::min(chunk, sbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s));
-            if (o < rbytes)
-                KMU_NCCL(ctx, rccl()->Recv(rb + recv_displs[p] * elem_bytes + o, (size_t) std::min(chunk, rbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s));
+                first = rccl()->Send(sb + send_displs[p] * elem_bytes + o, (size_t) std::min(chunk, sbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s);
+            if (first == ncclSuccess && o < rbytes)
+                first = rccl()->Recv(rb + recv_displs[p] * elem_bytes + o, (size_t) std::min(chunk, rbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s);
         }
-        KMU_NCCL(ctx, rccl()->GroupEnd());
+        const ncclResult_t ge = rccl()->GroupEnd();
+        if (first != ncclSuccess) return fail(ctx, KMU_E_RCCL, "ncclSend / ncclRecv in the all-to-all: %s", rccl()->GetErrorString(first));
+        if (ge != ncclSuccess) return fail(ctx, KMU_E_RCCL, "ncclGroupEnd: %s", rccl()->GetErrorString(ge));
     }
     if (getenv("KMU_COMM_SYNC")) KMU_HIP(ctx, hipStreamSynchronize(s)); // diagnostics
     return KMU_OK;

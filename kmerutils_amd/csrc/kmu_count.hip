@@ -14,6 +14,17 @@
 //    global atomics; then one workgroup per region builds the region in LDS (ds_cmpst / ds_add) and streams it
 //    out.  HBM sees only streaming reads/writes: bases, 8 B per k-mer per level, and the table image.
 //  * small batches / single values / merges: direct insertion with one 64-bit CAS + one 32-bit atomic add.
+//
+// Two slot formats (kmu_counter::qw):
+//  * WIDE, 12 bytes per slot: keys[] + counts[] as above (small tables).
+//  * QUOTIENT, 8 bytes per slot (tables of >= 2^23 / 2^29 slots for 8- / 16-bit counters: every big table): khash is a
+//    bijection and the region index IS its top w = lg - 12 bits, so a slot keeps only the other 64 - w bits and spends the w
+//    bits it saves on the count: slot = (khash(key) << w) | count, all-ones = free.  The key of an occupied slot is
+//    khash_inv(region << (64 - w) | slot >> w).  The count field stops at LIMIT = 2^w - 1024 >= 2^counter_bits - 1 (a plain
+//    ds_add of the region build may overshoot by the adds in flight, < 512, and never carries into the key bits); every
+//    reader clamps to 2^counter_bits - 1 anyway (kmercount.rs:1615).  The region of a build is 32 KiB of LDS instead of 48
+//    (four workgroups per CU), a first sighting is ONE ds_cmpst_rtn_b64, the LDS image is the HBM image: 68.7 GB instead of
+//    103 GB written per build of the bench workload.
 #include <algorithm>
 #include <vector>
 
@@ -27,8 +38,9 @@ struct kmu_counter {
     uint64_t nslots = 0; // power of two
     int lg = 0;
     int rbits = 0;       // log2 of the region size
-    uint64_t *keys = nullptr;
-    uint32_t *counts = nullptr;
+    int qw = 0;          // != 0: quotient format, width of a slot's count field (= lg - rbits); 0: wide format
+    uint64_t *keys = nullptr;    // wide: the keys; quotient: the slots
+    uint32_t *counts = nullptr;  // wide only
     uint64_t *scalars = nullptr; // device: [0] distinct, [1] unique, [2] cursor
     bool empty = true;           // table content not materialised yet (every slot is logically free)
     // COMPACT state (what a partitioned build leaves): region r holds its rcount[r] (key, count) pairs at the head of its
@@ -95,17 +107,72 @@ struct SampleArgs {
 };
 
 struct CountTable {
-    uint64_t *keys;
-    uint32_t *counts;
-    int shift;      // 64 - lg
-    uint32_t rmask; // region size - 1
+    uint64_t *keys;   // wide: keys; quotient: slots
+    uint32_t *counts; // wide only
+    int shift;        // 64 - lg
+    uint32_t rmask;   // region size - 1
+    int w;            // quotient format: width of the count field (the region bits of the table); 0 = wide format
+    int rbits;        // log2 of the region size
 };
 
-// KmerCounter::insert_kmer (kmercount.rs:241-267), exact form: count[v] += add
-__device__ __forceinline__ bool count_insert(const CountTable &t, uint64_t v, uint32_t add) {
-    const uint64_t idx0 = khash(v) >> t.shift;
+// quotient slots: (khash(key) << w) | count
+static constexpr uint32_t Q_MARGIN = 1024; // a count field stops at 2^w - Q_MARGIN (+ the plain adds in flight of a region build, < 512)
+__device__ __forceinline__ uint64_t q_cmask(int w) { return (1ull << w) - 1ull; }
+__device__ __forceinline__ uint64_t q_limit(int w) { return (1ull << w) - (uint64_t) Q_MARGIN; }
+__device__ __forceinline__ bool q_same(uint64_t slot, uint64_t hw, int w) { return ((slot ^ hw) >> w) == 0ull; }
+__device__ __forceinline__ uint64_t q_key_of(const CountTable &t, uint64_t idx, uint64_t slot) {
+    return khash_inv(((idx >> t.rbits) << (64 - t.w)) | (slot >> t.w));
+}
+
+// slot i of either format: false = free; `cnt` 0 = an entry that left for its owner (distributed counters)
+template <bool WANT_KEY>
+__device__ __forceinline__ bool slot_read(const CountTable &t, uint64_t i, uint64_t &key, uint32_t &cnt) {
+    const uint64_t s = t.keys[i];
+    if (s == CKEY_EMPTY) return false;
+    if (t.w) {
+        cnt = (uint32_t) (s & q_cmask(t.w));
+        if (WANT_KEY) key = q_key_of(t, i, s);
+    } else {
+        cnt = t.counts[i];
+        key = s;
+    }
+    return true;
+}
+__device__ __forceinline__ void slot_zero_count(const CountTable &t, uint64_t i) { // (one thread per slot, nothing concurrent)
+    if (t.w) t.keys[i] &= ~q_cmask(t.w);
+    else t.counts[i] = 0u;
+}
+
+// KmerCounter::insert_kmer (kmercount.rs:241-267), exact form: count[v] += add.  h = khash(v); the wide format compares
+// keys (v), the quotient format the hash bits a slot keeps (v is not looked at).
+__device__ __forceinline__ bool count_insert_h(const CountTable &t, uint64_t v, uint64_t h, uint32_t add) {
+    const uint64_t idx0 = h >> t.shift;
     const uint64_t base = idx0 & ~(uint64_t) t.rmask;
     uint32_t off = (uint32_t) idx0 & t.rmask;
+    if (t.w) {
+        const uint64_t hw = h << t.w, cmask = q_cmask(t.w), limit = q_limit(t.w);
+        const uint64_t a = add < limit ? add : limit;
+        for (uint32_t probes = 0; probes <= t.rmask; probes++) {
+            const uint64_t idx = base | off;
+            uint64_t cur = __hip_atomic_load(&t.keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == CKEY_EMPTY) {
+                cur = atomicCAS((unsigned long long *) &t.keys[idx], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw | a));
+                if (cur == CKEY_EMPTY) return true;
+            }
+            if (q_same(cur, hw, t.w)) { // saturating add (the key bits of an occupied slot never change)
+                for (;;) {
+                    const uint64_t cnt = cur & cmask;
+                    if (cnt >= limit) return true;
+                    const uint64_t n = cnt + a < limit ? cnt + a : limit;
+                    const uint64_t prev = atomicCAS((unsigned long long *) &t.keys[idx], (unsigned long long) cur, (unsigned long long) ((cur & ~cmask) | n));
+                    if (prev == cur) return true;
+                    cur = prev;
+                }
+            }
+            off = (off + 1) & t.rmask;
+        }
+        return false;
+    }
     for (uint32_t probes = 0; probes <= t.rmask; probes++) {
         const uint64_t idx = base | off;
         uint64_t cur = __hip_atomic_load(&t.keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -121,16 +188,21 @@ __device__ __forceinline__ bool count_insert(const CountTable &t, uint64_t v, ui
     }
     return false;
 }
+__device__ __forceinline__ bool count_insert(const CountTable &t, uint64_t v, uint32_t add) { return count_insert_h(t, v, khash(v), add); }
 
 __device__ __forceinline__ uint32_t count_lookup(const CountTable &t, uint64_t v) {
-    const uint64_t idx0 = khash(v) >> t.shift;
+    const uint64_t h = khash(v);
+    const uint64_t idx0 = h >> t.shift;
     const uint64_t base = idx0 & ~(uint64_t) t.rmask;
     uint32_t off = (uint32_t) idx0 & t.rmask;
+    const uint64_t hw = t.w ? h << t.w : 0ull;
     for (uint32_t probes = 0; probes <= t.rmask; probes++) {
         const uint64_t idx = base | off;
         uint64_t cur = t.keys[idx];
-        if (cur == v) return t.counts[idx];
         if (cur == CKEY_EMPTY) return 0;
+        if (t.w) {
+            if (q_same(cur, hw, t.w)) return (uint32_t) (cur & q_cmask(t.w));
+        } else if (cur == v) return t.counts[idx];
         off = (off + 1) & t.rmask;
     }
     return 0;
@@ -372,8 +444,9 @@ __global__ void __launch_bounds__(256) k_count_query(const uint64_t *kmers, uint
 __global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslots, uint64_t *scalars) {
     uint64_t d = 0, u = 0, tot = 0;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
-        if (t.keys[i] != CKEY_EMPTY) {
-            const uint32_t c = t.counts[i]; // 0: an entry that left for its owner (distributed counters)
+        uint64_t key;
+        uint32_t c; // 0: an entry that left for its owner (distributed counters)
+        if (slot_read<false>(t, i, key, c)) {
             d += c != 0u;
             u += c == 1u;
             tot += c;
@@ -402,12 +475,9 @@ __global__ void __launch_bounds__(256) k_count_select(CountTable t, uint64_t nsl
         bool take = false;
         uint64_t key = 0;
         uint32_t c = 0;
-        if (i < nslots) {
-            key = t.keys[i];
-            if (key != CKEY_EMPTY) {
-                c = t.counts[i];
-                take = c >= min_count && !(n_parts && kmer_owner(key, w32, n_parts) != part);
-            }
+        if (i < nslots && slot_read<true>(t, i, key, c)) {
+            // (a zero count: an entry that left for its owner at a MERGE finalize -- absent for every reader)
+            take = c != 0u && c >= min_count && !(n_parts && kmer_owner(key, w32, n_parts) != part);
         }
         // one global atomic per wave
         const uint64_t m = __ballot(take);
@@ -521,8 +591,9 @@ __global__ void __launch_bounds__(256) k_owner_census(CountTable t, uint64_t nsl
     for (uint32_t b = threadIdx.x; b < n_parts; b += blockDim.x) lo[b] = 0;
     __syncthreads();
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
-        const uint64_t key = t.keys[i];
-        if (key != CKEY_EMPTY && t.counts[i] != 0u) {
+        uint64_t key;
+        uint32_t cnt;
+        if (slot_read<true>(t, i, key, cnt) && cnt != 0u) {
             const uint32_t o = kmer_owner(key, w32, n_parts);
             if (o != me) atomicAdd(&lo[o], 1u);
         }
@@ -540,12 +611,8 @@ __global__ void __launch_bounds__(256) k_owner_emit(CountTable t, uint64_t nslot
         const uint64_t i = it * stride + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
         uint64_t key = CKEY_EMPTY;
         uint32_t cnt = 0, o = me;
-        if (i < nslots) {
-            key = t.keys[i];
-            if (key != CKEY_EMPTY) {
-                cnt = t.counts[i];
-                if (cnt) o = kmer_owner(key, w32, n_parts);
-            }
+        if (i < nslots && slot_read<true>(t, i, key, cnt)) {
+            if (cnt) o = kmer_owner(key, w32, n_parts);
         }
         bool send = o != me;
         // one global atomic per wave and owner present in the wave
@@ -561,7 +628,7 @@ __global__ void __launch_bounds__(256) k_owner_emit(CountTable t, uint64_t nslot
                 const uint64_t pos = base + (uint64_t) __popcll(grp & ((1ull << lane_id()) - 1ull));
                 out_k[pos] = key;
                 out_c[pos] = cnt;
-                t.counts[i] = 0u;
+                slot_zero_count(t, i);
             }
             todo &= ~grp;
         }
@@ -1283,7 +1350,7 @@ __global__ void __launch_bounds__(256) k_count_add_spill(const uint64_t *items, 
     const uint32_t n = ovf[1] < ovf[2] ? ovf[1] : ovf[2];
     bool full = false;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        if (!count_insert(t, khash_inv(items[i]), 1u)) full = true;
+        if (!count_insert_h(t, t.w ? 0ull : khash_inv(items[i]), items[i], 1u)) full = true;
     if (full) atomicOr(err, DERR_TABLE_FULL);
 }
 
@@ -1303,7 +1370,10 @@ __global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, 
 static constexpr int BUILD_THREADS = 512;
 static constexpr int BUILD_PRE = 6;
 
-template <int IT>
+// Q: the quotient slot format (see the top of the file): the region is R 8-byte words in LDS (32 KiB: four workgroups per CU),
+// a first sighting is one ds_cmpst_rtn_b64, a repeat one more ds_add_u64 (guarded: the count field stops at q_limit), and the
+// LDS image leaves as it is.  in_mode 2 / out_compact are wide-format states.
+template <int IT, bool Q>
 __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
                                                               uint32_t n_regions, CountTable t, int in_mode, int out_compact,
                                                               uint32_t *rcount, unsigned long long *stats, uint32_t *err,
@@ -1318,6 +1388,57 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
     const uint32_t tid = threadIdx.x, lane = (uint32_t) lane_id(), wave = tid >> 6;
     uint32_t full = 0;
     uint64_t st_d = 0, st_u = 0, st_o = 0;
+    if (Q) {
+        const int w = t.w;
+        const uint64_t cmask = q_cmask(w), limit = q_limit(w);
+        for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+            const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
+            const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (uint64_t) leafcnt[r] : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
+            uint64_t pre_it[BUILD_PRE];
+#pragma unroll
+            for (int q = 0; q < BUILD_PRE; q++) {
+                const uint64_t i = i0 + (uint64_t) q * BUILD_THREADS + tid;
+                pre_it[q] = i < i1 ? items[i] : CKEY_EMPTY;
+            }
+            uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + (uint64_t) r * R);
+            if (in_mode == 1) {
+                for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = gk4[s];
+            } else {
+                for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            }
+            lds_barrier();
+            auto insert = [&](uint64_t item) {
+                const uint64_t h = IT == IT_HASH ? item : khash(item);
+                const uint64_t hw = h << w;
+                uint32_t off = (uint32_t) (h >> t.shift) & t.rmask;
+                bool done = false;
+                for (uint32_t probes = 0; probes < R; probes++) {
+                    const unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw | 1ull));
+                    if (old == CKEY_EMPTY) { done = true; break; }
+                    if (q_same(old, hw, w)) {
+                        // fewer than BUILD_THREADS adds are in flight behind a count seen below the limit: no carry into the key bits
+                        if ((old & cmask) < limit) atomicAdd((unsigned long long *) &lk[off], 1ull);
+                        done = true;
+                        break;
+                    }
+                    off = (off + 1) & t.rmask;
+                }
+                if (!done) full = 1;
+            };
+#pragma unroll
+            for (int q = 0; q < BUILD_PRE; q++)
+                if (pre_it[q] != CKEY_EMPTY) insert(pre_it[q]);
+            for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) {
+                const uint64_t item = items[i];
+                if (item != CKEY_EMPTY) insert(item);
+            }
+            lds_barrier();
+            for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
+            lds_barrier();
+        }
+        if (full) atomicOr(err, DERR_TABLE_FULL);
+        return;
+    }
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
         const uint64_t gbase = (uint64_t) r * R;
         // the items of region r: [leafstart[r], leafstart[r + 1]), or a fixed-size range that may hold "no k-mer" marks (the
@@ -1445,12 +1566,17 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
 
 using namespace kmu;
 
+// bytes of the table image in HBM (what a pass over the table reads)
+static size_t table_image_bytes(const kmu_counter *c) { return (size_t) c->nslots * (c->qw ? 8 : 12); }
+
 static CountTable table_of(const kmu_counter *c) {
     CountTable t;
     t.keys = c->keys;
     t.counts = c->counts;
     t.shift = 64 - c->lg;
     t.rmask = (1u << c->rbits) - 1u;
+    t.w = c->qw;
+    t.rbits = c->rbits;
     return t;
 }
 static uint32_t max_count(const kmu_counter *c) { return c->p.counter_bits == 8 ? 255u : 65535u; }
@@ -1462,19 +1588,24 @@ static int grid_for(const kmu_ctx *ctx, uint64_t n, int per_block) {
 
 // The region build (and the expansion of a compact table: a build without items that writes the open image).
 // `to_compact`: leave the table compact (the partitioned builds) or as the open-addressing image.
-static size_t build_lds(const kmu_counter *c) { return ((size_t) 12 << c->rbits) + 64 * 8 + 65 * 4 + 16; }
+static size_t build_lds(const kmu_counter *c) { return c->qw ? (size_t) 8 << c->rbits : ((size_t) 12 << c->rbits) + 64 * 8 + 65 * 4 + 16; }
 template <int IT>
 static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, bool to_compact, uint32_t *d_err,
                         uint64_t leaf_stride = 0, const uint32_t *leafcnt = nullptr) {
     kmu_ctx *ctx = c->ctx;
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
-    const int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * 3 * 8);
+    if (c->qw) to_compact = false; // (the compact state is a wide-format state)
+    const int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * (c->qw ? 4 : 3) * 8);
     if (to_compact) KMU_HIP(ctx, hipMemsetAsync(c->scalars + 4, 0, 24, ctx->stream));
     {
         KernelTimer tm(ctx, items ? "k_part_build" : "k_part_expand");
-        hipLaunchKernelGGL(k_part_build<IT>, dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
-                           table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt);
+        if (c->qw)
+            hipLaunchKernelGGL((k_part_build<IT, true>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
+                               table_of(c), in_mode, 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt);
+        else
+            hipLaunchKernelGGL((k_part_build<IT, false>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
+                               table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt);
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;
@@ -1486,7 +1617,8 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
 // written per build, and 30.1 ms instead of 26.5 -- the region build is bound by its phases (fill, insert, write-out, three
 // workgroups per CU taking turns), not by the bytes it writes, and the compaction adds a phase.  The open image stays the
 // default; the compact form is there for tables that are built once and then only asked for their statistics.
-static bool want_compact() {
+static bool want_compact(const kmu_counter *c) {
+    if (c->qw) return false; // (a wide-format state)
     const char *e = getenv("KMU_COUNT_COMPACT");
     return e && atoi(e) != 0;
 }
@@ -1497,7 +1629,7 @@ static int materialize(kmu_counter *c) {
     kmu_ctx *ctx = c->ctx;
     if (c->empty) {
         KMU_HIP(ctx, hipMemsetAsync(c->keys, 0xFF, c->nslots * 8, ctx->stream));
-        KMU_HIP(ctx, hipMemsetAsync(c->counts, 0, c->nslots * 4, ctx->stream));
+        if (!c->qw) KMU_HIP(ctx, hipMemsetAsync(c->counts, 0, c->nslots * 4, ctx->stream));
         c->empty = false;
         c->compact = false;
         return KMU_OK;
@@ -1646,7 +1778,7 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     KMU_TRY(dev_buf(ctx, own_buffer ? "cnt.segA" : "cnt.partA", (size_t) bins1 * run->sp.bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &run->A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * run->sp.leafcap * 8 + 64, &run->B));
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &run->leafcnt));
-    KMU_TRY(seg_spill_setup(ctx, total_bases, !want_compact(), &run->ovf));
+    KMU_TRY(seg_spill_setup(ctx, total_bases, !want_compact(c), &run->ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &run->bnd));
     KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;
@@ -1687,7 +1819,7 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     {
         ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2, run->sp.units1, (uint32_t) run->sp.cap1, bins1};
         if (seg_layout_bin()) { ap.seg_units = 1; ap.seg_cap = (uint32_t) run->sp.bincap1; }
-        KernelTimer tm(ctx, "k_part_scatter2");
+        KernelTimer tm(ctx, "k_arr_scatter");
         hipLaunchKernelGGL((k_arr_scatter<IT_HASH, true>), dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream,
                            (const uint64_t *) run->A, (const uint64_t *) run->bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
                            (uint64_t *) run->B, run->sp.cap2, (uint32_t *) run->ovf, (uint32_t *) run->leafcnt);
@@ -1697,7 +1829,7 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     KMU_HIP(ctx, hipMemcpyAsync(h_ovf, run->ovf, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_ovf[0]) return KMU_OK;
-    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(), run->d_err, run->sp.leafcap, (const uint32_t *) run->leafcnt));
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(c), run->d_err, run->sp.leafcap, (const uint32_t *) run->leafcnt));
     KMU_TRY(seg_spill_add(c, run->ovf, h_ovf, run->d_err));
 #if KMU_DIAG
     if (getenv("KMU_DIAG_SEG")) { // thread-0 clocks of the tile sort, summed over the workgroups: [level] between / rank / scan / place / out / finish
@@ -1799,12 +1931,12 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     if (pl.b2) {
         ArrPlan ap{pl.region_bits, 0, bins2, bins1, pl.chunks2};
         {
-            KernelTimer tm(ctx, "k_part_hist2");
+            KernelTimer tm(ctx, "k_arr_hist");
             hipLaunchKernelGGL(k_arr_hist<IT_HASH>, dim3(units2), dim3(256), bins2 * 4, ctx->stream, (const uint64_t *) A,
                                (const uint64_t *) binstart1, ap, (uint32_t *) hist2);
         }
         {
-            KernelTimer tm(ctx, "k_part_scan2");
+            KernelTimer tm(ctx, "k_arr_scan");
             const uint32_t T = scan_threads_per_bin(ap.chunks), per_wg = 256u / T;
             hipLaunchKernelGGL(k_arr_scan_a, dim3(bins1 * ((bins2 + per_wg - 1) / per_wg)), dim3(256), 0, ctx->stream,
                                (const uint32_t *) hist2, ap, T, (uint64_t *) offs2, (uint64_t *) tot2);
@@ -1812,7 +1944,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
                                (const uint64_t *) binstart1, ap, (uint64_t *) leafstart);
         }
         {
-            KernelTimer tm(ctx, "k_part_scatter2");
+            KernelTimer tm(ctx, "k_arr_scatter");
             hipLaunchKernelGGL((k_arr_scatter<IT_HASH, false>), dim3(units2), dim3(SCATTER_THREADS), scatter_lds_bytes(bins2), ctx->stream,
                                (const uint64_t *) A, (const uint64_t *) binstart1, ap, (const uint64_t *) offs2,
                                (const uint64_t *) leafstart,
@@ -1821,7 +1953,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         items = (const uint64_t *) B;
         leaves = (const uint64_t *) leafstart;
     }
-    if (!dbg_split) KMU_TRY(launch_build<IT_HASH>(c, items, leaves, want_compact(), d_err));
+    if (!dbg_split) KMU_TRY(launch_build<IT_HASH>(c, items, leaves, want_compact(c), d_err));
     return KMU_OK;
 }
 
@@ -1915,7 +2047,7 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * cap2 * 8 + 64, &B));
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &leafcnt));
-    KMU_TRY(seg_spill_setup(ctx, n, !want_compact(), &ovf));
+    KMU_TRY(seg_spill_setup(ctx, n, !want_compact(c), &ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &bnd));
     KMU_TRY(dev_buf(ctx, "arr.bounds0", 16, &b0));
     hipLaunchKernelGGL(k_fill_linear, dim3(1), dim3(256), 0, ctx->stream, (uint64_t *) b0, (uint64_t) 2, n);
@@ -1940,7 +2072,7 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     KMU_HIP(ctx, hipMemcpyAsync(h_ovf, ovf, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_ovf[0]) return KMU_OK; // the table is untouched: the exact levels take over
-    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(), d_err, cap2, (const uint32_t *) leafcnt));
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(c), d_err, cap2, (const uint32_t *) leafcnt));
     KMU_TRY(seg_spill_add(c, ovf, h_ovf, d_err));
     *taken = 1;
     return KMU_OK;
@@ -1962,8 +2094,8 @@ static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64
     // (a table of a single region is not partitioned at all: the items stay keys)
     const bool hashed = region_bits > 0;
     KMU_TRY(partition_u64(ctx, d_kmers, n, region_bits, &items, &bounds, hashed));
-    if (hashed) return launch_build<IT_HASH>(c, items, bounds, want_compact(), d_err);
-    return launch_build<IT_KEY>(c, items, bounds, want_compact(), d_err);
+    if (hashed) return launch_build<IT_HASH>(c, items, bounds, want_compact(c), d_err);
+    return launch_build<IT_KEY>(c, items, bounds, want_compact(c), d_err);
 }
 
 // canonical k-mers of the reads, grouped by owner rank (one level of the partition machinery with digit = owner).
@@ -2075,13 +2207,18 @@ static int local_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, ui
 // (4.8 TB/s), a received (k-mer, count) entry added by direct insertion ~60 / entry; the links: KMU_XGMI_GBPS per GPU and
 // direction, all peers at once (default 350: seven links of 153 GB/s at ~1/3 efficiency until a multi-GPU measurement
 // replaces it).
-static void route_model(const kmu_counter *c, double n, double d, int nranks, double *ms_occ, double *ms_merge) {
+// Every input is either gathered from all ranks or a constant: the ranks MUST arrive at the same route (a rank on
+// OCCURRENCES enters an all-to-all that a rank on MERGE does not).  table_bytes: the largest table image among the ranks;
+// gbps: rank 0's KMU_XGMI_GBPS.
+static double local_xgmi_gbps() {
     const char *e = getenv("KMU_XGMI_GBPS");
-    const double gbps = e && atof(e) > 0 ? atof(e) : 350.0;
+    return e && atof(e) > 0 ? atof(e) : 350.0;
+}
+static void route_model(double table_bytes, double gbps, double n, double d, int nranks, double *ms_occ, double *ms_merge) {
     const double f = nranks > 1 ? (double) (nranks - 1) / nranks : 0.0;
     const double ps = 1e-9; // ps -> ms
     *ms_occ = n * (3.5 + 5.9 + 17.3) * ps + 8.0 * n * f / (gbps * 1e6);
-    *ms_merge = n * (3.5 + 16.4) * ps + 2.0 * (double) c->nslots * 12.0 / 4.8e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
+    *ms_merge = n * (3.5 + 16.4) * ps + 2.0 * table_bytes / 4.8e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
 }
 
 // first half of a distributed add: census of the owners + duplication sample, agreement on the route over all ranks, then
@@ -2090,6 +2227,7 @@ static void route_model(const kmu_counter *c, double n, double d, int nranks, do
 static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uint32_t *d_err) {
     kmu_ctx *ctx = c->ctx;
     kmu_comm *cm = ctx->comm;
+    if (!cm) return fail(ctx, KMU_E_BAD_ARG, "the communicator of this distributed counter's context is gone (kmu_comm_destroy)");
     const uint32_t N = (uint32_t) cm->nranks;
     cm->stats = kmu_comm_stats{};
     // ---- census + sample ----
@@ -2129,37 +2267,47 @@ static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uin
     // ---- the ranks agree: sampled occurrences / distinct, local k-mers, and the send counts of every rank ----
     // (a k-mer's occurrences on different ranks are in different samples: the global distinct count of the sample is not
     //  known; the per-rank ratio is what decides how much MERGE saves on each rank, and the sum of both sides is used)
-    std::vector<uint64_t> mine(4 + N), all((size_t) (4 + N) * N);
+    // Whatever differs between the ranks and enters the decision travels in the row: the table size (capacity hints from
+    // rank-specific read counts can straddle a power of two), the link rate and a forced route (environment of the rank's
+    // process).  The ranks then evaluate the same function of the same gathered numbers: the largest table, rank 0's link
+    // rate, rank 0's override.
+    const uint32_t H = 7; // header words of a row
+    std::vector<uint64_t> mine(H + N), all((size_t) (H + N) * N);
     mine[0] = n_s;
     mine[1] = h_sn[1] ? 0 : d_s;
     mine[2] = bounds[N];
     mine[3] = c->unmerged ? 1 : 0;
-    for (uint32_t p = 0; p < N; p++) mine[4 + p] = bounds[p + 1] - bounds[p];
-    KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), (4 + N) * 8));
-    double sum_ns = 0, sum_ds = 0, sum_n = 0;
+    mine[4] = (uint64_t) table_image_bytes(c);
+    mine[5] = (uint64_t) (local_xgmi_gbps() * 1000.0);
+    mine[6] = 0;
+    if (const char *e = getenv("KMU_COUNT_ROUTE")) {
+        if (!strcmp(e, "occurrences")) mine[6] = KMU_ROUTE_OCCURRENCES;
+        if (!strcmp(e, "merge")) mine[6] = KMU_ROUTE_MERGE;
+    }
+    for (uint32_t p = 0; p < N; p++) mine[H + p] = bounds[p + 1] - bounds[p];
+    KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), (H + N) * 8));
+    double sum_ns = 0, sum_ds = 0, sum_n = 0, max_table = 0;
     bool valid = true;
     for (uint32_t r = 0; r < N; r++) {
-        const uint64_t *row = &all[(size_t) r * (4 + N)];
+        const uint64_t *row = &all[(size_t) r * (H + N)];
         sum_ns += (double) row[0];
         sum_ds += (double) row[1];
         sum_n += (double) row[2];
+        max_table = std::max(max_table, (double) row[4]);
         if (row[0] && !row[1]) valid = false; // a truncated sample somewhere
     }
     const double ratio = valid && sum_ds > 0 ? sum_ns / sum_ds : 0.0;
     const double n_loc = sum_n / N, d_loc = ratio > 0 ? n_loc / ratio : n_loc;
     double ms_occ, ms_merge;
-    route_model(c, n_loc, d_loc, (int) N, &ms_occ, &ms_merge);
+    route_model(max_table, (double) all[5] / 1000.0, n_loc, d_loc, (int) N, &ms_occ, &ms_merge);
     int route = ms_merge < ms_occ ? KMU_ROUTE_MERGE : KMU_ROUTE_OCCURRENCES;
-    if (const char *e = getenv("KMU_COUNT_ROUTE")) { // (must be the same on every rank)
-        if (!strcmp(e, "occurrences")) route = KMU_ROUTE_OCCURRENCES;
-        if (!strcmp(e, "merge")) route = KMU_ROUTE_MERGE;
-    }
+    if (all[6]) route = (int) all[6]; // KMU_COUNT_ROUTE of rank 0's process
     const double f = N > 1 ? (double) (N - 1) / N : 0.0;
     cm->stats.route = route;
     cm->stats.sample_shift = (int32_t) shift;
     cm->stats.dup_ratio = ratio;
     cm->stats.kmers_local = bounds[N];
-    cm->stats.bytes_occurrences = (uint64_t) (8.0 * (double) (bounds[N] - mine[4 + cm->rank]));
+    cm->stats.bytes_occurrences = (uint64_t) (8.0 * (double) (bounds[N] - mine[H + cm->rank]));
     cm->stats.bytes_merge = (uint64_t) (12.0 * f * (ratio > 0 ? (double) bounds[N] / ratio : (double) bounds[N]));
     cm->stats.model_ms_occurrences = ms_occ;
     cm->stats.model_ms_merge = ms_merge;
@@ -2177,7 +2325,7 @@ static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uin
     for (uint32_t p = 0; p < N; p++) {
         scnt[p] = bounds[p + 1] - bounds[p];
         sdis[p] = bounds[p];
-        rcnt[p] = all[(size_t) p * (4 + N) + 4 + cm->rank];
+        rcnt[p] = all[(size_t) p * (H + N) + H + cm->rank];
         rdis[p] = n_recv;
         n_recv += rcnt[p];
     }
@@ -2197,6 +2345,7 @@ static int dist_add_end(kmu_counter *c) {
     kmu_ctx *ctx = c->ctx;
     if (!c->pending) return KMU_OK;
     c->pending = false;
+    if (!ctx->comm) return fail(ctx, KMU_E_BAD_ARG, "the communicator went away under an exchange of this counter (kmu_comm_destroy)");
     KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm->ev_b, 0));
     if (c->pend_recv == 0) return KMU_OK;
     return add_entries(c, (const uint64_t *) ctx->bufs["cnt.recv"].p, nullptr, c->pend_recv, KMU_MEM_DEVICE);
@@ -2206,6 +2355,11 @@ extern "C" {
 
 int kmu_count_reset(kmu_counter *c) {
     if (!c) return KMU_E_BAD_ARG;
+    if (c->pending && c->ctx->comm) // an exchange left open: what it writes ("cnt.recv") is dropped, but not under later work
+        (void) hipStreamWaitEvent(c->ctx->stream, c->ctx->comm->ev_b, 0);
+    c->pending = false;
+    c->pend_recv = 0;
+    c->unmerged = false;
     c->empty = true; // materialised lazily: a partitioned build writes every region itself
     c->compact = false;
     c->stats_cached = false;
@@ -2225,10 +2379,20 @@ int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out)
     uint64_t want = std::max<uint64_t>(1024, p->capacity_hint + p->capacity_hint / 2); // load factor <= 2/3
     c->lg = 10;
     while ((1ull << c->lg) < want) c->lg++;
+    // slot format: quotient (8 bytes per slot) whenever the region bits leave room for the count field (see the top of the
+    // file): w = lg - 12 >= 11 for 8-bit counters, >= 17 for 16-bit ones.  KMU_COUNT_FMT=wide keeps 12 bytes per slot;
+    // =quot (tests) raises a small table to the size the quotient format starts at.
+    const int q_need = 12 + (p->counter_bits == 8 ? 11 : 17);
+    bool quot = c->lg >= q_need;
+    if (const char *e = getenv("KMU_COUNT_FMT")) {
+        if (!strcmp(e, "wide")) quot = false;
+        if (!strcmp(e, "quot")) { quot = true; c->lg = std::max(c->lg, q_need); }
+    }
     c->nslots = 1ull << c->lg;
     c->rbits = std::min(c->lg, REGION_BITS_MAX);
+    c->qw = quot ? c->lg - c->rbits : 0;
     hipError_t e1 = hipMalloc((void **) &c->keys, c->nslots * 8);
-    hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **) &c->counts, c->nslots * 4) : e1;
+    hipError_t e2 = e1 == hipSuccess && !c->qw ? hipMalloc((void **) &c->counts, c->nslots * 4) : e1;
     hipError_t e3 = e2 == hipSuccess ? hipMalloc((void **) &c->scalars, 64) : e2;
     if (e3 == hipSuccess) e3 = hipMalloc((void **) &c->rcount, ((c->nslots >> c->rbits) + 1) * 4);
     if (e3 != hipSuccess) {
@@ -2504,6 +2668,14 @@ int kmu_count_nb_unique(kmu_counter *c, uint64_t *out) {
 int kmu_count_nb_occurrences(kmu_counter *c, uint64_t *out) {
     if (!c || !out) return KMU_E_BAD_ARG;
     return count_stats(c, nullptr, nullptr, out);
+}
+int kmu_count_table_info(const kmu_counter *c, kmu_count_table_info_t *out) {
+    if (!c || !out) return KMU_E_BAD_ARG;
+    out->nslots = c->nslots;
+    out->bytes_per_slot = c->qw ? 8u : 12u;
+    out->count_field_bits = c->qw ? (uint32_t) c->qw : 32u;
+    out->table_bytes = (uint64_t) table_image_bytes(c);
+    return KMU_OK;
 }
 
 // shared by dump / export: select into device buffers, then hand over

@@ -307,6 +307,67 @@ class TorchTransport:
         return b"".join(bytes(o.cpu().numpy().tobytes()) for o in outs)
 
 
+class ThreadGroup:
+    """Shared state of N ranks that are THREADS of one process (each with its own kmu context, all on one device): a host of
+    that shape -- one process driving several contexts -- hands the library a transport of this kind through
+    kmu_comm_init_custom.  It is also how the N-rank control flow (route agreement over N rows, N-way owner grouping, the
+    finalize of MERGE among N owners) is exercised on a box with one GPU and a limit on the processes that may hold it."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.a2a = [None] * world
+        self.ag = [None] * world
+
+
+class ThreadTransport:
+    def __init__(self, group, rank, device):
+        self.g, self.rank, self.device = group, rank, device
+
+    def _view(self, ptr, nbytes):
+        import torch
+        if nbytes == 0 or not ptr:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Dev(), device=self.device)
+
+    def alltoallv(self, sp, sc, sd, rp, rc, rd, eb):
+        import torch
+        g, W = self.g, self.g.world
+        g.a2a[self.rank] = (sp, list(sc), list(sd))
+        g.barrier.wait()  # every rank's send buffer is complete (the library synchronised its stream before the call)
+        recv = self._view(rp, max((rd[p] + rc[p]) * eb for p in range(W)))
+        for p in range(W):
+            psp, psc, psd = g.a2a[p]
+            assert psc[self.rank] == rc[p], "rank %d expects %d items from %d, which sends %d" % (self.rank, rc[p], p, psc[self.rank])
+            if rc[p]:
+                src = self._view(psp, (psd[self.rank] + psc[self.rank]) * eb)
+                recv[rd[p] * eb:(rd[p] + rc[p]) * eb].copy_(src[psd[self.rank] * eb:(psd[self.rank] + psc[self.rank]) * eb])
+        torch.cuda.synchronize(self.device)
+        g.barrier.wait()  # nobody's send buffer is reused before every peer has pulled from it
+
+    def allgather(self, payload):
+        g = self.g
+        g.ag[self.rank] = bytes(payload)
+        g.barrier.wait()
+        out = b"".join(g.ag)
+        g.barrier.wait()
+        return out
+
+
+def init_comm_threads(ctx, group, rank):
+    """communicator of rank `rank` of a ThreadGroup on `ctx` (kmu_comm_init_custom)"""
+    import torch
+    tt = ThreadTransport(group, rank, torch.device("cuda", ctx.device_id))
+    ctx._transport = tt
+    ctx.comm_init_custom(rank, group.world, tt.alltoallv, tt.allgather)
+    return tt
+
+
 def init_comm(ctx, group=None, transport=None):
     """Give `ctx` (kmerutils_amd.lib.Context) a communicator over the ranks of a torch process group.
 

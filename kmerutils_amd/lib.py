@@ -30,7 +30,7 @@ SYMBOLS = [
     "kmu_kmer_hashes_range", "kmu_kmer_distribution", "kmu_nthash",
     "kmu_comm_get_id", "kmu_comm_init", "kmu_comm_init_custom", "kmu_comm_destroy", "kmu_comm_rank", "kmu_comm_nranks",
     "kmu_comm_allgather", "kmu_comm_get_stats", "kmu_count_finalize", "kmu_kmer_owner",
-    "kmu_sketch_count", "kmu_host_alloc", "kmu_host_free", "kmu_count_nb_occurrences",
+    "kmu_sketch_count", "kmu_host_alloc", "kmu_host_free", "kmu_count_nb_occurrences", "kmu_count_table_info",
 ]
 
 
@@ -73,6 +73,7 @@ def load():
     L.kmu_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.kmu_host_free.argtypes = [vp, vp]
     L.kmu_count_nb_occurrences.argtypes = [vp, u64p]
+    L.kmu_count_table_info.argtypes = [vp, C.POINTER(A.CountTableInfo)]
     L.kmu_comm_get_id.argtypes = [C.POINTER(A.CommId)]
     L.kmu_comm_init.argtypes = [vp, C.POINTER(A.CommId), C.c_int, C.c_int]
     L.kmu_comm_init_custom.argtypes = [vp, C.c_int, C.c_int, A.ALLTOALLV_FN, A.ALLGATHER_FN, vp]
@@ -712,6 +713,16 @@ class Counter:
         v = C.c_uint64(0)
         self.ctx._check(self.L.kmu_count_nb_unique(self.h, C.byref(v)))
         return v.value
+
+    def table_info(self):
+        """kmu_count_table_info: {nslots, table_bytes, bytes_per_slot, count_field_bits}"""
+        ti = A.CountTableInfo()
+        self.ctx._check(self.L.kmu_count_table_info(self.h, C.byref(ti)))
+        return {"nslots": ti.nslots, "table_bytes": ti.table_bytes, "bytes_per_slot": ti.bytes_per_slot,
+                "count_field_bits": ti.count_field_bits}
+
+    def table_bytes(self):
+        return self.table_info()["table_bytes"]
 
     def nb_occurrences(self):
         """kmu_count_nb_occurrences: sum of the multiplicities held (= k-mer occurrences inserted)"""

@@ -748,7 +748,19 @@ static uint64_t unif_usize(uint64_t s[4], uint64_t low, uint64_t high, uint32_t 
  * kernels (kmu_device.h) so that the one comparison it feeds is evaluated identically on both sides.  The
  * reference calls libm's exp_m1 there; the two can differ by an ulp, which would matter only if a sample fell
  * within 1 ulp of the acceptance boundary (probability ~1e-16 per call). */
+/* The two places where this restatement knowingly departs from the recalled crate, as switches (tests/test_oracle_sketch.py
+ * shows that the committed fixtures' signatures are the same under all four combinations):
+ *   KMO_LIBM_EXPM1=1   the sampler's last acceptance test calls libm's expm1 (what `f64::exp_m1` is) instead of the
+ *                      fixed Horner form shared with the HIP kernels;
+ *   KMO_STRICT_TIES=1  a slot is taken on strict `<` only, as in the crate: of two points with the same f64 value the one
+ *                      met first in iteration order stays (here: insertion order of the map), instead of the smaller key. */
+static int kmo_opt(const char *name) {
+    const char *e = getenv(name);
+    return e && e[0] && e[0] != '0';
+}
+
 static double expm1_small(double x) {
+    if (kmo_opt("KMO_LIBM_EXPM1")) return expm1(x);
     static const double inv_fact[23] = {
         1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
         1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
@@ -882,9 +894,10 @@ int kmo_probminhash3a(const uint64_t *keys, const double *weights, uint64_t n, i
     double qmax;
     /* strict `<` against the slot value as in the crate, except that an exact tie goes to the smaller key so
      * that the result does not depend on the (arbitrary) map iteration order */
+    const int strict_ties = kmo_opt("KMO_STRICT_TIES");
 #define PMH_TRY(k_, h_, key_)                                                                        \
     do {                                                                                             \
-        if ((h_) < trk.v[k_] || ((h_) == trk.v[k_] && (key_) < sig_out[k_])) {                      \
+        if ((h_) < trk.v[k_] || (!strict_ties && (h_) == trk.v[k_] && (key_) < sig_out[k_])) {      \
             sig_out[k_] = (key_);                                                                    \
             mvt_update(&trk, (int) (k_), (h_));                                                      \
         }                                                                                            \
@@ -947,6 +960,7 @@ int kmo_probminhash3(const uint64_t *keys, const double *weights, uint64_t n, in
     mvt_t trk;
     mvt_init(&trk, m);
     for (int i = 0; i < m; i++) sig_out[i] = 0;
+    const int strict_ties = kmo_opt("KMO_STRICT_TIES");
     for (uint64_t it = 0; it < n; it++) {
         const double winv = 1.0 / weights[it];
         uint64_t s[4];
@@ -955,7 +969,7 @@ int kmo_probminhash3(const uint64_t *keys, const double *weights, uint64_t n, in
         uint64_t i = 1;
         while (h < mvt_max(&trk)) {
             uint64_t k = unif_usize(s, 0, (uint64_t) m, flags);
-            if (h < trk.v[k] || (h == trk.v[k] && keys[it] < sig_out[k])) {
+            if (h < trk.v[k] || (!strict_ties && h == trk.v[k] && keys[it] < sig_out[k])) {
                 sig_out[k] = keys[it];
                 mvt_update(&trk, (int) k, h);
             }

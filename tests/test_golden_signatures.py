@@ -38,6 +38,35 @@ def test_fixture_is_what_the_committed_script_writes():
         assert np.array_equal(rows, _rows(FIX["cases"][case[0]])), case[0]
 
 
+def test_oracle_departures_as_switches_change_no_fixture(monkeypatch):
+    """The oracle knowingly departs from the recalled probminhash crate in two measure-zero places (oracle/kmu_oracle.c):
+    exact f64 ties go to the smaller key (crate: strict `<`, first in iteration order stays) and the sampler's exp_m1 is a fixed
+    Horner form (crate: libm).  Both are switches -- KMO_STRICT_TIES, KMO_LIBM_EXPM1 -- and every ProbMinHash row of the
+    committed fixture, plus a batch of ONT-shaped reads at the bench's parameters, is identical under all four combinations
+    (call site: seqsketchjaccard.rs:235-240)."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_oracle_signatures as G
+    from kmerutils_amd import synth
+    from oracle import oracle as O
+    bases, off = synth.ont_reads(24, 120_000, 0xC3)
+    p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 200, A.SIG_U64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    p3 = A.SketchParams(A.ALGO_PROB3, A.KMER32BIT, 8, 200, A.SIG_U32, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+    base_rows = None
+    for ties in ("0", "1"):
+        for libm in ("0", "1"):
+            monkeypatch.setenv("KMO_STRICT_TIES", ties)
+            monkeypatch.setenv("KMO_LIBM_EXPM1", libm)
+            for case in G.CASES:
+                if case[2] not in (A.ALGO_PROB3A, A.ALGO_PROB3):
+                    continue
+                _, _, _, rows = G.compute(case)
+                assert np.array_equal(rows, _rows(FIX["cases"][case[0]])), (case[0], ties, libm)
+            rows = [O.sketch(bases, off, p), O.sketch(bases, off, p3)]
+            if base_rows is None:
+                base_rows = rows
+            assert all(np.array_equal(a, b) for a, b in zip(rows, base_rows)), (ties, libm)
+
+
 def test_reference_assertions_hold_on_the_frozen_rows():
     """the thresholds of the reference's tests (seqsketchjaccard.rs:784-785, 850, 902-909, 942-943, 992-1004;
     aautils/setsketchert.rs:1264, 1369) evaluated on the fixture"""

@@ -148,3 +148,108 @@ def test_two_ranks_one_gpu_library_exchange():
         p.join(600)
         assert p.exitcode == 0
     assert ret.get(0) is True and ret.get(1) is True
+
+
+def _thread_rank(rank, group, shards, expected, errors, empty_rank):
+    """one rank of an 8-rank job as a thread of this process: its own context on the one GPU, the library's distributed
+    counter, the exchange carried by kdist.ThreadTransport"""
+    import torch
+    from kmerutils_amd import lib
+    try:
+        torch.cuda.set_device(0)
+        ctx = lib.Context(0)
+        kdist.init_comm_threads(ctx, group, rank)
+        assert (ctx.comm_rank, ctx.comm_nranks) == (rank, group.world)
+        bases, off, cap = shards[rank]
+        c = ctx.counter(A.KMER64BIT, 31, 16, cap, distributed=True)
+        if rank == empty_rank:
+            c.add_reads(torch.zeros(16, dtype=torch.uint8).cuda(), torch.zeros(1, dtype=torch.int64).cuda())
+        else:
+            c.add_reads(torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda())
+        st = ctx.comm_stats()
+        c.finalize()
+        kk, cc = c.dump(1)
+        wk, wc = expected[rank]
+        assert np.array_equal(kk, wk) and np.array_equal(cc, wc), "rank %d: %d entries, expected %d" % (rank, kk.size, wk.size)
+        assert c.nb_distinct() == wk.size
+        # a k-mer owned by another rank is absent here (the MERGE finalize leaves zeroed counts behind, not entries)
+        other = expected[(rank + 1) % group.world][0][:1000]
+        if other.size:
+            assert (c.query(np.ascontiguousarray(other)) == 0).all()
+        errors[rank] = st
+        c.close()
+        ctx.close()
+    except BaseException as e:  # noqa: BLE001 -- the other ranks must not wait for this one for ever
+        errors[rank] = e
+        group.barrier.abort()
+        raise
+
+
+@pytest.mark.parametrize("world,empty_rank", [(8, 5), (6, None)])
+def test_eight_ranks_one_gpu_library_exchange(oracle, monkeypatch, world, empty_rank):
+    """N = 8 (and N = 6: owners by a true modulo, not a mask) ranks on one GPU, as threads of one process -- the box lets at most
+    six PROCESSES hold the card, so this is the form in which the 8-rank control flow runs here: route_model over 8 gathered
+    rows (ranks with different table sizes: ADVICE r02, the route must still agree), the 8-way owner grouping, both routes, the
+    automatic choice, one rank with an empty shard; every rank must end up with exactly the oracle's counts of the k-mers it
+    owns (count_kmer_threaded_one_to_many, src/base/kmercount.rs:881-974; owner = int64_hash(kmer) % n, :412-420)."""
+    import threading
+    L = oracle.lib()
+    for reads in (_reads(n=6000), synth.ont_reads(600, 500_000, 0xC3)):
+        bases, off = reads
+        lens = np.diff(off.astype(np.int64))
+        g = oracle.Counter(A.KMER64BIT, 31, 16, 1 << 21)
+        shards = []
+        for r, (r0, r1) in enumerate(kdist.shard_reads_by_bases(lens, world)):
+            sb = np.ascontiguousarray(bases[int(off[r0]):int(off[r1])])
+            so = (off[r0:r1 + 1] - off[r0]).astype(np.uint64)
+            if r != empty_rank:
+                g.add_reads(sb, so)
+            # capacity hints that differ between the ranks and straddle a power of two: the tables have different sizes
+            shards.append((sb, so, 60_000 if r % 2 else 200_000))
+        gk, gc = g.dump(1)
+        own = np.array([L.kmo_int64_hash(int(x)) % world for x in gk], dtype=np.int64)
+        expected = [(gk[own == r], gc[own == r]) for r in range(world)]
+        for route in ("occurrences", "merge", None):
+            if route:
+                monkeypatch.setenv("KMU_COUNT_ROUTE", route)
+            else:
+                monkeypatch.delenv("KMU_COUNT_ROUTE", raising=False)
+            group = kdist.ThreadGroup(world)
+            res = [None] * world
+            ts = [threading.Thread(target=_thread_rank, args=(r, group, shards, expected, res, empty_rank)) for r in range(world)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join(600)
+            bad = [(r, x) for r, x in enumerate(res) if not isinstance(x, dict)]
+            assert not bad, (route, bad)
+            routes = {st["route"] for st in res}
+            assert len(routes) == 1, (route, routes)  # every rank took the same route
+            if route:
+                assert routes == {{"occurrences": 1, "merge": 2}[route]}
+            assert all(st["bytes_sent"] > 0 for r, st in enumerate(res) if r != empty_rank)
+            # the model's inputs were the gathered ones: the same two times on every rank
+            assert len({(st["model_ms_occurrences"], st["model_ms_merge"]) for st in res}) == 1
+
+
+def test_rccl_many_rounds_to_self(oracle, monkeypatch):
+    """KMU_COMM_CHUNK_MB=1: the grouped ncclSend / ncclRecv all-to-all in many rounds (a pair's message cut at 1 MiB; the
+    production cut is 1 GiB, below RCCL's silent truncation at 4 GiB), one rank, both routes"""
+    import torch
+    from kmerutils_amd import lib
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
+    monkeypatch.setenv("KMU_COMM_CHUNK_MB", "1")
+    ctx = lib.Context(0)
+    ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
+    bases, off = synth.ont_reads(500, 3_000_000, 0xC6)  # 3 M k-mers: 24 MB to self in 23 rounds
+    wk, wc = _oracle_counts(oracle, bases, off)
+    db, do = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    for route in ("occurrences", "merge"):
+        monkeypatch.setenv("KMU_COUNT_ROUTE", route)
+        c = ctx.counter(A.KMER64BIT, 31, 16, int(off[-1]), distributed=True)
+        c.add_reads(db, do)
+        c.finalize()
+        gk, gc = c.dump(1)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc), route
+        c.close()
+    ctx.close()

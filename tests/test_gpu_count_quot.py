@@ -1,0 +1,147 @@
+"""The count table's 8-byte-per-slot (quotient) format.
+
+Big tables take it by themselves (>= 2^23 slots with 8-bit counters, >= 2^29 with 16-bit ones: the bench's table, and every
+count test of the suite whose capacity hint is >= 5.6 M with 8-bit counters); here it is FORCED (`KMU_COUNT_FMT=quot` raises a
+small table to the size the format starts at) on the count tests of the other files, so that every reader and writer of a slot
+-- direct insertion, the LDS region build on empty and on occupied tables, spill list, query, statistics, dump, export /
+merge / retain, eliminate-once, once-positions, the MERGE finalize with its tombstones -- runs on quotient slots against the
+same oracle answers (reference contract: src/base/kmercount.rs:241-287, KATs :1524-1617)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from kmerutils_amd import _abi as A
+from kmerutils_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location("_quot_" + name, os.path.join(HERE, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kmerutils_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture
+def quot(monkeypatch):
+    monkeypatch.setenv("KMU_COUNT_FMT", "quot")
+    return monkeypatch
+
+
+def test_table_formats(ctx, monkeypatch):
+    """which table gets which format, and what kmu_count_table_info says"""
+    for bits, hint, want in ((8, 1 << 16, 12), (8, 5_600_000, 8), (16, 12_000_000, 12), (16, 400_000_000, 8)):
+        c = ctx.counter(A.KMER64BIT, 31, bits, hint)
+        ti = c.table_info()
+        assert ti["bytes_per_slot"] == want and ti["table_bytes"] == ti["nslots"] * want, (bits, hint, ti)
+        assert ti["nslots"] >= 1.5 * hint and ti["nslots"] & (ti["nslots"] - 1) == 0
+        if want == 8:  # the count field: the region bits of the table; its ceiling is above what the counter reports
+            assert ti["count_field_bits"] == ti["nslots"].bit_length() - 1 - 12
+            assert (1 << ti["count_field_bits"]) - 1024 >= (1 << bits) - 1
+        c.close()
+    monkeypatch.setenv("KMU_COUNT_FMT", "wide")
+    c = ctx.counter(A.KMER64BIT, 31, 8, 5_600_000)
+    assert c.table_info()["bytes_per_slot"] == 12
+    c.close()
+    monkeypatch.setenv("KMU_COUNT_FMT", "quot")
+    for bits, lg in ((8, 23), (16, 29)):
+        c = ctx.counter(A.KMER64BIT, 31, bits, 1024)
+        assert c.table_info() == {"nslots": 1 << lg, "table_bytes": 8 << lg, "bytes_per_slot": 8, "count_field_bits": lg - 12}
+        c.close()
+
+
+def test_saturation_of_the_count_field(ctx, oracle, quot):
+    """a k-mer seen more often than the count field holds: direct insertion and the LDS region build both stop below the key
+    bits (no carry into the stored hash), the reported count is the counter's maximum, and the neighbours in the probe chain
+    are still found"""
+    bases, off = synth.ont_reads(300, 2_000_000, 0xCA)
+    poly = np.frombuffer(b"A" * 150_000 + b"C" * 70_000, np.uint8)  # 149 970 x poly-A 31-mer: > 2^11 - 1024 (8-bit: w = 11) and > 2^17 - 1024
+    allb = np.concatenate([bases, poly[:150_000], poly[150_000:]])
+    alloff = np.concatenate([off, [off[-1] + 150_000, off[-1] + 220_000]]).astype(np.uint64)
+    for bits in (8, 16):
+        o = oracle.Counter(A.KMER64BIT, 31, bits, 1 << 22)
+        o.add_reads(allb, alloff)
+        wk, wc = o.dump(1)
+        for path in ("partitioned", "direct"):
+            quot.setenv("KMU_COUNT_PATH", path)
+            c = ctx.counter(A.KMER64BIT, 31, bits, 1 << 16)
+            c.add_reads(allb, alloff)
+            gk, gc = c.dump(1)
+            assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (bits, path)
+            assert gc.max() == (1 << bits) - 1
+            assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())
+            c.add_reads(allb, alloff)  # onto the saturated fields
+            o2 = oracle.Counter(A.KMER64BIT, 31, bits, 1 << 22)
+            o2.add_reads(allb, alloff)
+            o2.add_reads(allb, alloff)
+            assert np.array_equal(c.query(wk), o2.query(wk)), (bits, path)
+            c.close()
+        quot.delenv("KMU_COUNT_PATH")
+
+
+PARITY = _load("test_gpu_parity")
+
+
+@pytest.mark.parametrize("kmer_type,k", [(A.KMER64BIT, 31), (A.KMER16B32BIT, 16), (A.KMER32BIT, 12)])
+def test_count_parity_quot(ctx, oracle, quot, kmer_type, k):
+    PARITY.test_count_parity(ctx, oracle, kmer_type, k)
+
+
+def test_partitioned_two_level_quot(ctx, oracle, quot):
+    PARITY.test_count_partitioned_two_level_vs_direct_and_oracle(ctx, oracle)
+
+
+def test_reference_kat_quot(ctx, oracle, quot):
+    PARITY.test_count_reference_kat(ctx, oracle)
+
+
+def test_add_kmers_partitioned_quot(ctx, oracle, quot):
+    PARITY.test_count_add_kmers_partitioned(ctx, oracle)
+
+
+def test_extract_by_owner_quot(ctx, oracle, quot):
+    PARITY.test_extract_by_owner_single_gpu(ctx, oracle)
+
+
+def test_single_pass_spill_list_quot(ctx, oracle, quot):
+    PARITY.test_count_single_pass_spill_list(ctx, oracle, quot)
+
+
+@pytest.mark.parametrize("pct", ["100", "60"])
+def test_single_pass_partition_quot(ctx, oracle, quot, pct):
+    PARITY.test_count_single_pass_partition(ctx, oracle, quot, pct)
+
+
+def test_once_kmers_quot(ctx, oracle, quot, tmp_path):
+    PARITY.test_once_kmers_with_positions(ctx, oracle, tmp_path)
+
+
+def test_distributed_counter_quot(oracle, quot):
+    """both routes of a distributed add through RCCL at world size 1, incl. the MERGE finalize (owner census, emit, zeroed
+    counts as tombstones) on quotient slots"""
+    _load("test_gpu_comm").test_rccl_world1_distributed_counter(oracle, quot)
+
+
+def test_sketch_count_quot(ctx, oracle, quot):
+    PIPE = _load("test_gpu_pipeline")
+    PIPE.test_sketch_count_host_and_device(ctx, oracle, quot, "1")
+    PIPE.test_sketch_count_host_chunked_level1(ctx, oracle, quot)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_counter_usage_sweep_quot(ctx, oracle, quot, seed):
+    FUZZ = _load("test_gpu_fuzz")
+    FUZZ.test_counter_usage_sweep(ctx, oracle, seed, quot)
+    FUZZ.test_count_sweep(ctx, oracle, seed)

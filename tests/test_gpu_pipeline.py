@@ -132,7 +132,7 @@ def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
         prof = ctx.profile_get()
         assert ("k_part_hist1" in prof) == (pct == "60")  # the histogram passes only run when the exact route takes over
         # (overflowing segments: the chunked attempt, then the exact levels -- no second attempt on the same k-mers)
-        assert prof["k_part_scatter2"][0] == (1 if pct == "100" else 2)
+        assert prof["k_arr_scatter"][0] == (1 if pct == "100" else 2)
         assert np.array_equal(got, want)
         assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())
         gk, gc = c.dump(2)
