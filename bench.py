@@ -449,7 +449,13 @@ def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000, rank
     return out
 
 
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0  # wave-instructions / s: 256 CUs x 4 SIMDs, one full-rate VALU instruction per 4 cycles at 2.4 GHz
+# wave-instructions / s the chip can issue, MEASURED (scripts/micro/valu_issue.hip, profiles/r03_valu_issue.txt): 1.03e9 per SIMD
+# for full-rate instructions (v_add_u32, v_xor_b32: one every ~2.3 cycles at the 2.2-2.3 GHz the chip holds under this load,
+# from two waves per SIMD up -- the guide's 2-cycle issue, MI355X_MICROARCH.md:54,473) x 4 SIMDs x 256 CUs.  The 64-bit shifts,
+# 32-bit multiplies, v_mad_u64_u32, carry adds and f64 FMAs that SplitMix64 / xoshiro / the Wang hash / Exp01 consist of issue at
+# HALF that rate (0.53-0.58e9 per SIMD) at any occupancy: VALU_HALF_RATE_PEAK is the ceiling of a kernel made of those alone.
+VALU_ISSUE_PEAK = 1.03e9 * 4 * 256
+VALU_HALF_RATE_PEAK = 0.57e9 * 4 * 256
 
 
 def pmc_alu(cfg, total_bases, kernel, avg_ms, per_step=None):
@@ -469,7 +475,8 @@ def pmc_alu(cfg, total_bases, kernel, avg_ms, per_step=None):
                 ach = valu / (avg_ms * 1e-3)
                 return {"bound": "valu-issue", "valu_wave_insts": valu,
                         "salu_wave_insts": sum(k.get("SQ_INSTS_SALU_per_launch", 0) * m for k, m in zip(ks, mult)),
-                        "achieved": ach, "peak": VALU_ISSUE_PEAK, "unit": "wave-inst/s", "frac": ach / VALU_ISSUE_PEAK}
+                        "achieved": ach, "peak": VALU_ISSUE_PEAK, "unit": "wave-inst/s", "frac": ach / VALU_ISSUE_PEAK,
+                        "peak_half_rate_insts": VALU_HALF_RATE_PEAK, "source": "profiles/r03_valu_issue.txt"}
     except Exception:
         pass
     return None

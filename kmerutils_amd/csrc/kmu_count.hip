@@ -130,7 +130,8 @@ __device__ __forceinline__ bool slot_read(const CountTable &t, uint64_t i, uint6
     const uint64_t s = t.keys[i];
     if (s == CKEY_EMPTY) return false;
     if (t.w) {
-        cnt = (uint32_t) (s & q_cmask(t.w));
+        const uint64_t f = s & q_cmask(t.w), lim = q_limit(t.w);
+        cnt = (uint32_t) (f < lim ? f : lim); // (a region build may leave a field a few hundred above its ceiling)
         if (WANT_KEY) key = q_key_of(t, i, s);
     } else {
         cnt = t.counts[i];
@@ -201,7 +202,10 @@ __device__ __forceinline__ uint32_t count_lookup(const CountTable &t, uint64_t v
         uint64_t cur = t.keys[idx];
         if (cur == CKEY_EMPTY) return 0;
         if (t.w) {
-            if (q_same(cur, hw, t.w)) return (uint32_t) (cur & q_cmask(t.w));
+            if (q_same(cur, hw, t.w)) {
+                const uint64_t f = cur & q_cmask(t.w), lim = q_limit(t.w);
+                return (uint32_t) (f < lim ? f : lim);
+            }
         } else if (cur == v) return t.counts[idx];
         off = (off + 1) & t.rmask;
     }
@@ -585,7 +589,7 @@ __global__ void __launch_bounds__(256) k_sample_distinct(const uint64_t *list, u
 // ---- finalize of the MERGE route: the entries this rank does not own leave the table ---------------------------------------
 // pass 1: entries per owner; pass 2: (key, count) appended to the owner's range of the send lists, the slot's count zeroed
 // (a zero count is "never seen" for every reader of the table; the key stays as a tombstone of the probe chain)
-__global__ void __launch_bounds__(256) k_owner_census(CountTable t, uint64_t nslots, int w32, uint32_t me, uint32_t n_parts,
+__global__ void __launch_bounds__(256) k_owner_census(CountTable t, uint64_t nslots, int w32, uint32_t n_parts,
                                                       unsigned long long *per_owner) {
     extern __shared__ uint32_t lo[];
     for (uint32_t b = threadIdx.x; b < n_parts; b += blockDim.x) lo[b] = 0;
@@ -593,10 +597,7 @@ __global__ void __launch_bounds__(256) k_owner_census(CountTable t, uint64_t nsl
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         uint64_t key;
         uint32_t cnt;
-        if (slot_read<true>(t, i, key, cnt) && cnt != 0u) {
-            const uint32_t o = kmer_owner(key, w32, n_parts);
-            if (o != me) atomicAdd(&lo[o], 1u);
-        }
+        if (slot_read<true>(t, i, key, cnt) && cnt != 0u) atomicAdd(&lo[kmer_owner(key, w32, n_parts)], 1u); // (lo[me]: the entries that stay)
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < n_parts; b += blockDim.x)
@@ -1377,9 +1378,14 @@ template <int IT, bool Q>
 __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
                                                               uint32_t n_regions, CountTable t, int in_mode, int out_compact,
                                                               uint32_t *rcount, unsigned long long *stats, uint32_t *err,
-                                                              uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt) {
+                                                              uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt, int contig) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t R = t.rmask + 1; // >= 1024
+    // the regions of this workgroup: every gridDim.x-th one, or (contig) one contiguous range -- a workgroup then walks
+    // through its own stretch of the leaves and of the table image
+    const uint32_t r_begin = contig ? (uint32_t) ((uint64_t) blockIdx.x * n_regions / gridDim.x) : blockIdx.x;
+    const uint32_t r_end = contig ? (uint32_t) ((uint64_t) (blockIdx.x + 1) * n_regions / gridDim.x) : n_regions;
+    const uint32_t r_step = contig ? 1u : gridDim.x;
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
     uint32_t *lc = reinterpret_cast<uint32_t *>(lk + R);
     uint64_t *bm = reinterpret_cast<uint64_t *>(lc + R); // 64 words: occupancy of the region's slots
@@ -1391,7 +1397,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
     if (Q) {
         const int w = t.w;
         const uint64_t cmask = q_cmask(w), limit = q_limit(w);
-        for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        for (uint32_t r = r_begin; r < r_end; r += r_step) {
             const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
             const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (uint64_t) leafcnt[r] : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
             uint64_t pre_it[BUILD_PRE];
@@ -1407,30 +1413,70 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
                 for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
             }
             lds_barrier();
-            auto insert = [&](uint64_t item) {
-                const uint64_t h = IT == IT_HASH ? item : khash(item);
-                const uint64_t hw = h << w;
-                uint32_t off = (uint32_t) (h >> t.shift) & t.rmask;
-                bool done = false;
-                for (uint32_t probes = 0; probes < R; probes++) {
-                    const unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw | 1ull));
-                    if (old == CKEY_EMPTY) { done = true; break; }
-                    if (q_same(old, hw, w)) {
-                        // fewer than BUILD_THREADS adds are in flight behind a count seen below the limit: no carry into the key bits
-                        if ((old & cmask) < limit) atomicAdd((unsigned long long *) &lk[off], 1ull);
-                        done = true;
-                        break;
-                    }
-                    off = (off + 1) & t.rmask;
-                }
-                if (!done) full = 1;
+            // one probe of `item` at slot `off`: true = the item is in (claimed a free slot, or met its own key)
+            auto probe = [&](uint64_t hw, uint32_t off) -> bool {
+                const unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw | 1ull));
+                if (old == CKEY_EMPTY) return true;
+                if (!q_same(old, hw, w)) return false;
+                // fewer than BUILD_THREADS adds are in flight behind a count seen below the limit: no carry into the key bits
+                if ((old & cmask) < limit) atomicAdd((unsigned long long *) &lk[off], 1ull);
+                return true;
             };
+            if (!(out_compact & 32)) {
+                // Every LANE walks through its prefetched items at its own pace: a lane whose item is in takes its next one in
+                // the next trip of the loop.  (Item by item, a wave repeats the probe loop until the unluckiest of its 64 lanes
+                // is through -- ~8 trips per item at a load factor of 0.47, ~30 per region -- while the lanes' SUMS of probes
+                // over their four items lie close together.  Thread-0 clocks of the item-by-item form, r03: 79 % of a region's
+                // time in this phase; KMU_BUILD_ABLATE=32 keeps that form for the A/B.)
+                static_assert(BUILD_PRE == 6, "the item queue of a lane is written out by hand");
+                // (two queues per lane with both probes in flight: 30.5 ms against 23.2 -- the loop is bound by the instructions
+                //  of a trip, not by the LDS round trip)
+                uint64_t q0 = pre_it[0], q1 = pre_it[1], q2 = pre_it[2], q3 = pre_it[3], q4 = pre_it[4], q5 = pre_it[5];
+                uint32_t left = BUILD_PRE + 1, guard = 0, off = 0;
+                uint64_t hw = 0;
+                bool have = false; // this lane is probing for an item
+                while (left) {
+                    if (!have) { // the lane's next item, if any ("no k-mer" marks are skipped a trip at a time)
+                        const uint64_t item = q0;
+                        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = CKEY_EMPTY;
+                        left--;
+                        if (left && item != CKEY_EMPTY) {
+                            const uint64_t h = IT == IT_HASH ? item : khash(item);
+                            hw = h << w;
+                            off = (uint32_t) (h >> t.shift) & t.rmask;
+                            guard = 0;
+                            have = true;
+                        }
+                    }
+                    if (have) {
+                        if (probe(hw, off)) have = false;
+                        else {
+                            off = (off + 1) & t.rmask;
+                            if (++guard >= R) { full = 1; have = false; }
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < BUILD_PRE; q++)
-                if (pre_it[q] != CKEY_EMPTY) insert(pre_it[q]);
-            for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) {
+                for (int q = 0; q < BUILD_PRE; q++)
+                    if (pre_it[q] != CKEY_EMPTY) {
+                        const uint64_t h = IT == IT_HASH ? pre_it[q] : khash(pre_it[q]);
+                        uint32_t off = (uint32_t) (h >> t.shift) & t.rmask, n = 0;
+                        while (!probe(h << w, off)) {
+                            off = (off + 1) & t.rmask;
+                            if (++n >= R) { full = 1; break; }
+                        }
+                    }
+            }
+            for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) { // (leaves beyond 3 072 items)
                 const uint64_t item = items[i];
-                if (item != CKEY_EMPTY) insert(item);
+                if (item == CKEY_EMPTY) continue;
+                const uint64_t h = IT == IT_HASH ? item : khash(item);
+                uint32_t off = (uint32_t) (h >> t.shift) & t.rmask, n = 0;
+                while (!probe(h << w, off)) {
+                    off = (off + 1) & t.rmask;
+                    if (++n >= R) { full = 1; break; }
+                }
             }
             lds_barrier();
             for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
@@ -1439,7 +1485,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
         if (full) atomicOr(err, DERR_TABLE_FULL);
         return;
     }
-    for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+    for (uint32_t r = r_begin; r < r_end; r += r_step) {
         const uint64_t gbase = (uint64_t) r * R;
         // the items of region r: [leafstart[r], leafstart[r + 1]), or a fixed-size range that may hold "no k-mer" marks (the
         // leaves of the single-pass partition), or none (the expansion of a compact table)
@@ -1596,16 +1642,25 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
     if (c->qw) to_compact = false; // (the compact state is a wide-format state)
-    const int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * (c->qw ? 4 : 3) * 8);
+    int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * (c->qw ? 4 : 3) * 8);
+    int contig = 0; // A/B: KMU_BUILD_MAP=1: one contiguous range of regions per workgroup, as many workgroups as fit the chip; =2: eight times as many
+    if (const char *e = getenv("KMU_BUILD_MAP")) {
+        contig = atoi(e);
+        if (contig == 1) grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * (c->qw ? 4 : 3));
+    }
     if (to_compact) KMU_HIP(ctx, hipMemsetAsync(c->scalars + 4, 0, 24, ctx->stream));
     {
         KernelTimer tm(ctx, items ? "k_part_build" : "k_part_expand");
+        size_t pad = 0; // A/B runs: extra dynamic LDS per workgroup (fewer workgroups per CU)
+        if (const char *e = getenv("KMU_BUILD_LDS_PAD")) pad = (size_t) std::max(0, atoi(e));
+        int abl = 0; // A/B: 32 = the prefetched items of a thread one after the other (the lanes of a wave in lock step)
+        if (const char *e = getenv("KMU_BUILD_ABLATE")) abl = atoi(e);
         if (c->qw)
-            hipLaunchKernelGGL((k_part_build<IT, true>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
-                               table_of(c), in_mode, 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt);
+            hipLaunchKernelGGL((k_part_build<IT, true>), dim3(grid), dim3(BUILD_THREADS), build_lds(c) + pad, ctx->stream, items, leaves, (uint32_t) n_regions,
+                               table_of(c), in_mode, abl, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt, contig);
         else
             hipLaunchKernelGGL((k_part_build<IT, false>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
-                               table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt);
+                               table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt, contig);
     }
     KMU_HIP(ctx, hipGetLastError());
     c->empty = false;
@@ -2859,11 +2914,13 @@ int kmu_count_finalize(kmu_counter *c) {
     if (have) {
         KernelTimer tm(ctx, "k_owner_census");
         hipLaunchKernelGGL(k_owner_census, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), (size_t) N * 4, ctx->stream, table_of(c),
-                           c->nslots, w32, me, N, (unsigned long long *) po);
+                           c->nslots, w32, N, (unsigned long long *) po);
     }
     std::vector<uint64_t> mine(N + 1), all((size_t) (N + 1) * N);
     KMU_HIP(ctx, hipMemcpyAsync(mine.data(), po, (size_t) N * 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n_stay = mine[me]; // entries this rank owns itself: they stay
+    mine[me] = 0;
     mine[N] = c->unmerged ? 1 : 0;
     KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), ((uint64_t) N + 1) * 8));
     bool any = false;
@@ -2901,6 +2958,18 @@ int kmu_count_finalize(kmu_counter *c) {
     KMU_HIP(ctx, hipEventRecord(cm->ev_b, cm->stream));
     KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, cm->ev_b, 0));
     cm->stats.bytes_merge = cm->stats.bytes_sent - sent0; // exact now
+    // The entries that left are still in the table as tombstones of their probe chains (key kept, count zero).  Where they
+    // and what arrives would crowd the table (a rank whose shard holds as many distinct k-mers as it ends up owning: every
+    // k-mer of a noisy long-read set occurs once), the table is rebuilt from the entries that stay before the merge.
+    if (n_send && (double) (n_stay + n_send + n_recv) > 0.55 * (double) c->nslots) {
+        void *kk = nullptr, *kc = nullptr;
+        KMU_TRY(dev_buf(ctx, "cnt.keep.k", n_stay * 8 + 8, &kk));
+        KMU_TRY(dev_buf(ctx, "cnt.keep.c", n_stay * 4 + 8, &kc));
+        uint64_t n2 = 0;
+        KMU_TRY(select_entries(c, 1u, 0xFFFFFFFFu, me, N, (uint64_t *) kk, (uint32_t *) kc, n_stay, KMU_MEM_DEVICE, false, &n2));
+        KMU_TRY(kmu_count_reset(c));
+        if (n2) KMU_TRY(add_entries(c, (const uint64_t *) kk, (const uint32_t *) kc, n2, KMU_MEM_DEVICE));
+    }
     if (n_recv) KMU_TRY(add_entries(c, (const uint64_t *) rk, (const uint32_t *) rc, n_recv, KMU_MEM_DEVICE));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // sdis / scnt are locals the copies above read
     return KMU_OK;

@@ -62,6 +62,10 @@ struct SketchArgs {
     uint64_t *lst_keys;
     uint32_t *lst_w;
     uint32_t *lst_n;
+    // the first lst_nu[r] entries of read r's list have weight 1 and NO entry in lst_w (k_multiset_uq: the keys proven to occur
+    // once, nine in ten of an ONT read, leave as 8 bytes instead of 12 and their weights are never read back); zeroed by the
+    // host before the multiset kernels, only k_multiset_uq writes it
+    uint32_t *lst_nu;
     uint32_t *queue2;     // read counter of k_pmh_points
     // The PLAIN instantiation leaves a sequence whose k-mers overflow a pass (repetitive reads: rounds with carry lists) to
     // the general one: it appends the sequence to redo_list (count in queue[56]); the second launch walks read_list.
@@ -1056,6 +1060,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         if (r >= a.n_seq) break;
         const uint64_t base = a.offsets[r] - a.offsets[0];
         const uint32_t n = a.lst_n[r];
+        const uint32_t n_u = uniform_u32(a.lst_nu[r]); // leading entries of weight 1 without a weight word
         for (int t = lane; t < a.m; t += 64) { hmin[t] = H_INIT; sig[t] = 0; }
         if (lane == 0) *qmax_sh = H_INIT;
         // ---- pass 1 ----
@@ -1064,14 +1069,18 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         uint64_t qb = H_INIT;
         uint64_t key_nx = 0; // the next chunk's pair is requested one iteration ahead
         uint32_t w_nx = 1;
-        if ((uint32_t) lane < n) { key_nx = a.lst_keys[base + lane]; w_nx = a.lst_w[base + lane]; }
+        if ((uint32_t) lane < n) { key_nx = a.lst_keys[base + lane]; w_nx = (uint32_t) lane < n_u ? 1u : a.lst_w[base + lane]; }
         for (uint32_t c = 0; c < n; c += 64, chunk++) { // uniform trip count
             const uint32_t i = c + (uint32_t) lane;
             const uint64_t key = key_nx;
             const uint32_t w = w_nx;
             const bool have = i < n && w != 0u; // weight 0: a repeat of an earlier entry
             if (have) wmax = w > wmax ? w : wmax;
-            if (i + 64u < n) { key_nx = a.lst_keys[base + i + 64u]; w_nx = a.lst_w[base + i + 64u]; }
+            if (i + 64u < n) key_nx = a.lst_keys[base + i + 64u];
+            w_nx = 1u;
+            if (c + 128u > n_u) { // (uniform: the next chunk reaches beyond the weight-1 prefix)
+                if (i + 64u < n && i + 64u >= n_u) w_nx = a.lst_w[base + i + 64u];
+            }
             if ((chunk & PTS_REFRESH_MASK) == 0u) {
                 qb = wave_qmax(hmin, a.m);
                 if (lane == 0) *qmax_sh = qb;
@@ -1104,12 +1113,15 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         qb = wave_qmax(hmin, a.m);
         wmax = (uint32_t) wave_max_u64((uint64_t) wmax);
         if (n && wmax && winv_of(winv_lut, wmax) < __longlong_as_double((long long) qb) && !ABL(512u)) { // (ABL: diagnostic builds, pass 2 left out: wrong rows, its share of the time)
-            for (uint32_t c = 0; c < n; c += 64) {
+            // (a key of weight 1 draws again only while q_max > 1: with every slot hit q_max < 1 -- Exp01 is restricted to
+            //  [0, 1) -- and the weight-1 prefix of the list is not read a second time)
+            const uint32_t c0 = 1.0 < __longlong_as_double((long long) qb) ? 0u : (n_u & ~63u);
+            for (uint32_t c = c0; c < n; c += 64) {
                 const uint32_t i = c + (uint32_t) lane;
                 double winv = 0.0;
                 bool alive = false;
                 if (i < n) {
-                    const uint32_t w = a.lst_w[base + i];
+                    const uint32_t w = i < n_u ? 1u : a.lst_w[base + i];
                     winv = winv_of(winv_lut, w);
                     alive = w != 0u && winv < __longlong_as_double((long long) qb);
                 }
@@ -1138,18 +1150,25 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
 // Two shapes: <512 threads, 2^16-bit bitmaps, 2 048 collected keys> for reads of up to 10 240 k-mers, two workgroups per CU;
 // <1024, 2^17, 4 096> for up to 20 480 k-mers, one workgroup per CU, run on the list the first shape leaves behind.
 static constexpr int UQ_KREG = 20;
-template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL>
+// TAB (round 3, the default; KMU_PMH_UQTAB=0 for the A/B): the keys of the collision groups are not collected and counting-
+// sorted (rank / scan / place / walk: five barriers) but meet in an open-addressing table of 2 x UQ_COLL slots in LDS
+// (ds_cmpst_rtn_b64 claims a slot, ds_add counts: the table of k_multiset_short, workgroup-wide) straight from the registers;
+// after ONE barrier the occupied slots leave as (key, weight) pairs and the table is free again: four barriers per read
+// instead of nine, and the list holds no zero-weight repeats.
+template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, bool TAB = false>
 struct UqShape {
     static constexpr uint32_t KEYS = (uint32_t) UQ_THREADS * UQ_KREG;
     static constexpr uint32_t BM_WORDS = (1u << UQ_BM_BITS) / 32;
     static constexpr uint32_t BUCKETS = 2u * UQ_THREADS; // of the collision groups' counting sort: two per thread
     static constexpr uint32_t TILE = (KEYS + 32 + 15) / 16 + 3; // staged code words of a read
-    static constexpr size_t LDS = (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64;
+    static constexpr uint32_t TABS = 2u * UQ_COLL;         // slots of the collision table (TAB)
+    static constexpr size_t LDS = TAB ? (size_t) BM_WORDS * 8 + (size_t) TABS * 12 + ((size_t) TILE + 16) * 4 + 64
+                                      : (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64;
 };
 
-template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, int MINW>
+template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, int MINW, bool TAB = false>
 __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) {
-    typedef UqShape<UQ_THREADS, UQ_BM_BITS, UQ_COLL> SH;
+    typedef UqShape<UQ_THREADS, UQ_BM_BITS, UQ_COLL, TAB> SH;
     constexpr uint32_t UQ_KEYS = SH::KEYS, UQ_BM_WORDS = SH::BM_WORDS, UQ_BUCKETS = SH::BUCKETS, UQ_TILE = SH::TILE;
     static_assert(UQ_BM_WORDS / 4 == (uint32_t) UQ_THREADS, "one 16-byte store per thread wipes a bitmap");
     static_assert(UQ_COLL % UQ_THREADS == 0 && UQ_COLL / UQ_THREADS <= 4, "collected keys per thread");
@@ -1160,12 +1179,23 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     uint64_t *dk = ck + UQ_COLL;                                     // ... grouped by bucket
     uint32_t *dw = reinterpret_cast<uint32_t *>(dk + UQ_COLL);
     uint32_t *bst = dw + UQ_COLL;          // UQ_BUCKETS + 1
-    uint32_t *words = bst + UQ_BUCKETS + 1; // UQ_TILE
-    uint32_t *wtot = words + UQ_TILE;       // one per wave
-    uint32_t *misc = wtot + UQ_THREADS / 64; // [0] unique entries, [1] collected keys, [4] first read, [5] the read after the current one
+    // TAB: the collision table in place of ck / dk / dw / bst / wtot
+    constexpr uint32_t UQ_TABS = SH::TABS;
+    uint64_t *tk = ck;                                         // UQ_TABS keys, all-ones = free
+    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + UQ_TABS); // their multiplicities
+    uint32_t *words = TAB ? tc + UQ_TABS : bst + UQ_BUCKETS + 1; // UQ_TILE
+    uint32_t *wtot = words + UQ_TILE;       // one per wave (not TAB)
+    // [0] unique entries, [1] keys in collision groups, [2] (TAB) occurrences of the all-ones key among them, [3] (TAB) table
+    // overflow, [4] first read, [5] the read after the current one, [6] (TAB) pairs that left the table
+    uint32_t *misc = TAB ? words + UQ_TILE : wtot + UQ_THREADS / 64;
     const KmerCfg cfg = a.cfg;
     const int k = cfg.k, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    for (uint32_t i = tid; i < UQ_BUCKETS + 1; i += UQ_THREADS) bst[i] = 0;
+    if (TAB) {
+        for (uint32_t i = tid; i < UQ_TABS; i += UQ_THREADS) { tk[i] = ~0ull; tc[i] = 0u; }
+        if (tid == 0) { misc[2] = 0; misc[3] = 0; misc[6] = 0; }
+    } else {
+        for (uint32_t i = tid; i < UQ_BUCKETS + 1; i += UQ_THREADS) bst[i] = 0;
+    }
     uint32_t q_next = 0, q_end = 0, q_pend = 0;
     bool q_pending = false;
     if (tid == 0) {
@@ -1326,12 +1356,26 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                     const uint64_t below = (1ull << lane) - 1ull;
                     if (uq[u]) {
                         const uint64_t at = lb + ub + (uint32_t) __popcll(um[u] & below);
-                        a.lst_keys[at] = rk[q0 + u];
-                        a.lst_w[at] = 1u;
+                        a.lst_keys[at] = rk[q0 + u]; // (weight 1, implied: lst_nu)
                     }
                     if (co[u]) {
-                        const uint32_t at = cb + (uint32_t) __popcll(cm[u] & below);
-                        if (at < UQ_COLL) ck[at] = rk[q0 + u];
+                        if (TAB) {
+                            const uint64_t key = rk[q0 + u];
+                            if (key == ~0ull) atomicAdd(&misc[2], 1u); // (the value that marks a free slot: counted aside)
+                            else {
+                                uint32_t sl = rbi[q0 + u] >> (UQ_BM_BITS - (31 - __builtin_clz(UQ_TABS)));
+                                bool done = false;
+                                for (int pr = 0; pr < 64; pr++) {
+                                    const unsigned long long old = atomicCAS((unsigned long long *) &tk[sl], ~0ull, (unsigned long long) key);
+                                    if (old == ~0ull || old == key) { atomicAdd(&tc[sl], 1u); done = true; break; }
+                                    sl = (sl + 1u) & (UQ_TABS - 1u);
+                                }
+                                if (!done) misc[3] = 1u; // (a crowded table: the read goes to the general kernel)
+                            }
+                        } else {
+                            const uint32_t at = cb + (uint32_t) __popcll(cm[u] & below);
+                            if (at < UQ_COLL) ck[at] = rk[q0 + u];
+                        }
                     }
                     ub += (uint32_t) __popcll(um[u]);
                     cb += (uint32_t) __popcll(cm[u]);
@@ -1340,7 +1384,44 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             lds_barrier();
             const uint32_t n_u = uniform_u32(misc[0]), n_c = uniform_u32(misc[1]);
             over = n_c > UQ_COLL;
-            if (!over && n_c) {
+            if (TAB) {
+                over = over || uniform_u32(misc[3]) != 0u;
+                if (n_c) { // the occupied slots leave as (key, weight) pairs behind the unique entries; the table is wiped
+                    constexpr int PER = (int) (UQ_TABS / UQ_THREADS);
+                    uint64_t key[PER];
+                    uint32_t cnt[PER];
+                    uint64_t om[PER];
+                    uint32_t tot = 0;
+#pragma unroll
+                    for (int j = 0; j < PER; j++) key[j] = tk[(uint32_t) j * UQ_THREADS + tid];
+#pragma unroll
+                    for (int j = 0; j < PER; j++) {
+                        const bool occ = key[j] != ~0ull;
+                        cnt[j] = 0;
+                        if (occ) {
+                            cnt[j] = tc[(uint32_t) j * UQ_THREADS + tid];
+                            tk[(uint32_t) j * UQ_THREADS + tid] = ~0ull;
+                            tc[(uint32_t) j * UQ_THREADS + tid] = 0u;
+                        }
+                        om[j] = __ballot(occ);
+                        tot += (uint32_t) __popcll(om[j]);
+                    }
+                    uint32_t ob = 0; // one atomic per wave
+                    if (lane == 0 && tot) ob = atomicAdd(&misc[6], tot);
+                    ob = bcast_u32(ob, 0);
+                    if (!over) {
+#pragma unroll
+                        for (int j = 0; j < PER; j++) {
+                            if (key[j] != ~0ull) {
+                                const uint64_t at = lb + n_u + ob + (uint32_t) __popcll(om[j] & ((1ull << lane) - 1ull));
+                                a.lst_keys[at] = key[j];
+                                a.lst_w[at] = cnt[j];
+                            }
+                            ob += (uint32_t) __popcll(om[j]);
+                        }
+                    }
+                }
+            } else if (!over && n_c) {
                 // ---- the collision groups: counting sort on 10 hash bits, equal keys hand their weight to the first ----
                 uint64_t key[UQ_COLL / UQ_THREADS];
                 uint32_t rb[UQ_COLL / UQ_THREADS];
@@ -1396,21 +1477,33 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                 bst[2 * tid] = 0;
                 bst[2 * tid + 1] = 0;
             }
-            if (tid == 0 && !over) a.lst_n[rs] = n_u + n_c;
+            if (!TAB && tid == 0 && !over) { a.lst_n[rs] = n_u + n_c; a.lst_nu[rs] = n_u; }
         }
+        if (TAB) lds_barrier(); // (the pairs of the table are out and counted)
         if (tid == 0) {
             if (nk == 0) a.lst_n[rs] = 0u; // no k-mer: k_pmh_points writes the row of an empty multiset
             else if (!mine || over) {       // the next kernel's: longer than the registers, or too repetitive
                 a.lst_n[rs] = 0u;
                 a.redo_list[atomicAdd(a.queue + 56, 1u)] = rs;
+            } else if (TAB) {
+                const uint32_t n_u = misc[0];
+                uint32_t n_t = misc[6];
+                if (misc[2]) { // the all-ones key, met more than once
+                    a.lst_keys[lb + n_u + n_t] = ~0ull;
+                    a.lst_w[lb + n_u + n_t] = misc[2];
+                    n_t++;
+                }
+                a.lst_n[rs] = n_u + n_t;
+                a.lst_nu[rs] = n_u;
             }
+            if (TAB) { misc[2] = 0; misc[3] = 0; misc[6] = 0; }
         }
         if (bad) atomicOr(a.err, DERR_NON_ACGT);
         pf_valid = nv_mine;
         r = r_next;
         rs = uniform_u32(rs_next);
         sv = nv;
-        lds_barrier();
+        if (!TAB) lds_barrier();
     }
 }
 
@@ -2216,10 +2309,12 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
                 void *lk, *lw, *ln;
                 KMU_TRY(dev_buf(ctx, "cnt.partA", need_k, &lk));
                 KMU_TRY(dev_buf(ctx, "pmh.lst_w", need_w, &lw));
-                KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 4 + 64, &ln));
+                KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 8 + 64, &ln));
                 a.lst_keys = (uint64_t *) lk;
                 a.lst_w = (uint32_t *) lw;
                 a.lst_n = (uint32_t *) ln;
+                a.lst_nu = a.lst_n + ds.n_seq;
+                KMU_HIP(ctx, hipMemsetAsync(a.lst_nu, 0, (size_t) ds.n_seq * 4, ctx->stream));
             }
         }
         const sketch_kernel_t kern = emit ? k_sketch_smallk<true> : k_sketch_smallk<false>;
@@ -2305,10 +2400,12 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             void *lk, *lw, *ln;
             KMU_TRY(dev_buf(ctx, "cnt.partA", need_k, &lk));
             KMU_TRY(dev_buf(ctx, "pmh.lst_w", need_w, &lw));
-            KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 4 + 64, &ln));
+            KMU_TRY(dev_buf(ctx, "pmh.lst_n", (size_t) ds.n_seq * 8 + 64, &ln));
             a.lst_keys = (uint64_t *) lk;
             a.lst_w = (uint32_t *) lw;
             a.lst_n = (uint32_t *) ln;
+            a.lst_nu = a.lst_n + ds.n_seq;
+            KMU_HIP(ctx, hipMemsetAsync(a.lst_nu, 0, (size_t) ds.n_seq * 4, ctx->stream));
         }
     }
     const char *plain_env = getenv("KMU_PMH_PLAIN"); // diagnostics: 0 = always the general instantiation
@@ -2398,6 +2495,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     // longer ones (and the rare read with too many repeated keys) are handed to the general list-emitting kernel.
     const char *uq_env = getenv("KMU_PMH_UQ"); // 0: every read through the counting-sort kernel (A/B)
     const bool uq = split && plain && !(uq_env && atoi(uq_env) == 0);
+    const char *uqt_env = getenv("KMU_PMH_UQTAB"); // 0: the collision groups through the counting sort (A/B)
+    const bool uq_tab = !(uqt_env && atoi(uqt_env) == 0);
     bool main_launched = false, short_route = false;
     const char *sh_env = getenv("KMU_PMH_SHORT"); // 0: short reads through k_multiset_uq like the others (A/B)
     if (uq && len_stats && len_stats[0] < (uint64_t) SHORT_KEYS + (uint64_t) p->kmer_size && !(sh_env && atoi(sh_env) == 0)) {
@@ -2413,11 +2512,11 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         short_route = true;
     } else if (uq) {
         {
-            typedef UqShape<512, 16, 2048> SA;
-            const auto ka = k_multiset_uq<512, 16, 2048, 4>;
+            const auto ka = uq_tab ? k_multiset_uq<512, 16, 2048, 4, true> : k_multiset_uq<512, 16, 2048, 4, false>;
+            const size_t lds_a = uq_tab ? UqShape<512, 16, 2048, true>::LDS : UqShape<512, 16, 2048, false>::LDS;
             KMU_HIP(ctx, hipFuncSetAttribute((const void *) ka, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             KernelTimer t(ctx, "k_multiset_uq");
-            hipLaunchKernelGGL(ka, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(ds.n_seq, (uint64_t) cus * 2))), dim3(512), SA::LDS,
+            hipLaunchKernelGGL(ka, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(ds.n_seq, (uint64_t) cus * 2))), dim3(512), lds_a,
                                ctx->stream, a);
         }
         KMU_HIP(ctx, hipGetLastError());
@@ -2426,8 +2525,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const char *uq2_env = getenv("KMU_PMH_UQ2"); // 0: no second shape (A/B)
         if (n_long && !(uq2_env && atoi(uq2_env) == 0)) { // the second shape: reads of up to 20 480 k-mers, from the first one's list
-            typedef UqShape<1024, 17, 4096> SB;
-            const auto kb = k_multiset_uq<1024, 17, 4096, 4>;
+            const auto kb = uq_tab ? k_multiset_uq<1024, 17, 4096, 4, true> : k_multiset_uq<1024, 17, 4096, 4, false>;
+            const size_t lds_b = uq_tab ? UqShape<1024, 17, 4096, true>::LDS : UqShape<1024, 17, 4096, false>::LDS;
             void *rl2;
             KMU_TRY(dev_buf(ctx, "pmh.redo2", (size_t) ds.n_seq * 4 + 64, &rl2));
             KMU_HIP(ctx, hipFuncSetAttribute((const void *) kb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2438,7 +2537,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             a.n_queue = n_long;
             {
                 KernelTimer t(ctx, "k_multiset_uq");
-                hipLaunchKernelGGL(kb, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(n_long, (uint64_t) cus))), dim3(1024), SB::LDS, ctx->stream, a);
+                hipLaunchKernelGGL(kb, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(n_long, (uint64_t) cus))), dim3(1024), lds_b, ctx->stream, a);
             }
             KMU_HIP(ctx, hipGetLastError());
             KMU_HIP(ctx, hipMemcpyAsync(&n_long, a.queue + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2886,13 +2985,37 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     uint64_t chunk_bytes = 512ull << 20;
     if (const char *e = getenv("KMU_PIPE_CHUNK_MB")) chunk_bytes = (uint64_t) std::max(1, atoi(e)) << 20;
     std::vector<uint32_t> cut(1, 0u); // chunk c = reads [cut[c], cut[c + 1])
-    for (uint32_t r = 0; r < n_seq;) {
-        // (the first chunk is an eighth of the others: the kernels start after 1 ms of upload instead of 9)
-        const uint64_t lim = h_off[r] + (r == 0 ? std::max<uint64_t>(chunk_bytes / 8, 1) : chunk_bytes);
-        uint32_t e = (uint32_t) (std::upper_bound(h_off.begin() + r + 1, h_off.end(), lim) - h_off.begin()) - 1;
-        if (e <= r) e = r + 1; // a read longer than a chunk travels alone
-        cut.push_back(e);
-        r = e;
+    // Chunk sizes: the first one is an eighth of the others (the kernels start after 1 ms of upload instead of 9) and the last
+    // ones taper off the same way (1/2, 1/4, 1/8): the sketch kernels and the count's level 1 keep pace with the upload (16.5
+    // against 18 ps per base), so what is left to do when the last byte has arrived is the last chunk's sketch + level 1 --
+    // made small -- and then level 2 and the region build, which need all of level 1.  KMU_PIPE_TAPER=0: no taper (A/B).
+    std::vector<uint64_t> plan; // chunk sizes, in order (a chunk ends at the first read boundary at or behind its target)
+    {
+        const char *te = getenv("KMU_PIPE_TAPER");
+        const bool taper = !(te && atoi(te) == 0) && total > 3 * chunk_bytes;
+        const uint64_t first = std::min<uint64_t>(std::max<uint64_t>(chunk_bytes / 8, 1), total);
+        uint64_t tail_sum = 0;
+        std::vector<uint64_t> tail;
+        if (taper)
+            for (uint64_t d = 2; d <= 8; d *= 2) { tail.push_back(std::max<uint64_t>(chunk_bytes / d, 1)); tail_sum += tail.back(); }
+        plan.push_back(first);
+        const uint64_t body = total - first - tail_sum; // (taper: total > 3 chunks, so the body is more than two)
+        const uint64_t n_body = std::max<uint64_t>(1, (body + chunk_bytes / 2) / chunk_bytes);
+        for (uint64_t i = 0; i < n_body && body; i++) plan.push_back(body / n_body + 1);
+        for (uint64_t t : tail) plan.push_back(t);
+    }
+    {
+        uint64_t target = 0;
+        uint32_t r = 0;
+        for (size_t i = 0; i < plan.size() && r < n_seq; i++) {
+            target += plan[i];
+            uint32_t e = i + 1 == plan.size() ? n_seq : (uint32_t) (std::lower_bound(h_off.begin() + r + 1, h_off.end(), target) - h_off.begin());
+            if (e > n_seq) e = n_seq;
+            if (e <= r) continue; // (a read that spans several targets: one chunk)
+            cut.push_back(e);
+            r = e;
+        }
+        if (r < n_seq) cut.push_back(n_seq);
     }
     const size_t n_chunks = cut.size() - 1;
     std::vector<hipEvent_t> ev_up(n_chunks), ev_sk(n_chunks);

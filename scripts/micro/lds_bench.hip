@@ -24,6 +24,11 @@ __global__ void __launch_bounds__(1024) k(uint64_t *out, uint32_t S) {
             if (OP == 3) r[u] = atomicAdd(&l32[idx[u]], 1u);                                          // ds_add_rtn_u32
             if (OP == 4) r[u] = atomicCAS((unsigned long long *) &lds[idx[u]], 0x1234ull, 0x5678ull); // cmpst rtn, never succeeds
             if (OP == 5) { lds[idx[u]] = x; r[u] = 0; }                                               // ds_write_b64
+            if (OP == 6) r[u] = atomicCAS(&l32[idx[u]], 0x1234u, 0x5678u);                            // cmpst_rtn_b32, never succeeds
+            if (OP == 7) { atomicAdd((unsigned long long *) &lds[idx[u]], 1ull); r[u] = 0; }          // ds_add_u64 no return
+            if (OP == 8) r[u] = atomicAdd((unsigned long long *) &lds[idx[u]], 1ull);                 // ds_add_rtn_u64
+            if (OP == 9) r[u] = atomicMin((unsigned long long *) &lds[idx[u]], (unsigned long long) x); // ds_min_rtn_u64
+            if (OP == 10) r[u] = atomicOr(&l32[idx[u]], 1u << (x & 31));                              // ds_or_rtn_b32
         }
 #pragma unroll
         for (int u = 0; u < ILP; u++) acc += r[u];
@@ -54,6 +59,8 @@ int main() {
             run<2, 1>("ds_add_u32 noret", th); run<2, 4>("ds_add_u32 noret", th);
             run<3, 1>("ds_add_rtn_u32", th); run<3, 4>("ds_add_rtn_u32", th); run<3, 16>("ds_add_rtn_u32", th); run<2, 16>("ds_add_u32 noret", th); run<5, 16>("ds_write_b64", th); run<0, 16>("ds_read_b64 random", th);
             run<5, 1>("ds_write_b64", th); run<5, 4>("ds_write_b64", th);
+            run<6, 1>("cmpst_rtn_b32 (fails)", th); run<6, 4>("cmpst_rtn_b32 (fails)", th); run<7, 4>("ds_add_u64 noret", th); run<8, 4>("ds_add_rtn_u64", th);
+            run<9, 4>("ds_min_rtn_u64", th); run<10, 4>("ds_or_rtn_b32", th); run<1, 4>("cmpst_rtn_b64 (claims)", th);
         } else {
             run<0, 1>("ds_read_b64 random", th); run<4, 1>("cmpst_rtn_b64 (fails)", th); run<4, 4>("cmpst_rtn_b64 (fails)", th); run<3, 1>("ds_add_rtn_u32", th);
         }

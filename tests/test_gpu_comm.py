@@ -166,8 +166,8 @@ def _thread_rank(rank, group, shards, expected, errors, empty_rank):
             c.add_reads(torch.zeros(16, dtype=torch.uint8).cuda(), torch.zeros(1, dtype=torch.int64).cuda())
         else:
             c.add_reads(torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda())
-        st = ctx.comm_stats()
         c.finalize()
+        st = ctx.comm_stats()
         kk, cc = c.dump(1)
         wk, wc = expected[rank]
         assert np.array_equal(kk, wk) and np.array_equal(cc, wc), "rank %d: %d entries, expected %d" % (rank, kk.size, wk.size)
@@ -204,8 +204,9 @@ def test_eight_ranks_one_gpu_library_exchange(oracle, monkeypatch, world, empty_
             so = (off[r0:r1 + 1] - off[r0]).astype(np.uint64)
             if r != empty_rank:
                 g.add_reads(sb, so)
-            # capacity hints that differ between the ranks and straddle a power of two: the tables have different sizes
-            shards.append((sb, so, 60_000 if r % 2 else 200_000))
+            # capacity hints that differ between the ranks (tables of different sizes: the route must still agree)
+            per_rank = int(off[-1]) // world + 1024
+            shards.append((sb, so, per_rank if r % 2 else 4 * per_rank))
         gk, gc = g.dump(1)
         own = np.array([L.kmo_int64_hash(int(x)) % world for x in gk], dtype=np.int64)
         expected = [(gk[own == r], gc[own == r]) for r in range(world)]

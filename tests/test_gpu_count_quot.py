@@ -96,7 +96,7 @@ PARITY = _load("test_gpu_parity")
 
 @pytest.mark.parametrize("kmer_type,k", [(A.KMER64BIT, 31), (A.KMER16B32BIT, 16), (A.KMER32BIT, 12)])
 def test_count_parity_quot(ctx, oracle, quot, kmer_type, k):
-    PARITY.test_count_parity(ctx, oracle, kmer_type, k)
+    PARITY._count_parity(ctx, oracle, kmer_type, k)
 
 
 def test_partitioned_two_level_quot(ctx, oracle, quot):

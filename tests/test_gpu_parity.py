@@ -302,6 +302,10 @@ def test_superminhash_aa(ctx, oracle):
 
 @pytest.mark.parametrize("kmer_type,k", [(A.KMER64BIT, 21), (A.KMER64BIT, 31), (A.KMER16B32BIT, 16), (A.KMER32BIT, 12)])
 def test_count_parity(ctx, oracle, kmer_type, k):
+    _count_parity(ctx, oracle, kmer_type, k)
+
+
+def _count_parity(ctx, oracle, kmer_type, k):
     bases, off = synth.illumina_reads(3000, 20000, 0xC2)  # ~22x coverage: multiplicities well above 2
     extra, eoff = oracle.concat([b"A" * 400, b"ACGT" * 5, b"AC", b"T" * 399])
     bases = np.concatenate([bases, extra])
@@ -335,7 +339,11 @@ def test_count_parity(ctx, oracle, kmer_type, k):
     o16 = oracle.Counter(kmer_type, k, 16, 1 << 16)
     o16.add_reads(bases, off)
     o16.add_reads(bases, off)
-    assert np.array_equal(g2.query(q), o16.query(q))
+    # (what an 8-bit counter exports is exact up to the ceiling of its table's count field: 32 bits wide in the 12-byte slot
+    #  format, 2^w - 1024 >= 255 in the 8-byte one -- the reference's own 8-bit counters stop at 255, kmercount.rs:1615)
+    ti = gc.table_info()
+    ceil = (1 << ti["count_field_bits"]) - 1024 if ti["bytes_per_slot"] == 8 else 1 << 32
+    assert np.array_equal(g2.query(q), np.minimum(o16.query(q), min(ceil, 65535)))
     gc.retain_part(1, 3)
     k1, c1 = g2.export_part(1, 3)
     assert gc.nb_distinct() == k1.size
