@@ -32,6 +32,10 @@
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
+#ifndef KMU_SCATTER_NT
+#define KMU_SCATTER_NT 0
+#endif
+
 struct kmu_counter {
     kmu_ctx *ctx = nullptr;
     kmu_count_params p{};
@@ -933,7 +937,11 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
         for (int u = 0; u < 8; u++) {
             const uint32_t p = p0 + (uint32_t) u * nthreads + tid;
             if (p < total) {
+#if KMU_SCATTER_NT // (A/B builds: non-temporal stores for the partition streams)
+                if (rel[u] < cap) __builtin_nontemporal_store(v[u], &out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])]);
+#else
                 if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
+#endif
                 else seg_spill(sg.ovf, v[u]);
             }
         }
@@ -1243,7 +1251,7 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds l = scatter_lds(smem, pl.bins);
     SegLds ls = seg_lds(smem, pl.bins);
-    const uint64_t sp = blockIdx.x / pl.chunks, sc = blockIdx.x % pl.chunks;
+    const uint64_t sp = blockIdx.x / pl.chunks;
     // segmented output: the bins' segments of a unit side by side, block blockIdx.x of pl.bins segments (level 2, one unit per
     // input partition: the region leaves in region order)
     SegOut sg{(uint64_t) blockIdx.x * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
@@ -1371,10 +1379,117 @@ __global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, 
 static constexpr int BUILD_THREADS = 512;
 static constexpr int BUILD_PRE = 6;
 
-// Q: the quotient slot format (see the top of the file): the region is R 8-byte words in LDS (32 KiB: four workgroups per CU),
-// a first sighting is one ds_cmpst_rtn_b64, a repeat one more ds_add_u64 (guarded: the count field stops at q_limit), and the
-// LDS image leaves as it is.  in_mode 2 / out_compact are wide-format states.
-template <int IT, bool Q>
+// The region build for the quotient slot format (see the top of the file): the region is R 8-byte words in LDS (32 KiB for
+// 4 096 slots: four workgroups of 512 threads per CU; 64 KiB for 8 192 slots: two workgroups of 1 024), a first sighting is
+// one ds_cmpst_rtn_b64, a repeat one more ds_add_u64 (guarded: the count field stops at q_limit), and the LDS image leaves as
+// it is.  in_mode: 0 = the table holds nothing yet, 1 = the slab is read first.  `flags`: A/B runs (KMU_BUILD_ABLATE).
+template <int IT, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_part_build_q(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
+                                                          uint32_t n_regions, CountTable t, int in_mode, int flags, uint32_t *err,
+                                                          uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt, int contig) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int BUILD_THREADS = THREADS; // (shadows the wide kernel's constant inside this function)
+    const int out_compact = flags;
+    const uint32_t R = t.rmask + 1;
+    uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
+    uint4 *lk4 = reinterpret_cast<uint4 *>(lk);
+    const uint32_t tid = threadIdx.x;
+    uint32_t full = 0;
+    const uint32_t r_begin = contig ? (uint32_t) ((uint64_t) blockIdx.x * n_regions / gridDim.x) : blockIdx.x;
+    const uint32_t r_end = contig ? (uint32_t) ((uint64_t) (blockIdx.x + 1) * n_regions / gridDim.x) : n_regions;
+    const uint32_t r_step = contig ? 1u : gridDim.x;
+    const int w = t.w;
+    const uint64_t cmask = q_cmask(w), add_limit = q_limit(w) - (THREADS > 512 ? (uint64_t) Q_MARGIN : 0ull);
+    for (uint32_t r = r_begin; r < r_end; r += r_step) {
+        const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
+        const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (uint64_t) leafcnt[r] : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
+        uint64_t pre_it[BUILD_PRE];
+#pragma unroll
+        for (int q = 0; q < BUILD_PRE; q++) {
+            const uint64_t i = i0 + (uint64_t) q * BUILD_THREADS + tid;
+            pre_it[q] = i < i1 ? items[i] : CKEY_EMPTY;
+        }
+        uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + (uint64_t) r * R);
+        if (in_mode == 1) {
+            for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = gk4[s];
+        } else {
+            for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+        lds_barrier();
+        // one probe of `item` at slot `off`: true = the item is in (claimed a free slot, or met its own key)
+        auto probe = [&](uint64_t hw, uint32_t off) -> bool {
+            const unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw | 1ull));
+            if (old == CKEY_EMPTY) return true;
+            if (!q_same(old, hw, w)) return false;
+            // fewer than BUILD_THREADS adds are in flight behind a count seen below the limit: no carry into the key bits
+            if ((old & cmask) < add_limit) atomicAdd((unsigned long long *) &lk[off], 1ull);
+            return true;
+        };
+        if (!(out_compact & 32)) {
+            // Every LANE walks through its prefetched items at its own pace: a lane whose item is in takes its next one in
+            // the next trip of the loop.  (Item by item, a wave repeats the probe loop until the unluckiest of its 64 lanes
+            // is through -- ~8 trips per item at a load factor of 0.47, ~30 per region -- while the lanes' SUMS of probes
+            // over their four items lie close together.  Thread-0 clocks of the item-by-item form, r03: 79 % of a region's
+            // time in this phase; KMU_BUILD_ABLATE=32 keeps that form for the A/B.)
+            static_assert(BUILD_PRE == 6, "the item queue of a lane is written out by hand");
+            // (two queues per lane with both probes in flight: 30.5 ms against 23.2 -- the loop is bound by the instructions
+            //  of a trip, not by the LDS round trip)
+            uint64_t q0 = pre_it[0], q1 = pre_it[1], q2 = pre_it[2], q3 = pre_it[3], q4 = pre_it[4], q5 = pre_it[5];
+            uint32_t left = BUILD_PRE + 1, guard = 0, off = 0;
+            uint64_t hw = 0;
+            bool have = false; // this lane is probing for an item
+            while (left) {
+                if (!have) { // the lane's next item, if any ("no k-mer" marks are skipped a trip at a time)
+                    const uint64_t item = q0;
+                    q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = CKEY_EMPTY;
+                    left--;
+                    if (left && item != CKEY_EMPTY) {
+                        const uint64_t h = IT == IT_HASH ? item : khash(item);
+                        hw = h << w;
+                        off = (uint32_t) (h >> t.shift) & t.rmask;
+                        guard = 0;
+                        have = true;
+                    }
+                }
+                if (have) {
+                    if (probe(hw, off)) have = false;
+                    else {
+                        off = (off + 1) & t.rmask;
+                        if (++guard >= R) { full = 1; have = false; }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < BUILD_PRE; q++)
+                if (pre_it[q] != CKEY_EMPTY) {
+                    const uint64_t h = IT == IT_HASH ? pre_it[q] : khash(pre_it[q]);
+                    uint32_t off = (uint32_t) (h >> t.shift) & t.rmask, n = 0;
+                    while (!probe(h << w, off)) {
+                        off = (off + 1) & t.rmask;
+                        if (++n >= R) { full = 1; break; }
+                    }
+                }
+        }
+        for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) { // (leaves beyond 3 072 items)
+            const uint64_t item = items[i];
+            if (item == CKEY_EMPTY) continue;
+            const uint64_t h = IT == IT_HASH ? item : khash(item);
+            uint32_t off = (uint32_t) (h >> t.shift) & t.rmask, n = 0;
+            while (!probe(h << w, off)) {
+                off = (off + 1) & t.rmask;
+                if (++n >= R) { full = 1; break; }
+            }
+        }
+        lds_barrier();
+        for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
+        lds_barrier();
+    }
+    if (full) atomicOr(err, DERR_TABLE_FULL);
+    return;
+}
+
+template <int IT>
 __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
                                                               uint32_t n_regions, CountTable t, int in_mode, int out_compact,
                                                               uint32_t *rcount, unsigned long long *stats, uint32_t *err,
@@ -1394,97 +1509,6 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
     const uint32_t tid = threadIdx.x, lane = (uint32_t) lane_id(), wave = tid >> 6;
     uint32_t full = 0;
     uint64_t st_d = 0, st_u = 0, st_o = 0;
-    if (Q) {
-        const int w = t.w;
-        const uint64_t cmask = q_cmask(w), limit = q_limit(w);
-        for (uint32_t r = r_begin; r < r_end; r += r_step) {
-            const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
-            const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (uint64_t) leafcnt[r] : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
-            uint64_t pre_it[BUILD_PRE];
-#pragma unroll
-            for (int q = 0; q < BUILD_PRE; q++) {
-                const uint64_t i = i0 + (uint64_t) q * BUILD_THREADS + tid;
-                pre_it[q] = i < i1 ? items[i] : CKEY_EMPTY;
-            }
-            uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + (uint64_t) r * R);
-            if (in_mode == 1) {
-                for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = gk4[s];
-            } else {
-                for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
-            }
-            lds_barrier();
-            // one probe of `item` at slot `off`: true = the item is in (claimed a free slot, or met its own key)
-            auto probe = [&](uint64_t hw, uint32_t off) -> bool {
-                const unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw | 1ull));
-                if (old == CKEY_EMPTY) return true;
-                if (!q_same(old, hw, w)) return false;
-                // fewer than BUILD_THREADS adds are in flight behind a count seen below the limit: no carry into the key bits
-                if ((old & cmask) < limit) atomicAdd((unsigned long long *) &lk[off], 1ull);
-                return true;
-            };
-            if (!(out_compact & 32)) {
-                // Every LANE walks through its prefetched items at its own pace: a lane whose item is in takes its next one in
-                // the next trip of the loop.  (Item by item, a wave repeats the probe loop until the unluckiest of its 64 lanes
-                // is through -- ~8 trips per item at a load factor of 0.47, ~30 per region -- while the lanes' SUMS of probes
-                // over their four items lie close together.  Thread-0 clocks of the item-by-item form, r03: 79 % of a region's
-                // time in this phase; KMU_BUILD_ABLATE=32 keeps that form for the A/B.)
-                static_assert(BUILD_PRE == 6, "the item queue of a lane is written out by hand");
-                // (two queues per lane with both probes in flight: 30.5 ms against 23.2 -- the loop is bound by the instructions
-                //  of a trip, not by the LDS round trip)
-                uint64_t q0 = pre_it[0], q1 = pre_it[1], q2 = pre_it[2], q3 = pre_it[3], q4 = pre_it[4], q5 = pre_it[5];
-                uint32_t left = BUILD_PRE + 1, guard = 0, off = 0;
-                uint64_t hw = 0;
-                bool have = false; // this lane is probing for an item
-                while (left) {
-                    if (!have) { // the lane's next item, if any ("no k-mer" marks are skipped a trip at a time)
-                        const uint64_t item = q0;
-                        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = CKEY_EMPTY;
-                        left--;
-                        if (left && item != CKEY_EMPTY) {
-                            const uint64_t h = IT == IT_HASH ? item : khash(item);
-                            hw = h << w;
-                            off = (uint32_t) (h >> t.shift) & t.rmask;
-                            guard = 0;
-                            have = true;
-                        }
-                    }
-                    if (have) {
-                        if (probe(hw, off)) have = false;
-                        else {
-                            off = (off + 1) & t.rmask;
-                            if (++guard >= R) { full = 1; have = false; }
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < BUILD_PRE; q++)
-                    if (pre_it[q] != CKEY_EMPTY) {
-                        const uint64_t h = IT == IT_HASH ? pre_it[q] : khash(pre_it[q]);
-                        uint32_t off = (uint32_t) (h >> t.shift) & t.rmask, n = 0;
-                        while (!probe(h << w, off)) {
-                            off = (off + 1) & t.rmask;
-                            if (++n >= R) { full = 1; break; }
-                        }
-                    }
-            }
-            for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) { // (leaves beyond 3 072 items)
-                const uint64_t item = items[i];
-                if (item == CKEY_EMPTY) continue;
-                const uint64_t h = IT == IT_HASH ? item : khash(item);
-                uint32_t off = (uint32_t) (h >> t.shift) & t.rmask, n = 0;
-                while (!probe(h << w, off)) {
-                    off = (off + 1) & t.rmask;
-                    if (++n >= R) { full = 1; break; }
-                }
-            }
-            lds_barrier();
-            for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
-            lds_barrier();
-        }
-        if (full) atomicOr(err, DERR_TABLE_FULL);
-        return;
-    }
     for (uint32_t r = r_begin; r < r_end; r += r_step) {
         const uint64_t gbase = (uint64_t) r * R;
         // the items of region r: [leafstart[r], leafstart[r + 1]), or a fixed-size range that may hold "no k-mer" marks (the
@@ -1642,11 +1666,12 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
     if (c->qw) to_compact = false; // (the compact state is a wide-format state)
-    int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * (c->qw ? 4 : 3) * 8);
+    const int per_cu = !c->qw ? 3 : c->rbits == 13 ? 2 : 4;
+    int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * per_cu * 8);
     int contig = 0; // A/B: KMU_BUILD_MAP=1: one contiguous range of regions per workgroup, as many workgroups as fit the chip; =2: eight times as many
     if (const char *e = getenv("KMU_BUILD_MAP")) {
         contig = atoi(e);
-        if (contig == 1) grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * (c->qw ? 4 : 3));
+        if (contig == 1) grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * per_cu);
     }
     if (to_compact) KMU_HIP(ctx, hipMemsetAsync(c->scalars + 4, 0, 24, ctx->stream));
     {
@@ -1655,11 +1680,19 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
         if (const char *e = getenv("KMU_BUILD_LDS_PAD")) pad = (size_t) std::max(0, atoi(e));
         int abl = 0; // A/B: 32 = the prefetched items of a thread one after the other (the lanes of a wave in lock step)
         if (const char *e = getenv("KMU_BUILD_ABLATE")) abl = atoi(e);
-        if (c->qw)
-            hipLaunchKernelGGL((k_part_build<IT, true>), dim3(grid), dim3(BUILD_THREADS), build_lds(c) + pad, ctx->stream, items, leaves, (uint32_t) n_regions,
-                               table_of(c), in_mode, abl, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt, contig);
+        if (c->qw && c->rbits == 13) {
+            const auto kq = k_part_build_q<IT, 1024>;
+            if (!(ctx->lds_attr_set & (IT == IT_HASH ? 4u : 8u))) {
+                KMU_HIP(ctx, hipFuncSetAttribute((const void *) kq, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                ctx->lds_attr_set |= IT == IT_HASH ? 4u : 8u;
+            }
+            hipLaunchKernelGGL(kq, dim3(grid), dim3(1024), build_lds(c) + pad, ctx->stream, items, leaves, (uint32_t) n_regions, table_of(c), in_mode, abl,
+                               d_err, leaf_stride, leafcnt, contig);
+        } else if (c->qw)
+            hipLaunchKernelGGL((k_part_build_q<IT, 512>), dim3(grid), dim3(512), build_lds(c) + pad, ctx->stream, items, leaves, (uint32_t) n_regions,
+                               table_of(c), in_mode, abl, d_err, leaf_stride, leafcnt, contig);
         else
-            hipLaunchKernelGGL((k_part_build<IT, false>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
+            hipLaunchKernelGGL((k_part_build<IT>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
                                table_of(c), in_mode, to_compact ? 1 : 0, c->rcount, (unsigned long long *) (c->scalars + 4), d_err, leaf_stride, leafcnt, contig);
     }
     KMU_HIP(ctx, hipGetLastError());
@@ -1729,6 +1762,10 @@ static bool part_plan_for(const kmu_counter *c, PartPlan *pl) {
     pl->region_bits = c->lg - c->rbits;
     if (pl->region_bits <= 11) { pl->b1 = pl->region_bits; pl->b2 = 0; }
     else { pl->b1 = (pl->region_bits + 1) / 2; pl->b2 = pl->region_bits - pl->b1; }
+    if (const char *e = getenv("KMU_COUNT_B1")) { // A/B: the split of the region bits between the two levels
+        const int b1 = atoi(e);
+        if (pl->b2 && b1 >= 1 && b1 <= 11 && pl->region_bits - b1 >= 1 && pl->region_bits - b1 <= 11) { pl->b1 = b1; pl->b2 = pl->region_bits - b1; }
+    }
     return pl->b1 <= 11 && pl->b2 <= 11;
 }
 
@@ -1916,10 +1953,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
     PartPlan pl;
     pl.owner_parts = 0;
     pl.owner_w32 = 0;
-    pl.region_bits = c->lg - c->rbits;
-    if (pl.region_bits <= 11) { pl.b1 = pl.region_bits; pl.b2 = 0; }
-    else { pl.b1 = (pl.region_bits + 1) / 2; pl.b2 = pl.region_bits - pl.b1; }
-    if (pl.b1 > 11 || pl.b2 > 11) return fail(ctx, KMU_E_UNSUPPORTED, "table too large for the two-level partitioned build");
+    if (!part_plan_for(c, &pl)) return fail(ctx, KMU_E_UNSUPPORTED, "table too large for the two-level partitioned build");
     bool dbg_split = false;
 #if KMU_DIAG // timing experiments of diagnostic builds only (scripts/dbg_split.sh): incomplete partition, no build
     if (const char *e = getenv("KMU_DBG_SPLIT")) {
@@ -2445,6 +2479,12 @@ int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out)
     }
     c->nslots = 1ull << c->lg;
     c->rbits = std::min(c->lg, REGION_BITS_MAX);
+    // quotient tables whose count field can spare a bit take regions of 8 192 slots (64 KiB of LDS, 1 024 threads): half as
+    // many leaves, so that both partition levels of the bench's table fan out 1 024 ways (KMU_COUNT_RBITS=12 / 13: A/B)
+    if (quot && c->lg - 13 >= q_need - 12 + 1) { // (one bit more: 1 024 threads may have 1 023 plain adds in flight, see k_part_build_q)
+        const char *e = getenv("KMU_COUNT_RBITS");
+        if (e && atoi(e) == 13) c->rbits = 13;
+    }
     c->qw = quot ? c->lg - c->rbits : 0;
     hipError_t e1 = hipMalloc((void **) &c->keys, c->nslots * 8);
     hipError_t e2 = e1 == hipSuccess && !c->qw ? hipMalloc((void **) &c->counts, c->nslots * 4) : e1;

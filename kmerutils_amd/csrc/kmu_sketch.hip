@@ -1150,7 +1150,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
 // Two shapes: <512 threads, 2^16-bit bitmaps, 2 048 collected keys> for reads of up to 10 240 k-mers, two workgroups per CU;
 // <1024, 2^17, 4 096> for up to 20 480 k-mers, one workgroup per CU, run on the list the first shape leaves behind.
 static constexpr int UQ_KREG = 20;
-// TAB (round 3, the default; KMU_PMH_UQTAB=0 for the A/B): the keys of the collision groups are not collected and counting-
+// TAB (round 3; opt-in with KMU_PMH_UQTAB=1, measured slower: 18.8 against 13.0 ms per launch of the first shape): the keys of the collision groups are not collected and counting-
 // sorted (rank / scan / place / walk: five barriers) but meet in an open-addressing table of 2 x UQ_COLL slots in LDS
 // (ds_cmpst_rtn_b64 claims a slot, ds_add counts: the table of k_multiset_short, workgroup-wide) straight from the registers;
 // after ONE barrier the occupied slots leave as (key, weight) pairs and the table is free again: four barriers per read
@@ -1213,6 +1213,12 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     SeqView sv;
     sv.base = a.bases; sv.packed = 0; sv.total = total; sv.begin = 0; sv.len = 0;
     if (r < a.n_queue) { sv.begin = uniform_u64(a.offsets[rs]); sv.len = uniform_u64(a.offsets[rs + 1]) - sv.begin; }
+    // diagnostic builds (KMU_PMH_ABLATE=256): thread-0 clocks per phase -> a.queue words 8..17 (u64)
+    const bool ph_on = KMU_DIAG && ABL(256u) && tid == 0;
+    uint64_t ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = ph_on ? __builtin_readcyclecounter() : 0;
+    auto phase = [&](int i) {
+        if (ph_on) { const uint64_t n = __builtin_readcyclecounter(); ph_acc[i] += n - ph_t; ph_t = n; }
+    };
     uint32_t pf_w[3] = {0, 0, 0}, pf_bad = 0; // this thread's words of the current read, fetched a read ahead
     bool pf_valid = false;                    // uniform
     auto n_words = [&](const SeqView &v) -> uint32_t { // staged words of a read of 1 .. UQ_KEYS k-mers (its k-mers' windows + 1)
@@ -1257,20 +1263,27 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             za[tid] = make_uint4(0u, 0u, 0u, 0u); // 2 048 words = 512 x 16 bytes each
             zb[tid] = make_uint4(0u, 0u, 0u, 0u);
         }
+        phase(0); // queue, staging, wipe
         lds_barrier();
+        phase(1);
         const uint32_t r_next = uniform_u32(misc[5]);
         const bool has_next = r_next < a.n_queue;
         // the next read's header: requested now, looked at after the key phase
         const uint32_t rs_next = has_next ? seq_of(r_next) : 0u;
         const uint64_t n_o0 = has_next ? a.offsets[rs_next] : 0ull, n_o1 = has_next ? a.offsets[rs_next + 1] : 0ull;
         uint64_t rk[UQ_KREG];
-        uint32_t rbi[UQ_KREG];
+        // the bitmap index of a key is a function of the key: computed again where the B bit is looked at instead of kept in
+        // twenty registers (the kernel sits at its 128: 33 spilled vector registers with the indices kept)
+        auto bm_index = [&](uint64_t key) -> uint32_t {
+            const uint32_t h = mix32(key);
+            return ((h ^ (h >> 13)) * 0x85EBCA6Bu) >> (32 - UQ_BM_BITS);
+        };
         bool over = false; // uniform: too many keys in collision groups
         if (mine) {
             // ---- keys: extract, closure, bitmaps; four positions' LDS round trips in flight at a time ----
 #pragma unroll
             for (int q0 = 0; q0 < UQ_KREG; q0 += 4) {
-                uint32_t bit[4];
+                uint32_t bit[4], rbi[UQ_KREG];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int q = q0 + u;
@@ -1283,9 +1296,8 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                         const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
                         const uint64_t val = v >> (64 - 2 * k);
                         const uint64_t key = apply_fhash(cfg, val, revcomp_val(val, k));
-                        const uint32_t h = mix32(key);
                         rk[q] = key;
-                        rbi[q] = ((h ^ (h >> 13)) * 0x85EBCA6Bu) >> (32 - UQ_BM_BITS);
+                        rbi[q] = bm_index(key);
                     }
                 }
 #pragma unroll
@@ -1301,7 +1313,9 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                 for (int u = 0; u < 4; u++)
                     if (bit[u]) atomicOr(&bmB[rbi[q0 + u] >> 5], bit[u]);
             }
+            phase(2); // keys, closure, bitmaps
             lds_barrier();
+            phase(3);
         }
         // ---- the next read's words are requested now and land while this read is sorted out and handed over ----
         SeqView nv = sv;
@@ -1323,17 +1337,21 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             }
         }
         const uint64_t lb = sv.begin - off_first; // list entries of read r start here
+        phase(4); // the next read's header and words requested
         if (mine) {
             // ---- sort out: B bit clear = occurs once = list entry (key, 1) from the register; else collect ----
+            // (r03: all twenty B bits read at once and ONE atomic pair per wave instead of five -- 15.9 against 13.0 ms per launch:
+            //  the kernel sits at its 128 registers, twenty more live values spill)
 #pragma unroll
             for (int q0 = 0; q0 < UQ_KREG; q0 += 4) {
                 bool uq[4], co[4];
                 uint64_t um[4], cm[4];
-                uint32_t ut = 0, ct = 0;
+                uint32_t ut = 0, ct = 0, rbi[UQ_KREG];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int q = q0 + u;
-                    const bool have = rbi[q] != 0xFFFFFFFFu;
+                    const bool have = (uint32_t) q * UQ_THREADS + tid < nk;
+                    rbi[q] = bm_index(rk[q]);
                     co[u] = have && (bmB[rbi[q] >> 5] & (1u << (rbi[q] & 31u))) != 0u;
                     uq[u] = have && !co[u];
                 }
@@ -1381,7 +1399,9 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                     cb += (uint32_t) __popcll(cm[u]);
                 }
             }
+            phase(5); // sort out: unique keys to the lists, the others collected
             lds_barrier();
+            phase(6);
             const uint32_t n_u = uniform_u32(misc[0]), n_c = uniform_u32(misc[1]);
             over = n_c > UQ_COLL;
             if (TAB) {
@@ -1479,6 +1499,7 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             }
             if (!TAB && tid == 0 && !over) { a.lst_n[rs] = n_u + n_c; a.lst_nu[rs] = n_u; }
         }
+        phase(7); // collision groups
         if (TAB) lds_barrier(); // (the pairs of the table are out and counted)
         if (tid == 0) {
             if (nk == 0) a.lst_n[rs] = 0u; // no k-mer: k_pmh_points writes the row of an empty multiset
@@ -1504,7 +1525,11 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         rs = uniform_u32(rs_next);
         sv = nv;
         if (!TAB) lds_barrier();
+        phase(8); // end of the read's turn
     }
+    if (ph_on)
+        for (int i = 0; i < 10; i++)
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.queue) + 8 + i, (unsigned long long) ph_acc[i]);
 }
 
 // ---- reads of at most 256 k-mers (short-read sequencers): the multiset by ONE WAVE per read ---------------------------------
@@ -2496,7 +2521,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     const char *uq_env = getenv("KMU_PMH_UQ"); // 0: every read through the counting-sort kernel (A/B)
     const bool uq = split && plain && !(uq_env && atoi(uq_env) == 0);
     const char *uqt_env = getenv("KMU_PMH_UQTAB"); // 0: the collision groups through the counting sort (A/B)
-    const bool uq_tab = !(uqt_env && atoi(uqt_env) == 0);
+    const bool uq_tab = uqt_env && atoi(uqt_env) != 0; // (measured r03: 18.8 against 13.0 ms per launch -- opt-in)
     bool main_launched = false, short_route = false;
     const char *sh_env = getenv("KMU_PMH_SHORT"); // 0: short reads through k_multiset_uq like the others (A/B)
     if (uq && len_stats && len_stats[0] < (uint64_t) SHORT_KEYS + (uint64_t) p->kmer_size && !(sh_env && atoi(sh_env) == 0)) {
@@ -2523,6 +2548,16 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         uint32_t n_long = 0;
         KMU_HIP(ctx, hipMemcpyAsync(&n_long, a.queue + 56, 4, hipMemcpyDeviceToHost, ctx->stream));
         KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ABL(256u)) { // diagnostics: thread-0 clocks of the first shape, share per phase
+            unsigned long long ph[10];
+            KMU_HIP(ctx, hipMemcpy(ph, (const uint64_t *) a.queue + 8, sizeof ph, hipMemcpyDeviceToHost));
+            static const char *nm[9] = {"stage+wipe", "B1", "keys+bitmaps", "B2", "next fetch", "sort out", "B3", "collisions", "end"};
+            double tot = 0;
+            for (int i = 0; i < 9; i++) tot += (double) ph[i];
+            fprintf(stderr, "[kmu uq phases]");
+            for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double) ph[i] / (tot > 0 ? tot : 1));
+            fprintf(stderr, "  (%.3g clocks)\n", tot);
+        }
         const char *uq2_env = getenv("KMU_PMH_UQ2"); // 0: no second shape (A/B)
         if (n_long && !(uq2_env && atoi(uq2_env) == 0)) { // the second shape: reads of up to 20 480 k-mers, from the first one's list
             const auto kb = uq_tab ? k_multiset_uq<1024, 17, 4096, 4, true> : k_multiset_uq<1024, 17, 4096, 4, false>;

@@ -1134,6 +1134,7 @@ def test_count_compact_state(ctx, oracle, monkeypatch):
     """KMU_COUNT_COMPACT=1: the partitioned build leaves every region as its (key, count) pairs + a per-region length; the
     statistics come from the build, a second batch re-inserts the pairs, and whatever probes slots expands the table first"""
     monkeypatch.setenv("KMU_COUNT_COMPACT", "1")
+    monkeypatch.setenv("KMU_COUNT_FMT", "wide")  # (the compact state belongs to the 12-byte slot format; this table would take the 8-byte one)
     monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
     bases, off = synth.ont_reads(500, 300_000, 0xC3)
     half = 250
