@@ -333,7 +333,7 @@ def main():
 SKETCH_UNIT = ("k_multiset_uq", "k_multiset_short", "k_sketch_smallk", "k_sketch_pmh3a", "k_sketch_pmh3a_redo", "k_pmh_points",
                "k_pmh_points_short")
 COUNT_UNIT = ("k_part_hist1", "k_part_scan1", "k_part_scatter1", "k_arr_hist", "k_arr_scan", "k_arr_scatter", "k_part_build",
-              "k_count_add_spill", "k_count_add_flat")
+              "k_part_build_q", "k_count_add_spill", "k_count_add_flat")
 
 
 def kernel_units(stats, steps, total_bases, nk, n_reads, m, sigw, table_bytes):
@@ -352,7 +352,8 @@ def kernel_units(stats, steps, total_bases, nk, n_reads, m, sigw, table_bytes):
         "k_part_scatter1": total_bases + nk * 8,
         "k_arr_hist": nk * 8,
         "k_arr_scatter": nk * 16,
-        "k_part_build": nk * 8 + table_bytes,                  # leaves in, the table image out
+        "k_part_build": nk * 8 + table_bytes,                  # leaves in, the table image out (12 bytes per slot)
+        "k_part_build_q": nk * 8 + table_bytes,                # ... (8 bytes per slot)
     }
     single = {"k_sketch_super": sketch_alg, "k_oph_reads": sketch_alg, "k_nthash": total_bases + nk * 8}
     kern = {}

@@ -1675,7 +1675,7 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     }
     if (to_compact) KMU_HIP(ctx, hipMemsetAsync(c->scalars + 4, 0, 24, ctx->stream));
     {
-        KernelTimer tm(ctx, items ? "k_part_build" : "k_part_expand");
+        KernelTimer tm(ctx, !items ? "k_part_expand" : c->qw ? "k_part_build_q" : "k_part_build"); // (the kernels' own names)
         size_t pad = 0; // A/B runs: extra dynamic LDS per workgroup (fewer workgroups per CU)
         if (const char *e = getenv("KMU_BUILD_LDS_PAD")) pad = (size_t) std::max(0, atoi(e));
         int abl = 0; // A/B: 32 = the prefetched items of a thread one after the other (the lanes of a wave in lock step)

@@ -3020,14 +3020,15 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     uint64_t chunk_bytes = 512ull << 20;
     if (const char *e = getenv("KMU_PIPE_CHUNK_MB")) chunk_bytes = (uint64_t) std::max(1, atoi(e)) << 20;
     std::vector<uint32_t> cut(1, 0u); // chunk c = reads [cut[c], cut[c + 1])
-    // Chunk sizes: the first one is an eighth of the others (the kernels start after 1 ms of upload instead of 9) and the last
-    // ones taper off the same way (1/2, 1/4, 1/8): the sketch kernels and the count's level 1 keep pace with the upload (16.5
-    // against 18 ps per base), so what is left to do when the last byte has arrived is the last chunk's sketch + level 1 --
-    // made small -- and then level 2 and the region build, which need all of level 1.  KMU_PIPE_TAPER=0: no taper (A/B).
+    // Chunk sizes: the first one is an eighth of the others (the kernels start after 1 ms of upload instead of 9).  The upload
+    // (4.38 GB at ~55 GB/s = 80 ms) is what the first phase is bound by -- a chunk's sketch + level 1 take 8 ms, its upload 9.3 --
+    // and what is left when the last byte has arrived is the last chunk's sketch + level 1, then level 2 and the region build,
+    // which need all of level 1.  Tapering the last chunks (1/2, 1/4, 1/8: KMU_PIPE_TAPER=1) shortens that tail by a chunk's
+    // sketch but pays for it in small launches: 149.1 / 149.2 ms against 146.2 / 144.0 without, same box (r03).  Off.
     std::vector<uint64_t> plan; // chunk sizes, in order (a chunk ends at the first read boundary at or behind its target)
     {
         const char *te = getenv("KMU_PIPE_TAPER");
-        const bool taper = !(te && atoi(te) == 0) && total > 3 * chunk_bytes;
+        const bool taper = te && atoi(te) != 0 && total > 3 * chunk_bytes;
         const uint64_t first = std::min<uint64_t>(std::max<uint64_t>(chunk_bytes / 8, 1), total);
         uint64_t tail_sum = 0;
         std::vector<uint64_t> tail;

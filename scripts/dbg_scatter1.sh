@@ -15,7 +15,7 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 k = d["kernels"]
 addr = {m.group(1): m.group(2) for m in re.finditer(r"kmu dev_buf (\S+)\s+(0x[0-9a-f]+)", open(sys.argv[2]).read())}
 print("scatter1 %.2f  arr_scatter %.2f  build %.2f | partA %s partB %s" % (k["k_part_scatter1"]["avg_ms"], k["k_arr_scatter"]["avg_ms"],
-      k["k_part_build"]["avg_ms"], addr.get("cnt.partA"), addr.get("cnt.partB")))
+      (k.get("k_part_build_q") or k["k_part_build"])["avg_ms"], addr.get("cnt.partA"), addr.get("cnt.partB")))
 PY
 done
 # counter passes (one group per process; the same command): durations come from the kernel trace of the same run
@@ -33,7 +33,7 @@ for r in csv.DictReader(open(kt[0])) if kt else []:
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); ms = collections.defaultdict(float); seen = set()
 for r in csv.DictReader(open(cc[0])):
     k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kmu::", "").strip()
-    if k not in ("k_part_scatter1", "k_arr_scatter", "k_part_build"): continue
+    if k not in ("k_part_scatter1", "k_arr_scatter", "k_part_build", "k_part_build_q"): continue
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if (k, r["Dispatch_Id"]) not in seen:
         seen.add((k, r["Dispatch_Id"])); n[k] += 1; ms[k] += dur.get(r["Dispatch_Id"], 0.0)

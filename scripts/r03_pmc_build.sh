@@ -16,7 +16,7 @@ for r in csv.DictReader(open(kt[0])) if kt else []:
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); ms = collections.defaultdict(float); seen = set()
 for r in csv.DictReader(open(cc[0])):
     k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kmu::", "").strip()
-    if k not in ("k_part_build",): continue
+    if k not in ("k_part_build", "k_part_build_q"): continue
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if (k, r["Dispatch_Id"]) not in seen:
         seen.add((k, r["Dispatch_Id"])); n[k] += 1; ms[k] += dur.get(r["Dispatch_Id"], 0.0)
