@@ -1666,7 +1666,7 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
     if (c->qw) to_compact = false; // (the compact state is a wide-format state)
-    const int per_cu = !c->qw ? 3 : c->rbits == 13 ? 2 : 4;
+    const int per_cu = !c->qw ? 3 : (c->rbits == 13 || getenv("KMU_BUILD_T1024")) ? 2 : 4;
     int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * per_cu * 8);
     int contig = 0; // A/B: KMU_BUILD_MAP=1: one contiguous range of regions per workgroup, as many workgroups as fit the chip; =2: eight times as many
     if (const char *e = getenv("KMU_BUILD_MAP")) {
@@ -1680,7 +1680,8 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
         if (const char *e = getenv("KMU_BUILD_LDS_PAD")) pad = (size_t) std::max(0, atoi(e));
         int abl = 0; // A/B: 32 = the prefetched items of a thread one after the other (the lanes of a wave in lock step)
         if (const char *e = getenv("KMU_BUILD_ABLATE")) abl = atoi(e);
-        if (c->qw && c->rbits == 13) {
+        const char *t1k = getenv("KMU_BUILD_T1024"); // A/B: 1 024 threads per region of 4 096 slots as well
+        if (c->qw && (c->rbits == 13 || (t1k && atoi(t1k) != 0))) {
             const auto kq = k_part_build_q<IT, 1024>;
             if (!(ctx->lds_attr_set & (IT == IT_HASH ? 4u : 8u))) {
                 KMU_HIP(ctx, hipFuncSetAttribute((const void *) kq, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
