@@ -1661,12 +1661,12 @@ static int grid_for(const kmu_ctx *ctx, uint64_t n, int per_block) {
 static size_t build_lds(const kmu_counter *c) { return c->qw ? (size_t) 8 << c->rbits : ((size_t) 12 << c->rbits) + 64 * 8 + 65 * 4 + 16; }
 template <int IT>
 static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, bool to_compact, uint32_t *d_err,
-                        uint64_t leaf_stride = 0, const uint32_t *leafcnt = nullptr) {
+                        uint64_t leaf_stride = 0, const uint32_t *leafcnt = nullptr, uint64_t n_items_hint = 0) {
     kmu_ctx *ctx = c->ctx;
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
     if (c->qw) to_compact = false; // (the compact state is a wide-format state)
-    const int per_cu = !c->qw ? 3 : (c->rbits == 13 || getenv("KMU_BUILD_T1024")) ? 2 : 4;
+    const int per_cu = !c->qw ? 3 : c->rbits == 13 ? 2 : 4;
     int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * per_cu * 8);
     int contig = 0; // A/B: KMU_BUILD_MAP=1: one contiguous range of regions per workgroup, as many workgroups as fit the chip; =2: eight times as many
     if (const char *e = getenv("KMU_BUILD_MAP")) {
@@ -1680,8 +1680,7 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
         if (const char *e = getenv("KMU_BUILD_LDS_PAD")) pad = (size_t) std::max(0, atoi(e));
         int abl = 0; // A/B: 32 = the prefetched items of a thread one after the other (the lanes of a wave in lock step)
         if (const char *e = getenv("KMU_BUILD_ABLATE")) abl = atoi(e);
-        const char *t1k = getenv("KMU_BUILD_T1024"); // A/B: 1 024 threads per region of 4 096 slots as well
-        if (c->qw && (c->rbits == 13 || (t1k && atoi(t1k) != 0))) {
+        if (c->qw && c->rbits == 13) {
             const auto kq = k_part_build_q<IT, 1024>;
             if (!(ctx->lds_attr_set & (IT == IT_HASH ? 4u : 8u))) {
                 KMU_HIP(ctx, hipFuncSetAttribute((const void *) kq, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -2043,7 +2042,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         items = (const uint64_t *) B;
         leaves = (const uint64_t *) leafstart;
     }
-    if (!dbg_split) KMU_TRY(launch_build<IT_HASH>(c, items, leaves, want_compact(c), d_err));
+    if (!dbg_split) KMU_TRY(launch_build<IT_HASH>(c, items, leaves, want_compact(c), d_err, 0, nullptr, total_bases));
     return KMU_OK;
 }
 
@@ -2184,8 +2183,8 @@ static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64
     // (a table of a single region is not partitioned at all: the items stay keys)
     const bool hashed = region_bits > 0;
     KMU_TRY(partition_u64(ctx, d_kmers, n, region_bits, &items, &bounds, hashed));
-    if (hashed) return launch_build<IT_HASH>(c, items, bounds, want_compact(c), d_err);
-    return launch_build<IT_KEY>(c, items, bounds, want_compact(c), d_err);
+    if (hashed) return launch_build<IT_HASH>(c, items, bounds, want_compact(c), d_err, 0, nullptr, n);
+    return launch_build<IT_KEY>(c, items, bounds, want_compact(c), d_err, 0, nullptr, n);
 }
 
 // canonical k-mers of the reads, grouped by owner rank (one level of the partition machinery with digit = owner).
