@@ -1150,6 +1150,11 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
 // Two shapes: <512 threads, 2^16-bit bitmaps, 2 048 collected keys> for reads of up to 10 240 k-mers, two workgroups per CU;
 // <1024, 2^17, 4 096> for up to 20 480 k-mers, one workgroup per CU, run on the list the first shape leaves behind.
 static constexpr int UQ_KREG = 20;
+// every vector-memory request of this wave has completed (the chunks of global_load_lds have landed in LDS)
+__device__ __forceinline__ void vm_wait_lds_loads() {
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0); expcnt / lgkmcnt untouched
+    asm volatile("" ::: "memory");
+}
 // TAB (round 3; opt-in with KMU_PMH_UQTAB=1, measured slower: 18.8 against 13.0 ms per launch of the first shape): the keys of the collision groups are not collected and counting-
 // sorted (rank / scan / place / walk: five barriers) but meet in an open-addressing table of 2 x UQ_COLL slots in LDS
 // (ds_cmpst_rtn_b64 claims a slot, ds_add counts: the table of k_multiset_short, workgroup-wide) straight from the registers;
@@ -1162,8 +1167,10 @@ struct UqShape {
     static constexpr uint32_t BUCKETS = 2u * UQ_THREADS; // of the collision groups' counting sort: two per thread
     static constexpr uint32_t TILE = (KEYS + 32 + 15) / 16 + 3; // staged code words of a read
     static constexpr uint32_t TABS = 2u * UQ_COLL;         // slots of the collision table (TAB)
-    static constexpr size_t LDS = TAB ? (size_t) BM_WORDS * 8 + (size_t) TABS * 12 + ((size_t) TILE + 16) * 4 + 64
-                                      : (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64;
+    static constexpr uint32_t RAW_WAVES = (TILE + 63) / 64; // landing area of the next read's 16-byte chunks: 1 KiB per wave instruction
+    static constexpr size_t LDS = (TAB ? (size_t) BM_WORDS * 8 + (size_t) TABS * 12 + ((size_t) TILE + 16) * 4 + 64
+                                       : (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64) +
+                                  (size_t) RAW_WAVES * 1024 + 16;
 };
 
 template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, int MINW, bool TAB = false>
@@ -1188,6 +1195,9 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     // [0] unique entries, [1] keys in collision groups, [2] (TAB) occurrences of the all-ones key among them, [3] (TAB) table
     // overflow, [4] first read, [5] the read after the current one, [6] (TAB) pairs that left the table
     uint32_t *misc = TAB ? words + UQ_TILE : wtot + UQ_THREADS / 64;
+    // the next read's chunks land here straight from HBM (global_load_lds: no register is held while they are in flight):
+    // chunk t of the read at byte 16 t, i.e. lane l of the wave instruction that fetches chunks 64 j .. 64 j + 63 at 1024 j + 16 l
+    uint8_t *rawp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(misc + 16) + 15) & ~(uintptr_t) 15);
     const KmerCfg cfg = a.cfg;
     const int k = cfg.k, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (TAB) {
@@ -1198,10 +1208,20 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     }
     uint32_t q_next = 0, q_end = 0, q_pend = 0;
     bool q_pending = false;
+    auto take = [&]() -> uint32_t { // thread 0: the next queue entry (the queue is asked a read before the chunk runs out)
+        if (q_next == q_end) {
+            if (!q_pending) q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
+            q_next = q_pend;
+            q_end = q_pend + QCHUNK;
+            q_pending = false;
+        }
+        const uint32_t v = q_next++;
+        if (q_next == q_end && !q_pending) { q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK); q_pending = true; }
+        return v;
+    };
     if (tid == 0) {
-        q_next = atomicAdd(a.queue, (uint32_t) QCHUNK);
-        q_end = q_next + QCHUNK;
-        misc[4] = q_next++;
+        misc[4] = take();
+        misc[5] = take(); // the header of a read is fetched TWO reads ahead: its words can then be requested a whole read ahead
     }
     __syncthreads();
     const uint64_t off_first = uniform_u64(a.offsets[0]);
@@ -1213,6 +1233,21 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     SeqView sv;
     sv.base = a.bases; sv.packed = 0; sv.total = total; sv.begin = 0; sv.len = 0;
     if (r < a.n_queue) { sv.begin = uniform_u64(a.offsets[rs]); sv.len = uniform_u64(a.offsets[rs + 1]) - sv.begin; }
+    auto fits = [&](const SeqView &v) -> bool { // a read this shape takes
+        const uint32_t Lv = v.len >= 0x80000000ull ? 0xFFFFFFFFu : (uint32_t) v.len;
+        return Lv >= (uint32_t) k && Lv - (uint32_t) k + 1u <= UQ_KEYS;
+    };
+    // the read after the current one: header known from the start of the current read's turn
+    uint32_t r_next = uniform_u32(misc[5]);
+    uint32_t rs_next = r_next < a.n_queue ? uniform_u32(seq_of(r_next)) : 0u;
+    SeqView nv = sv;
+    bool nv_mine = false;
+    if (r_next < a.n_queue) {
+        nv.begin = uniform_u64(a.offsets[rs_next]);
+        nv.len = uniform_u64(a.offsets[rs_next + 1]) - nv.begin;
+        nv_mine = fits(nv);
+    }
+    __syncthreads(); // (misc[5] is rewritten at the top of the first turn)
     // diagnostic builds (KMU_PMH_ABLATE=256): thread-0 clocks per phase -> a.queue words 8..17 (u64)
     const bool ph_on = KMU_DIAG && ABL(256u) && tid == 0;
     uint64_t ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = ph_on ? __builtin_readcyclecounter() : 0;
@@ -1226,15 +1261,8 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         return (uint32_t) ((Lv - 1 + ld) >> 4) + 2;
     };
     while (r < a.n_queue) {
-        if (tid == 0) { // the read after this one (the queue is asked a read before the chunk runs out)
-            if (q_next == q_end) {
-                if (!q_pending) q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK);
-                q_next = q_pend;
-                q_end = q_pend + QCHUNK;
-                q_pending = false;
-            }
-            misc[5] = q_next++;
-            if (q_next == q_end && !q_pending) { q_pend = atomicAdd(a.queue, (uint32_t) QCHUNK); q_pending = true; }
+        if (tid == 0) {
+            misc[5] = take(); // the read after the next one
             misc[0] = 0;
             misc[1] = 0;
         }
@@ -1266,11 +1294,24 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         phase(0); // queue, staging, wipe
         lds_barrier();
         phase(1);
-        const uint32_t r_next = uniform_u32(misc[5]);
-        const bool has_next = r_next < a.n_queue;
-        // the next read's header: requested now, looked at after the key phase
-        const uint32_t rs_next = has_next ? seq_of(r_next) : 0u;
-        const uint64_t n_o0 = has_next ? a.offsets[rs_next] : 0ull, n_o1 = has_next ? a.offsets[rs_next + 1] : 0ull;
+        const uint32_t r_nn = uniform_u32(misc[5]);
+        const bool has_nn = r_nn < a.n_queue;
+        // the header of the read after next: requested now, looked at at the end of this turn
+        const uint32_t rs_nn = has_nn ? seq_of(r_nn) : 0u;
+        const uint64_t nn_o0 = has_nn ? a.offsets[rs_nn] : 0ull, nn_o1 = has_nn ? a.offsets[rs_nn + 1] : 0ull;
+        // the next read's chunks: requested now, they land in LDS under the key phase and become code words behind it
+        // (round 2 requested them behind the key phase and converted them on the spot: 12 % of a read's turn in that wait)
+        uint32_t nwn = 0, wfn = 0;
+        if (nv_mine) {
+            nwn = n_words(nv);
+            wfn = seq_lead(nv) >> 4;
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const uint32_t tw = (uint32_t) tid + (uint32_t) u * UQ_THREADS;
+                if (tw < nwn && chunk_is_plain(nv, (uint64_t) wfn + tw))
+                    chunk16_to_lds(nv.base + (nv.begin & ~15ull) + 16 * ((uint64_t) wfn + tw), rawp + (size_t) (tw >> 6) * 1024);
+            }
+        }
         uint64_t rk[UQ_KREG];
         // the bitmap index of a key is a function of the key: computed again where the B bit is looked at instead of kept in
         // twenty registers (the kernel sits at its 128: 33 spilled vector registers with the indices kept)
@@ -1317,23 +1358,20 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             lds_barrier();
             phase(3);
         }
-        // ---- the next read's words are requested now and land while this read is sorted out and handed over ----
-        SeqView nv = sv;
-        bool nv_mine = false;
-        if (has_next) {
-            nv.begin = uniform_u64(n_o0);
-            nv.len = uniform_u64(n_o1) - nv.begin;
-            const uint32_t Ln = nv.len >= 0x80000000ull ? 0xFFFFFFFFu : (uint32_t) nv.len;
-            nv_mine = Ln >= (uint32_t) k && Ln - (uint32_t) k + 1u <= UQ_KEYS;
-            if (nv_mine) {
-                const uint32_t nwn = n_words(nv), wf = seq_lead(nv) >> 4;
-                pf_bad = 0;
+        // ---- the next read's chunks have landed: code words into this thread's registers ----
+        if (nv_mine) {
+            vm_wait_lds_loads();
+            pf_bad = 0;
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    uint32_t b = 0;
-                    pf_w[u] = (uint32_t) tid + (uint32_t) u * UQ_THREADS < nwn ? load_code_word(nv, (uint64_t) wf + tid + (uint32_t) u * UQ_THREADS, b) : 0u;
-                    pf_bad |= b;
-                }
+            for (int u = 0; u < 3; u++) {
+                const uint32_t tw = (uint32_t) tid + (uint32_t) u * UQ_THREADS;
+                uint32_t b = 0;
+                pf_w[u] = 0u;
+                if (tw < nwn)
+                    pf_w[u] = chunk_is_plain(nv, (uint64_t) wfn + tw)
+                                  ? code_word_from_chunk(nv, (uint64_t) wfn + tw, *reinterpret_cast<const u32x4 *>(rawp + (size_t) tw * 16), b)
+                                  : load_code_word(nv, (uint64_t) wfn + tw, b);
+                pf_bad |= b;
             }
         }
         const uint64_t lb = sv.begin - off_first; // list entries of read r start here
@@ -1522,8 +1560,16 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         if (bad) atomicOr(a.err, DERR_NON_ACGT);
         pf_valid = nv_mine;
         r = r_next;
-        rs = uniform_u32(rs_next);
+        rs = rs_next;
         sv = nv;
+        r_next = r_nn;
+        rs_next = uniform_u32(rs_nn);
+        nv_mine = false;
+        if (has_nn) {
+            nv.begin = uniform_u64(nn_o0);
+            nv.len = uniform_u64(nn_o1) - nv.begin;
+            nv_mine = fits(nv);
+        }
         if (!TAB) lds_barrier();
         phase(8); // end of the read's turn
     }
