@@ -35,6 +35,9 @@
 #ifndef KMU_SCATTER_NT
 #define KMU_SCATTER_NT 0
 #endif
+#ifndef KMU_SCATTER_NTLOAD // A/B builds: 1 = the level-2 input, 2 = the level-1 bases as well, with non-temporal loads
+#define KMU_SCATTER_NTLOAD 0
+#endif
 
 struct kmu_counter {
     kmu_ctx *ctx = nullptr;
@@ -1002,8 +1005,16 @@ __device__ __forceinline__ void flat_step_fetch(const uint8_t *bases, uint64_t t
     if (total < 16) return; // (wave-uniform; flat_step_words then reads the ragged chunk itself)
     const uint64_t lastc = (total - 16) & ~15ull;
     const uint64_t a0 = (st * 64 + (uint64_t) lane_id()) * 16, ax = (st * 64 + 64 + (uint64_t) (lane_id() & 1)) * 16;
+#if KMU_SCATTER_NTLOAD >= 2
+    typedef uint32_t u32x4nt __attribute__((ext_vector_type(4)));
+    const u32x4nt c0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4nt *>(bases + (a0 < lastc ? a0 : lastc)));
+    const u32x4nt cx = __builtin_nontemporal_load(reinterpret_cast<const u32x4nt *>(bases + (ax < lastc ? ax : lastc)));
+    r.c0 = make_uint4(c0.x, c0.y, c0.z, c0.w);
+    r.cx = make_uint4(cx.x, cx.y, cx.z, cx.w);
+#else
     r.c0 = *reinterpret_cast<const uint4 *>(bases + (a0 < lastc ? a0 : lastc));
     r.cx = *reinterpret_cast<const uint4 *>(bases + (ax < lastc ? ax : lastc));
+#endif
 }
 __device__ __forceinline__ void flat_step_words(const uint8_t *bases, uint64_t total, uint64_t st, bool active, const FlatRaw &r,
                                                 uint32_t &w0, uint32_t &ex, uint32_t &bad_acc) {
@@ -1293,7 +1304,11 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
 #pragma unroll
             for (int j2 = 0; j2 < 8; j2++) {
                 const uint32_t uu = u < pl.seg_units ? u : pl.seg_units - 1; // (beyond the partition: anything readable)
+#if KMU_SCATTER_NTLOAD >= 1
+                const u64x2 q = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + (uint64_t) uu * seg_stride + seg_base + o));
+#else
                 const u64x2 q = *reinterpret_cast<const u64x2 *>(in + (uint64_t) uu * seg_stride + seg_base + o);
+#endif
                 nxt[2 * j2] = q.x;
                 nxt[2 * j2 + 1] = q.y;
                 o += 2048u;
