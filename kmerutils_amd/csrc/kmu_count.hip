@@ -884,7 +884,8 @@ __device__ __forceinline__ void seg_spill(uint32_t *ovf, uint64_t item) {
 // items are khash values (IT_HASH); nbins a multiple of 4, <= 2048; all 1024 threads call this together; cnt[] zero on the
 // first call.  The digit is a bit field of the item's high word; a destination is one v_mad_u64_u32.  (A form without the
 // per-item branches -- "no k-mer" marks as items of a bin of their own behind the others -- needs 40 more registers than
-// the 128 a thread has: the compiler keeps both tiles' items and all sixteen addresses live.)
+// the 128 a thread has: the compiler keeps both tiles' items and all sixteen addresses live.  Tried again in round 3 with
+// the LDS round trips capped at four in flight: 16 / 31 spilled registers, level 1 23.4 ms against 19.3, level 2 25.3 against 22.9.)
 // VMWAIT: the caller prefetches the next tile with unconditional loads (see flat_step_fetch)
 template <bool VMWAIT>
 __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLds &l, uint32_t nbins, int region_bits, int shift,
