@@ -8,7 +8,11 @@
 // owns one item at a time and all lanes of the workgroup advance j in lock step; the slot minima live in LDS and
 // are updated with ds_min_u64 on the order-preserving bit pattern of the (positive) value; a_upper is refreshed
 // from them every few steps (any stale upper bound is valid).  Each lane's partial permutation is an LDS column
-// (entry-major, one byte or two per entry) that is restored to the identity after the item through a swap log.
+// (entry-major, one byte or two per entry) that is restored to the identity after the item through a swap log: the
+// swap partners of the first sixteen (eight for two-byte entries) steps of an item sit in four registers -- all active
+// lanes are at the same step, so a step's place in the log is wave-uniform -- and an item that needs more steps than
+// that (the first items of a short sequence, while slots are still empty) replays its draws.  (Until round 3 the log was
+// a second LDS column: with it a wave took 16 KiB at m = 128 and a CU held eight waves.)
 #include <algorithm>
 
 #include "kmu_ctx.hpp"
@@ -73,7 +77,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
     // lanes of a single wave get a column
     const int ncol = a.ncol;
     PT *perm = reinterpret_cast<PT *>(misc + 4);                  // [m][ncol]
-    PT *slog = perm + (size_t) m * ncol;                          // [m][ncol]
+    constexpr uint32_t LOG_BITS = 8 * sizeof(PT), LOG_PER = 64 / LOG_BITS, LOG_STEPS = 2 * LOG_PER; // swap partners kept in registers
     const bool aa = a.cfg.kmer_type == KMU_KMERAA32BIT || a.cfg.kmer_type == KMU_KMERAA64BIT;
     const uint64_t init_bits = super_init_bits(a.mode);
 
@@ -140,6 +144,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                 Xoshiro rng;
                 if (have) rng.seed(items[b0 + tid]);
                 uint32_t j = 0, round = 0;
+                uint64_t slog0 = 0, slog1 = 0; // the swap partners of steps 0 .. LOG_STEPS - 1
                 bool active = have;
                 for (;;) {
                     uint32_t a_upper = *(volatile uint32_t *) &misc[1];
@@ -160,7 +165,8 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         PT pk = perm[(size_t) k * ncol + tid];
                         perm[(size_t) j * ncol + tid] = pk;
                         perm[(size_t) k * ncol + tid] = pj;
-                        slog[(size_t) j * ncol + tid] = (PT) k;
+                        if (j < LOG_PER) slog0 |= (uint64_t) k << (LOG_BITS * j);
+                        else if (j < LOG_STEPS) slog1 |= (uint64_t) k << (LOG_BITS * (j - LOG_PER));
                         uint64_t bits;
                         switch (a.mode) {
                         case 0: bits = (uint64_t) __double_as_longlong(rd + (double) j); break;
@@ -183,10 +189,26 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                     }
                 }
                 // restore this lane's permutation column to the identity
-                for (uint32_t jj = 0; jj < j; jj++) {
-                    PT k = slog[(size_t) jj * ncol + tid];
-                    perm[(size_t) jj * ncol + tid] = (PT) jj;
-                    perm[(size_t) k * ncol + tid] = k;
+                if (j <= LOG_STEPS) {
+                    for (uint32_t jj = 0; jj < j; jj++) {
+                        const PT k = (PT) ((jj < LOG_PER ? slog0 >> (LOG_BITS * jj) : slog1 >> (LOG_BITS * (jj - LOG_PER))) & ((1ull << LOG_BITS) - 1ull));
+                        perm[(size_t) jj * ncol + tid] = (PT) jj;
+                        perm[(size_t) k * ncol + tid] = k;
+                    }
+                } else { // more steps than the registers log: the draws once more (same generator, same order)
+                    Xoshiro r2;
+                    r2.seed(items[b0 + tid]);
+                    for (uint32_t jj = 0; jj < j; jj++) {
+                        switch (a.mode) {
+                        case 0: (void) r2.unif01(); break;
+                        case 1: (void) r2.unif01_f32(); break;
+                        case 2: (void) r2.next(); break;
+                        default: (void) r2.next_u32(); break;
+                        }
+                        const PT k = (PT) r2.unif_index(jj, (uint32_t) m, a.rand08 != 0);
+                        perm[(size_t) jj * ncol + tid] = (PT) jj;
+                        perm[(size_t) k * ncol + tid] = k;
+                    }
                 }
             }
             __syncthreads();
@@ -272,21 +294,21 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     const size_t pt = wide ? 2 : 1;
     const size_t lds_max = 160 * 1024;
     auto fn = wide ? (const void *) k_sketch_super<uint16_t> : (const void *) k_sketch_super<uint8_t>;
-    // per-lane permutation + swap-log columns dominate the LDS footprint: shrink the workgroup for large m
+    // the per-lane permutation columns dominate the LDS footprint: shrink the workgroup for large m
     int threads = 64;
     if (const char *e = getenv("KMU_SUPER_THREADS")) threads = std::max(64, std::min(256, atoi(e) & ~63));
     size_t lds = 0;
     int ncol = 0;
     for (; threads >= 64; threads -= 64) {
-        lds = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + 2 * pt * a.m * threads;
+        lds = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + pt * a.m * threads;
         lds = (lds + 15) & ~(size_t) 15;
         if (lds <= lds_max) { ncol = threads; break; }
     }
     if (!ncol) { // very large sketches: one wave, as many item lanes as columns fit
         threads = 64;
         const size_t fixed = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + 16;
-        if (fixed < lds_max) ncol = (int) std::min<size_t>(64, (lds_max - fixed) / (2 * pt * (size_t) a.m));
-        lds = (fixed + 2 * pt * (size_t) a.m * ncol + 15) & ~(size_t) 15;
+        if (fixed < lds_max) ncol = (int) std::min<size_t>(64, (lds_max - fixed) / (pt * (size_t) a.m));
+        lds = (fixed + pt * (size_t) a.m * ncol + 15) & ~(size_t) 15;
     }
     a.ncol = ncol;
     if (ncol < 1) return fail(ctx, KMU_E_UNSUPPORTED, "sketch_size %d too large for LDS (%zu B)", a.m, lds);
