@@ -132,6 +132,9 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node: the RCCL bootstrap (torch's communicator and the library's own) over the loopback interface, whatever the
+        # container's other interfaces and its hostname resolve to; the data path is xGMI / shared memory either way
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
