@@ -1114,6 +1114,11 @@ struct SegPlan1 {
     uint64_t cap, bincap, unit_base, step_base; // step_base: first wave step of blockIdx.x == 0 (chunked calls)
     uint32_t *ovf;
     uint32_t *err;
+    // rounds (kmu_sketch_count under an upload): the same units take a slice of every round's wave steps [step_base, step_end)
+    // and keep the fills of their segments in `state` ([unit][bin]) between the launches; the tails are marked in the last one
+    uint64_t step_end;
+    uint32_t *state;
+    int first, last;
 };
 template <bool SEGM>
 __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
@@ -1143,12 +1148,18 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     }
     lds_barrier();
     const uint64_t total = offsets[n_seq], start = offsets[0];
-    const uint64_t nsteps = ((total + 15) / 16 + 63) / 64;
+    const uint64_t nsteps_all = ((total + 15) / 16 + 63) / 64;
+    const uint64_t nsteps = SEGM && seg.step_end ? seg.step_end : nsteps_all;
     const uint64_t s0 = seg.step_base + (uint64_t) blockIdx.x * pl.steps_per_unit;
     const uint64_t s1 = s0 + pl.steps_per_unit < nsteps ? s0 + pl.steps_per_unit : nsteps;
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t r_hint = 0xFFFFFFFFu, w0, ex, bad = 0;
     FlatRaw raw;
+    if (SEGM && seg.state && !seg.first && 2u * threadIdx.x < bins1) { // the fills of this unit's segments so far
+        const uint2 f = *reinterpret_cast<const uint2 *>(&seg.state[unit * bins1 + 2u * threadIdx.x]);
+        run[0] = f.x;
+        run[1] = f.y;
+    }
     if (SEGM) {
         flat_step_fetch(bases, total, s0 + wave, raw);
         vm_wait_all();
@@ -1171,7 +1182,9 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
         }
     }
     if (SEGM) {
-        seg_finish_unit(ls, bins1, sg, run, out, true, nullptr);
+        if (seg.state && !seg.last) {
+            if (2u * threadIdx.x < bins1) *reinterpret_cast<uint2 *>(&seg.state[unit * bins1 + 2u * threadIdx.x]) = make_uint2(run[0], run[1]);
+        } else seg_finish_unit(ls, bins1, sg, run, out, true, nullptr);
         clk.mark(5);
         clk.flush(0);
         if (bad) atomicOr(seg.err, DERR_NON_ACGT); // (the histogram pass that used to validate the bases did not run)
@@ -1866,7 +1879,11 @@ static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan
     // share of a bin staying around 2 048 items (margins of 18 %)
     const uint64_t by_size = total_bases / ((uint64_t) bins1 * 2048) + 1;
     uint64_t want = (uint64_t) ctx->num_cus;
-    if (chunked) want = std::min<uint64_t>(std::max<uint64_t>(by_size, want), want * 4);
+    // (round 2's chunked form took up to four times as many, smaller units -- one launch of a CU's worth per arrival -- with
+    //  margins of 18 %: 4 x 8 ms on the bench workload against 19 ms in one launch.  Round 3: the units persist across the
+    //  rounds, KMU_COUNT_SEG_ROUNDS=0 for the A/B)
+    const char *re = getenv("KMU_COUNT_SEG_ROUNDS");
+    if (chunked && re && atoi(re) == 0) want = std::min<uint64_t>(std::max<uint64_t>(by_size, want), want * 4);
     if (const char *e = getenv("KMU_COUNT_SEG_UNITS")) want = (uint64_t) std::max(1, atoi(e)); // A/B runs
     sp.units1 = (uint32_t) std::min<uint64_t>(nsteps, want);
     sp.steps_per_unit = (uint32_t) ((nsteps + sp.units1 - 1) / sp.units1);
@@ -1885,6 +1902,9 @@ struct SegRun {
     DevSeqs ds;
     uint64_t total_bases = 0;
     uint32_t units_done = 0;
+    uint64_t steps_done = 0; // rounds: wave steps of the stream that have been through level 1
+    bool rounds = false;     // the units persist across the launches (chunked calls)
+    void *state = nullptr;
     void *A = nullptr, *B = nullptr, *ovf = nullptr, *bnd = nullptr, *leafcnt = nullptr;
     uint32_t *d_err = nullptr;
 };
@@ -1898,6 +1918,11 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     run->ds = ds;
     run->total_bases = total_bases;
     run->units_done = 0;
+    run->steps_done = 0;
+    {
+        const char *re = getenv("KMU_COUNT_SEG_ROUNDS");
+        run->rounds = own_buffer && !(re && atoi(re) == 0) && !seg_layout_bin();
+    }
     run->d_err = d_err;
     const uint32_t bins1 = 1u << pl_in.b1;
     const uint64_t n_regions = 1ull << pl_in.region_bits;
@@ -1910,6 +1935,7 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &run->leafcnt));
     KMU_TRY(seg_spill_setup(ctx, total_bases, !want_compact(c), &run->ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &run->bnd));
+    if (run->rounds) KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.units1 * bins1 * 4 + 64, &run->state));
     KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;
 }
@@ -1918,6 +1944,32 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
     kmu_ctx *ctx = c->ctx;
     const uint64_t steps_ready = bases_ready >= run->total_bases ? ((run->total_bases + 15) / 16 + 63) / 64
                                                                  : (bases_ready >= 32 ? (bases_ready - 32) / 1024 : 0);
+    if (run->rounds) { // every unit takes its slice of the wave steps that have arrived since the last launch
+        if (run->units_done == run->sp.units1) return KMU_OK; // the last launch has been made
+        const bool last = bases_ready >= run->total_bases;
+        const uint64_t n_new = steps_ready > run->steps_done ? steps_ready - run->steps_done : 0;
+        // an arrival of less than a few tiles per wave waits for the next one; the last launch is made in any case (it marks
+        // the tails of the segments, over an empty range if nothing is left)
+        const char *mn = getenv("KMU_COUNT_SEG_ROUND_MIN");
+        const uint64_t min_steps = (uint64_t) run->sp.units1 * (mn ? (uint64_t) atoi(mn) : 64u);
+        if (!last && n_new < min_steps) return KMU_OK;
+        const uint32_t bins1 = 1u << run->pl.b1;
+        PartPlan pl = run->pl;
+        pl.steps_per_unit = (uint32_t) ((n_new + run->sp.units1 - 1) / run->sp.units1);
+        if (pl.steps_per_unit == 0) pl.steps_per_unit = 1;
+        {
+            KernelTimer tm(ctx, "k_part_scatter1");
+            hipLaunchKernelGGL(k_part_scatter1<true>, dim3(run->sp.units1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, run->ds.bases,
+                               run->ds.offsets, run->ds.n_seq, c->p.kmer_size, pl, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
+                               (uint64_t *) run->A,
+                               SegPlan1{run->sp.cap1, 0, 0, run->steps_done, (uint32_t *) run->ovf, run->d_err, run->steps_done + n_new,
+                                        (uint32_t *) run->state, run->steps_done == 0 ? 1 : 0, last ? 1 : 0});
+        }
+        KMU_HIP(ctx, hipGetLastError());
+        run->steps_done += n_new;
+        if (last) run->units_done = run->sp.units1;
+        return KMU_OK;
+    }
     uint32_t upto = bases_ready >= run->total_bases ? run->sp.units1
                                                     : (uint32_t) std::min<uint64_t>(steps_ready / run->sp.steps_per_unit, run->sp.units1);
     if (bases_ready < run->total_bases) { // partial launches in whole rounds of one workgroup per CU: a launch of fewer leaves CUs idle
@@ -1933,7 +1985,7 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                            run->ds.bases, run->ds.offsets, run->ds.n_seq, c->p.kmer_size, run->pl, (const uint64_t *) nullptr,
                            (const uint64_t *) nullptr, (uint64_t *) run->A,
                            SegPlan1{run->sp.cap1, seg_layout_bin() ? run->sp.bincap1 : 0, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
-                                    (uint32_t *) run->ovf, run->d_err});
+                                    (uint32_t *) run->ovf, run->d_err, 0, nullptr, 1, 1});
     }
     KMU_HIP(ctx, hipGetLastError());
     run->units_done = upto;
@@ -2051,7 +2103,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1<false>, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1,
-                           (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr});
+                           (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1});
     }
     const uint64_t *items = (const uint64_t *) A;
     const uint64_t *leaves = (const uint64_t *) binstart1;
@@ -2275,7 +2327,7 @@ static int owner_scatter(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1<false>, dim3(op.pl.units1), dim3(SCATTER_THREADS), scatter_lds_bytes(op.pl.owner_parts), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, c->p.kmer_size, op.pl, (const uint64_t *) op.offs1,
-                           (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr});
+                           (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1});
     }
     KMU_HIP(ctx, hipGetLastError());
     *dev_out = (uint64_t *) out;

@@ -114,6 +114,7 @@ def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
     import torch
     monkeypatch.setenv("KMU_PIPE_CHUNK_MB", "1")
     monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    monkeypatch.setenv("KMU_COUNT_SEG_ROUND_MIN", "1")  # (a launch per arrival of >= 1 wave step per unit: 256 KB here, 16 MB by default)
     dev = torch.device("cuda", 0)
     bases, off, lens = synth.ont_reads_device(1500, 9_000_000, 2_000_000, 0xC8, dev)
     hb, ho = bases[:int(off[-1])].cpu().numpy(), off.cpu().numpy().astype(np.uint64)
@@ -133,6 +134,7 @@ def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
         assert ("k_part_hist1" in prof) == (pct == "60")  # the histogram passes only run when the exact route takes over
         # (overflowing segments: the chunked attempt, then the exact levels -- no second attempt on the same k-mers)
         assert prof["k_arr_scatter"][0] == (1 if pct == "100" else 2)
+        assert prof["k_part_scatter1"][0] >= 5  # the level-1 units took their slices of the stream in rounds, chunk by chunk
         assert np.array_equal(got, want)
         assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())
         gk, gc = c.dump(2)
