@@ -887,9 +887,15 @@ __device__ __forceinline__ void seg_spill(uint32_t *ovf, uint64_t item) {
 // the 128 a thread has: the compiler keeps both tiles' items and all sixteen addresses live.  Tried again in round 3 with
 // the LDS round trips capped at four in flight: 16 / 31 spilled registers, level 1 23.4 ms against 19.3, level 2 25.3 against 22.9.)
 // VMWAIT: the caller prefetches the next tile with unconditional loads (see flat_step_fetch)
-template <bool VMWAIT>
+// cursor != nullptr: the segments are SHARED by the workgroups of an XCD -- a tile's run of a bin is placed by an atomic add on
+// the bin's cursor (cursor[bin]: items handed out so far) instead of the unit's own fill `run`: the runs of the XCD's 32
+// workgroups lie one behind the other in ONE stream per bin, so the half-written 128-byte lines at the head of a stream are
+// completed by the neighbours within a tile's time instead of waiting in L2 for this workgroup's next tile (32 workgroups x
+// 2 048 private streams x 128 bytes = 8 MB of open lines per XCD against 4 MB of L2: the two speeds of level 1, section 3.4).
+template <bool VMWAIT, bool CUR = false>
 __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLds &l, uint32_t nbins, int region_bits, int shift,
-                                                 uint64_t *out, const SegOut &sg, uint32_t (&run)[2], SegClk &clk) {
+                                                 uint64_t *out, const SegOut &sg, uint32_t (&run)[2], SegClk &clk,
+                                                 uint32_t *cursor = nullptr) {
     const uint32_t tid = threadIdx.x, nthreads = SCATTER_THREADS, mask = nbins - 1;
     const uint32_t sh32 = (uint32_t) (32 - region_bits + shift); // digit = (high word >> sh32) & mask  (region_bits <= 22)
     auto bin_of = [&](uint64_t item) -> uint32_t { return ((uint32_t) (item >> 32) >> sh32) & mask; };
@@ -909,6 +915,10 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
         c0 = c.x;
         c1 = c.y;
         *reinterpret_cast<uint2 *>(&l.cnt[b0]) = make_uint2(0u, 0u);
+        if (CUR) { // (the answers are looked at behind the staging)
+            run[0] = atomicAdd(&cursor[b0], c0);
+            run[1] = atomicAdd(&cursor[b0 + 1], c1);
+        }
     }
     const uint32_t incl = wave_incl_scan_u32(c0 + c1);
     if (lane_id() == 63) l.wtot[tid >> 6] = incl;
@@ -931,15 +941,21 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
     if (b0 < nbins) {
         const uint32_t excl = wpre + incl - (c0 + c1);
         *reinterpret_cast<uint2 *>(&l.lstart[b0]) = make_uint2(excl, excl + c0);
-        *reinterpret_cast<uint2 *>(&l.grel[b0]) = make_uint2(run[0] - excl, run[1] - (excl + c0));
-        run[0] += c0;
-        run[1] += c1;
+        if (!CUR) {
+            *reinterpret_cast<uint2 *>(&l.grel[b0]) = make_uint2(run[0] - excl, run[1] - (excl + c0));
+            run[0] += c0;
+            run[1] += c1;
+        }
     }
     lds_barrier();
     clk.mark(2);
 #pragma unroll
     for (int j = 0; j < 16; j++)
         if (it[j] != CKEY_EMPTY) l.stage[l.lstart[bin_of(it[j])] + ((rk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu)] = it[j];
+    if (CUR && b0 < nbins) {
+        const uint2 ls = *reinterpret_cast<const uint2 *>(&l.lstart[b0]);
+        *reinterpret_cast<uint2 *>(&l.grel[b0]) = make_uint2(run[0] - ls.x, run[1] - ls.y);
+    }
     lds_barrier();
     clk.mark(3);
     if (VMWAIT) vm_wait_all(); // the next tile's requests (in flight since before the ranks) and the last tile's stores: nothing younger
@@ -1119,8 +1135,12 @@ struct SegPlan1 {
     uint64_t step_end;
     uint32_t *state;
     int first, last;
+    // sets != 0: shared segments -- `state` holds one cursor per (set, bin), set = blockIdx.x % sets (the workgroups of an XCD:
+    // the dispatcher deals them out round robin), cap items per (set, bin) stream at out[(set * bins + bin) * cap]; nothing is
+    // loaded, stored or marked by the kernel (k_seg_tails marks the tails behind the last launch)
+    uint32_t sets;
 };
-template <bool SEGM>
+template <bool SEGM, bool SHARED = false>
 __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
                                                         int k, PartPlan pl, const uint64_t *offs1,
                                                         const uint64_t *binstart1, uint64_t *out, SegPlan1 seg) {
@@ -1135,6 +1155,12 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     // a slow state of the box -- 25 ms with either layout for minutes on end -- that no layout changes)
     SegOut sg{unit * bins1, seg.cap, seg.cap, seg.cap, seg.ovf};
     if (seg.bincap) sg = SegOut{0, seg.bincap, (unit + 1) * seg.cap, seg.cap, seg.ovf}; // (A/B: the bins' ranges side by side, KMU_COUNT_SEG_LAYOUT=bin)
+    uint32_t *cursor = nullptr;
+    if (SEGM && SHARED) {
+        const uint32_t set = seg.first & 2 ? blockIdx.x / ((gridDim.x + seg.sets - 1) / seg.sets) : blockIdx.x % seg.sets; // (A/B: bit 1 of first = sets of consecutive workgroups)
+        sg = SegOut{(uint64_t) set * bins1, seg.cap, seg.cap, seg.cap, seg.ovf};
+        cursor = seg.state + (size_t) set * bins1;
+    }
     uint32_t run[2] = {0u, 0u};
     SegClk clk;
     if (SEGM) {
@@ -1155,7 +1181,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     uint32_t r_hint = 0xFFFFFFFFu, w0, ex, bad = 0;
     FlatRaw raw;
-    if (SEGM && seg.state && !seg.first && 2u * threadIdx.x < bins1) { // the fills of this unit's segments so far
+    if (SEGM && !SHARED && seg.state && !(seg.first & 1) && 2u * threadIdx.x < bins1) { // the fills of this unit's segments so far
         const uint2 f = *reinterpret_cast<const uint2 *>(&seg.state[unit * bins1 + 2u * threadIdx.x]);
         run[0] = f.x;
         run[1] = f.y;
@@ -1177,12 +1203,13 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
         else { // from here on the k-mers travel as their table hash
 #pragma unroll
             for (int j = 0; j < 16; j++) it[j] = khash(it[j]); // (khash keeps the "no k-mer" mark)
-            if (SEGM) tile_scatter_seg<true>(it, ls, bins1, pl.region_bits, pl.b2, out, sg, run, clk);
+            if (SEGM) tile_scatter_seg<true, SHARED>(it, ls, bins1, pl.region_bits, pl.b2, out, sg, run, clk, cursor);
             else tile_scatter<IT_HASH>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
         }
     }
     if (SEGM) {
-        if (seg.state && !seg.last) {
+        if (SHARED) {
+        } else if (seg.state && !seg.last) {
             if (2u * threadIdx.x < bins1) *reinterpret_cast<uint2 *>(&seg.state[unit * bins1 + 2u * threadIdx.x]) = make_uint2(run[0], run[1]);
         } else seg_finish_unit(ls, bins1, sg, run, out, true, nullptr);
         clk.mark(5);
@@ -1210,6 +1237,9 @@ struct ArrPlan {
     // != 0: the input partition p is not contiguous but the p-th segment (seg_cap items) of each of seg_units blocks of
     // seg_bins segments -- what the single-pass level 1 leaves, one block per unit (k_part_scatter1<true>); bounds is not read
     uint32_t seg_units, seg_cap, seg_bins;
+    // k_arr_scatter<.., SHARED>: > 1 = that many sets of shared output streams per partition, a unit writes set blockIdx.x % out_sets
+    // (level 1 of an array: [set][bin][seg_cap], cursors in the same order); 0 / 1: one set (level 2: the leaves)
+    uint32_t out_sets;
 };
 
 __device__ __forceinline__ void arr_unit_range(const uint64_t *bounds, const ArrPlan &pl, uint32_t unit, uint64_t *i0,
@@ -1291,17 +1321,34 @@ __global__ void __launch_bounds__(256) k_arr_scan_b(const uint64_t *tot, const u
 // seg_cap != 0: the single-pass form -- no histogram ran; unit (partition p, chunk c) writes bin b into its own segment
 // [((p * bins + b) * chunks + c) * seg_cap, + seg_cap) of `out` (offs_rel / outbounds are not read); "no k-mer" marks in the
 // input (the tails of the previous level's segments) are skipped like everywhere else.
-template <int IT, bool SEGM>
+// SHARED (level 2 of the read path): the `chunks` units of an input partition write ONE set of leaves, a tile's run of a leaf
+// placed by an atomic add on the leaf's cursor (leafcnt[leaf], zero before the launch; it ends as the leaf's fill -- or more,
+// where items went to the spill list: the build clamps it).  The units of a partition are the workgroups 8 apart in the grid:
+// the dispatcher deals workgroups out to the 8 XCDs round robin, so they run at the same time on the same XCD and its L2 sees
+// their runs of a leaf side by side (see tile_scatter_seg).
+template <int IT, bool SEGM, bool SHARED = false>
 __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
                                                       const uint64_t *offs_rel, const uint64_t *outbounds, uint64_t *out,
                                                       uint64_t seg_cap, uint32_t *seg_ovf, uint32_t *leafcnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds l = scatter_lds(smem, pl.bins);
     SegLds ls = seg_lds(smem, pl.bins);
-    const uint64_t sp = blockIdx.x / pl.chunks;
+    uint64_t sp = blockIdx.x / pl.chunks;
+    uint32_t my_chunk = blockIdx.x % pl.chunks;
+    if (SHARED && pl.seg_units && (pl.nparts & 7u) == 0u) {
+        sp = 8u * (blockIdx.x / (8u * pl.chunks)) + (blockIdx.x & 7u);
+        my_chunk = (blockIdx.x >> 3) % pl.chunks;
+    }
     // segmented output: the bins' segments of a unit side by side, block blockIdx.x of pl.bins segments (level 2, one unit per
     // input partition: the region leaves in region order)
     SegOut sg{(uint64_t) blockIdx.x * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
+    uint32_t *cursor = nullptr;
+    if (SHARED) {
+        const uint32_t nsets = pl.out_sets > 1u ? pl.out_sets : 1u;
+        const uint64_t block = sp * nsets + (nsets > 1u ? blockIdx.x % nsets : 0u);
+        sg = SegOut{block * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
+        cursor = leafcnt + block * pl.bins;
+    }
     uint32_t run[2] = {0u, 0u};
     SegClk clk;
     if (SEGM) {
@@ -1315,8 +1362,15 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     }
     lds_barrier();
     uint64_t i0, i1;
-    if (pl.seg_units) { i0 = 0; i1 = (uint64_t) pl.seg_units * pl.seg_cap; } // (positions in the partition's segments, one after the other)
-    else arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
+    if (pl.seg_units) { // (positions in the partition's segments, one after the other)
+        i0 = 0;
+        i1 = (uint64_t) pl.seg_units * pl.seg_cap;
+        if (SHARED) { // this unit's slice, from a multiple of 16 positions on
+            const uint64_t per = ((i1 + pl.chunks - 1) / pl.chunks + 15) & ~(uint64_t) 15;
+            i0 = (uint64_t) my_chunk * per < i1 ? (uint64_t) my_chunk * per : i1;
+            i1 = i0 + per < i1 ? i0 + per : i1;
+        }
+    } else arr_unit_range(bounds, pl, blockIdx.x, &i0, &i1);
     // PADDED: the input is the segmented output of a single-pass level 1 (pl.seg_units != 0) -- a tile is requested whole by
     // unconditional loads (positions beyond the partition are mapped to its last block and not looked at) and the waits are
     // explicit (see flat_step_fetch); otherwise (arrays of the caller) the loads stay under their bounds tests and the
@@ -1384,12 +1438,12 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
         }
-        if (SEGM) tile_scatter_seg<PADDED>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk);
+        if (SEGM) tile_scatter_seg<PADDED, SHARED>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
         else tile_scatter<IT == IT_KEY_TO_HASH ? IT_HASH : IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
     if (SEGM) {
         // a level with one unit per input partition writes leaves: their fills go to leafcnt, no tail marks
-        seg_finish_unit(ls, pl.bins, sg, run, out, leafcnt == nullptr, leafcnt);
+        if (!SHARED) seg_finish_unit(ls, pl.bins, sg, run, out, leafcnt == nullptr, leafcnt);
         clk.mark(5);
         clk.flush(1);
     }
@@ -1403,6 +1457,12 @@ __global__ void __launch_bounds__(64) k_spill_header(uint32_t *ovf, uint32_t cap
         ovf[2] = cap;
         *reinterpret_cast<uint64_t **>(ovf + 4) = list;
     }
+}
+
+// shared segments (SegPlan1::sets): "no k-mer" marks from the fill of every (set, bin) stream to its capacity
+__global__ void __launch_bounds__(256) k_seg_tails(const uint32_t *cursor, uint32_t cap, uint64_t *out) {
+    const uint32_t n = cursor[blockIdx.x] < cap ? cursor[blockIdx.x] : cap;
+    for (uint32_t i = n + threadIdx.x; i < cap; i += blockDim.x) out[(uint64_t) blockIdx.x * cap + i] = CKEY_EMPTY;
 }
 
 // the spill list of a single-pass partition (khash values) into the finished table, by direct insertion
@@ -1453,7 +1513,7 @@ __global__ void __launch_bounds__(THREADS) k_part_build_q(const uint64_t *__rest
     const uint64_t cmask = q_cmask(w), add_limit = q_limit(w) - (THREADS > 512 ? (uint64_t) Q_MARGIN : 0ull);
     for (uint32_t r = r_begin; r < r_end; r += r_step) {
         const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
-        const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (uint64_t) leafcnt[r] : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
+        const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (leafcnt[r] < leaf_stride ? (uint64_t) leafcnt[r] : leaf_stride) : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
         uint64_t pre_it[BUILD_PRE];
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++) {
@@ -1565,7 +1625,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
         // the items of region r: [leafstart[r], leafstart[r + 1]), or a fixed-size range that may hold "no k-mer" marks (the
         // leaves of the single-pass partition), or none (the expansion of a compact table)
         const uint64_t i0 = leaf_stride ? (uint64_t) r * leaf_stride : leafstart ? leafstart[r] : 0;
-        const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (uint64_t) leafcnt[r] : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
+        const uint64_t i1 = leaf_stride ? i0 + (leafcnt ? (leafcnt[r] < leaf_stride ? (uint64_t) leafcnt[r] : leaf_stride) : leaf_stride) : leafstart ? leafstart[r + 1] : 0;
         uint64_t pre_it[BUILD_PRE];
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++) {
@@ -1798,10 +1858,10 @@ static int materialize(kmu_counter *c) {
 // (function attributes are per device: remembered per context, not per process)
 static int scatter_attrs(kmu_ctx *ctx) {
     if (ctx->lds_attr_set & 1u) return KMU_OK;
-    const void *fns[] = {(const void *) k_part_scatter1<false>, (const void *) k_part_scatter1<true>,
-                         (const void *) k_arr_scatter<IT_HASH, false>, (const void *) k_arr_scatter<IT_HASH, true>,
+    const void *fns[] = {(const void *) k_part_scatter1<false>, (const void *) k_part_scatter1<true>, (const void *) k_part_scatter1<true, true>,
+                         (const void *) k_arr_scatter<IT_HASH, false>, (const void *) k_arr_scatter<IT_HASH, true>, (const void *) k_arr_scatter<IT_HASH, true, true>,
                          (const void *) k_arr_scatter<IT_KEY, false>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, false>,
-                         (const void *) k_arr_scatter<IT_KEY_TO_HASH, true>};
+                         (const void *) k_arr_scatter<IT_KEY_TO_HASH, true>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, true, true>};
     for (const void *f : fns) KMU_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ctx->lds_attr_set |= 1u;
     return KMU_OK;
@@ -1869,7 +1929,21 @@ struct SegPlan {
     uint32_t units1, steps_per_unit;
     uint64_t cap1, bincap1, cap2, leafcap;
     uint32_t chunks2;
+    uint32_t shared2; // level 2: the chunks2 units of a bin share its leaves (cursors in leafcnt)
+    uint32_t sets; // level 1 with shared segments: one stream per (set, bin), cap1 items each (0: a segment per unit and bin)
 };
+// shared segments (tile_scatter_seg with cursors).  Level 1: sets of streams, two per XCD (bench workload, same box: 15.8-16.1 ms;
+// one per XCD 18.5, four 15.9-16.7, eight 20.3, one for the whole chip 19.8-20.1, a unit's own segments 17.6-21.5 in two states).
+static uint32_t seg_sets_wanted() {
+    const char *se = getenv("KMU_COUNT_SEG_SHARED");
+    return seg_layout_bin() ? 0u : se ? (uint32_t) std::max(0, atoi(se)) : 16u;
+}
+// Level 2: units per level-1 bin that share the bin's leaves (0: one unit, its own leaves: 23.5-24.2 ms; shared by 1 / 2 / 4 / 8 /
+// 16 / 32 / 64 / 128 units: 21.6 / 22.3 / 20.3-21.4 / 18.5 / 16.9-17.4 / 17.7-17.9 / 17.9 / 20.0)
+static uint32_t seg_l2_units_wanted() {
+    const char *se = getenv("KMU_COUNT_L2_SHARED");
+    return se ? (uint32_t) std::max(0, atoi(se)) : 16u;
+}
 static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan &pl, bool chunked) {
     SegPlan sp;
     const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
@@ -1890,9 +1964,18 @@ static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan
     sp.units1 = (uint32_t) ((nsteps + sp.steps_per_unit - 1) / sp.steps_per_unit);
     sp.cap1 = seg_cap_for((double) sp.steps_per_unit * 1024.0 / bins1);
     sp.bincap1 = (uint64_t) sp.units1 * sp.cap1;
+    sp.sets = 0;
+    if (const uint32_t want_sets = seg_sets_wanted()) {
+        sp.sets = std::min(want_sets, sp.units1);
+        const uint64_t units_per_set = (sp.units1 + sp.sets - 1) / sp.sets;
+        sp.cap1 = seg_cap_for((double) units_per_set * sp.steps_per_unit * 1024.0 / bins1);
+        sp.bincap1 = (uint64_t) sp.sets * sp.cap1;
+    }
     sp.chunks2 = 1; // a level-2 unit is a whole level-1 bin: the biggest segments, the smallest margins
     sp.cap2 = seg_cap_for((double) total_bases / bins1 / sp.chunks2 / bins2);
     sp.leafcap = (uint64_t) sp.chunks2 * sp.cap2;
+    sp.shared2 = 0;
+    if (const uint32_t want = seg_l2_units_wanted()) { sp.shared2 = 1; sp.chunks2 = want; }
     return sp;
 }
 // state of a single-pass partition between its level-1 launches (kmu_sketch_count runs them chunk by chunk under the upload)
@@ -1935,7 +2018,10 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &run->leafcnt));
     KMU_TRY(seg_spill_setup(ctx, total_bases, !want_compact(c), &run->ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &run->bnd));
-    if (run->rounds) KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.units1 * bins1 * 4 + 64, &run->state));
+    if (run->sp.sets) {
+        KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.sets * bins1 * 4 + 64, &run->state));
+        KMU_HIP(ctx, hipMemsetAsync(run->state, 0, (size_t) run->sp.sets * bins1 * 4, ctx->stream));
+    } else if (run->rounds) KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.units1 * bins1 * 4 + 64, &run->state));
     KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;
 }
@@ -1958,16 +2044,22 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
         pl.steps_per_unit = (uint32_t) ((n_new + run->sp.units1 - 1) / run->sp.units1);
         if (pl.steps_per_unit == 0) pl.steps_per_unit = 1;
         {
+            const auto k1 = run->sp.sets ? k_part_scatter1<true, true> : k_part_scatter1<true, false>;
             KernelTimer tm(ctx, "k_part_scatter1");
-            hipLaunchKernelGGL(k_part_scatter1<true>, dim3(run->sp.units1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, run->ds.bases,
+            hipLaunchKernelGGL(k1, dim3(run->sp.units1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, run->ds.bases,
                                run->ds.offsets, run->ds.n_seq, c->p.kmer_size, pl, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
                                (uint64_t *) run->A,
                                SegPlan1{run->sp.cap1, 0, 0, run->steps_done, (uint32_t *) run->ovf, run->d_err, run->steps_done + n_new,
-                                        (uint32_t *) run->state, run->steps_done == 0 ? 1 : 0, last ? 1 : 0});
+                                        (uint32_t *) run->state, (run->steps_done == 0 ? 1 : 0) | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), last ? 1 : 0, run->sp.sets});
         }
         KMU_HIP(ctx, hipGetLastError());
         run->steps_done += n_new;
-        if (last) run->units_done = run->sp.units1;
+        if (last) {
+            run->units_done = run->sp.units1;
+            if (run->sp.sets)
+                hipLaunchKernelGGL(k_seg_tails, dim3(run->sp.sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) run->state,
+                                   (uint32_t) run->sp.cap1, (uint64_t *) run->A);
+        }
         return KMU_OK;
     }
     uint32_t upto = bases_ready >= run->total_bases ? run->sp.units1
@@ -1980,15 +2072,19 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
     if (upto <= run->units_done) return KMU_OK;
     const uint32_t bins1 = 1u << run->pl.b1;
     {
+        const auto k1 = run->sp.sets ? k_part_scatter1<true, true> : k_part_scatter1<true, false>;
         KernelTimer tm(ctx, "k_part_scatter1");
-        hipLaunchKernelGGL(k_part_scatter1<true>, dim3(upto - run->units_done), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream,
+        hipLaunchKernelGGL(k1, dim3(upto - run->units_done), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream,
                            run->ds.bases, run->ds.offsets, run->ds.n_seq, c->p.kmer_size, run->pl, (const uint64_t *) nullptr,
                            (const uint64_t *) nullptr, (uint64_t *) run->A,
                            SegPlan1{run->sp.cap1, seg_layout_bin() ? run->sp.bincap1 : 0, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
-                                    (uint32_t *) run->ovf, run->d_err, 0, nullptr, 1, 1});
+                                    (uint32_t *) run->ovf, run->d_err, 0, (uint32_t *) run->state, 1 | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), 1, run->sp.sets});
     }
     KMU_HIP(ctx, hipGetLastError());
     run->units_done = upto;
+    if (run->sp.sets && upto == run->sp.units1)
+        hipLaunchKernelGGL(k_seg_tails, dim3(run->sp.sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) run->state,
+                           (uint32_t) run->sp.cap1, (uint64_t *) run->A);
     return KMU_OK;
 }
 // the rest of level 1, level 2, the overflow flag, the build.  *taken = 0: a segment overflowed, the table is untouched.
@@ -1999,10 +2095,12 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     const uint32_t bins1 = 1u << run->pl.b1, bins2 = 1u << run->pl.b2;
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) run->bnd, (uint64_t) bins1 + 1, run->sp.bincap1);
     {
-        ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2, run->sp.units1, (uint32_t) run->sp.cap1, bins1};
+        ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2, run->sp.sets ? run->sp.sets : run->sp.units1, (uint32_t) run->sp.cap1, bins1};
         if (seg_layout_bin()) { ap.seg_units = 1; ap.seg_cap = (uint32_t) run->sp.bincap1; }
+        if (run->sp.shared2) KMU_HIP(ctx, hipMemsetAsync(run->leafcnt, 0, (size_t) bins1 * bins2 * 4, ctx->stream));
+        const auto k2 = run->sp.shared2 ? k_arr_scatter<IT_HASH, true, true> : k_arr_scatter<IT_HASH, true, false>;
         KernelTimer tm(ctx, "k_arr_scatter");
-        hipLaunchKernelGGL((k_arr_scatter<IT_HASH, true>), dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream,
+        hipLaunchKernelGGL(k2, dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream,
                            (const uint64_t *) run->A, (const uint64_t *) run->bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
                            (uint64_t *) run->B, run->sp.cap2, (uint32_t *) run->ovf, (uint32_t *) run->leafcnt);
     }
@@ -2103,7 +2201,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1<false>, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1,
-                           (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1});
+                           (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1, 0});
     }
     const uint64_t *items = (const uint64_t *) A;
     const uint64_t *leaves = (const uint64_t *) binstart1;
@@ -2220,29 +2318,40 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
     const uint64_t n_regions = 1ull << pl.region_bits;
     const uint32_t chunks1 = (uint32_t) ctx->num_cus; // one unit per CU: the biggest segments, the smallest margins
-    const uint64_t cap1 = seg_cap_for((double) n / chunks1 / bins1), bincap1 = (uint64_t) chunks1 * cap1;
+    // (shared segments as in the read path: sets of level-1 streams with cursors, the leaves of a bin shared by level 2's units)
+    const uint32_t sets = std::min(seg_sets_wanted(), chunks1), units2 = seg_l2_units_wanted();
+    const uint32_t pieces = sets ? sets : chunks1;
+    const uint64_t cap1 = seg_cap_for((double) n / pieces / bins1), bincap1 = (uint64_t) pieces * cap1;
     const uint64_t cap2 = seg_cap_for((double) n / bins1 / bins2);
-    void *A, *B, *ovf, *bnd, *b0, *leafcnt;
+    void *A, *B, *ovf, *bnd, *b0, *leafcnt, *cur1 = nullptr;
     KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &A));
     KMU_TRY(dev_buf(ctx, "cnt.partB", (size_t) n_regions * cap2 * 8 + 64, &B));
     KMU_TRY(dev_buf(ctx, "cnt.leafcnt", (size_t) n_regions * 4 + 64, &leafcnt));
     KMU_TRY(seg_spill_setup(ctx, n, !want_compact(c), &ovf));
     KMU_TRY(dev_buf(ctx, "cnt.seg_bounds", ((size_t) bins1 + 1) * 8, &bnd));
     KMU_TRY(dev_buf(ctx, "arr.bounds0", 16, &b0));
+    if (sets) {
+        KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) sets * bins1 * 4 + 64, &cur1));
+        KMU_HIP(ctx, hipMemsetAsync(cur1, 0, (size_t) sets * bins1 * 4, ctx->stream));
+    }
     hipLaunchKernelGGL(k_fill_linear, dim3(1), dim3(256), 0, ctx->stream, (uint64_t *) b0, (uint64_t) 2, n);
     KMU_TRY(scatter_attrs(ctx));
     {
-        ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1};
+        ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1, 0u, 0u, 0u, sets};
+        const auto k1 = sets ? k_arr_scatter<IT_KEY_TO_HASH, true, true> : k_arr_scatter<IT_KEY_TO_HASH, true, false>;
         KernelTimer tm(ctx, "k_arr_scatter");
-        hipLaunchKernelGGL((k_arr_scatter<IT_KEY_TO_HASH, true>), dim3(chunks1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, d_kmers,
-                           (const uint64_t *) b0, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) A, cap1, (uint32_t *) ovf,
-                           (uint32_t *) nullptr);
+        hipLaunchKernelGGL(k1, dim3(chunks1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, d_kmers, (const uint64_t *) b0, ap,
+                           (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) A, cap1, (uint32_t *) ovf, (uint32_t *) cur1);
     }
+    if (sets)
+        hipLaunchKernelGGL(k_seg_tails, dim3(sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) cur1, (uint32_t) cap1, (uint64_t *) A);
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) bnd, (uint64_t) bins1 + 1, bincap1);
     {
-        ArrPlan ap{pl.region_bits, 0, bins2, bins1, 1u, chunks1, (uint32_t) cap1, bins1};
+        ArrPlan ap{pl.region_bits, 0, bins2, bins1, units2 ? units2 : 1u, pieces, (uint32_t) cap1, bins1, 0u};
+        if (units2) KMU_HIP(ctx, hipMemsetAsync(leafcnt, 0, (size_t) bins1 * bins2 * 4, ctx->stream));
+        const auto k2 = units2 ? k_arr_scatter<IT_HASH, true, true> : k_arr_scatter<IT_HASH, true, false>;
         KernelTimer tm(ctx, "k_arr_scatter");
-        hipLaunchKernelGGL((k_arr_scatter<IT_HASH, true>), dim3(bins1), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream, (const uint64_t *) A,
+        hipLaunchKernelGGL(k2, dim3(bins1 * ap.chunks), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream, (const uint64_t *) A,
                            (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf,
                            (uint32_t *) leafcnt);
     }
@@ -2327,7 +2436,7 @@ static int owner_scatter(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1<false>, dim3(op.pl.units1), dim3(SCATTER_THREADS), scatter_lds_bytes(op.pl.owner_parts), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, c->p.kmer_size, op.pl, (const uint64_t *) op.offs1,
-                           (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1});
+                           (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1, 0});
     }
     KMU_HIP(ctx, hipGetLastError());
     *dev_out = (uint64_t *) out;
