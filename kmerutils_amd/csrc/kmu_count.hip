@@ -844,16 +844,16 @@ struct SegLds {
     uint32_t *grel;   // nbins
     uint32_t *wtot;   // 16 wave totals
 };
-__device__ __forceinline__ SegLds seg_lds(uint8_t *smem, uint32_t nbins) {
+__device__ __forceinline__ SegLds seg_lds(uint8_t *smem, uint32_t nbins, uint32_t tile_items = TILE_ITEMS) {
     SegLds l;
     l.stage = reinterpret_cast<uint64_t *>(smem);
-    l.cnt = reinterpret_cast<uint32_t *>(l.stage + TILE_ITEMS);
+    l.cnt = reinterpret_cast<uint32_t *>(l.stage + tile_items);
     l.lstart = l.cnt + nbins + 2;
     l.grel = l.lstart + nbins + 2;
     l.wtot = l.grel + nbins;
     return l;
 }
-static size_t seg_lds_bytes(uint32_t nbins) { return (size_t) TILE_ITEMS * 8 + ((size_t) nbins * 3 + 4) * 4 + 64; }
+static size_t seg_lds_bytes(uint32_t nbins, uint32_t tile_items = TILE_ITEMS) { return (size_t) tile_items * 8 + ((size_t) nbins * 3 + 4) * 4 + 64; }
 
 #if KMU_DIAG
 __device__ unsigned long long g_diag_seg[2][8]; // [level][phase]: thread-0 clocks of the tile sort (diagnostic builds)
@@ -892,11 +892,13 @@ __device__ __forceinline__ void seg_spill(uint32_t *ovf, uint64_t item) {
 // workgroups lie one behind the other in ONE stream per bin, so the half-written 128-byte lines at the head of a stream are
 // completed by the neighbours within a tile's time instead of waiting in L2 for this workgroup's next tile (32 workgroups x
 // 2 048 private streams x 128 bytes = 8 MB of open lines per XCD against 4 MB of L2: the two speeds of level 1, section 3.4).
-template <bool VMWAIT, bool CUR = false>
+// (Round 3, measured and not kept: level 1 taking an item's rank as soon as its hash is made, so that a wave's LDS atomics run
+// under the arithmetic of its next items -- 16.2 / 17.9 / 18.0 ms against 15.7 / 16.2, scripts/r03_prerank.sh.)
+template <bool VMWAIT, bool CUR = false, int THREADS = SCATTER_THREADS>
 __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLds &l, uint32_t nbins, int region_bits, int shift,
                                                  uint64_t *out, const SegOut &sg, uint32_t (&run)[2], SegClk &clk,
                                                  uint32_t *cursor = nullptr) {
-    const uint32_t tid = threadIdx.x, nthreads = SCATTER_THREADS, mask = nbins - 1;
+    const uint32_t tid = threadIdx.x, nthreads = THREADS, mask = nbins - 1;
     const uint32_t sh32 = (uint32_t) (32 - region_bits + shift); // digit = (high word >> sh32) & mask  (region_bits <= 22)
     auto bin_of = [&](uint64_t item) -> uint32_t { return ((uint32_t) (item >> 32) >> sh32) & mask; };
     clk.mark(0); // everything between two tiles: the loads, the front end of level 1
@@ -928,7 +930,7 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
         const uint4 *w4 = reinterpret_cast<const uint4 *>(l.wtot);
         const uint32_t wave = tid >> 6;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < THREADS / 256; q++) {
             const uint4 v = w4[q];
             const uint32_t e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1326,13 +1328,14 @@ __global__ void __launch_bounds__(256) k_arr_scan_b(const uint64_t *tot, const u
 // where items went to the spill list: the build clamps it).  The units of a partition are the workgroups 8 apart in the grid:
 // the dispatcher deals workgroups out to the 8 XCDs round robin, so they run at the same time on the same XCD and its L2 sees
 // their runs of a leaf side by side (see tile_scatter_seg).
-template <int IT, bool SEGM, bool SHARED = false>
-__global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
+template <int IT, bool SEGM, bool SHARED = false, int THREADS = SCATTER_THREADS>
+__global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
                                                       const uint64_t *offs_rel, const uint64_t *outbounds, uint64_t *out,
                                                       uint64_t seg_cap, uint32_t *seg_ovf, uint32_t *leafcnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t TILE = 16u * THREADS; // (THREADS < 1024: SEGM only -- half tiles, two workgroups per CU)
     ScatterLds l = scatter_lds(smem, pl.bins);
-    SegLds ls = seg_lds(smem, pl.bins);
+    SegLds ls = seg_lds(smem, pl.bins, TILE);
     uint64_t sp = blockIdx.x / pl.chunks;
     uint32_t my_chunk = blockIdx.x % pl.chunks;
     if (SHARED && pl.seg_units && (pl.nparts & 7u) == 0u) {
@@ -1378,7 +1381,7 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
     constexpr bool PADDED = IT == IT_HASH && SEGM;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     uint64_t nxt[16];
-    // PADDED: 16 bytes per lane and request -- item 2 j2 + e of a thread is element j2 * 2048 + 2 tid + e of the tile (the
+    // PADDED: 16 bytes per lane and request -- item 2 j2 + e of a thread is element j2 * 2 THREADS + 2 tid + e of the tile (the
     // unit starts on a multiple of 16 items: segment sizes are multiples of 16)
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -1401,8 +1404,8 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
 #endif
                 nxt[2 * j2] = q.x;
                 nxt[2 * j2 + 1] = q.y;
-                o += 2048u;
-                if (pl.seg_cap >= 2048u) { if (o >= pl.seg_cap) { o -= pl.seg_cap; u++; } }
+                o += 2u * THREADS;
+                if (pl.seg_cap >= 2u * THREADS) { if (o >= pl.seg_cap) { o -= pl.seg_cap; u++; } }
                 else { const uint32_t d = o / pl.seg_cap; u += d; o -= d * pl.seg_cap; }
             }
         }
@@ -1416,20 +1419,20 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
         vm_wait_all();
     }
     clk.start();
-    for (uint64_t t0 = i0; t0 < i1; t0 += TILE_ITEMS) {
+    for (uint64_t t0 = i0; t0 < i1; t0 += TILE) {
         uint64_t it[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            if (PADDED) it[j] = t0 + (uint64_t) (j >> 1) * 2048 + 2u * threadIdx.x + (j & 1) < i1 ? nxt[j] : CKEY_EMPTY;
+            if (PADDED) it[j] = t0 + (uint64_t) (j >> 1) * (2u * THREADS) + 2u * threadIdx.x + (j & 1) < i1 ? nxt[j] : CKEY_EMPTY;
             else it[j] = nxt[j];
         }
         // the next tile is requested before this one is sorted: its HBM latency hides under the LDS work
         if (PADDED) {
-            tile_request(t0 + TILE_ITEMS);
+            tile_request(t0 + TILE);
         } else {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const uint64_t i = t0 + TILE_ITEMS + (uint64_t) j * blockDim.x + threadIdx.x;
+                const uint64_t i = t0 + TILE + (uint64_t) j * blockDim.x + threadIdx.x;
                 nxt[j] = i < i1 ? in[i] : CKEY_EMPTY;
             }
         }
@@ -1438,7 +1441,7 @@ __global__ void __launch_bounds__(1024) k_arr_scatter(const uint64_t *in, const 
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
         }
-        if (SEGM) tile_scatter_seg<PADDED, SHARED>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
+        if (SEGM) tile_scatter_seg<PADDED, SHARED, THREADS>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
         else tile_scatter<IT == IT_KEY_TO_HASH ? IT_HASH : IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
     if (SEGM) {
@@ -1859,7 +1862,7 @@ static int materialize(kmu_counter *c) {
 static int scatter_attrs(kmu_ctx *ctx) {
     if (ctx->lds_attr_set & 1u) return KMU_OK;
     const void *fns[] = {(const void *) k_part_scatter1<false>, (const void *) k_part_scatter1<true>, (const void *) k_part_scatter1<true, true>,
-                         (const void *) k_arr_scatter<IT_HASH, false>, (const void *) k_arr_scatter<IT_HASH, true>, (const void *) k_arr_scatter<IT_HASH, true, true>,
+                         (const void *) k_arr_scatter<IT_HASH, false>, (const void *) k_arr_scatter<IT_HASH, true>, (const void *) k_arr_scatter<IT_HASH, true, true>, (const void *) k_arr_scatter<IT_HASH, true, true, 512>,
                          (const void *) k_arr_scatter<IT_KEY, false>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, false>,
                          (const void *) k_arr_scatter<IT_KEY_TO_HASH, true>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, true, true>};
     for (const void *f : fns) KMU_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1908,7 +1911,8 @@ static bool seg_partition_wanted(uint64_t total_bases) {
     const char *e = getenv("KMU_COUNT_SEG"); // 0: always the exact two-pass levels (A/B); 2: also for small batches (tests)
     if (e && atoi(e) == 0) return false;
     if (e && atoi(e) == 2) return true;
-    if (total_bases >> 40) return false; // (positions inside a level-1 bin are 32-bit numbers)
+    if (total_bases >> 35) return false; // (positions inside a level-1 bin and the cursors of the shared segments are 32-bit numbers:
+                                         //  a set of streams sees at most total / sets items, whatever their bins)
     return total_bases >= (1ull << 27); // (the margins are a small share of the mean only for big batches)
 }
 static bool seg_layout_bin() { // A/B runs: level 1's output with the ranges of the bins side by side instead of the units' blocks
@@ -2087,6 +2091,30 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                            (uint32_t) run->sp.cap1, (uint64_t *) run->A);
     return KMU_OK;
 }
+// level 2 of a single-pass partition: A (level 1's segments: ap.seg_*) -> the leaves in B; shared: ap.chunks units per bin share
+// the bin's leaves (cursors in leafcnt).  Shared leaves free the tile size from the length of a run: with <= 1 024 bins a
+// workgroup is 512 threads on tiles of 8 192 items (76 KiB of LDS), TWO per CU, and the LDS phases of one run under the memory
+// phases of the other (thread-0 clocks of the one-workgroup form: rank / scan / place 65 %, loads + stores 35 %, one after the
+// other) -- measured: 19.4-19.6 ms against 16.4-17.8 for one workgroup of 1 024 threads (18.4 / 17.8 with 32 / 64 units per bin):
+// the level runs at 4 TB/s either way, the memory system's rate for this mix; KMU_COUNT_L2_THREADS=512 keeps the A/B
+static int seg_launch_level2(kmu_ctx *ctx, const ArrPlan &ap, bool shared, const void *A, const void *bnd, void *B, uint64_t cap2, void *ovf,
+                             void *leafcnt) {
+    const uint32_t bins2 = ap.bins;
+    if (shared) KMU_HIP(ctx, hipMemsetAsync(leafcnt, 0, (size_t) ap.nparts * bins2 * 4, ctx->stream));
+    int threads = SCATTER_THREADS;
+    if (shared && bins2 <= 1024u) {
+        const char *te = getenv("KMU_COUNT_L2_THREADS");
+        threads = te ? atoi(te) : 1024;
+        if (threads != 512) threads = SCATTER_THREADS;
+    }
+    auto k2 = shared ? k_arr_scatter<IT_HASH, true, true> : k_arr_scatter<IT_HASH, true, false>;
+    if (threads == 512) k2 = k_arr_scatter<IT_HASH, true, true, 512>;
+    KernelTimer tm(ctx, "k_arr_scatter");
+    hipLaunchKernelGGL(k2, dim3(ap.nparts * ap.chunks), dim3(threads), seg_lds_bytes(bins2, 16u * (uint32_t) threads), ctx->stream, (const uint64_t *) A,
+                       (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf,
+                       (uint32_t *) leafcnt);
+    return KMU_OK;
+}
 // the rest of level 1, level 2, the overflow flag, the build.  *taken = 0: a segment overflowed, the table is untouched.
 static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     kmu_ctx *ctx = c->ctx;
@@ -2097,12 +2125,7 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     {
         ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2, run->sp.sets ? run->sp.sets : run->sp.units1, (uint32_t) run->sp.cap1, bins1};
         if (seg_layout_bin()) { ap.seg_units = 1; ap.seg_cap = (uint32_t) run->sp.bincap1; }
-        if (run->sp.shared2) KMU_HIP(ctx, hipMemsetAsync(run->leafcnt, 0, (size_t) bins1 * bins2 * 4, ctx->stream));
-        const auto k2 = run->sp.shared2 ? k_arr_scatter<IT_HASH, true, true> : k_arr_scatter<IT_HASH, true, false>;
-        KernelTimer tm(ctx, "k_arr_scatter");
-        hipLaunchKernelGGL(k2, dim3(bins1 * run->sp.chunks2), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream,
-                           (const uint64_t *) run->A, (const uint64_t *) run->bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
-                           (uint64_t *) run->B, run->sp.cap2, (uint32_t *) run->ovf, (uint32_t *) run->leafcnt);
+        KMU_TRY(seg_launch_level2(ctx, ap, run->sp.shared2 != 0, run->A, run->bnd, run->B, run->sp.cap2, run->ovf, run->leafcnt));
     }
     KMU_HIP(ctx, hipGetLastError());
     uint32_t h_ovf[2] = {0, 0}; // read before the table is touched: a full spill list leaves the call to the exact route
@@ -2348,12 +2371,7 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) bnd, (uint64_t) bins1 + 1, bincap1);
     {
         ArrPlan ap{pl.region_bits, 0, bins2, bins1, units2 ? units2 : 1u, pieces, (uint32_t) cap1, bins1, 0u};
-        if (units2) KMU_HIP(ctx, hipMemsetAsync(leafcnt, 0, (size_t) bins1 * bins2 * 4, ctx->stream));
-        const auto k2 = units2 ? k_arr_scatter<IT_HASH, true, true> : k_arr_scatter<IT_HASH, true, false>;
-        KernelTimer tm(ctx, "k_arr_scatter");
-        hipLaunchKernelGGL(k2, dim3(bins1 * ap.chunks), dim3(SCATTER_THREADS), seg_lds_bytes(bins2), ctx->stream, (const uint64_t *) A,
-                           (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf,
-                           (uint32_t *) leafcnt);
+        KMU_TRY(seg_launch_level2(ctx, ap, units2 != 0, A, bnd, B, cap2, ovf, leafcnt));
     }
     KMU_HIP(ctx, hipGetLastError());
     uint32_t h_ovf[2] = {0, 0};

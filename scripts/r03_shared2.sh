@@ -2,7 +2,7 @@
 # level 2 with the leaves of a bin shared by several units (cursors): tests with it forced, then the A/B
 cd $GRAFT_REPO_ROOT
 if [ -z "$SKIP_TESTS" ]; then
-KMU_COUNT_L2_SHARED=4 timeout -k 10 600 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_count_quot.py tests/test_gpu_parity.py -x -q -m gpu -k "count or pipeline or single_pass" > gpurun_out/t_shared2.log 2>&1
+KMU_COUNT_L2_THREADS=512 timeout -k 10 600 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_count_quot.py tests/test_gpu_parity.py -x -q -m gpu -k "count or pipeline or single_pass" > gpurun_out/t_shared2.log 2>&1
 rc=$?
 tail -5 gpurun_out/t_shared2.log
 [ $rc -eq 0 ] || exit 1
@@ -17,11 +17,10 @@ run() { # label env...
 import json;d=json.loads(open('gpurun_out/ab_shared2_$label.json').read().strip().splitlines()[-1])
 print('$label', 'dev ms',round(d['ms_per_step'],2), {k:round(v['avg_ms'],2) for k,v in d['kernels'].items() if k.startswith('k_part') or k.startswith('k_arr')}, d['checks'])"
 }
-run c16 KMU_COUNT_L2_SHARED=16
-run c32 KMU_COUNT_L2_SHARED=32
-run c64 KMU_COUNT_L2_SHARED=64
-run c128 KMU_COUNT_L2_SHARED=128
-run c32b KMU_COUNT_L2_SHARED=32
-run c16b KMU_COUNT_L2_SHARED=16
-run c32_s32 KMU_COUNT_L2_SHARED=32 KMU_COUNT_SEG_SHARED=32
-run c32_s8 KMU_COUNT_L2_SHARED=32 KMU_COUNT_SEG_SHARED=8
+run t1024 KMU_X=1
+run t512 KMU_COUNT_L2_THREADS=512
+run t512_c8 KMU_COUNT_L2_THREADS=512 KMU_COUNT_L2_SHARED=8
+run t512_c32 KMU_COUNT_L2_THREADS=512 KMU_COUNT_L2_SHARED=32
+run t1024b KMU_X=1
+run t512b KMU_COUNT_L2_THREADS=512
+run t512_c64 KMU_COUNT_L2_THREADS=512 KMU_COUNT_L2_SHARED=64
