@@ -2506,13 +2506,13 @@ static int local_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, ui
 
 // ---- distributed counting (KMU_COUNT_DISTRIBUTED; kmu.h "multi-GPU") ---------------------------------------------------------
 // Cost model of the two routes for a rank's batch of n k-mer occurrences holding d distinct k-mers, in picoseconds per item,
-// measured on one MI355X with the single-rank communicator (scripts/routes.sh, profiles/r02_routes.json as of r02e; ONT-shaped
-// 4.36 G k-mers and config 4's 0.75 G agree within 20 %): the owner census + duplication sample 3.5 / occurrence (both routes
-// pay it), the scatter by owner 5.9, building a table from received keys 17.3 / key (two single-pass array-partition levels
-// + region build), the local build from reads 16.4 / occurrence, two passes over the table image for the export of MERGE
-// (4.8 TB/s), a received (k-mer, count) entry added by direct insertion ~60 / entry; the links: KMU_XGMI_GBPS per GPU and
-// direction, all peers at once (default 350: seven links of 153 GB/s at ~1/3 efficiency until a multi-GPU measurement
-// replaces it).
+// measured on one MI355X with the single-rank communicator (scripts/routes.sh; r03c: gpurun_out/routes_r03c.txt, ONT-shaped 4.36 G
+// k-mers / config 4's 0.75 G): the owner census + duplication sample 2.4 / 4.1 per occurrence (both routes pay it), the scatter by
+// owner 5.9 / 7.5, building a table from received keys 13.1 / 13.0 per key (two single-pass array-partition levels with shared
+// segments + region build; 17.3 before round 3), the local build from reads 13.2 / 15.5 per occurrence (16.4 before), two passes
+// over the table image for the export of MERGE (17.5 ms per pass over 68.7 GB: 4.0 TB/s), a received (k-mer, count) entry
+// added by direct insertion ~60 / entry; the links: KMU_XGMI_GBPS per GPU and direction, all peers at once (default 350: seven
+// links of 153 GB/s at ~1/3 efficiency until a multi-GPU measurement replaces it).
 // Every input is either gathered from all ranks or a constant: the ranks MUST arrive at the same route (a rank on
 // OCCURRENCES enters an all-to-all that a rank on MERGE does not).  table_bytes: the largest table image among the ranks;
 // gbps: rank 0's KMU_XGMI_GBPS.
@@ -2523,8 +2523,8 @@ static double local_xgmi_gbps() {
 static void route_model(double table_bytes, double gbps, double n, double d, int nranks, double *ms_occ, double *ms_merge) {
     const double f = nranks > 1 ? (double) (nranks - 1) / nranks : 0.0;
     const double ps = 1e-9; // ps -> ms
-    *ms_occ = n * (3.5 + 5.9 + 17.3) * ps + 8.0 * n * f / (gbps * 1e6);
-    *ms_merge = n * (3.5 + 16.4) * ps + 2.0 * table_bytes / 4.8e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
+    *ms_occ = n * (3.0 + 6.2 + 13.1) * ps + 8.0 * n * f / (gbps * 1e6);
+    *ms_merge = n * (3.0 + 13.5) * ps + 2.0 * table_bytes / 4.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
 }
 
 // first half of a distributed add: census of the owners + duplication sample, agreement on the route over all ranks, then
