@@ -67,6 +67,8 @@ struct SketchArgs {
     // host before the multiset kernels, only k_multiset_uq writes it
     uint32_t *lst_nu;
     uint32_t *queue2;     // read counter of k_pmh_points
+    uint32_t *pts_long;   // k_pmh_points: reads a whole workgroup takes ([0] count, [2..] indices; k_pts_long_list), or null
+    uint32_t pts_long_t;  // ... those with more list entries than this
     // The PLAIN instantiation leaves a sequence whose k-mers overflow a pass (repetitive reads: rounds with carry lists) to
     // the general one: it appends the sequence to redo_list (count in queue[56]); the second launch walks read_list.
     uint32_t *redo_list;
@@ -1030,22 +1032,164 @@ __device__ __forceinline__ void pmh3a_first_point_rest(const SketchArgs &a, bool
 // minima (16 m bytes) + the shared q_max word.  Pass 1 = first point of every key; pass 2 = further rounds for the keys
 // with winv < q_max (a key is deferred in pass 1 exactly when winv < q_max then, and q_max only falls: re-testing
 // against the settled q_max selects a subset of the deferred keys, those that can still produce a point below it).
-template <bool SIG32>
-__global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// LONG reads (more than pts_long_t list entries; their indices are in pts_long: [0] count, [2..] indices, k_pts_long_list)
+// come first and are taken by a whole WORKGROUP: its four waves walk every fourth chunk of the list with slot arrays of their
+// own and the row is the per-slot minimum of the four (smaller h, then smaller key: the rule of slot_update_wave).  A wave
+// prunes with the q_max of ITS minima, which is >= the q_max of the merged ones -- it only rejects points that cannot be a
+// slot's minimum -- so the row is the one a single wave makes.  One wave does 4.6e4 k-mers per ms: a 200 kb read alone took
+// 4.3 ms, twice what the kernel needs for a 512 MB chunk of the host leg.
+__global__ void __launch_bounds__(256) k_pts_long_list(const uint32_t *lst_n, uint32_t n_seq, uint32_t thr, uint32_t *out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_seq && lst_n[r] > thr) out[2 + atomicAdd(&out[0], 1u)] = r;
+}
+// q_max over the minima of the four waves of a workgroup together (a long read's waves prune with it: a point at or above it
+// cannot be the minimum of its slot in the merged row either; without it every wave fills all m slots from its quarter of the
+// keys alone and the four make ~3x the accepted points of one wave)
+__device__ __forceinline__ uint64_t wg4_qmax(const uint64_t *arrays, size_t wave_words, int m) {
+    uint64_t q = 0;
+    for (int t = lane_id(); t < m; t += 64) {
+        uint64_t v = H_INIT;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; w4++) {
+            const uint64_t x = __hip_atomic_load(&arrays[(size_t) w4 * wave_words + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            v = x < v ? x : v;
+        }
+        q = v > q ? v : q;
+    }
+    return wave_max_u64(q);
+}
+
+// one read's points.  WG = false: by this wave alone (chunks 0, 64, 128, ...).  WG = true: by the four waves of the workgroup,
+// wave w on chunks 64 w, 64 w + 256, ... with slot arrays of its own, the row = per-slot minimum of the four.
+template <bool SIG32, bool WG>
+__device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, uint8_t *smem, size_t wave_words, const double *winv_lut) {
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    constexpr bool sig32 = SIG32; // (the host instantiates both widths)
-    // per wave: slot minima, arg-min keys, q_max word, and a queue of 128 (key, weight) pairs that passed the cheap test:
-    // they are worked off 64 at a time, so the expensive half of a first point always runs with all lanes busy
-    uint64_t *hmin = reinterpret_cast<uint64_t *>(smem) + (size_t) wave * (2 * (size_t) a.m + PTS_WAVE_WORDS);
+    constexpr bool sig32 = SIG32;
+    constexpr uint32_t cstride = WG ? 256u : 64u;
+    const uint32_t cstart = WG ? 64u * (uint32_t) wave : 0u;
+    uint64_t *arrays = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *hmin = arrays + (size_t) wave * wave_words;
     uint64_t *sig = hmin + a.m;
     uint64_t *qmax_sh = sig + a.m;
     uint64_t *qk = qmax_sh + 2;
     uint32_t *qw = reinterpret_cast<uint32_t *>(qk + 128);
     uint64_t *qs0 = qk + 128 + 64, *qs3 = qs0 + 128; // the two xoshiro state words the cheap test computed
-    double *winv_lut = reinterpret_cast<double *>(reinterpret_cast<uint64_t *>(smem) + (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS));
+    const uint64_t base = a.offsets[r] - a.offsets[0];
+    const uint32_t n = uniform_u32(a.lst_n[r]);
+    const uint32_t n_u = uniform_u32(a.lst_nu[r]); // leading entries of weight 1 without a weight word
+    for (int t = lane; t < a.m; t += 64) { hmin[t] = H_INIT; sig[t] = 0; }
+    if (lane == 0) *qmax_sh = H_INIT;
+    if (WG) __syncthreads(); // (the other waves' arrays are looked at from the first refresh on)
+    // ---- pass 1 ----
+    uint32_t chunk = 0, qn = 0; // qn: queued pairs (uniform)
+    uint32_t wmax = 0;          // largest weight this lane saw
+    uint64_t qb = H_INIT;
+    uint64_t key_nx = 0; // the next chunk's pair is requested one iteration ahead
+    uint32_t w_nx = 1;
+    {
+        const uint32_t i = cstart + (uint32_t) lane;
+        if (i < n) { key_nx = a.lst_keys[base + i]; w_nx = i < n_u ? 1u : a.lst_w[base + i]; }
+    }
+    for (uint32_t c = cstart; c < n; c += cstride, chunk++) { // uniform trip count
+        const uint32_t i = c + (uint32_t) lane;
+        const uint64_t key = key_nx;
+        const uint32_t w = w_nx;
+        const bool have = i < n && w != 0u; // weight 0: a repeat of an earlier entry
+        if (have) wmax = w > wmax ? w : wmax;
+        if (i + cstride < n) key_nx = a.lst_keys[base + i + cstride];
+        w_nx = 1u;
+        if (c + cstride + 64u > n_u) { // (uniform: the next chunk reaches beyond the weight-1 prefix)
+            if (i + cstride < n && i + cstride >= n_u) w_nx = a.lst_w[base + i + cstride];
+        }
+        if ((chunk & (WG ? PTS_REFRESH_MASK >> 2 : PTS_REFRESH_MASK)) == 0u) {
+            qb = WG ? wg4_qmax(arrays, wave_words, a.m) : wave_qmax(hmin, a.m);
+            if (lane == 0) *qmax_sh = qb;
+        }
+        uint64_t s0 = 0, s3 = 0;
+        const bool pass = have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
+        const uint64_t pm = __ballot(pass);
+        if (pass) {
+            const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));
+            qk[pos] = key;
+            qw[pos] = w;
+            qs0[pos] = s0;
+            qs3[pos] = s3;
+        }
+        qn += (uint32_t) __popcll(pm);
+        if (qn >= 64u) { // the newest 64
+            qn -= 64u;
+            pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane], qs3[qn + lane],
+                                   winv_lut);
+        }
+    }
+    if (qn) {
+        const bool have = (uint32_t) lane < qn;
+        pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u, have ? qs0[lane] : 0ull,
+                               have ? qs3[lane] : 0ull, winv_lut);
+    }
+    // ---- pass 2 ----
+    // (only a key with 1 / w < q_max draws again: with the largest weight of the read at hand the lists are read a
+    //  second time only where that can happen at all)
+    if (WG) {
+        __syncthreads(); // every wave's first points are in
+        qb = wg4_qmax(arrays, wave_words, a.m);
+    } else qb = wave_qmax(hmin, a.m);
+    wmax = (uint32_t) wave_max_u64((uint64_t) wmax);
+    if (n && wmax && winv_of(winv_lut, wmax) < __longlong_as_double((long long) qb) && !ABL(512u)) { // (ABL: diagnostic builds, pass 2 left out: wrong rows, its share of the time)
+        // (a key of weight 1 draws again only while q_max > 1: with every slot hit q_max < 1 -- Exp01 is restricted to
+        //  [0, 1) -- and the weight-1 prefix of the list is not read a second time)
+        const uint32_t c0 = 1.0 < __longlong_as_double((long long) qb) ? 0u : (n_u & ~63u);
+        uint32_t c = cstart;
+        if (c < c0) c += (c0 - c + cstride - 1u) / cstride * cstride; // this wave's first chunk at or behind c0
+        for (; c < n; c += cstride) {
+            const uint32_t i = c + (uint32_t) lane;
+            double winv = 0.0;
+            bool alive = false;
+            if (i < n) {
+                const uint32_t w = i < n_u ? 1u : a.lst_w[base + i];
+                winv = winv_of(winv_lut, w);
+                alive = w != 0u && winv < __longlong_as_double((long long) qb);
+            }
+            if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
+        }
+    }
+    // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
+    if (WG) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < a.m; t += 256) {
+            uint64_t bh = arrays[t], bk = arrays[a.m + t];
+#pragma unroll
+            for (int w4 = 1; w4 < 4; w4++) { // smaller h, then smaller key: slot_update_wave's rule
+                const uint64_t h = arrays[(size_t) w4 * wave_words + t], kk = arrays[(size_t) w4 * wave_words + a.m + t];
+                if (h < bh || (h == bh && kk < bk)) { bh = h; bk = kk; }
+            }
+            const uint64_t v = bh == H_INIT ? 0ull : bk;
+            if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * a.m + t] = (uint32_t) v;
+            else reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = v;
+        }
+        __syncthreads(); // (the arrays are wiped for the next read behind it)
+    } else {
+        for (int t = lane; t < a.m; t += 64) {
+            const uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
+            if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * a.m + t] = (uint32_t) v;
+            else reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = v;
+        }
+    }
+}
+
+template <bool SIG32>
+__global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = lane_id();
+    // per wave: slot minima, arg-min keys, q_max word, and a queue of 128 (key, weight) pairs that passed the cheap test:
+    // they are worked off 64 at a time, so the expensive half of a first point always runs with all lanes busy
+    const size_t wave_words = 2 * (size_t) a.m + PTS_WAVE_WORDS;
+    double *winv_lut = reinterpret_cast<double *>(reinterpret_cast<uint64_t *>(smem) + (size_t) 4 * wave_words);
     for (uint32_t t = threadIdx.x; t < WINV_LUT; t += blockDim.x) winv_lut[t] = t ? 1.0 / (double) t : 0.0;
     __syncthreads();
+    // the long reads first, a workgroup each (workgroup b: entries b, b + grid, ... of the list)
+    const uint32_t n_long = a.pts_long ? a.pts_long[0] : 0u;
+    for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) pts_one_read<SIG32, true>(a, a.pts_long[2 + li], smem, wave_words, winv_lut);
     uint32_t q_next = 0, q_end = 0; // lane 0: reads are taken QCHUNK at a time
     for (;;) {
         uint32_t r = 0;
@@ -1058,82 +1202,8 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         }
         r = uniform_u32(r);
         if (r >= a.n_seq) break;
-        const uint64_t base = a.offsets[r] - a.offsets[0];
-        const uint32_t n = a.lst_n[r];
-        const uint32_t n_u = uniform_u32(a.lst_nu[r]); // leading entries of weight 1 without a weight word
-        for (int t = lane; t < a.m; t += 64) { hmin[t] = H_INIT; sig[t] = 0; }
-        if (lane == 0) *qmax_sh = H_INIT;
-        // ---- pass 1 ----
-        uint32_t chunk = 0, qn = 0; // qn: queued pairs (uniform)
-        uint32_t wmax = 0;          // largest weight this lane saw
-        uint64_t qb = H_INIT;
-        uint64_t key_nx = 0; // the next chunk's pair is requested one iteration ahead
-        uint32_t w_nx = 1;
-        if ((uint32_t) lane < n) { key_nx = a.lst_keys[base + lane]; w_nx = (uint32_t) lane < n_u ? 1u : a.lst_w[base + lane]; }
-        for (uint32_t c = 0; c < n; c += 64, chunk++) { // uniform trip count
-            const uint32_t i = c + (uint32_t) lane;
-            const uint64_t key = key_nx;
-            const uint32_t w = w_nx;
-            const bool have = i < n && w != 0u; // weight 0: a repeat of an earlier entry
-            if (have) wmax = w > wmax ? w : wmax;
-            if (i + 64u < n) key_nx = a.lst_keys[base + i + 64u];
-            w_nx = 1u;
-            if (c + 128u > n_u) { // (uniform: the next chunk reaches beyond the weight-1 prefix)
-                if (i + 64u < n && i + 64u >= n_u) w_nx = a.lst_w[base + i + 64u];
-            }
-            if ((chunk & PTS_REFRESH_MASK) == 0u) {
-                qb = wave_qmax(hmin, a.m);
-                if (lane == 0) *qmax_sh = qb;
-            }
-            uint64_t s0 = 0, s3 = 0;
-            const bool pass = have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
-            const uint64_t pm = __ballot(pass);
-            if (pass) {
-                const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));
-                qk[pos] = key;
-                qw[pos] = w;
-                qs0[pos] = s0;
-                qs3[pos] = s3;
-            }
-            qn += (uint32_t) __popcll(pm);
-            if (qn >= 64u) { // the newest 64
-                qn -= 64u;
-                pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane],
-                                       qs3[qn + lane], winv_lut);
-            }
-        }
-        if (qn) {
-            const bool have = (uint32_t) lane < qn;
-            pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u,
-                                   have ? qs0[lane] : 0ull, have ? qs3[lane] : 0ull, winv_lut);
-        }
-        // ---- pass 2 ----
-        // (only a key with 1 / w < q_max draws again: with the largest weight of the read at hand the lists are read a
-        //  second time only where that can happen at all)
-        qb = wave_qmax(hmin, a.m);
-        wmax = (uint32_t) wave_max_u64((uint64_t) wmax);
-        if (n && wmax && winv_of(winv_lut, wmax) < __longlong_as_double((long long) qb) && !ABL(512u)) { // (ABL: diagnostic builds, pass 2 left out: wrong rows, its share of the time)
-            // (a key of weight 1 draws again only while q_max > 1: with every slot hit q_max < 1 -- Exp01 is restricted to
-            //  [0, 1) -- and the weight-1 prefix of the list is not read a second time)
-            const uint32_t c0 = 1.0 < __longlong_as_double((long long) qb) ? 0u : (n_u & ~63u);
-            for (uint32_t c = c0; c < n; c += 64) {
-                const uint32_t i = c + (uint32_t) lane;
-                double winv = 0.0;
-                bool alive = false;
-                if (i < n) {
-                    const uint32_t w = i < n_u ? 1u : a.lst_w[base + i];
-                    winv = winv_of(winv_lut, w);
-                    alive = w != 0u && winv < __longlong_as_double((long long) qb);
-                }
-                if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
-            }
-        }
-        // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
-        for (int t = lane; t < a.m; t += 64) {
-            const uint64_t v = hmin[t] == H_INIT ? 0ull : sig[t];
-            if (sig32) reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * a.m + t] = (uint32_t) v;
-            else reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * a.m + t] = v;
-        }
+        if (n_long && uniform_u32(a.lst_n[r]) > a.pts_long_t) continue; // (taken by a workgroup above)
+        pts_one_read<SIG32, false>(a, r, smem, wave_words, winv_lut);
     }
 }
 
@@ -2312,6 +2382,34 @@ static bool smallk_route(const kmu_sketch_params *p, int hashed_bytes, bool part
     return !(e && atoi(e) == 0);
 }
 
+// k_pmh_points over the lists of a.n_seq reads; reads with more than KMU_PMH_PTS_LONG list entries (default 32 768; 0: none)
+// are listed first (k_pts_long_list) and taken by whole workgroups
+static int launch_points(kmu_ctx *ctx, SketchArgs a, int cus) {
+    void (*const kpts)(SketchArgs) = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
+    const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
+    if (lds2 > 64 * 1024)
+        KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
+    const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) a.n_seq + 3) / 4, (uint64_t) cus * per_cu)); // (cus: see KMU_PMH_RESERVE_CUS)
+    uint32_t thr = 32768; // (bench: the device leg is the same with or without; the host leg's chunks gain 1.3 ms of 128; 16 384: +0.4 ms on the device leg, 8 192: +2)
+    if (const char *e = getenv("KMU_PMH_PTS_LONG")) thr = (uint32_t) std::max(0, atoi(e));
+    a.pts_long = nullptr;
+    a.pts_long_t = thr;
+    if (thr && a.n_seq) {
+        if (thr < 1024u) a.pts_long_t = thr = 1024u; // (a workgroup's four waves all need chunks of their own)
+        void *pl;
+        KMU_TRY(dev_buf(ctx, "pts.long", ((size_t) a.n_seq + 2) * 4 + 64, &pl));
+        KMU_HIP(ctx, hipMemsetAsync(pl, 0, 8, ctx->stream));
+        a.pts_long = (uint32_t *) pl;
+        hipLaunchKernelGGL(k_pts_long_list, dim3((a.n_seq + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *) a.lst_n, a.n_seq, thr,
+                           (uint32_t *) pl);
+    }
+    KernelTimer t(ctx, "k_pmh_points");
+    hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+
 static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, const uint64_t *d_block_rows,
                         void *d_sig, uint32_t *d_counts, uint32_t *d_err, const void *hashed = nullptr,
                         int hashed_bytes = 0, uint64_t *part_h = nullptr, uint64_t *part_k = nullptr,
@@ -2409,15 +2507,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         }
         KMU_HIP(ctx, hipGetLastError());
         if (emit) {
-            const sketch_kernel_t kpts = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
-            const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
-            if (lds2 > 64 * 1024)
-                KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
-            const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) cus * per_cu));
-            KernelTimer t(ctx, "k_pmh_points");
-            hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
-            KMU_HIP(ctx, hipGetLastError());
+            KMU_TRY(launch_points(ctx, a, cus));
         }
         return KMU_OK;
     }
@@ -2447,7 +2537,11 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         }
         if (split_mode != 1) {
             const double cu_share = (double) ctx->num_cus / 256.0;
-            const double t_ideal = (double) total / (2.05e8 * cu_share), t_tail = (double) len_stats[0] / 4.0e4; // ms
+            // (a wave of k_pmh_points does 4.0e4 k-mers per ms; a read beyond KMU_PMH_PTS_LONG is taken by four)
+            const char *ple = getenv("KMU_PMH_PTS_LONG");
+            const uint64_t pts_thr = ple ? (uint64_t) std::max(0, atoi(ple)) : 32768u;
+            const double wave_rate = pts_thr && len_stats[0] > pts_thr ? 1.6e5 : 4.0e4;
+            const double t_ideal = (double) total / (2.05e8 * cu_share), t_tail = (double) len_stats[0] / wave_rate; // ms
             const double overhang = t_tail >= t_ideal ? t_tail - 0.5 * t_ideal : t_tail * t_tail / (2.0 * t_ideal);
             // (r02: with the reads that fit a workgroup's registers on k_multiset_uq the two-kernel route takes 53 ms where the
             //  single kernel takes 87 on the ONT workload: 39 % of the single kernel's time, 16 % before)
@@ -2659,15 +2753,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
         KMU_HIP(ctx, hipGetLastError());
     } else if (split) {
-        const sketch_kernel_t kpts = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
-        const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
-        if (lds2 > 64 * 1024)
-            KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2));
-        const int grid2 = (int) std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t) ds.n_seq + 3) / 4, (uint64_t) cus * per_cu)); // (cus: see KMU_PMH_RESERVE_CUS)
-        KernelTimer t(ctx, "k_pmh_points");
-        hipLaunchKernelGGL(kpts, dim3(grid2), dim3(256), lds2, ctx->stream, a);
-        KMU_HIP(ctx, hipGetLastError());
+        KMU_TRY(launch_points(ctx, a, cus));
     }
     if (plain && !uq) { // (after the points kernel, whose row for such a sequence is empty)
         // sequences whose k-mers overflowed a pass (repetitive ones): the general instantiation redoes them in rounds

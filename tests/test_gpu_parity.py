@@ -1058,6 +1058,33 @@ def test_partial_sketches_merge_to_the_all_sequences_sketch(ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("thr", ["1024", "0"])
+def test_points_of_long_reads_by_workgroups(ctx, oracle, monkeypatch, thr):
+    """k_pmh_points hands reads with more than KMU_PMH_PTS_LONG list entries (default 32 768; here 1 024, and 0 = never) to a
+    whole workgroup: four waves with slot minima of their own on every fourth chunk of the list, the row their per-slot
+    minimum.  Same rows as the oracle -- for unique keys, for weights > 1 (tandem repeats, a unit repeated ten times: the later
+    ProbMinHash rounds run per wave against the merged q_max), for lists that are not a multiple of a chunk, both signature
+    widths, m below and above a wave."""
+    monkeypatch.setenv("KMU_PMH_SPLIT", "1")
+    monkeypatch.setenv("KMU_PMH_PTS_LONG", thr)
+    rng = np.random.default_rng(2103)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs = [rng.choice(acgt, size=int(n)).tobytes() for n in (12, 300, 1100, 1054, 5000, 20001, 45000, 9000, 1311)]
+    seqs.append(b"ACGGT" * 3000)
+    seqs.append(rng.choice(acgt, size=2000).tobytes() * 10)
+    seqs.append(rng.choice(acgt, size=700).tobytes() * 3 + rng.choice(acgt, size=3000).tobytes())
+    bases, off = oracle.concat(seqs)
+    for kmer_type, k, sig, m in ((A.KMER64BIT, 31, A.SIG_U64, 200), (A.KMER64BIT, 21, A.SIG_U64, 37), (A.KMER16B32BIT, 16, A.SIG_U32, 64)):
+        p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, m, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        got = np.asarray(ctx.sketch(bases, off, p))
+        ctx.profile_enable(False)
+        assert "k_pmh_points" in ctx.profile_get()
+        assert np.array_equal(got, oracle.sketch(bases, off, p)), (kmer_type, k, m)
+
+
+@pytest.mark.gpu
 def test_probminhash_many_reads_default_route(ctx, oracle, monkeypatch):
     """A big batch of reads takes the two-kernel route by itself (multiset kernel -> (key, weight) lists -> k_pmh_points,
     one wave per read): rows equal to the oracle's, for u64 and u32 signatures, with reads shorter than k and repetitive
