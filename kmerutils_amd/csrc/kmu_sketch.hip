@@ -98,6 +98,9 @@ static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions 
 static constexpr uint32_t DEF_PARTS = 32;           //   one sub-list of DEF_CAP / DEF_PARTS keys per later partition
 static constexpr uint32_t DEF_SEG = DEF_CAP / DEF_PARTS;
 #define ABL(bits) (KMU_DIAG && (a.ablate & (bits)))
+#ifndef KMU_PTS_UNITW // (A/B builds: 0 = the cheap test of k_pmh_points looks 1 / w up for every chunk)
+#define KMU_PTS_UNITW 1
+#endif
 
 static constexpr uint32_t LONG_SEQ_KMERS = 1u << 18; // longer sequences take the global partitioned route (kmu_sketch)
 static constexpr int BUCKET_BITS = 12;               // counting-sort buckets
@@ -989,6 +992,8 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
 
 // the cheap half of pmh3a_first_point: can the first point of this key lie below q_max (bits `qb`)?  Needs two of the four
 // SplitMix64 words and one f64 product; the rare keys whose first Exp01 draw falls in the sampler's rejection branch pass.
+// UNIT_W: every key of the call has weight 1 (a chunk inside the weight-1 prefix of a list): 1 / w = 1.0 needs no look-up
+template <bool UNIT_W = false>
 __device__ __forceinline__ bool pmh3a_first_point_may_matter(const SketchArgs &a, bool sig32, uint64_t qb, uint64_t key,
                                                              uint32_t w, const double *winv_lut, uint64_t &s0, uint64_t &s3) {
     const uint64_t seed = hasher_finish(KMU_HASHER_NOHASH, key, sig32);
@@ -997,6 +1002,7 @@ __device__ __forceinline__ bool pmh3a_first_point_may_matter(const SketchArgs &a
     const uint64_t r1 = rotl64(s0 + s3, 23) + s0;
     const double u1 = __longlong_as_double((long long) ((r1 >> 12) | 0x3FF0000000000000ull)) - 1.0;
     const double x = a.e01.c1 * u1;
+    if (UNIT_W) return !(x < 1.0) || x < __longlong_as_double((long long) qb);
     return !(x < 1.0) || winv_of(winv_lut, w) * x < __longlong_as_double((long long) qb);
 }
 
@@ -1106,7 +1112,8 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
             if (lane == 0) *qmax_sh = qb;
         }
         uint64_t s0 = 0, s3 = 0;
-        const bool pass = have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
+        const bool pass = KMU_PTS_UNITW && c + 64u <= n_u ? have && pmh3a_first_point_may_matter<true>(a, sig32, qb, key, w, winv_lut, s0, s3) // (uniform)
+                                         : have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
         const uint64_t pm = __ballot(pass);
         if (pass) {
             const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));

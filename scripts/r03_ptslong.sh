@@ -19,7 +19,9 @@ import json;d=json.loads(open('gpurun_out/ab_pl_$label.json').read().strip().spl
 print('$label', 'dev ms',round(d['ms_per_step'],2),'host ms', round(d['host_to_host']['ms_per_step'],2), {k:round(v['avg_ms'],2) for k,v in d['kernels'].items() if 'pmh' in k and '+' not in k}, d['checks']['sig_checksum'], d['checks'].get('host_leg_equals_device_leg'))"
 }
 run dflt KMU_X=1
-run nolist KMU_PMH_LIST_ORDER=0
+run taper KMU_PIPE_TAPER=1
+run c384 KMU_PIPE_CHUNK_MB=384
 run dflt_b KMU_X=1
-run nolist_b KMU_PMH_LIST_ORDER=0
-run alloff KMU_PMH_LIST_ORDER=0 KMU_PMH_PTS_LONG=0
+run taper_b KMU_PIPE_TAPER=1
+run c640 KMU_PIPE_CHUNK_MB=640
+run c384_taper KMU_PIPE_CHUNK_MB=384 KMU_PIPE_TAPER=1
