@@ -32,6 +32,9 @@
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
+#ifndef KMU_STEP_TAB // (A/B builds: 0 = level 1 looks the read of a step up at the top of the step)
+#define KMU_STEP_TAB 1
+#endif
 #ifndef KMU_SCATTER_NT
 #define KMU_SCATTER_NT 0
 #endif
@@ -1039,10 +1042,32 @@ __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t to
 // of the last tile are long gone.
 struct FlatRaw {
     uint4 c0, cx;
+    uint2 tb; // the step's entry of the read table (k_step_table), requested with the chunks
 };
-__device__ __forceinline__ void flat_step_fetch(const uint8_t *bases, uint64_t total, uint64_t st, FlatRaw &r) {
+// The read that holds the first base of every wave step, and where it ends, made once per call: x = the read's index, y = its
+// end relative to the step's first base (0xFFFFFFFF: more than 4 G bases away).  Level 1 used to look both up at the top of
+// every step -- offsets[hint], offsets[hint + 1 + lane], offsets[r + 1]: three dependent loads that all sixteen waves of a CU
+// wait for at the same time; an entry of this table is requested a tile ahead, next to the step's bases.
+__global__ void __launch_bounds__(256) k_step_table(const uint64_t *offsets, uint32_t n_seq, uint64_t nsteps, uint2 *tab) {
+    const uint64_t st = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (st >= nsteps) return;
+    const uint64_t total = offsets[n_seq];
+    const uint64_t g = st * 1024 < total ? st * 1024 : (total ? total - 1 : 0);
+    uint32_t lo = 0, hi = n_seq; // largest i with offsets[i] <= g (0 if there is none): wave_find_read's answer
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (offsets[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t rend = offsets[lo + 1], s0 = st * 1024;
+    tab[st] = make_uint2(lo, rend > s0 && rend - s0 < 0xFFFFFFFFull ? (uint32_t) (rend - s0) : (rend > s0 ? 0xFFFFFFFFu : 0u));
+}
+template <bool TAB = false>
+__device__ __forceinline__ void flat_step_fetch(const uint8_t *bases, uint64_t total, uint64_t st, FlatRaw &r, const uint2 *tab = nullptr,
+                                                uint64_t last_step = 0) {
     r.c0 = make_uint4(0u, 0u, 0u, 0u);
     r.cx = r.c0;
+    if (TAB) r.tb = tab[st < last_step ? st : last_step];
     if (total < 16) return; // (wave-uniform; flat_step_words then reads the ragged chunk itself)
     const uint64_t lastc = (total - 16) & ~15ull;
     const uint64_t a0 = (st * 64 + (uint64_t) lane_id()) * 16, ax = (st * 64 + 64 + (uint64_t) (lane_id() & 1)) * 16;
@@ -1077,9 +1102,10 @@ __device__ __forceinline__ void flat_step_words(const uint8_t *bases, uint64_t t
 }
 
 // up to 16 canonical k-mers of this lane for wave step `st` (CKEY_EMPTY where a k-mer would straddle a read end)
+template <bool TAB = false>
 __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_t n_seq, uint64_t total, uint64_t start, int k,
                                                 uint64_t st, bool active, uint32_t w0, uint32_t ex, uint32_t &r_hint,
-                                                uint64_t (&it)[16]) {
+                                                uint64_t (&it)[16], uint2 tb = make_uint2(0u, 0u)) {
 #pragma unroll
     for (int j = 0; j < 16; j++) it[j] = CKEY_EMPTY;
     if (!active) return; // wave-uniform
@@ -1089,14 +1115,23 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
     uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
     if (lane == 63) { w1 = e0; w2 = e1; }
     if (lane == 62) { w2 = e0; }
-    uint32_t r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
-    r_hint = r;
+    uint32_t r;
     const uint64_t g0 = widx * 16;
     const bool in = g0 < total && g0 + 16 > start;
     uint64_t rend = 0;
-    if (in) {
-        rend = offsets[r + 1];
-        while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
+    if (TAB) { // (the wave-uniform entry of the step: k_step_table)
+        r = (uint32_t) __builtin_amdgcn_readfirstlane((int) tb.x);
+        const uint32_t rel = (uint32_t) __builtin_amdgcn_readfirstlane((int) tb.y);
+        rend = rel == 0xFFFFFFFFu ? ~0ull : st * 1024 + rel;
+        if (in)
+            while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
+    } else {
+        r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
+        r_hint = r;
+        if (in) {
+            rend = offsets[r + 1];
+            while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
+        }
     }
     const uint64_t hi = ((uint64_t) w0 << 32) | w1;
     const int sh = 64 - 2 * k;
@@ -1141,6 +1176,7 @@ struct SegPlan1 {
     // the dispatcher deals them out round robin), cap items per (set, bin) stream at out[(set * bins + bin) * cap]; nothing is
     // loaded, stored or marked by the kernel (k_seg_tails marks the tails behind the last launch)
     uint32_t sets;
+    const uint2 *step_tab; // k_step_table's entries of all wave steps of the stream (single-pass form)
 };
 template <bool SEGM, bool SHARED = false>
 __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
@@ -1188,8 +1224,9 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
         run[0] = f.x;
         run[1] = f.y;
     }
+    const uint64_t last_step = nsteps_all ? nsteps_all - 1 : 0;
     if (SEGM) {
-        flat_step_fetch(bases, total, s0 + wave, raw);
+        flat_step_fetch<KMU_STEP_TAB != 0>(bases, total, s0 + wave, raw, seg.step_tab, last_step);
         vm_wait_all();
     }
     clk.start();
@@ -1197,10 +1234,11 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
         uint64_t it[16];
         if (SEGM) flat_step_words(bases, total, t0 + wave, t0 + wave < s1, raw, w0, ex, bad);
         else flat_step_load(bases, total, t0 + wave, t0 + wave < s1, w0, ex, &bad); // (the exact levels and the owner grouping: the older tile sort leaves no registers for a chunk in flight)
-        flat_step_items(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
-        // the next step's chunks are requested now (behind the read-bound look-ups of this step, which are waited for in
-        // order); they arrive under the tile sort, which waits for them before its write-out
-        if (SEGM) flat_step_fetch(bases, total, t0 + nwaves + wave, raw);
+        if (SEGM) flat_step_items<KMU_STEP_TAB != 0>(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it, raw.tb);
+        else flat_step_items(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
+        // the next step's chunks and its entry of the read table are requested now; they arrive under the tile sort, which waits
+        // for them before its write-out
+        if (SEGM) flat_step_fetch<KMU_STEP_TAB != 0>(bases, total, t0 + nwaves + wave, raw, seg.step_tab, last_step);
         if (!SEGM && pl.owner_parts) tile_scatter<IT_OWNER>(it, l, bins1, -1, (int) pl.owner_parts, (uint32_t) pl.owner_w32, out);
         else { // from here on the k-mers travel as their table hash
 #pragma unroll
@@ -1991,7 +2029,7 @@ struct SegRun {
     uint32_t units_done = 0;
     uint64_t steps_done = 0; // rounds: wave steps of the stream that have been through level 1
     bool rounds = false;     // the units persist across the launches (chunked calls)
-    void *state = nullptr;
+    void *state = nullptr, *step_tab = nullptr;
     void *A = nullptr, *B = nullptr, *ovf = nullptr, *bnd = nullptr, *leafcnt = nullptr;
     uint32_t *d_err = nullptr;
 };
@@ -2026,6 +2064,12 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
         KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.sets * bins1 * 4 + 64, &run->state));
         KMU_HIP(ctx, hipMemsetAsync(run->state, 0, (size_t) run->sp.sets * bins1 * 4, ctx->stream));
     } else if (run->rounds) KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.units1 * bins1 * 4 + 64, &run->state));
+    {
+        const uint64_t nsteps = std::max<uint64_t>(1, ((total_bases + 15) / 16 + 63) / 64);
+        KMU_TRY(dev_buf(ctx, "cnt.step_tab", (size_t) nsteps * 8 + 64, &run->step_tab));
+        hipLaunchKernelGGL(k_step_table, dim3((unsigned) ((nsteps + 255) / 256)), dim3(256), 0, ctx->stream, ds.offsets, ds.n_seq, nsteps,
+                           (uint2 *) run->step_tab);
+    }
     KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;
 }
@@ -2054,7 +2098,8 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                                run->ds.offsets, run->ds.n_seq, c->p.kmer_size, pl, (const uint64_t *) nullptr, (const uint64_t *) nullptr,
                                (uint64_t *) run->A,
                                SegPlan1{run->sp.cap1, 0, 0, run->steps_done, (uint32_t *) run->ovf, run->d_err, run->steps_done + n_new,
-                                        (uint32_t *) run->state, (run->steps_done == 0 ? 1 : 0) | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), last ? 1 : 0, run->sp.sets});
+                                        (uint32_t *) run->state, (run->steps_done == 0 ? 1 : 0) | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), last ? 1 : 0, run->sp.sets,
+                                        (const uint2 *) run->step_tab});
         }
         KMU_HIP(ctx, hipGetLastError());
         run->steps_done += n_new;
@@ -2082,7 +2127,8 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                            run->ds.bases, run->ds.offsets, run->ds.n_seq, c->p.kmer_size, run->pl, (const uint64_t *) nullptr,
                            (const uint64_t *) nullptr, (uint64_t *) run->A,
                            SegPlan1{run->sp.cap1, seg_layout_bin() ? run->sp.bincap1 : 0, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
-                                    (uint32_t *) run->ovf, run->d_err, 0, (uint32_t *) run->state, 1 | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), 1, run->sp.sets});
+                                    (uint32_t *) run->ovf, run->d_err, 0, (uint32_t *) run->state, 1 | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), 1, run->sp.sets,
+                                    (const uint2 *) run->step_tab});
     }
     KMU_HIP(ctx, hipGetLastError());
     run->units_done = upto;
@@ -2224,7 +2270,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1<false>, dim3(units1), dim3(SCATTER_THREADS), scatter_lds_bytes(bins1), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, k, pl, (const uint64_t *) offs1, (const uint64_t *) binstart1,
-                           (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1, 0});
+                           (uint64_t *) A, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1, 0, nullptr});
     }
     const uint64_t *items = (const uint64_t *) A;
     const uint64_t *leaves = (const uint64_t *) binstart1;
@@ -2454,7 +2500,7 @@ static int owner_scatter(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases
         KernelTimer tm(ctx, "k_part_scatter1");
         hipLaunchKernelGGL(k_part_scatter1<false>, dim3(op.pl.units1), dim3(SCATTER_THREADS), scatter_lds_bytes(op.pl.owner_parts), ctx->stream,
                            ds.bases, ds.offsets, ds.n_seq, c->p.kmer_size, op.pl, (const uint64_t *) op.offs1,
-                           (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1, 0});
+                           (const uint64_t *) op.binstart1, (uint64_t *) out, SegPlan1{0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 1, 1, 0, nullptr});
     }
     KMU_HIP(ctx, hipGetLastError());
     *dev_out = (uint64_t *) out;
