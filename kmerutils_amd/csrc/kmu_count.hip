@@ -1042,13 +1042,14 @@ __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t to
 // of the last tile are long gone.
 struct FlatRaw {
     uint4 c0, cx;
-    uint2 tb; // the step's entry of the read table (k_step_table), requested with the chunks
+    uint4 tb; // the step's entry of the read table (k_step_table), requested with the chunks
 };
-// The read that holds the first base of every wave step, and where it ends, made once per call: x = the read's index, y = its
-// end relative to the step's first base (0xFFFFFFFF: more than 4 G bases away).  Level 1 used to look both up at the top of
-// every step -- offsets[hint], offsets[hint + 1 + lane], offsets[r + 1]: three dependent loads that all sixteen waves of a CU
-// wait for at the same time; an entry of this table is requested a tile ahead, next to the step's bases.
-__global__ void __launch_bounds__(256) k_step_table(const uint64_t *offsets, uint32_t n_seq, uint64_t nsteps, uint2 *tab) {
+// The read that holds the first base of every wave step, and where it and the next two reads end, made once per call: x = the
+// read's index, y / z / w = the ends relative to the step's first base (0xFFFFFFFF: more than 4 G bases away).  Level 1 used to
+// look these up inside the step -- offsets[hint], offsets[hint + 1 + lane], offsets[r + 1], and offsets[r + 2] ... in the lanes
+// behind a read end: dependent loads that the other fifteen waves of the tile wait for at the next barrier (a tile of sixteen
+// steps of 1 024 bases meets a read end more often than not); an entry is requested a tile ahead, next to the step's bases.
+__global__ void __launch_bounds__(256) k_step_table(const uint64_t *offsets, uint32_t n_seq, uint64_t nsteps, uint4 *tab) {
     const uint64_t st = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (st >= nsteps) return;
     const uint64_t total = offsets[n_seq];
@@ -1059,11 +1060,16 @@ __global__ void __launch_bounds__(256) k_step_table(const uint64_t *offsets, uin
         if (offsets[mid] <= g) lo = mid;
         else hi = mid;
     }
-    const uint64_t rend = offsets[lo + 1], s0 = st * 1024;
-    tab[st] = make_uint2(lo, rend > s0 && rend - s0 < 0xFFFFFFFFull ? (uint32_t) (rend - s0) : (rend > s0 ? 0xFFFFFFFFu : 0u));
+    const uint64_t s0 = st * 1024;
+    uint32_t rel[3];
+    for (int i = 0; i < 3; i++) { // the ends of reads lo, lo + 1, lo + 2 (a step and its halo rarely see more)
+        const uint64_t e = offsets[(uint64_t) lo + 1 + i < n_seq ? lo + 1 + i : n_seq];
+        rel[i] = e > s0 ? (e - s0 < 0xFFFFFFFFull ? (uint32_t) (e - s0) : 0xFFFFFFFFu) : 0u;
+    }
+    tab[st] = make_uint4(lo, rel[0], rel[1], rel[2]);
 }
 template <bool TAB = false>
-__device__ __forceinline__ void flat_step_fetch(const uint8_t *bases, uint64_t total, uint64_t st, FlatRaw &r, const uint2 *tab = nullptr,
+__device__ __forceinline__ void flat_step_fetch(const uint8_t *bases, uint64_t total, uint64_t st, FlatRaw &r, const uint4 *tab = nullptr,
                                                 uint64_t last_step = 0) {
     r.c0 = make_uint4(0u, 0u, 0u, 0u);
     r.cx = r.c0;
@@ -1105,7 +1111,7 @@ __device__ __forceinline__ void flat_step_words(const uint8_t *bases, uint64_t t
 template <bool TAB = false>
 __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_t n_seq, uint64_t total, uint64_t start, int k,
                                                 uint64_t st, bool active, uint32_t w0, uint32_t ex, uint32_t &r_hint,
-                                                uint64_t (&it)[16], uint2 tb = make_uint2(0u, 0u)) {
+                                                uint64_t (&it)[16], uint4 tb = make_uint4(0u, 0u, 0u, 0u)) {
 #pragma unroll
     for (int j = 0; j < 16; j++) it[j] = CKEY_EMPTY;
     if (!active) return; // wave-uniform
@@ -1119,12 +1125,26 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
     const uint64_t g0 = widx * 16;
     const bool in = g0 < total && g0 + 16 > start;
     uint64_t rend = 0;
-    if (TAB) { // (the wave-uniform entry of the step: k_step_table)
-        r = (uint32_t) __builtin_amdgcn_readfirstlane((int) tb.x);
-        const uint32_t rel = (uint32_t) __builtin_amdgcn_readfirstlane((int) tb.y);
-        rend = rel == 0xFFFFFFFFu ? ~0ull : st * 1024 + rel;
+    uint32_t r0 = 0;
+    uint64_t te0 = 0, te1 = 0, te2 = 0; // TAB: the wave-uniform entry of the step (k_step_table)
+    // the end of read rr (>= r0): from the entry for the first three, a load beyond
+    auto end_of = [&](uint32_t rr) -> uint64_t {
+        const uint32_t d = rr - r0;
+        return d == 0u ? te0 : d == 1u ? te1 : d == 2u ? te2 : offsets[rr + 1];
+    };
+    if (TAB) {
+        auto abs_end = [&](uint32_t rel) -> uint64_t {
+            const uint32_t u = (uint32_t) __builtin_amdgcn_readfirstlane((int) rel);
+            return u == 0xFFFFFFFFu ? ~0ull : st * 1024 + u;
+        };
+        r0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) tb.x);
+        te0 = abs_end(tb.y);
+        te1 = abs_end(tb.z);
+        te2 = abs_end(tb.w);
+        r = r0;
+        rend = te0;
         if (in)
-            while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
+            while (g0 >= rend && r + 1 < n_seq) { r++; rend = end_of(r); } // the read of this lane's first base
     } else {
         r = wave_find_read_from(offsets, n_seq, st * 1024 < total ? st * 1024 : total - 1, r_hint);
         r_hint = r;
@@ -1149,7 +1169,7 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint64_t g = g0 + j;
-            while (g >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; }
+            while (g >= rend && r + 1 < n_seq) { r++; rend = TAB ? end_of(r) : offsets[r + 1]; }
             if (g >= start && g + k <= rend) {
                 uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
                 uint64_t val = v >> sh;
@@ -1176,7 +1196,7 @@ struct SegPlan1 {
     // the dispatcher deals them out round robin), cap items per (set, bin) stream at out[(set * bins + bin) * cap]; nothing is
     // loaded, stored or marked by the kernel (k_seg_tails marks the tails behind the last launch)
     uint32_t sets;
-    const uint2 *step_tab; // k_step_table's entries of all wave steps of the stream (single-pass form)
+    const uint4 *step_tab; // k_step_table's entries of all wave steps of the stream (single-pass form)
 };
 template <bool SEGM, bool SHARED = false>
 __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
@@ -2066,9 +2086,9 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     } else if (run->rounds) KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.units1 * bins1 * 4 + 64, &run->state));
     {
         const uint64_t nsteps = std::max<uint64_t>(1, ((total_bases + 15) / 16 + 63) / 64);
-        KMU_TRY(dev_buf(ctx, "cnt.step_tab", (size_t) nsteps * 8 + 64, &run->step_tab));
+        KMU_TRY(dev_buf(ctx, "cnt.step_tab", (size_t) nsteps * 16 + 64, &run->step_tab));
         hipLaunchKernelGGL(k_step_table, dim3((unsigned) ((nsteps + 255) / 256)), dim3(256), 0, ctx->stream, ds.offsets, ds.n_seq, nsteps,
-                           (uint2 *) run->step_tab);
+                           (uint4 *) run->step_tab);
     }
     KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;
@@ -2099,7 +2119,7 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                                (uint64_t *) run->A,
                                SegPlan1{run->sp.cap1, 0, 0, run->steps_done, (uint32_t *) run->ovf, run->d_err, run->steps_done + n_new,
                                         (uint32_t *) run->state, (run->steps_done == 0 ? 1 : 0) | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), last ? 1 : 0, run->sp.sets,
-                                        (const uint2 *) run->step_tab});
+                                        (const uint4 *) run->step_tab});
         }
         KMU_HIP(ctx, hipGetLastError());
         run->steps_done += n_new;
@@ -2128,7 +2148,7 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                            (const uint64_t *) nullptr, (uint64_t *) run->A,
                            SegPlan1{run->sp.cap1, seg_layout_bin() ? run->sp.bincap1 : 0, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
                                     (uint32_t *) run->ovf, run->d_err, 0, (uint32_t *) run->state, 1 | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), 1, run->sp.sets,
-                                    (const uint2 *) run->step_tab});
+                                    (const uint4 *) run->step_tab});
     }
     KMU_HIP(ctx, hipGetLastError());
     run->units_done = upto;

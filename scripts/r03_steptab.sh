@@ -5,4 +5,4 @@ timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_count
 rc=$?; tail -2 gpurun_out/t_steptab.log
 grep -q "Memory access fault" gpurun_out/t_steptab.log && { echo GPU FAULT; exit 1; }
 [ $rc -eq 0 ] || exit 1
-VARIANT=notab bash scripts/r03_prerank.sh
+VARIANT=${VARIANT:-notab} bash scripts/r03_prerank.sh
