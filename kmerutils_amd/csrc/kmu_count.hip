@@ -2589,8 +2589,10 @@ static double local_xgmi_gbps() {
 static void route_model(double table_bytes, double gbps, double n, double d, int nranks, double *ms_occ, double *ms_merge) {
     const double f = nranks > 1 ? (double) (nranks - 1) / nranks : 0.0;
     const double ps = 1e-9; // ps -> ms
-    *ms_occ = n * (3.0 + 6.2 + 13.1) * ps + 8.0 * n * f / (gbps * 1e6);
-    *ms_merge = n * (3.0 + 13.5) * ps + 2.0 * table_bytes / 4.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
+    // (the share a rank keeps travels too, through the device-to-device copy of the all-to-all's own slot: 35 GB in 29 ms at the
+    //  bench size with one rank; MERGE's second table pass, the emit, only runs when something leaves)
+    *ms_occ = n * (3.0 + 6.2 + 13.1) * ps + 8.0 * n * f / (gbps * 1e6) + 8.0 * n * (1.0 - f) / 1.2e9;
+    *ms_merge = n * (3.0 + 13.5) * ps + (f > 0 ? 2.0 : 1.0) * table_bytes / 4.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
 }
 
 // first half of a distributed add: census of the owners + duplication sample, agreement on the route over all ranks, then
