@@ -2010,32 +2010,30 @@ static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan
     SegPlan sp;
     const uint64_t nsteps = ((total_bases + 15) / 16 + 63) / 64;
     const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
-    // units of level 1: one per CU (the biggest segments, the smallest margins: 8.6 % of the bench workload's stream); the
-    // chunked form of kmu_sketch_count launches them in rounds under the upload and takes up to four rounds' worth, a unit's
-    // share of a bin staying around 2 048 items (margins of 18 %)
+    // units of level 1: one workgroup per CU.  Under the upload of kmu_sketch_count (chunked) the same units take a slice of every
+    // arrival (seg_level1: rounds); round 2 launched FINISHED units instead -- up to four times as many, smaller ones, a CU's worth
+    // per arrival, margins of 18 %: 4 x 8 ms at the bench size against 19 ms in one launch (KMU_COUNT_SEG_ROUNDS=0 keeps that form
+    // for the A/B)
     const uint64_t by_size = total_bases / ((uint64_t) bins1 * 2048) + 1;
     uint64_t want = (uint64_t) ctx->num_cus;
-    // (round 2's chunked form took up to four times as many, smaller units -- one launch of a CU's worth per arrival -- with
-    //  margins of 18 %: 4 x 8 ms on the bench workload against 19 ms in one launch.  Round 3: the units persist across the
-    //  rounds, KMU_COUNT_SEG_ROUNDS=0 for the A/B)
     const char *re = getenv("KMU_COUNT_SEG_ROUNDS");
     if (chunked && re && atoi(re) == 0) want = std::min<uint64_t>(std::max<uint64_t>(by_size, want), want * 4);
     if (const char *e = getenv("KMU_COUNT_SEG_UNITS")) want = (uint64_t) std::max(1, atoi(e)); // A/B runs
     sp.units1 = (uint32_t) std::min<uint64_t>(nsteps, want);
     sp.steps_per_unit = (uint32_t) ((nsteps + sp.units1 - 1) / sp.units1);
     sp.units1 = (uint32_t) ((nsteps + sp.steps_per_unit - 1) / sp.steps_per_unit);
-    sp.cap1 = seg_cap_for((double) sp.steps_per_unit * 1024.0 / bins1);
+    sp.cap1 = seg_cap_for((double) sp.steps_per_unit * 1024.0 / bins1); // a segment per (unit, bin): margins of 5.9 % at the bench size
     sp.bincap1 = (uint64_t) sp.units1 * sp.cap1;
     sp.sets = 0;
-    if (const uint32_t want_sets = seg_sets_wanted()) {
+    if (const uint32_t want_sets = seg_sets_wanted()) { // a stream per (set, bin), shared by the set's units: margins of 1.4 %
         sp.sets = std::min(want_sets, sp.units1);
         const uint64_t units_per_set = (sp.units1 + sp.sets - 1) / sp.sets;
         sp.cap1 = seg_cap_for((double) units_per_set * sp.steps_per_unit * 1024.0 / bins1);
         sp.bincap1 = (uint64_t) sp.sets * sp.cap1;
     }
-    sp.chunks2 = 1; // a level-2 unit is a whole level-1 bin: the biggest segments, the smallest margins
-    sp.cap2 = seg_cap_for((double) total_bases / bins1 / sp.chunks2 / bins2);
-    sp.leafcap = (uint64_t) sp.chunks2 * sp.cap2;
+    sp.chunks2 = 1; // a leaf has ONE capacity, whoever fills it: a unit per level-1 bin, or (shared2) several through the leaf's cursor
+    sp.cap2 = seg_cap_for((double) total_bases / bins1 / bins2);
+    sp.leafcap = sp.cap2;
     sp.shared2 = 0;
     if (const uint32_t want = seg_l2_units_wanted()) { sp.shared2 = 1; sp.chunks2 = want; }
     return sp;
