@@ -1107,7 +1107,9 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
         if (c + cstride + 64u > n_u) { // (uniform: the next chunk reaches beyond the weight-1 prefix)
             if (i + cstride < n && i + cstride >= n_u) w_nx = a.lst_w[base + i + cstride];
         }
-        if ((chunk & (WG ? PTS_REFRESH_MASK >> 2 : PTS_REFRESH_MASK)) == 0u) {
+        // (WG: the four waves advance through the list together, so the merged q_max is refreshed four times as often per own
+        //  chunk while it still falls fast -- the first 64 own chunks -- and at the single wave's cadence per own chunk after that)
+        if ((chunk & (WG && chunk < 64u ? PTS_REFRESH_MASK >> 2 : PTS_REFRESH_MASK)) == 0u) {
             qb = WG ? wg4_qmax(arrays, wave_words, a.m) : wave_qmax(hmin, a.m);
             if (lane == 0) *qmax_sh = qb;
         }
@@ -1195,7 +1197,10 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     for (uint32_t t = threadIdx.x; t < WINV_LUT; t += blockDim.x) winv_lut[t] = t ? 1.0 / (double) t : 0.0;
     __syncthreads();
     // the long reads first, a workgroup each (workgroup b: entries b, b + grid, ... of the list)
-    const uint32_t n_long = a.pts_long ? a.pts_long[0] : 0u;
+    // (only where a long read would be a tail: with more than four of them per workgroup of the grid they balance among themselves
+    //  as single waves' reads, and the workgroup form costs more per key -- three barriers per read, q_max over four arrays)
+    uint32_t n_long = a.pts_long ? a.pts_long[0] : 0u;
+    if (n_long > 4u * gridDim.x) n_long = 0u;
     for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) pts_one_read<SIG32, true>(a, a.pts_long[2 + li], smem, wave_words, winv_lut);
     uint32_t q_next = 0, q_end = 0; // lane 0: reads are taken QCHUNK at a time
     for (;;) {
