@@ -1971,7 +1971,11 @@ static bool seg_partition_wanted(uint64_t total_bases) {
     if (e && atoi(e) == 2) return true;
     if (total_bases >> 35) return false; // (positions inside a level-1 bin and the cursors of the shared segments are 32-bit numbers:
                                          //  a set of streams sees at most total / sets items, whatever their bins)
-    return total_bases >= (1ull << 27); // (the margins are a small share of the mean only for big batches)
+    // (round 2: from 2^27 bases on -- the margins of a segment per unit and bin are a small share of the mean only for big batches.
+    //  With streams shared by a set's units they are sixteen times smaller, and the route wins wherever a table has two levels:
+    //  5.9 / 8.8 / 17.6 / 35 / 70 Mbases: 0.22 / 0.27 / 0.40 / 0.66 / 1.14 ms against 0.65 / 0.70 / 0.83 / 1.14 / 1.68 for the exact levels,
+    //  scripts/r03_segthr.sh.  A partitioned add is a batch of at least a quarter of the table's slots, so this is every one of them.)
+    return total_bases >= (1ull << 22);
 }
 static bool seg_layout_bin() { // A/B runs: level 1's output with the ranges of the bins side by side instead of the units' blocks
     const char *e = getenv("KMU_COUNT_SEG_LAYOUT");
