@@ -2549,8 +2549,12 @@ static int local_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, ui
     bool partitioned = false;
     const char *force = getenv("KMU_COUNT_PATH"); // "direct" / "partitioned": diagnostics
     if (!ds.packed) {
-        // the streaming build pays off once the batch is a sizeable fraction of the table
-        partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
+        // the streaming build rewrites the table image, direct insertion costs ~52 ps per k-mer whatever the table: at the bench
+        // table (2^33 slots, `scripts/r03_incr.py`) a batch of 1/8 of the slots takes 37.8 ms partitioned against 67.6 direct, one of
+        // 1/16 33.0 against 28.3; into an EMPTY table (no image to read, and direct insertion has to wipe it first) 19.2 against
+        // 36.9 at 1/16 of the slots, 16.0 against 23.4 at 1/32, 13.9 against 18.0 at 1/64.  (Round 2's rule was a quarter of the slots
+        // in either case.)
+        partitioned = total_bases * (c->empty ? 64u : 10u) >= c->nslots && total_bases >= (1u << 16);
         if (force && !strcmp(force, "direct")) partitioned = false;
         if (force && !strcmp(force, "partitioned")) partitioned = total_bases > 0;
     }
@@ -2948,7 +2952,7 @@ static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *co
     KMU_TRY(get_err_word(ctx, &d_err));
     {
         const char *force = getenv("KMU_COUNT_PATH");
-        bool partitioned = !counts && n * 4 >= c->nslots && n >= (1u << 16) && c->lg - c->rbits <= 22;
+        bool partitioned = !counts && n * (c->empty ? 64u : 10u) >= c->nslots && n >= (1u << 16) && c->lg - c->rbits <= 22; // (see local_add)
         if (force && !strcmp(force, "direct")) partitioned = false;
         if (force && !strcmp(force, "partitioned")) partitioned = !counts;
         if (partitioned) {
