@@ -2553,11 +2553,12 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             const char *ple = getenv("KMU_PMH_PTS_LONG");
             const uint64_t pts_thr = ple ? (uint64_t) std::max(0, atoi(ple)) : 32768u;
             const double wave_rate = pts_thr && len_stats[0] > pts_thr ? 1.6e5 : 4.0e4;
-            const double t_ideal = (double) total / (2.05e8 * cu_share), t_tail = (double) len_stats[0] / wave_rate; // ms
+            const double t_ideal = (double) total / (2.35e8 * cu_share), t_tail = (double) len_stats[0] / wave_rate; // ms
             const double overhang = t_tail >= t_ideal ? t_tail - 0.5 * t_ideal : t_tail * t_tail / (2.0 * t_ideal);
             // (r02: with the reads that fit a workgroup's registers on k_multiset_uq the two-kernel route takes 53 ms where the
             //  single kernel takes 87 on the ONT workload: 39 % of the single kernel's time, 16 % before)
-            const double gain = 0.39 * (double) total / (4.9e7 * cu_share);
+            // (r03: 49.8 ms, 43 %; the points kernel 18.5 ms for 4.36 G k-mers)
+            const double gain = 0.43 * (double) total / (4.9e7 * cu_share);
             if (gain <= overhang + 0.02) split = false; // (0.02 ms: the second launch)
         }
     }
