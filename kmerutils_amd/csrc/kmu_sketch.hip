@@ -2746,6 +2746,16 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             KMU_HIP(ctx, hipGetLastError());
             a.read_list = nullptr;
             a.n_queue = ds.n_seq;
+            if (ABL(256u)) { // diagnostics: the phases of the list-emitting launch (the words are wiped for the points kernel below)
+                unsigned long long ph[10];
+                KMU_HIP(ctx, hipMemcpy(ph, (const uint64_t *) a.queue + 8, sizeof ph, hipMemcpyDeviceToHost));
+                static const char *nm[10] = {"header", "stage", "A1", "scan", "place", "A3", "B1", "B2+clear", "row", "next+parked"};
+                double tot = 0;
+                for (int i = 0; i < 10; i++) tot += (double) ph[i];
+                fprintf(stderr, "[kmu list phases] grid %d, %u reads:", gridl, n_long);
+                for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double) ph[i] / (tot > 0 ? tot : 1));
+                fprintf(stderr, "  (clocks/wg %.3g)\n", tot / gridl);
+            }
         }
         KMU_HIP(ctx, hipMemsetAsync(a.queue, 0, 256, ctx->stream)); // (the points kernel's cursor; nothing is left to redo)
         main_launched = true;
