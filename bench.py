@@ -412,9 +412,10 @@ def _np_int32_hash(key):
 def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000, rank=0, world=1):
     """SURVEY.md 8(d) parity set: the first 1 000 reads of the workload.  The rows / counts / hashes the TIMED steps left
     behind are compared with the oracle's on those reads (the oracle is the checker here, nothing it computes is timed).
-    world > 1 (a distributed counter): after kmu_count_finalize this rank holds exactly the k-mers with owner == rank
-    (int64_hash(kmer) % world, kmercount.rs:412-420): the k-mers of its 1 000 reads that it owns must be there with at
-    least the oracle's count, the ones it does not own must be absent."""
+    world > 1 (a distributed counter): after kmu_count_finalize this rank holds exactly the k-mers with owner == rank (the
+    owner of the k-mer's minimizer by default, int64_hash(kmer) % world -- kmercount.rs:412-420 -- with KMU_COUNT_OWNER=hash):
+    the k-mers of its 1 000 reads that it owns must be there with at least the oracle's count, the ones it does not own
+    must be absent."""
     import torch
     from kmerutils_amd import _abi as A
     from oracle import oracle as O
@@ -440,7 +441,10 @@ def parity_check(cfg, ctx, bases, offsets, sig, counter, nth, n_check=1000, rank
         got = got_d.cpu().numpy().astype(np.int64)
         if world > 1:
             w32 = A.kmer_val_bytes(cfg["kmer_type"]) == 4
-            own = ((_np_int32_hash(wk).astype(np.uint64) if w32 else _np_int64_hash(wk)) % np.uint64(world)) == np.uint64(rank)
+            if counter.owner_kind == A.OWNER_MINIMIZER:  # the default between GPUs: the k-mer's minimizer decides (kmu_smer.h)
+                own = O.minimizer_owners(wk, cfg["k"], world) == rank
+            else:
+                own = ((_np_int32_hash(wk).astype(np.uint64) if w32 else _np_int64_hash(wk)) % np.uint64(world)) == np.uint64(rank)
             out["parity_counts_ok"] = bool((got[own] >= np.minimum(wc[own].astype(np.int64), 255)).all() and (got[own] >= 1).all()
                                            and (got[~own] == 0).all())
             out["parity_kmers_owned"] = int(own.sum())

@@ -158,7 +158,7 @@ typedef struct kmu_count_params {
     int32_t kmer_type;     /* DNA types only */
     int32_t kmer_size;
     int32_t counter_bits;  /* 8 or 16 (reference default 8: saturates at 255, src/base/kmercount.rs:1615) */
-    int32_t flags;         /* 0, or KMU_COUNT_DISTRIBUTED (see "multi-GPU" below) */
+    int32_t flags;         /* 0, or KMU_COUNT_DISTRIBUTED [| KMU_COUNT_OWNER_HASH] (see "multi-GPU" below) */
     uint64_t capacity_hint; /* expected number of distinct canonical k-mers */
 } kmu_count_params;
 
@@ -415,35 +415,69 @@ int kmu_comm_allgather(kmu_ctx *ctx, const void *send_host, void *recv_host, uin
 /* Distributed counting.  A counter created with KMU_COUNT_DISTRIBUTED on a context that has a communicator is one member of
  * a KmerCounterPool spread over the ranks: kmu_count_add_reads takes THIS rank's reads (collective: every rank calls it,
  * with its own shard, possibly empty), kmu_count_finalize (collective) completes the exchange; afterwards rank r's counter
- * holds exactly the canonical k-mers with owner r -- kmu_kmer_owner, DispatchableT (kmercount.rs:382-420) -- with their
- * multiplicities over ALL ranks' reads, and every query / dump / statistic of this header sees that partition.
- * Two routes, chosen per add from the measured duplication (occurrences / distinct k-mers, estimated on a hash sample of
- * this batch over all ranks) with a cost model of both (kmu_comm_stats; KMU_COUNT_ROUTE=occurrences|merge forces one):
- *   OCCURRENCES  every k-mer occurrence travels to its owner (8 B each), the owner builds its table from what it receives:
- *                the reference's own dispatch; best when most k-mers are distinct (long noisy reads).
+ * holds exactly the canonical k-mers with owner r with their multiplicities over ALL ranks' reads, and every query / dump /
+ * statistic of this header sees that partition.
+ * Who owns a k-mer (kmu_count_owner_kind; every rank of a pool must create its counter alike):
+ *   KMU_OWNER_MINIMIZER  (default where a minimizer window fits: Kmer64bit, 17 <= k <= 31) the owner is a function of the k-mer's
+ *                MINIMIZER -- the canonical m-mer of smallest hash among the k - m + 1 it contains (m = 9 .. 15 by k), the same on
+ *                both strands: kmu_kmer_owner_minimizer.  Consecutive k-mers of a read mostly share it, so the occurrences travel
+ *                as SUPER-K-MER RECORDS: a run of up to 16 consecutive k-mers with one owner as its 2-bit bases, 12 bytes, ~1.35 B
+ *                per k-mer at k = 31 instead of one 8-byte message per k-mer (the reference's unit of dispatch, kmercount.rs:936-943).
+ *   KMU_OWNER_HASH       (KMU_COUNT_OWNER_HASH, KMU_COUNT_OWNER=hash, and every k <= 16) the reference's own dispatch
+ *                kmu_kmer_owner: int32_hash / int64_hash(kmer) % n, DispatchableT (kmercount.rs:382-420).
+ * Routes, chosen per add from the measured duplication (occurrences / distinct k-mers, estimated on a hash sample of this batch
+ * over all ranks) with a cost model (kmu_comm_stats; KMU_COUNT_ROUTE=occurrences|superkmers|merge forces one):
+ *   OCCURRENCES  (hash owners) every k-mer occurrence travels to its owner (8 B each), the owner builds its table from what it
+ *                receives: the reference's own dispatch.
+ *   SUPERKMERS   (minimizer owners) the same with 12-byte records in place of k-mers; the owner expands them inside the first
+ *                level of its partitioned build.
  *   MERGE        every rank counts its shard locally; at finalize the (k-mer, count) entries it does not own travel
- *                (12 B per DISTINCT k-mer) and are added to the owner's table: less traffic once a k-mer occurs more than
- *                ~1.5 times per rank (deep short-read coverage), at the price of building twice. */
+ *                (12 B per DISTINCT k-mer) and are added to the owner's table: less traffic only once a k-mer occurs many times
+ *                per rank (more than ~1.5 with hash owners, ~9 with minimizer owners), at the price of building twice. */
 #define KMU_COUNT_DISTRIBUTED 0x1 /* kmu_count_params.flags */
-typedef enum kmu_count_route { KMU_ROUTE_NONE = 0, KMU_ROUTE_OCCURRENCES = 1, KMU_ROUTE_MERGE = 2 } kmu_count_route;
+#define KMU_COUNT_OWNER_HASH 0x2  /* with KMU_COUNT_DISTRIBUTED: owners by the reference's dispatch (kmu_kmer_owner) */
+typedef enum kmu_owner_kind { KMU_OWNER_HASH = 0, KMU_OWNER_MINIMIZER = 1 } kmu_owner_kind;
+typedef enum kmu_count_route { KMU_ROUTE_NONE = 0, KMU_ROUTE_OCCURRENCES = 1, KMU_ROUTE_MERGE = 2, KMU_ROUTE_SUPERKMERS = 3 } kmu_count_route;
 typedef struct kmu_comm_stats {
     int32_t route;                 /* kmu_count_route of the last distributed kmu_count_add_reads */
     int32_t sample_shift;          /* the duplication was measured on the k-mers whose owner hash has this many zero bits */
     double dup_ratio;              /* occurrences / distinct over all ranks (sampled); 0 = not measured */
     uint64_t kmers_local;          /* k-mer occurrences of this rank's shard (last add) */
-    uint64_t bytes_occurrences;    /* what OCCURRENCES moves off this rank for that add: 8 B x occurrences x (N-1)/N */
+    uint64_t bytes_occurrences;    /* what OCCURRENCES / SUPERKMERS moves off this rank for that add: 8 B x the occurrences (12 B x
+                                      the records) that other ranks own */
     uint64_t bytes_merge;          /* what MERGE moves off this rank: 12 B x distinct x (N-1)/N (from dup_ratio until
                                       finalize has run, exact afterwards) */
     uint64_t bytes_sent;           /* bytes that really left this rank / arrived, last add + its finalize */
     uint64_t bytes_received;
-    double model_ms_occurrences;   /* the cost model's estimates the choice was made from */
+    double model_ms_occurrences;   /* the cost model's estimates the choice was made from (OCCURRENCES or SUPERKMERS; MERGE) */
     double model_ms_merge;
+    int32_t owner_kind;            /* kmu_owner_kind of the counter of the last add */
+    int32_t exchanges;             /* all-to-alls of the last add + its finalize */
+    uint64_t records_local;        /* super-k-mer records of this rank's shard (0 with hash owners) */
+    double exchange_ms;            /* MEASURED duration of those all-to-alls: events around them on the exchange stream (RCCL), wall
+                                      time of the host's function (kmu_comm_init_custom).  kmu_comm_get_stats waits for them. */
+    double exchange_gbps_out;      /* bytes_sent / exchange_ms and bytes_received / exchange_ms, in GB/s: the link rate the route */
+    double exchange_gbps_in;       /* model assumes as KMU_XGMI_GBPS */
 } kmu_comm_stats;
 int kmu_comm_get_stats(const kmu_ctx *ctx, kmu_comm_stats *out);
 int kmu_count_finalize(kmu_counter *c);
+int kmu_count_owner_kind(const kmu_counter *c); /* kmu_owner_kind of a distributed counter (KMU_OWNER_HASH for any other) */
 /* owner of canonical k-mer values in an n_parts-way pool: int32_hash / int64_hash(kmer) % n_parts by the width of the
  * k-mer type (Kmer32bit / Kmer16b32bit: kmercount.rs:386-402; Kmer64bit :412-420).  Host arithmetic, no device needed. */
 int kmu_kmer_owner(int kmer_type, const uint64_t *canon_kmers, uint64_t n, uint32_t n_parts, uint32_t *owners_out);
+/* the minimizer owner of Kmer64bit values of kmer_size bases (17 .. 31; forward or canonical value: both strands agree).  Host
+ * arithmetic, no device needed. */
+int kmu_kmer_owner_minimizer(int kmer_size, const uint64_t *canon_kmers, uint64_t n, uint32_t n_parts, uint32_t *owners_out);
+/* The two halves of the SUPERKMERS route for hosts that run the exchange themselves (kmu_count_extract_by_owner's counterpart).
+ * A record is 12 bytes = three uint32: up to 46 bases, 2 bits each, the first in bits 31..30 of word 0, zeros behind the last;
+ * bits 3..0 of word 2 = number of k-mers - 1 (1 .. 16 k-mers: consecutive k-mers of one read with one minimizer owner).
+ * kmu_count_extract_superkmers: the records of the reads grouped by owner; *dev_records_out points to a device buffer owned
+ * by the counter's context (valid until its next call), record_bounds_out[n_parts + 1] (host, in records) delimits the group of
+ * every owner, kmers_per_part_out[n_parts] (host, may be NULL) says how many k-mers each group holds.
+ * kmu_count_add_superkmers: the k-mers of n_records records into the table (KMU_MEM_DEVICE or KMU_MEM_HOST). */
+int kmu_count_extract_superkmers(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem,
+                                 uint32_t n_parts, void **dev_records_out, uint64_t *record_bounds_out, uint64_t *kmers_per_part_out);
+int kmu_count_add_superkmers(kmu_counter *c, const void *records, uint64_t n_records, int mem);
 
 /* ---- L-1 ingest: the step before the path ----------------------------------------------------
  * FASTQ / FASTA text -> the accepted reads as (bases, offsets), in file order.  kmu_ingest_fastq: 4-line records,

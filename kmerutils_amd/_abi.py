@@ -60,7 +60,10 @@ class CountParams(C.Structure):
 
 
 COUNT_DISTRIBUTED = 0x1
-ROUTE_NONE, ROUTE_OCCURRENCES, ROUTE_MERGE = 0, 1, 2
+COUNT_OWNER_HASH = 0x2
+OWNER_HASH, OWNER_MINIMIZER = 0, 1
+ROUTE_NONE, ROUTE_OCCURRENCES, ROUTE_MERGE, ROUTE_SUPERKMERS = 0, 1, 2, 3
+SMER_REC_BYTES = 12
 COMM_ID_BYTES = 128
 
 
@@ -72,7 +75,9 @@ class CommStats(C.Structure):
     """kmu_comm_stats"""
     _fields_ = [("route", C.c_int32), ("sample_shift", C.c_int32), ("dup_ratio", C.c_double), ("kmers_local", C.c_uint64),
                 ("bytes_occurrences", C.c_uint64), ("bytes_merge", C.c_uint64), ("bytes_sent", C.c_uint64),
-                ("bytes_received", C.c_uint64), ("model_ms_occurrences", C.c_double), ("model_ms_merge", C.c_double)]
+                ("bytes_received", C.c_uint64), ("model_ms_occurrences", C.c_double), ("model_ms_merge", C.c_double),
+                ("owner_kind", C.c_int32), ("exchanges", C.c_int32), ("records_local", C.c_uint64),
+                ("exchange_ms", C.c_double), ("exchange_gbps_out", C.c_double), ("exchange_gbps_in", C.c_double)]
 
 
 class CountTableInfo(C.Structure):

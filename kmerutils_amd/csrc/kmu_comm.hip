@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 
 #include "kmu_comm.hpp"
@@ -99,12 +100,24 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
         if (p != c->rank) { out += send_counts[p] * elem_bytes; in += recv_counts[p] * elem_bytes; }
     c->stats.bytes_sent += out;
     c->stats.bytes_received += in;
+    c->stats.exchanges++;
     if (c->a2a) {
         KMU_HIP(ctx, hipStreamSynchronize(s));
+        const auto t0 = std::chrono::steady_clock::now();
         const int rc = c->a2a(c->user, send_dev, send_counts, send_displs, recv_dev, recv_counts, recv_displs, elem_bytes, (void *) s);
+        c->stats.exchange_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (rc) return fail(ctx, KMU_E_RCCL, "the host's all-to-all failed (%d)", rc);
         return KMU_OK;
     }
+    // the exchange is timed where it runs: an event pair around it on the exchange stream, read by kmu_comm_get_stats
+    auto take_event = [&]() -> hipEvent_t {
+        hipEvent_t e = nullptr;
+        if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    };
+    hipEvent_t t_a = take_event(), t_b = take_event();
+    if (t_a) (void) hipEventRecord(t_a, s);
     // every pair of ranks exchanges one message per round: xGMI is point to point, all seven links of a GPU carry traffic at
     // once.  A message is at most KMU_COMM_CHUNK_MB (default 1024) long: rounds of grouped sends / receives until every
     // pair is through (sizes are known on both sides, so both sides run the same number of rounds for a pair).
@@ -130,8 +143,35 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
         if (first != ncclSuccess) return fail(ctx, KMU_E_RCCL, "ncclSend / ncclRecv in the all-to-all: %s", rccl()->GetErrorString(first));
         if (ge != ncclSuccess) return fail(ctx, KMU_E_RCCL, "ncclGroupEnd: %s", rccl()->GetErrorString(ge));
     }
+    if (t_a && t_b) {
+        (void) hipEventRecord(t_b, s);
+        c->timed.emplace_back(t_a, t_b);
+    }
     if (getenv("KMU_COMM_SYNC")) KMU_HIP(ctx, hipStreamSynchronize(s)); // diagnostics
     return KMU_OK;
+}
+
+// the event pairs of finished exchanges -> stats.exchange_ms (waits for the ones still running)
+static void comm_collect_timed(kmu_comm *c) {
+    for (auto &pr : c->timed) {
+        float ms = 0;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->stats.exchange_ms += ms;
+        c->ev_pool.push_back(pr.first);
+        c->ev_pool.push_back(pr.second);
+    }
+    c->timed.clear();
+    (void) hipGetLastError();
+}
+
+void comm_stats_reset(kmu_ctx *ctx) {
+    kmu_comm *c = ctx->comm;
+    if (!c) return;
+    for (auto &pr : c->timed) {
+        c->ev_pool.push_back(pr.first);
+        c->ev_pool.push_back(pr.second);
+    }
+    c->timed.clear();
+    c->stats = kmu_comm_stats{};
 }
 
 static int comm_new(kmu_ctx *ctx, int rank, int nranks) {
@@ -157,6 +197,8 @@ void comm_free(kmu_ctx *ctx) {
     (void) hipStreamSynchronize(ctx->stream);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     if (c->nccl) (void) rccl()->CommDestroy((ncclComm_t) c->nccl);
+    for (auto &pr : c->timed) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
+    for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
     if (c->ev_a) (void) hipEventDestroy(c->ev_a);
     if (c->ev_b) (void) hipEventDestroy(c->ev_b);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -218,7 +260,12 @@ int kmu_comm_nranks(const kmu_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->n
 
 int kmu_comm_get_stats(const kmu_ctx *ctx, kmu_comm_stats *out) {
     if (!ctx || !out || !ctx->comm) return KMU_E_BAD_ARG;
-    *out = ctx->comm->stats;
+    kmu_comm *c = ctx->comm;
+    (void) hipSetDevice(ctx->device);
+    comm_collect_timed(c);
+    c->stats.exchange_gbps_out = c->stats.exchange_ms > 0 ? (double) c->stats.bytes_sent / (c->stats.exchange_ms * 1e6) : 0.0;
+    c->stats.exchange_gbps_in = c->stats.exchange_ms > 0 ? (double) c->stats.bytes_received / (c->stats.exchange_ms * 1e6) : 0.0;
+    *out = c->stats;
     return KMU_OK;
 }
 

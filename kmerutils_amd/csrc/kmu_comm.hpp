@@ -6,6 +6,8 @@
 // pointers) serves hosts that own a communicator already and the tests that run more ranks than the box has GPUs.
 #pragma once
 
+#include <utility>
+
 #include "kmu_ctx.hpp"
 
 struct kmu_comm {
@@ -17,6 +19,9 @@ struct kmu_comm {
     hipStream_t stream = nullptr; // the exchange runs here, so that kernels on the context's stream can run under it
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     kmu_comm_stats stats{};
+    // measured exchanges (kmu_comm_stats::exchange_ms): event pairs on the exchange stream not read yet, and the pool they return to
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace kmu {
@@ -27,5 +32,8 @@ int comm_allgather_host(kmu_ctx *ctx, const void *send, void *recv, uint64_t byt
 // Enqueued on `s` (RCCL) or completed at return (host transport; `s` is synchronised first).
 int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
                    const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s);
+
+// zero the statistics for a new distributed add (event pairs not read yet are dropped)
+void comm_stats_reset(kmu_ctx *ctx);
 
 } // namespace kmu

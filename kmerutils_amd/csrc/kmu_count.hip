@@ -30,6 +30,8 @@
 
 #include "kmu_comm.hpp"
 #include "kmu_ctx.hpp"
+#include "kmu_flat.h"
+#include "kmu_smer.hpp"
 #include "kmu_stream.h"
 
 #ifndef KMU_STEP_TAB // (A/B builds: 0 = level 1 looks the read of a step up at the top of the step)
@@ -60,9 +62,11 @@ struct kmu_counter {
     bool stats_cached = false;   // scalars[4..6] = distinct / unique / occurrences, left by the last compact build
     // distributed counters (KMU_COUNT_DISTRIBUTED): one member of a KmerCounterPool spread over the ranks
     bool dist = false;
+    int okind = 0;               // owner of a k-mer among the ranks: 0 = the reference's dispatch (intNN_hash(kmer) % n), 1 = its minimizer (kmu_smer.h)
     bool unmerged = false;       // holds entries this rank does not own (MERGE route adds): finalize moves them
     // an exchange in flight between dist_add_begin and dist_add_end
-    uint64_t pend_recv = 0;      // k-mers arriving in "cnt.recv"
+    uint64_t pend_recv = 0;      // k-mers (okind 0) / super-k-mer records (okind 1) arriving in "cnt.recv"
+    uint64_t pend_kmers = 0;     // okind 1: the k-mers those records hold
     bool pending = false;
     bool no_seg = false;         // the single-pass partition of this batch has just overflowed: straight to the exact levels
 };
@@ -103,18 +107,14 @@ __device__ __forceinline__ uint32_t owner_of_hash(uint64_t h, int w32, uint32_t 
     if ((n_parts & (n_parts - 1u)) == 0u) return (uint32_t) h & (n_parts - 1u);
     return w32 ? (uint32_t) h % n_parts : (uint32_t) (h % (uint64_t) n_parts);
 }
-__device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int w32, uint32_t n_parts) { return owner_of_hash(owner_hash(v, w32), w32, n_parts); }
-
-// Duplication sample of a batch: the k-mers whose owner hash has `shift` zero bits above bit 8 (a sample by KEY: every
-// occurrence of a sampled k-mer is in it, so occurrences / distinct of the sample estimates the ratio of the batch).
-// Collected per workgroup in LDS and flushed with one global atomic per workgroup.
-static constexpr uint32_t SAMPLE_LDS = 4096; // entries per workgroup
-struct SampleArgs {
-    uint64_t *list;   // null: no sampling
-    uint32_t *n;      // [0] entries written, [1] overflow flag
-    uint32_t cap;
-    uint32_t shift;
-};
+// `mode`: 0 = int64_hash(kmer) % n, 1 = int32_hash(kmer) % n (the reference's dispatch by k-mer width), OWNER_MODE_SMER | k << 8 =
+// the minimizer owner of a k-mer of k bases (kmu_smer.h; distributed counters)
+static constexpr int OWNER_MODE_SMER = 2;
+__host__ __device__ __forceinline__ int owner_mode_smer(int k) { return OWNER_MODE_SMER | (k << 8); }
+__device__ __forceinline__ uint32_t kmer_owner(uint64_t v, int mode, uint32_t n_parts) {
+    if ((mode & 0xFF) == OWNER_MODE_SMER) return smer_owner_of_kmer(v, mode >> 8, n_parts);
+    return owner_of_hash(owner_hash(v, mode), mode, n_parts);
+}
 
 struct CountTable {
     uint64_t *keys;   // wide: keys; quotient: slots
@@ -220,32 +220,6 @@ __device__ __forceinline__ uint32_t count_lookup(const CountTable &t, uint64_t v
         off = (off + 1) & t.rmask;
     }
     return 0;
-}
-
-// largest i with offsets[i] <= g, g wave-uniform; 64-ary search, one coalesced probe per round
-__device__ __forceinline__ uint32_t wave_find_read(const uint64_t *offsets, uint32_t n, uint64_t g) {
-    uint32_t lo = 0, hi = n; // invariant offsets[lo] <= g < offsets[hi]
-    const uint32_t lane = (uint32_t) lane_id();
-    while (hi - lo > 1) {
-        const uint32_t step = (hi - lo + 63) / 64;
-        const uint64_t idx = (uint64_t) lo + (uint64_t) (lane + 1) * step;
-        const bool le = idx < hi && offsets[idx] <= g;
-        const uint32_t c = (uint32_t) __popcll(__ballot(le));
-        const uint64_t nhi = (uint64_t) lo + (uint64_t) (c + 1) * step;
-        lo = lo + c * step;
-        hi = nhi < hi ? (uint32_t) nhi : hi;
-    }
-    return lo;
-}
-
-// the same with a hint: a wave walks the flat stream forwards, so the read is usually one of the next 64
-__device__ __forceinline__ uint32_t wave_find_read_from(const uint64_t *offsets, uint32_t n, uint64_t g, uint32_t hint) {
-    if (hint >= n || offsets[hint] > g) return wave_find_read(offsets, n, g);
-    const uint64_t idx = (uint64_t) hint + 1 + (uint32_t) lane_id();
-    const bool le = idx < n && offsets[idx] <= g;
-    const uint32_t c = (uint32_t) __popcll(__ballot(le));
-    if (c < 64u) return hint + c;
-    return wave_find_read(offsets, n, g);
 }
 
 // One wave step (64 words = 1024 bases) of the flat base stream: f(canon) for every k-mer that lies inside one read.
@@ -1510,6 +1484,55 @@ __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, con
     }
 }
 
+// Level 1 of the receiver of a super-k-mer exchange (kmu_smer.h): the input is an array of 12-byte records, a thread takes one
+// record per tile and expands it into its <= 16 canonical k-mers with the window arithmetic of the read path (a record IS the
+// lane's three code words); from there on the tile sort of the single-pass partition, shared streams and cursors as in
+// k_arr_scatter<IT_KEY_TO_HASH, true, SHARED>.  Unit u of `chunks` takes records [n u / chunks, n (u + 1) / chunks).
+template <bool SHARED>
+__global__ void __launch_bounds__(SCATTER_THREADS) k_smer_scatter1(const uint32_t *recs, uint64_t n_rec, int k, ArrPlan pl, uint64_t *out,
+                                                                  uint64_t seg_cap, uint32_t *seg_ovf, uint32_t *cursors) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SegLds ls = seg_lds(smem, pl.bins);
+    SegOut sg{(uint64_t) blockIdx.x * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
+    uint32_t *cursor = nullptr;
+    if (SHARED) {
+        const uint32_t nsets = pl.out_sets > 1u ? pl.out_sets : 1u;
+        const uint64_t block = nsets > 1u ? blockIdx.x % nsets : 0u;
+        sg = SegOut{block * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
+        cursor = cursors + block * pl.bins;
+    }
+    uint32_t run[2] = {0u, 0u};
+    SegClk clk;
+    for (uint32_t b = threadIdx.x; b <= pl.bins; b += blockDim.x) ls.cnt[b] = 0;
+    lds_barrier();
+    const uint64_t i0 = n_rec * blockIdx.x / pl.chunks, i1 = n_rec * (blockIdx.x + 1) / pl.chunks;
+    const int sh = 64 - 2 * k;
+    uint32_t nx0 = 0, nx1 = 0, nx2 = 0;
+    bool nxv = false;
+    auto fetch = [&](uint64_t i) {
+        nxv = i < i1;
+        if (nxv) { nx0 = recs[i * 3]; nx1 = recs[i * 3 + 1]; nx2 = recs[i * 3 + 2]; }
+    };
+    fetch(i0 + threadIdx.x);
+    clk.start();
+    for (uint64_t t0 = i0; t0 < i1; t0 += SCATTER_THREADS) {
+        const uint32_t w0 = nx0, w1 = nx1, w2 = nx2, L = nxv ? (nx2 & 15u) + 1u : 0u;
+        fetch(t0 + SCATTER_THREADS + threadIdx.x); // the next tile's record arrives under this tile's sort
+        uint64_t it[16];
+        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint64_t v = ((hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32)) >> sh;
+            const uint64_t rc = revcomp_val(v, k);
+            it[j] = (uint32_t) j < L ? khash(rc < v ? rc : v) : CKEY_EMPTY; // kmer.reverse_complement().min(kmer), kmercount.rs:938
+        }
+        tile_scatter_seg<false, SHARED>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
+    }
+    if (!SHARED) seg_finish_unit(ls, pl.bins, sg, run, out, true, nullptr);
+    clk.mark(5);
+    clk.flush(1);
+}
+
 // the overflow word block of a single-pass partition (seg_spill): flag and count zero, capacity and address of the list
 __global__ void __launch_bounds__(64) k_spill_header(uint32_t *ovf, uint32_t cap, uint64_t *list) {
     if (threadIdx.x < 16) ovf[threadIdx.x] = 0u;
@@ -1809,6 +1832,8 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
 using namespace kmu;
 
 // bytes of the table image in HBM (what a pass over the table reads)
+// kmer_owner's mode for the counter's own owner function (distributed counters)
+static int owner_mode_of(const kmu_counter *c) { return c->okind == 1 ? owner_mode_smer(c->p.kmer_size) : (kmer_val_bytes(c->p.kmer_type) == 4 ? 1 : 0); }
 static size_t table_image_bytes(const kmu_counter *c) { return (size_t) c->nslots * (c->qw ? 8 : 12); }
 
 static CountTable table_of(const kmu_counter *c) {
@@ -1922,7 +1947,8 @@ static int scatter_attrs(kmu_ctx *ctx) {
     const void *fns[] = {(const void *) k_part_scatter1<false>, (const void *) k_part_scatter1<true>, (const void *) k_part_scatter1<true, true>,
                          (const void *) k_arr_scatter<IT_HASH, false>, (const void *) k_arr_scatter<IT_HASH, true>, (const void *) k_arr_scatter<IT_HASH, true, true>, (const void *) k_arr_scatter<IT_HASH, true, true, 512>,
                          (const void *) k_arr_scatter<IT_KEY, false>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, false>,
-                         (const void *) k_arr_scatter<IT_KEY_TO_HASH, true>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, true, true>};
+                         (const void *) k_arr_scatter<IT_KEY_TO_HASH, true>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, true, true>,
+                         (const void *) k_smer_scatter1<false>, (const void *) k_smer_scatter1<true>};
     for (const void *f : fns) KMU_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ctx->lds_attr_set |= 1u;
     return KMU_OK;
@@ -2403,7 +2429,9 @@ int partition_u64(kmu_ctx *ctx, const uint64_t *in, uint64_t n, int region_bits,
 
 // the single-pass partition for an ARRAY of canonical k-mers (what the owner of a key range receives in the OCCURRENCES
 // route of a distributed add): level 1 cuts the array into chunks, every (chunk, bin) a fixed segment, no histograms
-static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64_t n, const PartPlan &pl, uint32_t *d_err, int *taken) {
+// recs != nullptr: the input is n_rec super-k-mer records holding n k-mers (kmu_smer.h) instead of an array of n k-mers
+static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64_t n, const PartPlan &pl, uint32_t *d_err, int *taken,
+                                     const void *recs = nullptr, uint64_t n_rec = 0) {
     kmu_ctx *ctx = c->ctx;
     *taken = 0;
     const uint32_t bins1 = 1u << pl.b1, bins2 = 1u << pl.b2;
@@ -2427,7 +2455,13 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     }
     hipLaunchKernelGGL(k_fill_linear, dim3(1), dim3(256), 0, ctx->stream, (uint64_t *) b0, (uint64_t) 2, n);
     KMU_TRY(scatter_attrs(ctx));
-    {
+    if (recs) {
+        ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1, 0u, 0u, 0u, sets};
+        const auto k1 = sets ? k_smer_scatter1<true> : k_smer_scatter1<false>;
+        KernelTimer tm(ctx, "k_smer_scatter1");
+        hipLaunchKernelGGL(k1, dim3(chunks1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, (const uint32_t *) recs, n_rec, c->p.kmer_size,
+                           ap, (uint64_t *) A, cap1, (uint32_t *) ovf, (uint32_t *) cur1);
+    } else {
         ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1, 0u, 0u, 0u, sets};
         const auto k1 = sets ? k_arr_scatter<IT_KEY_TO_HASH, true, true> : k_arr_scatter<IT_KEY_TO_HASH, true, false>;
         KernelTimer tm(ctx, "k_arr_scatter");
@@ -2457,7 +2491,7 @@ static int partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64
     kmu_ctx *ctx = c->ctx;
     {
         PartPlan pl;
-        if (part_plan_for(c, &pl) && pl.b2 && seg_partition_wanted(n)) {
+        if (!c->no_seg && part_plan_for(c, &pl) && pl.b2 && seg_partition_wanted(n)) {
             int taken = 0;
             KMU_TRY(seg_partitioned_add_kmers(c, d_kmers, n, pl, d_err, &taken));
             if (taken) return KMU_OK;
@@ -2540,6 +2574,7 @@ static int extract_by_owner(kmu_counter *c, const DevSeqs &ds, uint64_t total_ba
 }
 
 static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *counts, uint64_t n, int mem);
+static int add_superkmers(kmu_counter *c, const void *recs, uint64_t n_rec, uint64_t n_kmers);
 static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err);
 
 // the canonical k-mers of device-resident reads into THIS table: the streaming build for big batches of unpacked reads,
@@ -2600,21 +2635,33 @@ static void route_model(double table_bytes, double gbps, double n, double d, int
     *ms_occ = n * (3.0 + 6.2 + 13.1) * ps + 8.0 * n * f / (gbps * 1e6) + 8.0 * n * (1.0 - f) / 1.2e9;
     *ms_merge = n * (3.0 + 13.5) * ps + (f > 0 ? 2.0 : 1.0) * table_bytes / 4.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
 }
+// The same with minimizer owners: the occurrences travel as `recs` super-k-mer records of 12 bytes (kmu_smer.h).  Per occurrence:
+// census 1.0 ps + record scatter 1.3 ps (neither forms a k-mer), the receiver's build from records 13.3 ps (record expansion inside
+// the first partition level + level 2 + region build); MERGE pays the census, the local build, its table passes and a minimizer per
+// entry in them (r04, scripts/r04_routes.sh).
+static void route_model_smer(double table_bytes, double gbps, double n, double recs, double d, int nranks, double *ms_occ, double *ms_merge) {
+    const double f = nranks > 1 ? (double) (nranks - 1) / nranks : 0.0;
+    const double ps = 1e-9;
+    *ms_occ = n * (1.0 + 1.3 + 13.3) * ps + 12.0 * recs * f / (gbps * 1e6) + 12.0 * recs * (1.0 - f) / 1.2e9;
+    *ms_merge = n * (1.0 + 13.5) * ps + (f > 0 ? 2.0 : 1.0) * table_bytes / 3.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
+}
 
 // first half of a distributed add: census of the owners + duplication sample, agreement on the route over all ranks, then
-// OCCURRENCES: scatter by owner and the all-to-all (on the communicator's stream; the context's stream is free for other
-// work until dist_add_end), MERGE: the local build.
+// OCCURRENCES / SUPERKMERS: scatter by owner and the all-to-all (on the communicator's stream; the context's stream is free for
+// other work until dist_add_end), MERGE: the local build.
 static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uint32_t *d_err) {
     kmu_ctx *ctx = c->ctx;
     kmu_comm *cm = ctx->comm;
     if (!cm) return fail(ctx, KMU_E_BAD_ARG, "the communicator of this distributed counter's context is gone (kmu_comm_destroy)");
     const uint32_t N = (uint32_t) cm->nranks;
-    cm->stats = kmu_comm_stats{};
+    const bool smer = c->okind == 1;
+    comm_stats_reset(ctx);
+    cm->stats.owner_kind = c->okind;
     // ---- census + sample ----
     void *slist, *sn, *stab;
-    const uint64_t nsteps = std::max<uint64_t>(1, ((total_bases + 15) / 16 + 63) / 64);
-    const uint64_t units = std::min<uint64_t>(nsteps, (uint64_t) ctx->num_cus * 8);
-    const uint64_t kmers_per_unit = (nsteps + units - 1) / units * 1024;
+    const uint64_t units = smer ? smer_units(ctx, total_bases)
+                                : std::min<uint64_t>(std::max<uint64_t>(1, ((total_bases + 15) / 16 + 63) / 64), (uint64_t) ctx->num_cus * 8);
+    const uint64_t kmers_per_unit = (total_bases + units - 1) / units;
     uint32_t shift = 0; // ~1024 sampled k-mers per workgroup (its LDS list holds 4096)
     while (shift < 24 && (kmers_per_unit >> shift) > 1024) shift++;
     const uint32_t cap = (uint32_t) std::min<uint64_t>(units * SAMPLE_LDS, 1u << 26);
@@ -2622,12 +2669,24 @@ static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uin
     KMU_TRY(dev_buf(ctx, "cnt.sample_n", 64, &sn));
     KMU_HIP(ctx, hipMemsetAsync(sn, 0, 64, ctx->stream));
     OwnerPlan op;
-    KMU_TRY(owner_census(c, ds, total_bases, N, d_err, &op, SampleArgs{(uint64_t *) slist, (uint32_t *) sn, cap, shift}));
+    SmerGroups sg;
+    const SampleArgs sa{(uint64_t *) slist, (uint32_t *) sn, cap, shift};
+    std::vector<uint64_t> bounds(N + 1), kto(N, 0); // groups (k-mers or records) per owner, as a prefix; k-mers per owner
+    if (smer) {
+        KMU_TRY(smer_census(ctx, ds, total_bases, c->p.kmer_size, N, d_err, sa, &sg));
+        KMU_HIP(ctx, hipMemcpyAsync(bounds.data(), sg.binstart, (size_t) (N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KMU_HIP(ctx, hipMemcpyAsync(kto.data(), sg.kmers, (size_t) N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        KMU_TRY(owner_census(c, ds, total_bases, N, d_err, &op, sa));
+        KMU_HIP(ctx, hipMemcpyAsync(bounds.data(), op.binstart1, (size_t) (N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     uint32_t h_sn[4] = {0, 0, 0, 0};
     KMU_HIP(ctx, hipMemcpyAsync(h_sn, sn, 8, hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<uint64_t> bounds(N + 1);
-    KMU_HIP(ctx, hipMemcpyAsync(bounds.data(), op.binstart1, (size_t) (N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!smer)
+        for (uint32_t p = 0; p < N; p++) kto[p] = bounds[p + 1] - bounds[p];
+    uint64_t n_local = 0;
+    for (uint32_t p = 0; p < N; p++) n_local += kto[p];
     const uint32_t n_s = std::min(h_sn[0], cap);
     uint32_t d_s = 0;
     if (n_s && !h_sn[1]) {
@@ -2651,44 +2710,56 @@ static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uin
     // rank-specific read counts can straddle a power of two), the link rate and a forced route (environment of the rank's
     // process).  The ranks then evaluate the same function of the same gathered numbers: the largest table, rank 0's link
     // rate, rank 0's override.
-    const uint32_t H = 7; // header words of a row
-    std::vector<uint64_t> mine(H + N), all((size_t) (H + N) * N);
+    const uint32_t H = 8; // header words of a row; then N group sizes (what travels: k-mers or records), then N k-mer counts
+    const uint32_t RW = H + 2 * N;
+    std::vector<uint64_t> mine(RW), all((size_t) RW * N);
     mine[0] = n_s;
     mine[1] = h_sn[1] ? 0 : d_s;
-    mine[2] = bounds[N];
+    mine[2] = n_local;
     mine[3] = c->unmerged ? 1 : 0;
     mine[4] = (uint64_t) table_image_bytes(c);
     mine[5] = (uint64_t) (local_xgmi_gbps() * 1000.0);
     mine[6] = 0;
     if (const char *e = getenv("KMU_COUNT_ROUTE")) {
-        if (!strcmp(e, "occurrences")) mine[6] = KMU_ROUTE_OCCURRENCES;
+        if (!strcmp(e, "occurrences") || !strcmp(e, "superkmers")) mine[6] = KMU_ROUTE_OCCURRENCES;
         if (!strcmp(e, "merge")) mine[6] = KMU_ROUTE_MERGE;
     }
-    for (uint32_t p = 0; p < N; p++) mine[H + p] = bounds[p + 1] - bounds[p];
-    KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), (H + N) * 8));
-    double sum_ns = 0, sum_ds = 0, sum_n = 0, max_table = 0;
+    mine[7] = (uint64_t) c->okind;
+    for (uint32_t p = 0; p < N; p++) {
+        mine[H + p] = bounds[p + 1] - bounds[p];
+        mine[H + N + p] = kto[p];
+    }
+    KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), (uint64_t) RW * 8));
+    double sum_ns = 0, sum_ds = 0, sum_n = 0, sum_g = 0, max_table = 0;
     bool valid = true;
     for (uint32_t r = 0; r < N; r++) {
-        const uint64_t *row = &all[(size_t) r * (H + N)];
+        const uint64_t *row = &all[(size_t) r * RW];
         sum_ns += (double) row[0];
         sum_ds += (double) row[1];
         sum_n += (double) row[2];
         max_table = std::max(max_table, (double) row[4]);
         if (row[0] && !row[1]) valid = false; // a truncated sample somewhere
+        if (row[7] != (uint64_t) c->okind)
+            return fail(ctx, KMU_E_BAD_ARG, "rank %u counts with another owner function than rank %d (KMU_COUNT_OWNER_HASH / KMU_COUNT_OWNER must agree)", r, cm->rank);
+        for (uint32_t p = 0; p < N; p++) sum_g += (double) row[H + p];
     }
     const double ratio = valid && sum_ds > 0 ? sum_ns / sum_ds : 0.0;
     const double n_loc = sum_n / N, d_loc = ratio > 0 ? n_loc / ratio : n_loc;
     double ms_occ, ms_merge;
-    route_model(max_table, (double) all[5] / 1000.0, n_loc, d_loc, (int) N, &ms_occ, &ms_merge);
+    if (smer) route_model_smer(max_table, (double) all[5] / 1000.0, n_loc, sum_g / N, d_loc, (int) N, &ms_occ, &ms_merge);
+    else route_model(max_table, (double) all[5] / 1000.0, n_loc, d_loc, (int) N, &ms_occ, &ms_merge);
     int route = ms_merge < ms_occ ? KMU_ROUTE_MERGE : KMU_ROUTE_OCCURRENCES;
     if (all[6]) route = (int) all[6]; // KMU_COUNT_ROUTE of rank 0's process
+    if (smer && route == KMU_ROUTE_OCCURRENCES) route = KMU_ROUTE_SUPERKMERS; // (the occurrences travel, as records)
     const double f = N > 1 ? (double) (N - 1) / N : 0.0;
+    const uint64_t g_local = bounds[N], g_self = mine[H + cm->rank];
     cm->stats.route = route;
     cm->stats.sample_shift = (int32_t) shift;
     cm->stats.dup_ratio = ratio;
-    cm->stats.kmers_local = bounds[N];
-    cm->stats.bytes_occurrences = (uint64_t) (8.0 * (double) (bounds[N] - mine[H + cm->rank]));
-    cm->stats.bytes_merge = (uint64_t) (12.0 * f * (ratio > 0 ? (double) bounds[N] / ratio : (double) bounds[N]));
+    cm->stats.kmers_local = n_local;
+    cm->stats.records_local = smer ? g_local : 0;
+    cm->stats.bytes_occurrences = (uint64_t) ((smer ? 12.0 : 8.0) * (double) (g_local - g_self));
+    cm->stats.bytes_merge = (uint64_t) (12.0 * f * (ratio > 0 ? (double) n_local / ratio : (double) n_local));
     cm->stats.model_ms_occurrences = ms_occ;
     cm->stats.model_ms_merge = ms_merge;
     c->pending = false;
@@ -2697,25 +2768,35 @@ static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uin
         c->unmerged = true;
         return KMU_OK;
     }
-    // ---- OCCURRENCES: group, exchange ----
-    uint64_t *grouped = nullptr;
-    KMU_TRY(owner_scatter(c, ds, total_bases, op, &grouped));
+    // ---- OCCURRENCES / SUPERKMERS: group, exchange ----
+    const uint32_t eb = smer ? SMER_REC_BYTES : 8u;
+    void *grouped = nullptr;
+    if (smer) {
+        KMU_TRY(dev_buf(ctx, "cnt.smer_send", (size_t) g_local * eb + 64, &grouped));
+        KMU_TRY(smer_scatter(ctx, ds, total_bases, sg, grouped));
+    } else {
+        uint64_t *g8 = nullptr;
+        KMU_TRY(owner_scatter(c, ds, total_bases, op, &g8));
+        grouped = g8;
+    }
     std::vector<uint64_t> scnt(N), sdis(N), rcnt(N), rdis(N);
-    uint64_t n_recv = 0;
+    uint64_t n_recv = 0, k_recv = 0;
     for (uint32_t p = 0; p < N; p++) {
         scnt[p] = bounds[p + 1] - bounds[p];
         sdis[p] = bounds[p];
-        rcnt[p] = all[(size_t) p * (H + N) + H + cm->rank];
+        rcnt[p] = all[(size_t) p * RW + H + cm->rank];
         rdis[p] = n_recv;
         n_recv += rcnt[p];
+        k_recv += all[(size_t) p * RW + H + N + cm->rank];
     }
     void *recv;
-    KMU_TRY(dev_buf(ctx, "cnt.recv", n_recv * 8 + 64, &recv));
+    KMU_TRY(dev_buf(ctx, "cnt.recv", n_recv * eb + 64, &recv));
     KMU_HIP(ctx, hipEventRecord(cm->ev_a, ctx->stream));
     KMU_HIP(ctx, hipStreamWaitEvent(cm->stream, cm->ev_a, 0));
-    KMU_TRY(comm_alltoallv(ctx, grouped, scnt.data(), sdis.data(), recv, rcnt.data(), rdis.data(), 8, cm->stream));
+    KMU_TRY(comm_alltoallv(ctx, grouped, scnt.data(), sdis.data(), recv, rcnt.data(), rdis.data(), eb, cm->stream));
     KMU_HIP(ctx, hipEventRecord(cm->ev_b, cm->stream));
     c->pend_recv = n_recv;
+    c->pend_kmers = k_recv;
     c->pending = true;
     return KMU_OK;
 }
@@ -2728,6 +2809,7 @@ static int dist_add_end(kmu_counter *c) {
     if (!ctx->comm) return fail(ctx, KMU_E_BAD_ARG, "the communicator went away under an exchange of this counter (kmu_comm_destroy)");
     KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm->ev_b, 0));
     if (c->pend_recv == 0) return KMU_OK;
+    if (c->okind == 1) return add_superkmers(c, ctx->bufs["cnt.recv"].p, c->pend_recv, c->pend_kmers);
     return add_entries(c, (const uint64_t *) ctx->bufs["cnt.recv"].p, nullptr, c->pend_recv, KMU_MEM_DEVICE);
 }
 
@@ -2739,6 +2821,7 @@ int kmu_count_reset(kmu_counter *c) {
         (void) hipStreamWaitEvent(c->ctx->stream, c->ctx->comm->ev_b, 0);
     c->pending = false;
     c->pend_recv = 0;
+    c->pend_kmers = 0;
     c->unmerged = false;
     c->empty = true; // materialised lazily: a partitioned build writes every region itself
     c->compact = false;
@@ -2797,6 +2880,14 @@ int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out)
             return fail(ctx, KMU_E_BAD_ARG, "KMU_COUNT_DISTRIBUTED needs a communicator on the context (kmu_comm_init)");
         }
         c->dist = true;
+        // who owns a k-mer: its minimizer wherever a window fits (Kmer64bit, k >= 17: the occurrences then travel as super-k-mer
+        // records, ~1.35 B per k-mer instead of 8), else -- or with KMU_COUNT_OWNER_HASH / KMU_COUNT_OWNER=hash -- the reference's
+        // dispatch.  Every rank of a pool must choose alike (the choice is a function of the parameters and the environment).
+        c->okind = smer_supported(p->kmer_type, p->kmer_size) && !(p->flags & KMU_COUNT_OWNER_HASH) ? 1 : 0;
+        if (const char *e = getenv("KMU_COUNT_OWNER")) {
+            if (!strcmp(e, "hash")) c->okind = 0;
+            if (!strcmp(e, "minimizer") && smer_supported(p->kmer_type, p->kmer_size)) c->okind = 1;
+        }
     }
     *out = c;
     return KMU_OK;
@@ -2972,6 +3063,40 @@ static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *co
     return finish_call(ctx, mem);
 }
 
+// the k-mers of n_rec super-k-mer records in device memory (kmu_smer.h: what the owner of a key range receives) into this
+// table: big batches straight into the single-pass partition (k_smer_scatter1 expands a record inside the tile sort), small
+// ones and the fall-back through an array of their canonical k-mers
+static int add_superkmers(kmu_counter *c, const void *recs, uint64_t n_rec, uint64_t n_kmers) {
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_rec == 0) return KMU_OK;
+    uint32_t *d_err;
+    KMU_TRY(get_err_word(ctx, &d_err));
+    const char *force = getenv("KMU_COUNT_PATH");
+    bool partitioned = n_kmers * (c->empty ? 64u : 10u) >= c->nslots && n_kmers >= (1u << 16) && c->lg - c->rbits <= 22; // (see local_add)
+    if (force && !strcmp(force, "direct")) partitioned = false;
+    if (force && !strcmp(force, "partitioned")) partitioned = true;
+    PartPlan pl;
+    bool overflowed = false;
+    if (partitioned && part_plan_for(c, &pl) && pl.b2 && seg_partition_wanted(n_kmers)) {
+        int taken = 0;
+        KMU_TRY(seg_partitioned_add_kmers(c, nullptr, n_kmers, pl, d_err, &taken, recs, n_rec));
+        if (taken) {
+            if (!ctx->async_device) KMU_TRY(check_err_word(ctx, d_err));
+            return finish_call(ctx, KMU_MEM_DEVICE);
+        }
+        overflowed = true; // a segment and the spill list overflowed, the table is untouched: the exact levels, on the k-mers
+    }
+    void *x, *cur;
+    KMU_TRY(dev_buf(ctx, "cnt.smer_x", n_kmers * 8 + 64, &x));
+    KMU_TRY(dev_buf(ctx, "cnt.smer_cur", 64, &cur));
+    KMU_TRY(smer_expand(ctx, recs, n_rec, c->p.kmer_size, (uint64_t *) x, (uint64_t *) cur));
+    c->no_seg = overflowed;
+    const int rc = add_entries(c, (const uint64_t *) x, nullptr, n_kmers, KMU_MEM_DEVICE);
+    c->no_seg = false;
+    return rc;
+}
+
 int kmu_count_add_kmers(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int mem) {
     if (!c || (!canon_kmers && n)) return KMU_E_BAD_ARG;
     return add_entries(c, canon_kmers, nullptr, n, mem);
@@ -3066,7 +3191,8 @@ int kmu_count_table_info(const kmu_counter *c, kmu_count_table_info_t *out) {
 
 // shared by dump / export: select into device buffers, then hand over
 static int select_entries(kmu_counter *c, uint32_t min_count, uint32_t maxc, uint32_t part, uint32_t n_parts,
-                          uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap, int mem, bool sort, uint64_t *n_out) {
+                          uint64_t *kmers_out, uint32_t *counts_out, uint64_t cap, int mem, bool sort, uint64_t *n_out,
+                          bool own_owner = false /* parts by the counter's own owner function instead of the reference's dispatch */) {
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     if (c->empty) {
@@ -3074,7 +3200,7 @@ static int select_entries(kmu_counter *c, uint32_t min_count, uint32_t maxc, uin
         return KMU_OK;
     }
     KMU_TRY(materialize(c));
-    const int w32 = kmer_val_bytes(c->p.kmer_type) == 4;
+    const int w32 = own_owner ? owner_mode_of(c) : kmer_val_bytes(c->p.kmer_type) == 4;
     uint64_t *d_k = nullptr;
     uint32_t *d_c = nullptr;
     if (kmers_out) {
@@ -3235,7 +3361,7 @@ int kmu_count_finalize(kmu_counter *c) {
     if (!cm) return fail(ctx, KMU_E_BAD_ARG, "the communicator of this counter's context is gone");
     KMU_TRY(dist_add_end(c));
     const uint32_t N = (uint32_t) cm->nranks, me = (uint32_t) cm->rank;
-    const int w32 = kmer_val_bytes(c->p.kmer_type) == 4;
+    const int w32 = owner_mode_of(c);
     // who has entries of other owners, and how many for whom
     void *po;
     KMU_TRY(dev_buf(ctx, "cnt.per_owner", ((size_t) N + 1) * 8 * 2 + 64, &po));
@@ -3297,7 +3423,7 @@ int kmu_count_finalize(kmu_counter *c) {
         KMU_TRY(dev_buf(ctx, "cnt.keep.k", n_stay * 8 + 8, &kk));
         KMU_TRY(dev_buf(ctx, "cnt.keep.c", n_stay * 4 + 8, &kc));
         uint64_t n2 = 0;
-        KMU_TRY(select_entries(c, 1u, 0xFFFFFFFFu, me, N, (uint64_t *) kk, (uint32_t *) kc, n_stay, KMU_MEM_DEVICE, false, &n2));
+        KMU_TRY(select_entries(c, 1u, 0xFFFFFFFFu, me, N, (uint64_t *) kk, (uint32_t *) kc, n_stay, KMU_MEM_DEVICE, false, &n2, true));
         KMU_TRY(kmu_count_reset(c));
         if (n2) KMU_TRY(add_entries(c, (const uint64_t *) kk, (const uint32_t *) kc, n2, KMU_MEM_DEVICE));
     }
@@ -3350,6 +3476,57 @@ int kmu_count_extract_by_owner(kmu_counter *c, const uint8_t *bases, const uint6
     KMU_TRY(check_err_word(ctx, d_err));
     if (ctx->profiling) profile_collect(ctx);
     return KMU_OK;
+}
+
+int kmu_count_owner_kind(const kmu_counter *c) { return c && c->dist ? c->okind : KMU_OWNER_HASH; }
+
+int kmu_count_extract_superkmers(kmu_counter *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int mem, uint32_t n_parts,
+                                 void **dev_records_out, uint64_t *record_bounds_out, uint64_t *kmers_per_part_out) {
+    if (!c || !dev_records_out || !record_bounds_out) return KMU_E_BAD_ARG;
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (!smer_supported(c->p.kmer_type, c->p.kmer_size)) return fail(ctx, KMU_E_UNSUPPORTED, "super-k-mers need Kmer64bit with 17 <= k <= 31");
+    DevSeqs ds;
+    KMU_TRY(stage_sequences(ctx, bases, offsets, nullptr, n_seq, KMU_INPUT_ASCII, mem, &ds));
+    uint64_t total_bases = 0;
+    KMU_TRY(flat_stream_extent(ctx, offsets, n_seq, mem, ds, &total_bases));
+    uint32_t *d_err;
+    KMU_TRY(get_err_word(ctx, &d_err));
+    SmerGroups sg;
+    KMU_TRY(smer_census(ctx, ds, total_bases, c->p.kmer_size, n_parts, d_err, SampleArgs{nullptr, nullptr, 0u, 0u}, &sg));
+    KMU_HIP(ctx, hipMemcpyAsync(record_bounds_out, sg.binstart, (size_t) (n_parts + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (kmers_per_part_out) KMU_HIP(ctx, hipMemcpyAsync(kmers_per_part_out, sg.kmers, (size_t) n_parts * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void *out;
+    KMU_TRY(dev_buf(ctx, "cnt.smer_send", (size_t) record_bounds_out[n_parts] * SMER_REC_BYTES + 64, &out));
+    KMU_TRY(smer_scatter(ctx, ds, total_bases, sg, out));
+    KMU_TRY(check_err_word(ctx, d_err));
+    if (ctx->profiling) profile_collect(ctx);
+    *dev_records_out = out;
+    return KMU_OK;
+}
+
+int kmu_count_add_superkmers(kmu_counter *c, const void *records, uint64_t n_records, int mem) {
+    if (!c || (!records && n_records)) return KMU_E_BAD_ARG;
+    kmu_ctx *ctx = c->ctx;
+    KMU_HIP(ctx, hipSetDevice(ctx->device));
+    if (!smer_supported(c->p.kmer_type, c->p.kmer_size)) return fail(ctx, KMU_E_UNSUPPORTED, "super-k-mers need Kmer64bit with 17 <= k <= 31");
+    if (n_records == 0) return KMU_OK;
+    const void *d_r = records;
+    if (mem == KMU_MEM_HOST) {
+        void *q;
+        KMU_TRY(dev_buf(ctx, "cnt.in.k", n_records * SMER_REC_BYTES + 64, &q));
+        KMU_HIP(ctx, hipMemcpyAsync(q, records, n_records * SMER_REC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+        d_r = q;
+    }
+    void *cur;
+    KMU_TRY(dev_buf(ctx, "cnt.smer_cur", 64, &cur));
+    uint64_t n_kmers = 0;
+    KMU_TRY(smer_count_kmers(ctx, d_r, n_records, (uint64_t *) cur));
+    KMU_HIP(ctx, hipMemcpyAsync(&n_kmers, cur, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KMU_TRY(add_superkmers(c, d_r, n_records, n_kmers));
+    return finish_call(ctx, mem);
 }
 
 } // extern "C"

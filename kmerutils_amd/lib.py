@@ -31,6 +31,7 @@ SYMBOLS = [
     "kmu_comm_get_id", "kmu_comm_init", "kmu_comm_init_custom", "kmu_comm_destroy", "kmu_comm_rank", "kmu_comm_nranks",
     "kmu_comm_allgather", "kmu_comm_get_stats", "kmu_count_finalize", "kmu_kmer_owner",
     "kmu_sketch_count", "kmu_host_alloc", "kmu_host_free", "kmu_count_nb_occurrences", "kmu_count_table_info",
+    "kmu_kmer_owner_minimizer", "kmu_count_owner_kind", "kmu_count_extract_superkmers", "kmu_count_add_superkmers",
 ]
 
 
@@ -84,6 +85,10 @@ def load():
     L.kmu_comm_get_stats.argtypes = [vp, C.POINTER(A.CommStats)]
     L.kmu_count_finalize.argtypes = [vp]
     L.kmu_kmer_owner.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
+    L.kmu_kmer_owner_minimizer.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, vp]
+    L.kmu_count_owner_kind.argtypes = [vp]
+    L.kmu_count_extract_superkmers.argtypes = [vp, vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(vp), vp, vp]
+    L.kmu_count_add_superkmers.argtypes = [vp, vp, C.c_uint64, C.c_int]
     L.kmu_sketch.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, vp, C.c_uint32, vp, vp, vp]
     L.kmu_block_layout.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.kmu_sketch_hashed.argtypes = [vp, C.POINTER(A.SketchParams), vp, vp, C.c_uint32, vp, vp]
@@ -646,17 +651,18 @@ class Context:
                                                       mem, _ptr(out)[0]))
         return out[:n]
 
-    def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False):
-        return Counter(self, kmer_type, k, counter_bits, capacity_hint, distributed)
+    def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False, owner_hash=False):
+        return Counter(self, kmer_type, k, counter_bits, capacity_hint, distributed, owner_hash)
 
 
 class Counter:
     """kmu_counter: exact canonical k-mer multiplicities on the device (KmerCountT contract)."""
 
-    def __init__(self, ctx, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False):
+    def __init__(self, ctx, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False, owner_hash=False):
         self.ctx = ctx
         self.L = ctx.L
-        self.p = A.CountParams(kmer_type, k, counter_bits, A.COUNT_DISTRIBUTED if distributed else 0, capacity_hint)
+        flags = (A.COUNT_DISTRIBUTED if distributed else 0) | (A.COUNT_OWNER_HASH if owner_hash else 0)
+        self.p = A.CountParams(kmer_type, k, counter_bits, flags, capacity_hint)
         h = C.c_void_p()
         ctx._check(self.L.kmu_count_create(ctx.h, C.byref(self.p), C.byref(h)))
         self.h = h
@@ -799,6 +805,39 @@ class Counter:
         t = torch.as_tensor(_Dev(), device=dev)
         return t[:n], bounds
 
+    @property
+    def owner_kind(self):
+        """kmu_count_owner_kind: A.OWNER_MINIMIZER / A.OWNER_HASH"""
+        return int(self.L.kmu_count_owner_kind(self.h))
+
+    def extract_superkmers(self, bases, offsets, n_parts):
+        """the k-mers of the reads as super-k-mer records grouped by minimizer owner.  Returns (records, bounds, kmers):
+        `records` a zero-copy [n, 3] int32 view (torch cuda tensor) of a buffer owned by the context, valid until the next
+        counter call; bounds[n_parts + 1] (numpy, in records); kmers[n_parts] the k-mers every group holds."""
+        import torch
+        mem = Context._mem(bases, offsets)
+        self.ctx._wait_producers(bases)
+        ptr = C.c_void_p()
+        bounds = np.zeros(n_parts + 1, np.uint64)
+        kmers = np.zeros(n_parts, np.uint64)
+        self.ctx._check(self.L.kmu_count_extract_superkmers(self.h, _ptr(bases)[0], _ptr(offsets)[0], len(offsets) - 1, mem, n_parts,
+                                                            C.byref(ptr), _ptr(bounds)[0], _ptr(kmers)[0]))
+        n = int(bounds[-1])
+
+        class _Dev:  # CUDA array interface v2 over the library-owned buffer
+            __cuda_array_interface__ = {"shape": (max(n, 1), 3), "typestr": "<i4", "data": (ptr.value, False), "version": 2}
+
+        dev = bases.device if _is_torch(bases) else torch.device("cuda", self.ctx.device_id)
+        t = torch.as_tensor(_Dev(), device=dev)
+        return t[:n], bounds, kmers
+
+    def add_superkmers(self, records):
+        """kmu_count_add_superkmers: records as an [n, 3] int32 / uint32 array (numpy or torch cuda tensor)"""
+        mem = Context._mem(records)
+        self.ctx._wait_producers(records)
+        n = (records.numel() if _is_torch(records) else records.size) // 3
+        self.ctx._check(self.L.kmu_count_add_superkmers(self.h, _ptr(records)[0], n, mem))
+
     def merge_entries(self, kmers, counts):
         mem = Context._mem(kmers, counts)
         self.ctx._wait_producers(kmers)
@@ -818,3 +857,14 @@ def kmer_owner(kmer_type, canon_kmers, n_parts):
     if rc:
         raise KmuError(rc, "kmu_kmer_owner")
     return out[:k.size]
+
+
+def kmer_owner_minimizer(k, canon_kmers, n_parts):
+    """kmu_kmer_owner_minimizer: the minimizer owner of Kmer64bit values of k bases (host arithmetic)"""
+    L = load()
+    v = np.ascontiguousarray(canon_kmers, np.uint64)
+    out = np.zeros(max(v.size, 1), np.uint32)
+    rc = L.kmu_kmer_owner_minimizer(k, _ptr(v)[0], v.size, n_parts, _ptr(out)[0])
+    if rc:
+        raise KmuError(rc, "kmu_kmer_owner_minimizer")
+    return out[:v.size]

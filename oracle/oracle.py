@@ -43,6 +43,10 @@ def lib():
         L.kmo_kmer_less.argtypes = [C.c_int, C.c_uint64, C.c_uint64]; L.kmo_kmer_less.restype = C.c_int
         L.kmo_int32_hash.argtypes = [C.c_uint32]; L.kmo_int32_hash.restype = C.c_uint32
         L.kmo_int64_hash.argtypes = [C.c_uint64]; L.kmo_int64_hash.restype = C.c_uint64
+        L.kmo_minimizer_hash.argtypes = [C.c_uint64, C.c_int]; L.kmo_minimizer_hash.restype = C.c_uint32
+        L.kmo_minimizer_owner.argtypes = [C.c_uint64, C.c_int, C.c_uint32]; L.kmo_minimizer_owner.restype = C.c_uint32
+        L.kmo_minimizer_owners.argtypes = [vp, C.c_uint64, C.c_int, C.c_uint32, vp]; L.kmo_minimizer_owners.restype = None
+        L.kmo_superkmer_expand.argtypes = [vp, C.c_uint64, C.c_int, vp, C.POINTER(C.c_int)]; L.kmo_superkmer_expand.restype = C.c_uint64
         L.kmo_nohash_finish.argtypes = [C.c_uint64, C.c_int]; L.kmo_nohash_finish.restype = C.c_uint64
         L.kmo_fnv1a.argtypes = [C.c_uint64, C.c_int]; L.kmo_fnv1a.restype = C.c_uint64
         L.kmo_nthash_init_8b.argtypes = [vp, C.c_int]; L.kmo_nthash_init_8b.restype = C.c_uint64
@@ -327,3 +331,20 @@ def set_hll_params(b=1.001, a=20.0, q=65534):
     f.argtypes = [C.c_double, C.c_double, C.c_uint32]
     f.restype = None
     f(b, a, q)
+
+
+def minimizer_owners(canon_kmers, k, n_parts):
+    """the minimizer owner of Kmer64bit values of k bases (the product's owner function between GPUs, restated base by base)"""
+    v = np.ascontiguousarray(canon_kmers, np.uint64)
+    out = np.zeros(max(v.size, 1), np.uint32)
+    lib().kmo_minimizer_owners(_p(v), v.size, k, n_parts, _p(out))
+    return out[:v.size]
+
+
+def superkmer_expand(records, k):
+    """canonical k-mers held by [n, 3] uint32 super-k-mer records, in record order; also whether every record is zero-padded"""
+    r = np.ascontiguousarray(records, np.uint32).reshape(-1, 3)
+    out = np.zeros(max(16 * r.shape[0], 1), np.uint64)
+    clean = C.c_int(1)
+    n = lib().kmo_superkmer_expand(_p(r), r.shape[0], k, _p(out), C.byref(clean))
+    return out[:n], bool(clean.value)

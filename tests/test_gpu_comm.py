@@ -21,16 +21,34 @@ def _reads(seed=0xC4, n=3000, fixed=150, genome=40_000):
     return synth.genome_reads(n, np.full(n, fixed, np.int64), genome, seed, sub=0.005, ins=0.0, dele=0.0)
 
 
+OWNERS = ("minimizer", "hash")  # KMU_COUNT_OWNER: the default (minimizer owners, super-k-mer records) and the reference's dispatch
+
+
+def _owners_of(oracle, kmers, world, owner, k=31):
+    """owner rank of canonical 31-mers: the minimizer owner (kmu_smer.h, restated in the oracle) or int64_hash(kmer) % n
+    (DispatchableT, src/base/kmercount.rs:412-420)"""
+    if owner == "minimizer":
+        return oracle.minimizer_owners(kmers, k, world).astype(np.int64)
+    L = oracle.lib()
+    return np.array([L.kmo_int64_hash(int(x)) % world for x in kmers], dtype=np.int64)
+
+
+def _route_code(route, owner):
+    return {"occurrences": 3 if owner == "minimizer" else 1, "merge": 2}[route]
+
+
 def _oracle_counts(oracle, bases, off, k=31):
     g = oracle.Counter(A.KMER64BIT, k, 16, 1 << 20)
     g.add_reads(bases, off)
     return g.dump(1)
 
 
-def test_rccl_world1_distributed_counter(oracle, monkeypatch):
+@pytest.mark.parametrize("owner", OWNERS)
+def test_rccl_world1_distributed_counter(oracle, monkeypatch, owner):
     import torch
     from kmerutils_amd import lib
     monkeypatch.setenv("NCCL_SOCKET_IFNAME", os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
+    monkeypatch.setenv("KMU_COUNT_OWNER", owner)
     ctx = lib.Context(0)
     ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
     assert (ctx.comm_rank, ctx.comm_nranks) == (0, 1)
@@ -47,13 +65,17 @@ def test_rccl_world1_distributed_counter(oracle, monkeypatch):
                 monkeypatch.delenv("KMU_COUNT_ROUTE", raising=False)
             for mem_dev in (True, False):
                 c = ctx.counter(A.KMER64BIT, 31, 16, max(nk, 1 << 16), distributed=True)
+                assert c.owner_kind == (A.OWNER_MINIMIZER if owner == "minimizer" else A.OWNER_HASH)
                 c.add_reads(db, do) if mem_dev else c.add_reads(bases, off)
                 st = ctx.comm_stats()
                 c.finalize()
                 gk, gc = c.dump(1)
                 assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (hint, route, mem_dev)
                 assert c.nb_distinct() == wk.size and c.nb_unique() == int((wc == 1).sum())
-                assert st["kmers_local"] == nk and st["route"] == {"occurrences": 1, "merge": 2}.get(route, st["route"])
+                assert st["kmers_local"] == nk and st["route"] == (_route_code(route, owner) if route else st["route"])
+                assert st["owner_kind"] == c.owner_kind and (st["records_local"] > 0) == (owner == "minimizer")
+                if st["route"] != 2:  # the exchange (to self) ran and was timed where it ran
+                    assert st["exchanges"] == 1 and st["exchange_ms"] > 0
                 # the sampled duplication is an estimate of occurrences / distinct of the batch
                 assert st["dup_ratio"] == 0 or abs(st["dup_ratio"] - nk / wk.size) < 0.15 * nk / wk.size, (st, nk, wk.size)
                 assert st["bytes_sent"] == 0  # nothing leaves a single rank
@@ -76,19 +98,19 @@ def test_rccl_world1_distributed_counter(oracle, monkeypatch):
     ctx.close()
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, owner):
     import torch
     import torch.distributed as dist
     from kmerutils_amd import lib
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["KMU_COUNT_OWNER"] = owner
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ctx = lib.Context(0)
         assert kdist.init_comm(ctx) == "torch"
         ok = (ctx.comm_rank, ctx.comm_nranks) == (rank, world)
-        L = O.lib()
         for reads in (_reads(), synth.ont_reads(400, 300_000, 0xC3)):
             bases, off = reads  # the same set on both ranks, sharded by bases
             lens = np.diff(off.astype(np.int64))
@@ -98,7 +120,7 @@ def _worker(rank, world, port, ret):
             g = O.Counter(A.KMER64BIT, 31, 16, 1 << 20)
             g.add_reads(bases, off)
             gk, gc = g.dump(1)
-            own = np.array([L.kmo_int64_hash(int(x)) % world for x in gk], dtype=np.int64) == rank
+            own = _owners_of(O, gk, world, owner) == rank
             for route in ("occurrences", "merge", None):
                 if route:
                     os.environ["KMU_COUNT_ROUTE"] = route
@@ -109,11 +131,14 @@ def _worker(rank, world, port, ret):
                 kk, cc = c.dump(1)
                 ok = ok and np.array_equal(kk, gk[own]) and np.array_equal(cc, gc[own])
                 ok = ok and c.nb_distinct() == int(own.sum())
-                ok = ok and st["bytes_sent"] > 0 and st["route"] in (1, 2)
+                ok = ok and st["bytes_sent"] > 0 and st["route"] in ((2, 3) if owner == "minimizer" else (1, 2))
+                ok = ok and st["exchange_ms"] > 0 and st["exchange_gbps_out"] > 0
                 if route == "merge":  # 12 bytes per entry that left
                     ok = ok and st["bytes_merge"] == st["bytes_sent"] and st["bytes_sent"] % 12 == 0
                 if route == "occurrences":
-                    ok = ok and st["bytes_sent"] == st["bytes_occurrences"]
+                    ok = ok and st["bytes_sent"] == st["bytes_occurrences"] and st["route"] == _route_code(route, owner)
+                    if owner == "minimizer":  # 12-byte records: a fraction of the 8 bytes per k-mer of the reference's dispatch
+                        ok = ok and st["bytes_sent"] % 12 == 0 and st["bytes_sent"] < 2.2 * st["kmers_local"] / 2
                 c.close()
             # an empty shard on one rank is a legal participant
             os.environ["KMU_COUNT_ROUTE"] = "merge"
@@ -133,7 +158,8 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_library_exchange():
+@pytest.mark.parametrize("owner", OWNERS)
+def test_two_ranks_one_gpu_library_exchange(owner):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -141,7 +167,7 @@ def test_two_ranks_one_gpu_library_exchange():
     s.close()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, owner)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -185,15 +211,16 @@ def _thread_rank(rank, group, shards, expected, errors, empty_rank):
         raise
 
 
+@pytest.mark.parametrize("owner", OWNERS)
 @pytest.mark.parametrize("world,empty_rank", [(8, 5), (6, None)])
-def test_eight_ranks_one_gpu_library_exchange(oracle, monkeypatch, world, empty_rank):
+def test_eight_ranks_one_gpu_library_exchange(oracle, monkeypatch, world, empty_rank, owner):
     """N = 8 (and N = 6: owners by a true modulo, not a mask) ranks on one GPU, as threads of one process -- the box lets at most
     six PROCESSES hold the card, so this is the form in which the 8-rank control flow runs here: route_model over 8 gathered
     rows (ranks with different table sizes: ADVICE r02, the route must still agree), the 8-way owner grouping, both routes, the
     automatic choice, one rank with an empty shard; every rank must end up with exactly the oracle's counts of the k-mers it
     owns (count_kmer_threaded_one_to_many, src/base/kmercount.rs:881-974; owner = int64_hash(kmer) % n, :412-420)."""
     import threading
-    L = oracle.lib()
+    monkeypatch.setenv("KMU_COUNT_OWNER", owner)
     for reads in (_reads(n=6000), synth.ont_reads(600, 500_000, 0xC3)):
         bases, off = reads
         lens = np.diff(off.astype(np.int64))
@@ -208,7 +235,7 @@ def test_eight_ranks_one_gpu_library_exchange(oracle, monkeypatch, world, empty_
             per_rank = int(off[-1]) // world + 1024
             shards.append((sb, so, per_rank if r % 2 else 4 * per_rank))
         gk, gc = g.dump(1)
-        own = np.array([L.kmo_int64_hash(int(x)) % world for x in gk], dtype=np.int64)
+        own = _owners_of(oracle, gk, world, owner)
         expected = [(gk[own == r], gc[own == r]) for r in range(world)]
         for route in ("occurrences", "merge", None):
             if route:
@@ -227,19 +254,21 @@ def test_eight_ranks_one_gpu_library_exchange(oracle, monkeypatch, world, empty_
             routes = {st["route"] for st in res}
             assert len(routes) == 1, (route, routes)  # every rank took the same route
             if route:
-                assert routes == {{"occurrences": 1, "merge": 2}[route]}
+                assert routes == {_route_code(route, owner)}
             assert all(st["bytes_sent"] > 0 for r, st in enumerate(res) if r != empty_rank)
             # the model's inputs were the gathered ones: the same two times on every rank
             assert len({(st["model_ms_occurrences"], st["model_ms_merge"]) for st in res}) == 1
 
 
-def test_rccl_many_rounds_to_self(oracle, monkeypatch):
+@pytest.mark.parametrize("owner", OWNERS)
+def test_rccl_many_rounds_to_self(oracle, monkeypatch, owner):
     """KMU_COMM_CHUNK_MB=1: the grouped ncclSend / ncclRecv all-to-all in many rounds (a pair's message cut at 1 MiB; the
     production cut is 1 GiB, below RCCL's silent truncation at 4 GiB), one rank, both routes"""
     import torch
     from kmerutils_amd import lib
     monkeypatch.setenv("NCCL_SOCKET_IFNAME", os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
     monkeypatch.setenv("KMU_COMM_CHUNK_MB", "1")
+    monkeypatch.setenv("KMU_COUNT_OWNER", owner)
     ctx = lib.Context(0)
     ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
     bases, off = synth.ont_reads(500, 3_000_000, 0xC6)  # 3 M k-mers: 24 MB to self in 23 rounds

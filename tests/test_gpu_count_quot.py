@@ -128,10 +128,11 @@ def test_once_kmers_quot(ctx, oracle, quot, tmp_path):
     PARITY.test_once_kmers_with_positions(ctx, oracle, tmp_path)
 
 
-def test_distributed_counter_quot(oracle, quot):
+@pytest.mark.parametrize("owner", ["minimizer", "hash"])
+def test_distributed_counter_quot(oracle, quot, owner):
     """both routes of a distributed add through RCCL at world size 1, incl. the MERGE finalize (owner census, emit, zeroed
-    counts as tombstones) on quotient slots"""
-    _load("test_gpu_comm").test_rccl_world1_distributed_counter(oracle, quot)
+    counts as tombstones) on quotient slots, with either owner function"""
+    _load("test_gpu_comm").test_rccl_world1_distributed_counter(oracle, quot, owner)
 
 
 def test_sketch_count_quot(ctx, oracle, quot):
