@@ -74,13 +74,14 @@ def workload_cfg(args):
         cfg.update(n_reads=1_000_000, total_bases=1.5e8, fixed_len=150, errors=(0.005, 0, 0), k=21, count=False, seed=0xC2,
                    genome=10_000_000)
     elif w == "c4_count":  # config 4's per-GPU shard: 6.25 M x 150 bp of the 50 M reads, 100 Mbp genome, k = 31, count only
-        cfg.update(n_reads=6_250_000, total_bases=9.375e8, fixed_len=150, errors=(0.005, 0, 0), k=31, sketch=False, seed=0xC4)
+        cfg.update(n_reads=6_250_000, total_bases=9.375e8, fixed_len=150, errors=(0.005, 0, 0), k=31, sketch=False, seed=0xC4,
+                   strong_total_reads=50_000_000)
     elif w == "c1_super":
         cfg.update(n_reads=10_000, total_bases=1e7, fixed_len=1000, errors=(0, 0, 0), k=16, kmer_type=A.KMER16B32BIT,
                    m=64, algo=A.ALGO_SUPER, sig=A.SIG_F64, count=False, seed=0xC1, genome=20_000_000)
     elif w == "c5_aa":  # config 5, one GPU's share of the 5 M proteins
         cfg.update(n_reads=625_000, total_bases=2.1e8, k=12, kmer_type=A.KMERAA64BIT, m=128, algo=A.ALGO_SUPER,
-                   sig=A.SIG_F64, fhash=A.FHASH_VALUE_MASKED, count=False, seed=0xC5, protein=True)
+                   sig=A.SIG_F64, fhash=A.FHASH_VALUE_MASKED, count=False, seed=0xC5, protein=True, strong_total_reads=5_000_000)
     if args.genome:
         cfg["genome"] = args.genome
     if args.reads:
@@ -93,22 +94,73 @@ def workload_cfg(args):
     return cfg
 
 
-def launch_ranks(args):
-    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks as a CHILD `torch.distributed.run`
-    (one process per GPU, rendezvous on 127.0.0.1), relay its output and exit code.  Nothing in this process has touched
-    the GPU (no torch import yet), and the child is a child -- never an exec of a process that holds the device."""
-    import socket
+def _run_child(cmd, env):
+    """one attempt: the child's exit code and what it wrote to stdout (its stderr goes straight through)"""
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.call(cmd, env=env)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    return p.returncode, p.stdout.decode(errors="replace")
+
+
+def _last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                pass
+    return None
+
+
+SKETCH_ONLY = {"ont_k31": "ont_k31_sketch"}  # the same reads without the collective: the last resort of an N-rank run
+
+
+def launch_ranks(args, argv=None, runner=_run_child, environ=None):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks as a CHILD `torch.distributed.run`
+    (one process per GPU, rendezvous on 127.0.0.1) and relay its JSON line.  Nothing in this process has touched the GPU (no
+    torch import yet), and every child is a child -- never an exec of a process that holds the device.
+
+    The first contact with N real GPUs must not be wasted: if the child exits non-zero or prints no JSON line, a FRESH child
+    runs with the library's exchange carried by torch's process group instead of the library's own RCCL communicator
+    (KMU_BENCH_TRANSPORT=torch), then one with the sketch-only workload (no collective at all); the line that comes out says
+    which attempt it is (`fallback_from`)."""
+    import socket
+    argv = list(sys.argv[1:] if argv is None else argv)
+    environ = dict(os.environ if environ is None else environ)
+    attempts = [({}, None, "rccl: the library's communicator")]
+    if environ.get("KMU_BENCH_TRANSPORT", "rccl") != "torch" and environ.get("KMU_BENCH_BACKEND", "nccl") == "nccl":
+        attempts.append(({"KMU_BENCH_TRANSPORT": "torch"}, None, "torch: the process group carries the exchange"))
+    if args.workload in SKETCH_ONLY:
+        attempts.append(({}, SKETCH_ONLY[args.workload], "no collective: %s" % SKETCH_ONLY[args.workload]))
+    failed = []
+    rc = 1
+    for envo, wl, what in attempts:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        av = list(argv)
+        if wl:
+            av = [a for i, a in enumerate(av) if a != "--workload" and (i == 0 or av[i - 1] != "--workload") and not a.startswith("--workload=")]
+            av += ["--workload", wl]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + av
+        env = dict(environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        env.update(envo)
+        rc, out = runner(cmd, env)
+        line = _last_json_line(out)
+        if rc == 0 and line is not None:
+            if failed:
+                line["fallback_from"] = failed
+            line.setdefault("attempt", what)
+            print(json.dumps(line))
+            return 0
+        failed.append({"attempt": what, "exit_code": rc, "json_line": line is not None})
+        print("bench.py: attempt '%s' failed (exit code %d, %s JSON line)%s" % (
+            what, rc, "a" if line is not None else "no", "; trying the next transport" if what != attempts[-1][2] else ""), file=sys.stderr)
+    return rc or 1
 
 
 def main():
@@ -146,9 +198,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cfg = workload_cfg(args)
-    if args.scaling == "strong" and world > 1:  # the workload's reads split over the ranks (different reads per rank)
-        cfg["n_reads"] = max(1, cfg["n_reads"] // world)
-        cfg["total_bases"] = cfg["total_bases"] / world
+    if args.scaling == "strong":
+        # the job's reads split over the ranks (different reads per rank).  BASELINE.json states config 4 and config 5 as job
+        # totals (50 M reads, 5 M proteins): those are what a strong-scaling line of these workloads divides; the others
+        # divide the per-GPU figure the weak default gives every rank
+        tot = cfg.get("strong_total_reads", cfg["n_reads"])
+        cfg["total_bases"] = cfg["total_bases"] * (tot / cfg["n_reads"]) / world
+        cfg["n_reads"] = max(1, tot // world)
 
     # ---- synthetic reads, generated in HBM (same genome on every rank, rank-specific reads) -----------------
     t_gen = time.time()
@@ -166,16 +222,56 @@ def main():
     transport = None
     # KMU_BENCH_FORCE_COMM=1: a communicator (RCCL, to self) also on one rank, so that one GPU executes and times the very
     # path N ranks take -- census, route choice, all-to-all, build from what arrives, finalize
-    use_comm = world > 1 or bool(os.environ.get("KMU_BENCH_FORCE_COMM"))
-    if use_comm:  # the library's own communicator: RCCL over xGMI (the id travels over the process group)
-        transport = kdist.init_comm(ctx, transport="rccl" if backend == "nccl" else "torch")
+    use_comm = (world > 1 or bool(os.environ.get("KMU_BENCH_FORCE_COMM"))) and cfg["count"]
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    comm_fallbacks = []
+
+    def all_ok(ok):
+        """did every rank get through?  (a rank that failed must not leave the others in a collective it never enters)"""
+        if world == 1:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() == 1.0)
+
+    if use_comm:
+        # the library's own communicator, RCCL over xGMI (the id travels over the process group), probed with a small
+        # distributed count before anything is timed; if any rank fails there, EVERY rank drops it and the process group
+        # carries the exchange instead (KMU_BENCH_TRANSPORT=torch asks for that from the start); if that fails too the
+        # step loses its collective (sketch only) -- and the line says so
+        want = os.environ.get("KMU_BENCH_TRANSPORT", "rccl" if backend == "nccl" else "torch")
+        for tr in ([want] if want == "torch" else [want, "torch"]):
+            err = None
+            try:
+                kdist.init_comm(ctx, transport=tr)
+                pn = min(1000, n_reads)
+                pc = ctx.counter(cfg["kmer_type"], cfg["k"], 8, 1 << 22, distributed=True)
+                pc.add_reads(bases[:int(offsets[pn].item())], offsets[:pn + 1])
+                pc.finalize()
+                ctx.synchronize()
+                pc.close()
+            except Exception as e:  # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+                err = "%s: %s" % (type(e).__name__, e)
+            if all_ok(err is None):
+                transport = tr
+                break
+            comm_fallbacks.append({"transport": tr, "rank": rank, "error": err})
+            try:
+                ctx.comm_destroy()
+            except Exception:  # noqa: BLE001
+                pass
+        else:
+            use_comm = False
+            if cfg["sketch"]:
+                cfg["count"] = False  # no collective left: the sketch half of the step, sharded
     p = A.SketchParams(cfg["algo"], cfg["kmer_type"], cfg["k"], cfg["m"], cfg["sig"], cfg["hasher"], cfg["fhash"], 0,
                        A.MODE_PER_SEQ, A.INPUT_ASCII, A.MEM_DEVICE, 0)
     sig_dtype = {A.SIG_U32: torch.int32, A.SIG_U64: torch.int64, A.SIG_F32: torch.float32,
                  A.SIG_F64: torch.float64}[cfg["sig"]]
     sig = torch.zeros((n_reads, cfg["m"]), dtype=sig_dtype, device=dev) if cfg["sketch"] else None
-    # (weak scaling: every rank ends up owning about one shard's worth of distinct k-mers)
-    counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024), distributed=use_comm) if cfg["count"] else None
+    # what a caller knows is the number of k-mer OCCURRENCES of its reads: the first add sizes the table from the duplication it
+    # measures (KMU_COUNT_HINT_OCCURRENCES; weak scaling: every rank ends up owning about one shard's worth of distinct k-mers)
+    counter = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(nk, 1024), distributed=use_comm, hint_occurrences=True) if cfg["count"] else None
     nth = torch.zeros(total_bases + 64, dtype=torch.int64, device=dev) if cfg["nthash"] else None
 
     def step_device():
@@ -226,8 +322,16 @@ def main():
     elapsed, dev_ms = timed(step_device, True)
     stats = ctx.profile_get()
     comm_stats = ctx.comm_stats() if use_comm and cfg["count"] else None
+    comm_ranks = None
+    if world > 1:  # what every rank measured: its exchange (the link rate the route model assumes) and its kernels
+        mine_r = {"rank": rank, "kernels_ms": {n: round(ms / max(1, ln), 3) for n, (ln, ms) in stats.items() if ln},
+                  "ms_per_step": elapsed / args.steps * 1e3}
+        if comm_stats:
+            mine_r.update({k: comm_stats[k] for k in ("exchange_ms", "bytes_sent", "bytes_received", "exchange_gbps_out",
+                                                      "exchange_gbps_in", "records_local", "kmers_local", "route")})
+        comm_ranks = [None] * world
+        dist.all_gather_object(comm_ranks, mine_r)
     if world > 1:
-        cdev = dev if backend == "nccl" else torch.device("cpu")
         tb = torch.tensor([total_bases], dtype=torch.float64, device=cdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         job_bases = float(tb.item())
@@ -323,12 +427,31 @@ def main():
             "cpu_baseline": cpu, "host_to_host": host, "value_device_resident": value,
             "value_host_to_host": host["value"] if host else None,
             "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
-            "checks": checks, "comm": dict(comm_stats, transport=transport) if comm_stats else None, "gen_seconds": t_gen,
+            "checks": checks, "comm": _comm_summary(comm_stats, transport, comm_fallbacks, comm_ranks), "gen_seconds": t_gen,
         }
+        if comm_fallbacks:
+            out["fallback_from"] = comm_fallbacks
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _comm_summary(comm_stats, transport, fallbacks, ranks):
+    """the `comm` object of the line: rank 0's statistics of the last step, and over all ranks the measured exchange (min /
+    mean / max) with every rank's kernel times -- the first run on N real GPUs calibrates KMU_XGMI_GBPS from these"""
+    if not comm_stats and not ranks:
+        return None
+    out = dict(comm_stats or {}, transport=transport)
+    if fallbacks:
+        out["fallback_from"] = fallbacks
+    if ranks:
+        for key in ("exchange_ms", "exchange_gbps_out", "exchange_gbps_in", "bytes_sent", "ms_per_step"):
+            v = [r[key] for r in ranks if r and key in r]
+            if v:
+                out[key + "_ranks"] = {"min": min(v), "mean": sum(v) / len(v), "max": max(v)}
+        out["per_rank"] = ranks
+    return out
 
 
 # the kernels of the two units of a step, by the names the library's timers carry (= the kernels' function names, the
@@ -336,7 +459,9 @@ def main():
 SKETCH_UNIT = ("k_multiset_uq", "k_multiset_short", "k_sketch_smallk", "k_sketch_pmh3a", "k_sketch_pmh3a_redo", "k_pmh_points",
                "k_pmh_points_short")
 COUNT_UNIT = ("k_part_hist1", "k_part_scan1", "k_part_scatter1", "k_arr_hist", "k_arr_scan", "k_arr_scatter", "k_part_build",
-              "k_part_build_q", "k_count_add_spill", "k_count_add_flat")
+              "k_part_build_q", "k_count_add_spill", "k_count_add_flat",
+              # N > 1, minimizer owners: the sender's census + record scatter, the receiver's first level from records
+              "k_smer_census", "k_smer_scan", "k_smer_scatter", "k_smer_scatter1", "k_smer_expand", "k_sample_distinct")
 
 
 def kernel_units(stats, steps, total_bases, nk, n_reads, m, sigw, table_bytes):

@@ -158,8 +158,8 @@ typedef struct kmu_count_params {
     int32_t kmer_type;     /* DNA types only */
     int32_t kmer_size;
     int32_t counter_bits;  /* 8 or 16 (reference default 8: saturates at 255, src/base/kmercount.rs:1615) */
-    int32_t flags;         /* 0, or KMU_COUNT_DISTRIBUTED [| KMU_COUNT_OWNER_HASH] (see "multi-GPU" below) */
-    uint64_t capacity_hint; /* expected number of distinct canonical k-mers */
+    int32_t flags;         /* 0, or KMU_COUNT_DISTRIBUTED [| KMU_COUNT_OWNER_HASH] (see "multi-GPU" below), KMU_COUNT_HINT_OCCURRENCES */
+    uint64_t capacity_hint; /* expected number of distinct canonical k-mers (KMU_COUNT_HINT_OCCURRENCES: of k-mer occurrences) */
 } kmu_count_params;
 
 /* ---- context ------------------------------------------------------------------------------------- */
@@ -330,6 +330,14 @@ int kmu_sketch_merge_partials(kmu_ctx *ctx, const kmu_sketch_params *p, const ui
 
 /* ---- L3 counting: KmerCountT (src/base/kmercount.rs:48-59), KmerCounter::insert_kmer :241-267,
  * count_kmer_threaded_one_to_many :881-974, KmerCounterPool :424-565 --------------------------------- */
+/* KMU_COUNT_HINT_OCCURRENCES (kmu_count_params.flags): capacity_hint counts the k-mer OCCURRENCES the caller is going to add (what
+ * a caller knows: the bases of its reads), not distinct k-mers.  The table is then allocated by the first add and sized from the
+ * duplication that add measures on a key sample of its batch (one extra pass over those reads, once per counter): 1.5 x
+ * occurrences / ratio slots.  The reference's filters are sized the same blind way -- capacity 3e9 / n whatever the reads,
+ * src/base/kmercount.rs:888-892 --; a table nine tenths empty costs nothing there, here every partitioned build writes the image.
+ * Batches added later must fit the table the first one made (KMU_E_TABLE_FULL otherwise): give a distinct-k-mer hint where the
+ * first batch is not representative.  Until that add kmu_count_table_info reports nslots = 0. */
+#define KMU_COUNT_HINT_OCCURRENCES 0x4
 int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out);
 void kmu_count_destroy(kmu_counter *c);
 int kmu_count_reset(kmu_counter *c);

@@ -61,6 +61,7 @@ class CountParams(C.Structure):
 
 COUNT_DISTRIBUTED = 0x1
 COUNT_OWNER_HASH = 0x2
+COUNT_HINT_OCCURRENCES = 0x4
 OWNER_HASH, OWNER_MINIMIZER = 0, 1
 ROUTE_NONE, ROUTE_OCCURRENCES, ROUTE_MERGE, ROUTE_SUPERKMERS = 0, 1, 2, 3
 SMER_REC_BYTES = 12

@@ -69,6 +69,8 @@ struct kmu_counter {
     uint64_t pend_kmers = 0;     // okind 1: the k-mers those records hold
     bool pending = false;
     bool no_seg = false;         // the single-pass partition of this batch has just overflowed: straight to the exact levels
+    // KMU_COUNT_HINT_OCCURRENCES: no table yet -- the first add allocates it, sized from the duplication it measures
+    bool deferred = false;
 };
 
 namespace kmu {
@@ -1910,7 +1912,9 @@ static bool want_compact(const kmu_counter *c) {
 
 // make the table's open-addressing image physical before anything probes or updates slots in place: the logical "all
 // free" state is written out, a compact table is expanded (one pass of the build kernel without items)
+static int table_alloc(kmu_counter *c, uint64_t distinct_hint);
 static int materialize(kmu_counter *c) {
+    if (c->deferred) KMU_TRY(table_alloc(c, c->p.capacity_hint)); // (a reader before the first add: the table the hint asks for, empty)
     kmu_ctx *ctx = c->ctx;
     if (c->empty) {
         KMU_HIP(ctx, hipMemsetAsync(c->keys, 0xFF, c->nslots * 8, ctx->stream));
@@ -2573,6 +2577,98 @@ static int extract_by_owner(kmu_counter *c, const DevSeqs &ds, uint64_t total_ba
     return KMU_OK;
 }
 
+// the table of a counter for `distinct_hint` distinct canonical k-mers: slots = the power of two >= 1.5 x the hint (load <= 2/3)
+static int table_alloc(kmu_counter *c, uint64_t distinct_hint) {
+    kmu_ctx *ctx = c->ctx;
+    const kmu_count_params *p = &c->p;
+    uint64_t want = std::max<uint64_t>(1024, distinct_hint + distinct_hint / 2);
+    c->lg = 10;
+    while ((1ull << c->lg) < want) c->lg++;
+    // slot format: quotient (8 bytes per slot) whenever the region bits leave room for the count field (see the top of the
+    // file): w = lg - 12 >= 11 for 8-bit counters, >= 17 for 16-bit ones.  KMU_COUNT_FMT=wide keeps 12 bytes per slot;
+    // =quot (tests) raises a small table to the size the quotient format starts at.
+    const int q_need = 12 + (p->counter_bits == 8 ? 11 : 17);
+    bool quot = c->lg >= q_need;
+    if (const char *e = getenv("KMU_COUNT_FMT")) {
+        if (!strcmp(e, "wide")) quot = false;
+        if (!strcmp(e, "quot")) { quot = true; c->lg = std::max(c->lg, q_need); }
+    }
+    c->nslots = 1ull << c->lg;
+    c->rbits = std::min(c->lg, REGION_BITS_MAX);
+    // quotient tables whose count field can spare a bit take regions of 8 192 slots (64 KiB of LDS, 1 024 threads): half as
+    // many leaves, so that both partition levels of the bench's table fan out 1 024 ways (KMU_COUNT_RBITS=12 / 13: A/B)
+    if (quot && c->lg - 13 >= q_need - 12 + 1) { // (one bit more: 1 024 threads may have 1 023 plain adds in flight, see k_part_build_q)
+        const char *e = getenv("KMU_COUNT_RBITS");
+        if (e && atoi(e) == 13) c->rbits = 13;
+    }
+    c->qw = quot ? c->lg - c->rbits : 0;
+    hipError_t e1 = hipMalloc((void **) &c->keys, c->nslots * 8);
+    hipError_t e2 = e1 == hipSuccess && !c->qw ? hipMalloc((void **) &c->counts, c->nslots * 4) : e1;
+    if (e2 == hipSuccess) e2 = hipMalloc((void **) &c->rcount, ((c->nslots >> c->rbits) + 1) * 4);
+    if (e2 != hipSuccess) {
+        if (c->keys) (void) hipFree(c->keys);
+        if (c->counts) (void) hipFree(c->counts);
+        c->keys = nullptr;
+        c->counts = nullptr;
+        const unsigned long long ns = c->nslots;
+        c->nslots = 0;
+        (void) hipGetLastError();
+        return fail(ctx, KMU_E_OOM, "cannot allocate a %llu-slot count table", ns);
+    }
+    c->empty = true;
+    c->deferred = false;
+    return KMU_OK;
+}
+
+// KMU_COUNT_HINT_OCCURRENCES: the table is allocated when the first k-mers come.  `ds` (unpacked reads, or null): their
+// duplication is measured first -- a sample by key of the batch (k_part_hist1's: every occurrence of a sampled k-mer is in it),
+// distinct keys of the sample counted in a scratch table -- and the table holds 1.5 x occurrences / ratio slots instead of
+// 1.5 x occurrences: config 4's shard (0.75 G occurrences of 0.207 G distinct 31-mers) gets 2^29 slots = 4.3 GB where the
+// occurrences ask for 2^31 = 17 GB, nine tenths of it empty, all of it written by every build.  One pass over the reads, once
+// per counter.  `known_ratio` > 0: the caller has measured it (a distributed add); `occurrences`: the k-mers this table is to
+// hold (0: the hint of kmu_count_create).
+// occurrences / distinct of the k-mers of a batch of reads, from the key sample of a census pass (0: no estimate)
+static int sample_ratio(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err, double *ratio_out) {
+    kmu_ctx *ctx = c->ctx;
+    *ratio_out = 0.0;
+    void *slist, *sn, *stab;
+    const uint64_t units = std::min<uint64_t>(std::max<uint64_t>(1, ((total_bases + 15) / 16 + 63) / 64), (uint64_t) ctx->num_cus * 8);
+    const uint64_t kmers_per_unit = (total_bases + units - 1) / units;
+    uint32_t shift = 0; // ~1024 sampled k-mers per workgroup (its LDS list holds 4096)
+    while (shift < 24 && (kmers_per_unit >> shift) > 1024) shift++;
+    const uint32_t cap = (uint32_t) std::min<uint64_t>(units * SAMPLE_LDS, 1u << 26);
+    KMU_TRY(dev_buf(ctx, "cnt.sample", (size_t) cap * 8 + 64, &slist));
+    KMU_TRY(dev_buf(ctx, "cnt.sample_n", 64, &sn));
+    KMU_HIP(ctx, hipMemsetAsync(sn, 0, 64, ctx->stream));
+    OwnerPlan op;
+    KMU_TRY(owner_census(c, ds, total_bases, 1, d_err, &op, SampleArgs{(uint64_t *) slist, (uint32_t *) sn, cap, shift}));
+    uint32_t h_sn[2] = {0, 0};
+    KMU_HIP(ctx, hipMemcpyAsync(h_sn, sn, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t n_s = std::min(h_sn[0], cap);
+    if (!n_s || h_sn[1]) return KMU_OK; // nothing sampled, or a truncated sample: no estimate
+    uint32_t tbits = 10, d_s = 0;
+    while ((1ull << tbits) < 2ull * n_s) tbits++;
+    KMU_TRY(dev_buf(ctx, "cnt.sample_tab", ((size_t) 8 << tbits) + 64, &stab));
+    KMU_HIP(ctx, hipMemsetAsync(stab, 0xFF, (size_t) 8 << tbits, ctx->stream));
+    KMU_HIP(ctx, hipMemsetAsync((uint32_t *) sn + 2, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_sample_distinct, dim3(grid_for(ctx, n_s, 256)), dim3(256), 0, ctx->stream, (const uint64_t *) slist, n_s, (uint64_t *) stab,
+                       (uint32_t) ((1u << tbits) - 1u), (uint32_t *) sn + 2);
+    KMU_HIP(ctx, hipMemcpyAsync(&d_s, (uint32_t *) sn + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (d_s) *ratio_out = (double) n_s / (double) d_s;
+    return KMU_OK;
+}
+static int table_alloc_for(kmu_counter *c, const DevSeqs *ds, uint64_t total_bases, uint32_t *d_err, double known_ratio = 0.0, uint64_t occurrences = 0) {
+    if (!c->deferred) return KMU_OK;
+    double ratio = known_ratio;
+    if (ratio <= 0.0 && ds && !ds->packed && total_bases >= (1u << 16)) KMU_TRY(sample_ratio(c, *ds, total_bases, d_err, &ratio));
+    if (const char *e = getenv("KMU_COUNT_DUP_RATIO")) ratio = atof(e); // (tests: the decision without the data)
+    const uint64_t occ = occurrences ? occurrences : std::max<uint64_t>(c->p.capacity_hint, ds && !ds->packed ? total_bases : 0);
+    uint64_t distinct = ratio > 1.0 ? (uint64_t) ((double) occ / ratio * 1.05) + 1024 : occ; // (5 %: the sample's error)
+    return table_alloc(c, std::min(distinct, occ));
+}
+
 static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *counts, uint64_t n, int mem);
 static int add_superkmers(kmu_counter *c, const void *recs, uint64_t n_rec, uint64_t n_kmers);
 static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err);
@@ -2581,6 +2677,7 @@ static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bas
 // direct insertion otherwise (total_bases: extent of the flat stream, 0 for packed input)
 static int local_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err) {
     kmu_ctx *ctx = c->ctx;
+    KMU_TRY(table_alloc_for(c, &ds, total_bases, d_err));
     bool partitioned = false;
     const char *force = getenv("KMU_COUNT_PATH"); // "direct" / "partitioned": diagnostics
     if (!ds.packed) {
@@ -2717,7 +2814,8 @@ static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uin
     mine[1] = h_sn[1] ? 0 : d_s;
     mine[2] = n_local;
     mine[3] = c->unmerged ? 1 : 0;
-    mine[4] = (uint64_t) table_image_bytes(c);
+    // (a table that is not allocated yet -- KMU_COUNT_HINT_OCCURRENCES -- enters the model with the size it is going to get)
+    mine[4] = c->deferred ? 8ull * (uint64_t) (1.5 * (double) n_local / (n_s && d_s ? std::max(1.0, (double) n_s / d_s) : 1.0)) : (uint64_t) table_image_bytes(c);
     mine[5] = (uint64_t) (local_xgmi_gbps() * 1000.0);
     mine[6] = 0;
     if (const char *e = getenv("KMU_COUNT_ROUTE")) {
@@ -2745,6 +2843,9 @@ static int dist_add_begin(kmu_counter *c, DevSeqs &ds, uint64_t total_bases, uin
     }
     const double ratio = valid && sum_ds > 0 ? sum_ns / sum_ds : 0.0;
     const double n_loc = sum_n / N, d_loc = ratio > 0 ? n_loc / ratio : n_loc;
+    // the table of a counter created with KMU_COUNT_HINT_OCCURRENCES: every rank ends up owning about 1 / N of the job's distinct
+    // k-mers (the MERGE route holds its shard's own first: no more than that many either); the same size on every rank
+    KMU_TRY(table_alloc_for(c, nullptr, 0, d_err, ratio > 0 ? ratio : 1.0, (uint64_t) n_loc + 1));
     double ms_occ, ms_merge;
     if (smer) route_model_smer(max_table, (double) all[5] / 1000.0, n_loc, sum_g / N, d_loc, (int) N, &ms_occ, &ms_merge);
     else route_model(max_table, (double) all[5] / 1000.0, n_loc, d_loc, (int) N, &ms_occ, &ms_merge);
@@ -2839,39 +2940,20 @@ int kmu_count_create(kmu_ctx *ctx, const kmu_count_params *p, kmu_counter **out)
     kmu_counter *c = new kmu_counter();
     c->ctx = ctx;
     c->p = *p;
-    uint64_t want = std::max<uint64_t>(1024, p->capacity_hint + p->capacity_hint / 2); // load factor <= 2/3
-    c->lg = 10;
-    while ((1ull << c->lg) < want) c->lg++;
-    // slot format: quotient (8 bytes per slot) whenever the region bits leave room for the count field (see the top of the
-    // file): w = lg - 12 >= 11 for 8-bit counters, >= 17 for 16-bit ones.  KMU_COUNT_FMT=wide keeps 12 bytes per slot;
-    // =quot (tests) raises a small table to the size the quotient format starts at.
-    const int q_need = 12 + (p->counter_bits == 8 ? 11 : 17);
-    bool quot = c->lg >= q_need;
-    if (const char *e = getenv("KMU_COUNT_FMT")) {
-        if (!strcmp(e, "wide")) quot = false;
-        if (!strcmp(e, "quot")) { quot = true; c->lg = std::max(c->lg, q_need); }
-    }
-    c->nslots = 1ull << c->lg;
-    c->rbits = std::min(c->lg, REGION_BITS_MAX);
-    // quotient tables whose count field can spare a bit take regions of 8 192 slots (64 KiB of LDS, 1 024 threads): half as
-    // many leaves, so that both partition levels of the bench's table fan out 1 024 ways (KMU_COUNT_RBITS=12 / 13: A/B)
-    if (quot && c->lg - 13 >= q_need - 12 + 1) { // (one bit more: 1 024 threads may have 1 023 plain adds in flight, see k_part_build_q)
-        const char *e = getenv("KMU_COUNT_RBITS");
-        if (e && atoi(e) == 13) c->rbits = 13;
-    }
-    c->qw = quot ? c->lg - c->rbits : 0;
-    hipError_t e1 = hipMalloc((void **) &c->keys, c->nslots * 8);
-    hipError_t e2 = e1 == hipSuccess && !c->qw ? hipMalloc((void **) &c->counts, c->nslots * 4) : e1;
-    hipError_t e3 = e2 == hipSuccess ? hipMalloc((void **) &c->scalars, 64) : e2;
-    if (e3 == hipSuccess) e3 = hipMalloc((void **) &c->rcount, ((c->nslots >> c->rbits) + 1) * 4);
-    if (e3 != hipSuccess) {
-        if (c->keys) (void) hipFree(c->keys);
-        if (c->counts) (void) hipFree(c->counts);
-        if (c->scalars) (void) hipFree(c->scalars);
-        unsigned long long ns = c->nslots;
+    hipError_t e0 = hipMalloc((void **) &c->scalars, 64);
+    if (e0 != hipSuccess) {
         delete c;
         (void) hipGetLastError();
-        return fail(ctx, KMU_E_OOM, "cannot allocate a %llu-slot count table", ns);
+        return fail(ctx, KMU_E_OOM, "cannot allocate a counter");
+    }
+    if (p->flags & KMU_COUNT_HINT_OCCURRENCES) c->deferred = true; // the first add sizes the table (table_alloc_for)
+    else {
+        const int rc = table_alloc(c, p->capacity_hint);
+        if (rc != KMU_OK) {
+            (void) hipFree(c->scalars);
+            delete c;
+            return rc;
+        }
     }
     c->empty = true;
     if (p->flags & KMU_COUNT_DISTRIBUTED) {
@@ -2951,6 +3033,7 @@ int count_chunked_begin(kmu_counter *c, DevSeqs &all, const uint64_t *host_offse
     if (c->dist || all.n_seq == 0) return KMU_OK;
     uint64_t total_bases = 0;
     KMU_TRY(flat_stream_extent(c->ctx, host_offsets, all.n_seq, KMU_MEM_HOST, all, &total_bases));
+    KMU_TRY(table_alloc_for(c, nullptr, 0, d_err)); // (the reads are not on the device yet: a table by the hint)
     PartPlan pl;
     const bool partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
     if (!partitioned || !part_plan_for(c, &pl) || !pl.b2 || !seg_partition_wanted(total_bases)) return KMU_OK;
@@ -3041,6 +3124,7 @@ static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *co
     }
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
+    KMU_TRY(table_alloc_for(c, nullptr, 0, d_err, 0.0, std::max<uint64_t>(c->p.capacity_hint, n)));
     {
         const char *force = getenv("KMU_COUNT_PATH");
         bool partitioned = !counts && n * (c->empty ? 64u : 10u) >= c->nslots && n >= (1u << 16) && c->lg - c->rbits <= 22; // (see local_add)
@@ -3072,6 +3156,7 @@ static int add_superkmers(kmu_counter *c, const void *recs, uint64_t n_rec, uint
     if (n_rec == 0) return KMU_OK;
     uint32_t *d_err;
     KMU_TRY(get_err_word(ctx, &d_err));
+    KMU_TRY(table_alloc_for(c, nullptr, 0, d_err, 0.0, std::max<uint64_t>(c->p.capacity_hint, n_kmers)));
     const char *force = getenv("KMU_COUNT_PATH");
     bool partitioned = n_kmers * (c->empty ? 64u : 10u) >= c->nslots && n_kmers >= (1u << 16) && c->lg - c->rbits <= 22; // (see local_add)
     if (force && !strcmp(force, "direct")) partitioned = false;
@@ -3182,7 +3267,7 @@ int kmu_count_nb_occurrences(kmu_counter *c, uint64_t *out) {
 }
 int kmu_count_table_info(const kmu_counter *c, kmu_count_table_info_t *out) {
     if (!c || !out) return KMU_E_BAD_ARG;
-    out->nslots = c->nslots;
+    out->nslots = c->nslots; // (0 while a KMU_COUNT_HINT_OCCURRENCES counter waits for its first add)
     out->bytes_per_slot = c->qw ? 8u : 12u;
     out->count_field_bits = c->qw ? (uint32_t) c->qw : 32u;
     out->table_bytes = (uint64_t) table_image_bytes(c);

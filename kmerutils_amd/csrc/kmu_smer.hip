@@ -106,16 +106,56 @@ __device__ __forceinline__ uint32_t smer_len(const SmerLane &a, uint32_t s) {
     return L < SMER_REC_KMERS ? L : SMER_REC_KMERS;
 }
 
-// `own[j]`: owner of position j.  The reads occupy [start, total) of the stream.
+// Which positions of the flat stream start a k-mer is looked up, not derived: bit p of `novalid` is set where position p starts
+// none -- the last k - 1 positions of every read, what lies before the first read and behind the last (k_smer_novalid, one
+// thread per read, once per batch).  A lane's 16 positions are one 16-bit load next to its 16 bases; no kernel of this file
+// searches the read offsets (round 3's count levels spend a wave-wide search and up to three dependent look-ups per step there).
+__global__ void __launch_bounds__(256) k_smer_novalid(const uint64_t *offsets, uint32_t n_seq, int k, uint64_t total, uint64_t nbits, uint32_t *mask) {
+    const uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > (uint64_t) n_seq + 1) return;
+    uint64_t lo, hi;
+    if (r < n_seq) { // the positions of read r that start no k-mer
+        const uint64_t b = offsets[r], e = offsets[r + 1];
+        lo = e - b >= (uint64_t) k ? e - (uint64_t) (k - 1) : b;
+        hi = e;
+    } else if (r == n_seq) { lo = 0; hi = offsets[0]; }  // before the first read (a range of a larger read set)
+    else { lo = total; hi = nbits; }                      // behind the last read, to the end of the last wave step's halo
+    while (lo < hi) { // (reads: at most two words; the tail: a few dozen)
+        const uint64_t w = lo >> 5, e = (w + 1) << 5 < hi ? (w + 1) << 5 : hi;
+        const uint32_t n = (uint32_t) (e - lo), sh = (uint32_t) (lo & 31u);
+        atomicOr(&mask[w], (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << sh);
+        lo = e;
+    }
+}
+
+// what a wave step needs from memory, requested a step ahead: the lane's 16 bases and its 16 "no k-mer" bits.  Unconditional
+// loads from clamped addresses: their number in flight is a constant for the compiler's waits (see flat_step_fetch, kmu_count.hip).
+struct SmerRaw {
+    uint4 c;
+    uint32_t nv;
+};
+__device__ __forceinline__ void smer_fetch(const uint8_t *bases, const uint16_t *novalid, uint64_t total, uint64_t nwords_mask, uint64_t st, SmerRaw &r) {
+    const uint64_t widx = st * SMER_STEP_WORDS + (uint64_t) lane_id();
+    r.c = make_uint4(0u, 0u, 0u, 0u);
+    if (total >= 16) { // (wave-uniform)
+        const uint64_t lastc = (total - 16) & ~15ull, a0 = widx * 16;
+        r.c = *reinterpret_cast<const uint4 *>(bases + (a0 < lastc ? a0 : lastc));
+    }
+    r.nv = novalid[widx < nwords_mask ? widx : nwords_mask - 1];
+}
+
+// `own[j]`: owner of position j.
 template <int W>
-__device__ __forceinline__ void smer_step(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, uint64_t total, uint64_t start,
-                                          const SmerCfg &cf, uint32_t n_parts, uint64_t st, uint32_t &r_hint, SmerLane &a,
-                                          uint32_t (&mw)[16], uint32_t (&own)[16]) {
+__device__ __forceinline__ void smer_step(const uint8_t *bases, uint64_t total, const SmerCfg &cf, uint32_t n_parts, uint64_t st,
+                                          const SmerRaw &raw, SmerLane &a, uint32_t (&mw)[16], uint32_t (&own)[16]) {
     const uint32_t lane = (uint32_t) lane_id();
     const uint64_t widx = st * SMER_STEP_WORDS + lane;
-    SeqView s;
-    s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
-    a.w0 = load_code_word(s, widx, a.bad);
+    if (__all(widx * 16 + 16 <= total)) a.w0 = pack16_ascii(raw.c, a.bad); // every chunk of the step whole: all but the stream's last step
+    else {
+        SeqView s;
+        s.base = bases; s.begin = 0; s.len = total; s.total = total; s.packed = 0;
+        a.w0 = load_code_word(s, widx, a.bad);
+    }
     a.w1 = dpp_shl1(a.w0);
     a.w2 = dpp_shl1(a.w1);
     a.w3 = dpp_shl1(a.w2);
@@ -125,27 +165,7 @@ __device__ __forceinline__ void smer_step(const uint8_t *bases, const uint64_t *
         const uint32_t x = (mw[j] * 0xC2B2AE35u) >> 16;
         own[j] = (n_parts & (n_parts - 1u)) == 0u ? x & (n_parts - 1u) : x % n_parts; // = smer_owner_of(mw[j], n_parts)
     }
-    // ---- which positions start a k-mer: inside [start, total) and k bases before the end of their read ----
-    const uint64_t gs = st * (uint64_t) (SMER_STEP_WORDS * 16);
-    uint32_t r = wave_find_read_from(offsets, n_seq, gs < total ? gs : total - 1, r_hint);
-    r_hint = r;
-    const uint64_t g0 = widx * 16;
-    const bool in = g0 < total && g0 + 16 > start;
-    uint64_t rend = 0;
-    if (in) {
-        rend = offsets[r + 1];
-        while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
-    }
-    uint32_t V = 0;
-    if (__all(!in || (g0 >= start && rend - g0 >= (uint64_t) (15 + cf.k)))) V = in ? 0xFFFFu : 0u; // well inside a read: most waves
-    else if (in) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint64_t g = g0 + j;
-            while (g >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; }
-            if (g >= start && g + cf.k <= rend) V |= 1u << j;
-        }
-    }
+    const uint32_t V = ~raw.nv & 0xFFFFu;
     // ---- boundaries: the first k-mer behind a position without one (every read's first k-mer: the k - 1 positions before it
     // start none), an owner change, and the step's first position ----
     const uint32_t pv = dpp_shr1(V) >> 15, po = dpp_shr1(own[15]);
@@ -189,6 +209,23 @@ __device__ __forceinline__ uint32_t sel16(const uint32_t (&v)[16], uint32_t s) {
     for (int j = 1; j < 16; j++) r = s == (uint32_t) j ? v[j] : r;
     return r;
 }
+// the owner of position s: up to eight owners travel as sixteen nibbles of two registers (one shift instead of fifteen selects)
+template <bool PACK8>
+struct OwnerOf {
+    uint32_t lo = 0, hi = 0;
+    __device__ __forceinline__ void set(const uint32_t (&own)[16]) {
+        if (!PACK8) return;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            lo |= own[j] << (4 * j);
+            hi |= own[8 + j] << (4 * j);
+        }
+    }
+    __device__ __forceinline__ uint32_t at(const uint32_t (&own)[16], uint32_t s) const {
+        if (!PACK8) return sel16(own, s);
+        return ((s & 8u ? hi : lo) >> (4u * (s & 7u))) & 15u;
+    }
+};
 
 struct SmerGeom {
     uint64_t total, start, nsteps;
@@ -198,7 +235,7 @@ struct SmerGeom {
 // PACK8 (n_parts <= 8: one node's GPUs): per-owner counts travel in 8-bit fields of a register and reach LDS as wave sums;
 // otherwise one LDS atomic per record.
 template <int W, bool PACK8>
-__global__ void __launch_bounds__(SMER_THREADS) k_smer_census(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
+__global__ void __launch_bounds__(SMER_THREADS) k_smer_census(const uint8_t *bases, const uint16_t *novalid, uint64_t total, int k,
                                                                uint32_t n_parts, uint32_t steps_per_unit, uint32_t *hist,
                                                                unsigned long long *kmers_per_owner, uint32_t *err, SampleArgs sa) {
     extern __shared__ uint32_t lh[]; // [n_parts] records, [n_parts] k-mers, then the sample: counter (2 words) + list
@@ -209,12 +246,13 @@ __global__ void __launch_bounds__(SMER_THREADS) k_smer_census(const uint8_t *bas
     if (sa.list && threadIdx.x == 0) ls_n[0] = 0;
     __syncthreads();
     const SmerCfg cf = smer_cfg(k);
-    const uint64_t total = offsets[n_seq], start = offsets[0];
-    const uint64_t nwords = (total + 15) / 16, nsteps = (nwords + SMER_STEP_WORDS - 1) / SMER_STEP_WORDS;
+    const uint64_t nwords = (total + 15) / 16, nsteps = (nwords + SMER_STEP_WORDS - 1) / SMER_STEP_WORDS, nwm = nsteps * SMER_STEP_WORDS + 64;
     const uint64_t s0 = (uint64_t) blockIdx.x * steps_per_unit;
     const uint64_t s1 = s0 + steps_per_unit < nsteps ? s0 + steps_per_unit : nsteps;
     const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    uint32_t r_hint = 0xFFFFFFFFu, bad = 0;
+    uint32_t bad = 0;
+    SmerRaw raw;
+    smer_fetch(bases, novalid, total, nwm, s0 + wave, raw);
     uint32_t accr[4] = {0, 0, 0, 0}, acck[4] = {0, 0, 0, 0}, since = 0;
     auto flush = [&]() { // the lanes' 16-bit fields -> LDS, one atomic per field and wave
 #pragma unroll
@@ -237,14 +275,18 @@ __global__ void __launch_bounds__(SMER_THREADS) k_smer_census(const uint8_t *bas
     for (uint64_t st = s0 + wave; st < s1; st += nwaves) {
         SmerLane a;
         uint32_t mw[16], own[16];
-        smer_step<W>(bases, offsets, n_seq, total, start, cf, n_parts, st, r_hint, a, mw, own);
+        const SmerRaw cur = raw;
+        smer_fetch(bases, novalid, total, nwm, st + nwaves, raw); // the next step of this wave, in flight under this one's arithmetic
+        smer_step<W>(bases, total, cf, n_parts, st, cur, a, mw, own);
         bad |= a.bad;
         uint64_t pr = 0, pk = 0;
         uint32_t rm = a.rm;
+        OwnerOf<PACK8> oo;
+        oo.set(own);
         while (rm) {
             const uint32_t s = (uint32_t) __builtin_ctz(rm);
             rm &= rm - 1u;
-            const uint32_t L = smer_len(a, s), o = sel16(own, s);
+            const uint32_t L = smer_len(a, s), o = oo.at(own, s);
             if (PACK8) {
                 pr += 1ull << (8u * o);
                 pk += (uint64_t) L << (8u * o);
@@ -332,7 +374,7 @@ __global__ void k_smer_scan_b(const uint64_t *tot, uint32_t n_parts, uint64_t *b
 }
 
 template <int W, bool PACK8>
-__global__ void __launch_bounds__(SMER_THREADS) k_smer_scatter(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq, int k,
+__global__ void __launch_bounds__(SMER_THREADS) k_smer_scatter(const uint8_t *bases, const uint16_t *novalid, uint64_t total, int k,
                                                                 uint32_t n_parts, uint32_t steps_per_unit, const uint64_t *offs,
                                                                 const uint64_t *binstart, uint32_t *out) {
     extern __shared__ __attribute__((aligned(8))) uint8_t smem[];
@@ -345,24 +387,28 @@ __global__ void __launch_bounds__(SMER_THREADS) k_smer_scatter(const uint8_t *ba
     }
     __syncthreads();
     const SmerCfg cf = smer_cfg(k);
-    const uint64_t total = offsets[n_seq], start = offsets[0];
-    const uint64_t nwords = (total + 15) / 16, nsteps = (nwords + SMER_STEP_WORDS - 1) / SMER_STEP_WORDS;
+    const uint64_t nwords = (total + 15) / 16, nsteps = (nwords + SMER_STEP_WORDS - 1) / SMER_STEP_WORDS, nwm = nsteps * SMER_STEP_WORDS + 64;
     const uint64_t s0 = (uint64_t) blockIdx.x * steps_per_unit;
     const uint64_t s1 = s0 + steps_per_unit < nsteps ? s0 + steps_per_unit : nsteps;
     const uint32_t wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, lane = (uint32_t) lane_id();
-    uint32_t r_hint = 0xFFFFFFFFu;
+    SmerRaw raw;
+    smer_fetch(bases, novalid, total, nwm, s0 + wave, raw);
     for (uint64_t st = s0 + wave; st < s1; st += nwaves) {
         SmerLane a;
         uint32_t mw[16], own[16];
-        smer_step<W>(bases, offsets, n_seq, total, start, cf, n_parts, st, r_hint, a, mw, own);
+        const SmerRaw cur = raw;
+        smer_fetch(bases, novalid, total, nwm, st + nwaves, raw);
+        smer_step<W>(bases, total, cf, n_parts, st, cur, a, mw, own);
         uint32_t ex[4] = {0, 0, 0, 0}; // PACK8: records of the lower lanes of this step, per owner
+        OwnerOf<PACK8> oo;
+        oo.set(own);
         if (PACK8) {
             uint64_t pr = 0;
             uint32_t rm = a.rm;
             while (rm) {
                 const uint32_t s = (uint32_t) __builtin_ctz(rm);
                 rm &= rm - 1u;
-                pr += 1ull << (8u * sel16(own, s));
+                pr += 1ull << (8u * oo.at(own, s));
             }
             uint32_t w[4], tot[4];
             spread8(pr, w);
@@ -383,7 +429,7 @@ __global__ void __launch_bounds__(SMER_THREADS) k_smer_scatter(const uint8_t *ba
         while (rm) {
             const uint32_t s = (uint32_t) __builtin_ctz(rm);
             rm &= rm - 1u;
-            const uint32_t L = smer_len(a, s), o = sel16(own, s);
+            const uint32_t L = smer_len(a, s), o = oo.at(own, s);
             uint64_t pos;
             if (PACK8) {
                 pos = ubase[o] + lwb[wave * 8u + o] + field16(ex, o) + (uint32_t) ((seen >> (8u * o)) & 0xFFu);
@@ -484,13 +530,20 @@ int smer_census(kmu_ctx *ctx, const DevSeqs &ds, uint64_t total_bases, int k, ui
     KMU_TRY(dev_buf(ctx, "smer.binstart", ((size_t) n_parts + 1) * 8 + 64, &g->binstart));
     KMU_TRY(dev_buf(ctx, "smer.kmers", (size_t) n_parts * 8 + 64, &g->kmers));
     KMU_HIP(ctx, hipMemsetAsync(g->kmers, 0, (size_t) n_parts * 8, ctx->stream));
+    // the positions that start no k-mer: 16 bits per code word of every wave step incl. the last one's halo
+    const uint64_t nwm = nsteps * SMER_STEP_WORDS + 64, mask_bytes = (nwm * 2 + 3) & ~(uint64_t) 3;
+    KMU_TRY(dev_buf(ctx, "smer.novalid", (size_t) mask_bytes + 64, &g->novalid));
+    KMU_HIP(ctx, hipMemsetAsync(g->novalid, 0, (size_t) mask_bytes, ctx->stream));
+    hipLaunchKernelGGL(k_smer_novalid, dim3((unsigned) (((uint64_t) ds.n_seq + 2 + 255) / 256)), dim3(256), 0, ctx->stream, ds.offsets, ds.n_seq, k,
+                       total_bases, (uint64_t) mask_bytes * 8, (uint32_t *) g->novalid);
+    g->total = total_bases;
     const size_t lds = ((size_t) 2 * n_parts + 4) * 4 + (sa.list ? (size_t) SAMPLE_LDS * 8 : 0);
     const SmerCfg cf = smer_cfg(k);
     {
         KernelTimer tm(ctx, "k_smer_census");
         KMU_TRY(smer_dispatch(cf.w, n_parts <= 8, [&](auto W, auto P8) {
             hipLaunchKernelGGL((k_smer_census<decltype(W)::value, decltype(P8)::value>), dim3(units), dim3(SMER_THREADS), lds, ctx->stream, ds.bases,
-                               ds.offsets, ds.n_seq, k, n_parts, spu, (uint32_t *) g->hist, (unsigned long long *) g->kmers, d_err, sa);
+                               (const uint16_t *) g->novalid, total_bases, k, n_parts, spu, (uint32_t *) g->hist, (unsigned long long *) g->kmers, d_err, sa);
             return (int) KMU_OK;
         }));
     }
@@ -505,15 +558,14 @@ int smer_census(kmu_ctx *ctx, const DevSeqs &ds, uint64_t total_bases, int k, ui
 }
 
 int smer_scatter(kmu_ctx *ctx, const DevSeqs &ds, uint64_t total_bases, const SmerGroups &g, void *records_out) {
-    (void) total_bases;
-    if (g.units == 0) return KMU_OK;
+    if (g.units == 0 || total_bases != g.total) return g.units == 0 ? (int) KMU_OK : fail(ctx, KMU_E_BAD_ARG, "smer_scatter: not the batch of the census");
     const size_t lds = (size_t) g.n_parts * 12 + 4 * 8 * 4 + 16;
     const SmerCfg cf = smer_cfg(g.k);
     KernelTimer tm(ctx, "k_smer_scatter");
     KMU_TRY(smer_dispatch(cf.w, g.n_parts <= 8, [&](auto W, auto P8) {
         hipLaunchKernelGGL((k_smer_scatter<decltype(W)::value, decltype(P8)::value>), dim3(g.units), dim3(SMER_THREADS), lds, ctx->stream, ds.bases,
-                           ds.offsets, ds.n_seq, g.k, g.n_parts, g.steps_per_unit, (const uint64_t *) g.offs, (const uint64_t *) g.binstart,
-                           (uint32_t *) records_out);
+                           (const uint16_t *) g.novalid, g.total, g.k, g.n_parts, g.steps_per_unit, (const uint64_t *) g.offs,
+                           (const uint64_t *) g.binstart, (uint32_t *) records_out);
         return (int) KMU_OK;
     }));
     KMU_HIP(ctx, hipGetLastError());

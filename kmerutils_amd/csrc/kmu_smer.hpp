@@ -27,6 +27,8 @@ struct SmerGroups {
     void *offs = nullptr;     // u64 [units][n_parts]: exclusive prefix over the units
     void *binstart = nullptr; // u64 [n_parts + 1]: first record of every owner's group; [n_parts] = records in all
     void *kmers = nullptr;    // u64 [n_parts]: k-mers in every owner's group
+    void *novalid = nullptr;  // bit p set: position p of the flat stream starts no k-mer (k_smer_novalid)
+    uint64_t total = 0;       // extent of the flat stream the census walked
 };
 
 // units of the grouping kernels for a flat stream of total_bases bytes (the sample's capacity is sized from it)

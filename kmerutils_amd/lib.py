@@ -651,17 +651,20 @@ class Context:
                                                       mem, _ptr(out)[0]))
         return out[:n]
 
-    def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False, owner_hash=False):
-        return Counter(self, kmer_type, k, counter_bits, capacity_hint, distributed, owner_hash)
+    def counter(self, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False, owner_hash=False, hint_occurrences=False):
+        return Counter(self, kmer_type, k, counter_bits, capacity_hint, distributed, owner_hash, hint_occurrences)
 
 
 class Counter:
     """kmu_counter: exact canonical k-mer multiplicities on the device (KmerCountT contract)."""
 
-    def __init__(self, ctx, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False, owner_hash=False):
+    def __init__(self, ctx, kmer_type, k, counter_bits=8, capacity_hint=1 << 20, distributed=False, owner_hash=False,
+                 hint_occurrences=False):
+        """hint_occurrences: capacity_hint counts k-mer occurrences; the first add sizes the table from the duplication it measures"""
         self.ctx = ctx
         self.L = ctx.L
-        flags = (A.COUNT_DISTRIBUTED if distributed else 0) | (A.COUNT_OWNER_HASH if owner_hash else 0)
+        flags = ((A.COUNT_DISTRIBUTED if distributed else 0) | (A.COUNT_OWNER_HASH if owner_hash else 0)
+                 | (A.COUNT_HINT_OCCURRENCES if hint_occurrences else 0))
         self.p = A.CountParams(kmer_type, k, counter_bits, flags, capacity_hint)
         h = C.c_void_p()
         ctx._check(self.L.kmu_count_create(ctx.h, C.byref(self.p), C.byref(h)))

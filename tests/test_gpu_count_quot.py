@@ -146,3 +146,48 @@ def test_counter_usage_sweep_quot(ctx, oracle, quot, seed):
     FUZZ = _load("test_gpu_fuzz")
     FUZZ.test_counter_usage_sweep(ctx, oracle, seed, quot)
     FUZZ.test_count_sweep(ctx, oracle, seed)
+
+
+@pytest.mark.parametrize("genome,n_reads,what", [(4_000_000, 4000, "ratio ~1"), (150_000, 4000, "ratio ~3.6"), (10_000, 4000, "ratio ~50")])
+def test_table_sized_from_the_measured_duplication(oracle, genome, n_reads, what):
+    """KMU_COUNT_HINT_OCCURRENCES: the hint counts k-mer occurrences, the first add measures occurrences / distinct on a key
+    sample of its batch and allocates 1.5 x occurrences / ratio slots (config 4's shard: 2^29 instead of 2^31).  The reference
+    sizes its filters blind (capacity 3e9 / n, src/base/kmercount.rs:888-892); counts are the same whatever the size."""
+    import torch
+    from kmerutils_amd import lib
+    bases, off = synth.genome_reads(n_reads, np.full(n_reads, 150, np.int64), genome, 0xD1, sub=0.002)
+    nk = n_reads * 120
+    g = oracle.Counter(A.KMER64BIT, 31, 16, 1 << 20)
+    g.add_reads(bases, off)
+    wk, wc = g.dump(1)
+    ctx = lib.Context(0)
+    blind = ctx.counter(A.KMER64BIT, 31, 16, nk)
+    blind_slots = blind.table_info()["nslots"]
+    blind.close()
+    for dev in (True, False):
+        c = ctx.counter(A.KMER64BIT, 31, 16, nk, hint_occurrences=True)
+        assert c.table_info()["nslots"] == 0  # nothing allocated yet
+        if dev:
+            c.add_reads(torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda())
+        else:
+            c.add_reads(bases, off)
+        slots = c.table_info()["nslots"]
+        gk, gc = c.dump(1)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc), what
+        # load <= 2/3, and no more than the power of two that 1.5 x 1.1 x distinct asks for
+        assert 1.5 * wk.size <= slots <= max(1024, 2 * 1.5 * 1.1 * wk.size + 2048), (what, slots, wk.size, nk / wk.size)
+        assert slots <= blind_slots
+        # a second batch goes into the table the first one made
+        c.add_reads(bases, off)
+        assert c.table_info()["nslots"] == slots
+        assert np.array_equal(c.dump(1)[1], 2 * wc)
+        c.close()
+    # readers before the first add see an empty table of the hinted size; explicit k-mers size it by their number
+    c = ctx.counter(A.KMER64BIT, 31, 16, nk, hint_occurrences=True)
+    assert c.nb_distinct() == 0 and (c.query(wk[:10].copy()) == 0).all()
+    c.close()
+    c = ctx.counter(A.KMER64BIT, 31, 16, 16, hint_occurrences=True)
+    c.add_kmers(wk)
+    assert c.table_info()["nslots"] >= 1.5 * wk.size and c.nb_distinct() == wk.size
+    c.close()
+    ctx.close()
