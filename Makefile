@@ -28,7 +28,19 @@ $(BIN)/%: kmerutils_amd/tools/%.cpp include/kmerutils.hpp include/kmu.h $(LIB)
 examples/sketch_c: examples/sketch.c include/kmu.h $(LIB)
 	$(CC) -std=c99 -O2 -Wall -Wextra $< -o $@ $(LINK) -Wl,-rpath,'$$ORIGIN/../kmerutils_amd'
 
-clean:
-	rm -rf $(OBJDIR) $(LIB) $(BIN) examples/sketch_c
+# CPU-side sanitizer pass (no GPU): the oracle's C restatement and the host-only code of include/kmerutils.hpp under
+# AddressSanitizer + UndefinedBehaviorSanitizer -- the host-only C++ test program, then the whole `-m "not gpu"` suite with the
+# sanitized oracle preloaded into python.  GPU AddressSanitizer is not available on this pool.
+SANFLAGS := -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer
+sanitize:
+	@mkdir -p oracle/_build/san tests/cpp/_build/san
+	$(CC) -std=c99 -fPIC $(SANFLAGS) -ffp-contract=off -fno-fast-math -Wall -Wextra -shared -o oracle/_build/san/libkmu_oracle.so oracle/kmu_oracle.c -lm
+	$(CXX) -std=c++17 $(SANFLAGS) -Wall -Wextra -pthread tests/cpp/test_host_san.cpp -o tests/cpp/_build/san/test_host_san
+	ASAN_OPTIONS=detect_leaks=1 tests/cpp/_build/san/test_host_san tests/cpp/_build/san
+	KMU_ORACLE_SO=$(CURDIR)/oracle/_build/san/libkmu_oracle.so LD_PRELOAD=$$($(CC) -print-file-name=libasan.so):$$($(CC) -print-file-name=libubsan.so) \
+	  ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
 
-.PHONY: all clean
+clean:
+	rm -rf $(OBJDIR) $(LIB) $(BIN) examples/sketch_c oracle/_build/san tests/cpp/_build/san
+
+.PHONY: all clean sanitize

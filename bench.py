@@ -408,8 +408,10 @@ def main():
                         "what": "SURVEY 8(d) bytes of the unit (sketch: bases in + signature rows out; count: bases in + 16 B per "
                                 "k-mer occurrence) / the summed launch time of the unit's kernels in one step"}
             # the other units of the step, priced the same way
+            # (every unit also from the instruction-issue side: the sketch unit is far from HBM because it is bound there)
             roofline["units"] = {n: {"frac": e["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": e["avg_ms"], "alg_bytes_per_launch": e["alg_bytes"],
-                                     "traffic": pmc_traffic(cfg, total_bases, n, e.get("per_step"))}
+                                     "traffic": pmc_traffic(cfg, total_bases, n, e.get("per_step")),
+                                     "alu": pmc_alu(cfg, total_bases, n, e["avg_ms"], e.get("per_step"))}
                                  for n, e in kern.items() if "alg_bytes" in e}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -426,6 +428,9 @@ def main():
             "roofline": roofline, "alu": pmc_alu(cfg, total_bases, dom, kern[dom]["avg_ms"], per_step) if dom else None,
             "cpu_baseline": cpu, "host_to_host": host, "value_device_resident": value,
             "value_host_to_host": host["value"] if host else None,
+            # SURVEY.md 8(d) defines the metric host to host (bases in host memory -> signatures in host memory + counts on the
+            # device); `value` is the bench contract's device-resident figure.  Quote THIS one as the 8(d) number.
+            "metric_value_8d": host["value"] if host else None,
             "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
             "checks": checks, "comm": _comm_summary(comm_stats, transport, comm_fallbacks, comm_ranks), "gen_seconds": t_gen,
         }

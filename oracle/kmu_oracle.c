@@ -765,6 +765,7 @@ static double unif01_f64(uint64_t s[4]) {
     memcpy(&d, &bits, 8);
     return d - 1.0;
 }
+double kmo_unif01_f64(uint64_t s[4]) { return unif01_f64(s); } /* (exported for the known-answer tests) */
 /* Uniform::<f32>::new(0.,1.).sample: 23 bits from next_u32 */
 static float unif01_f32(uint64_t s[4]) {
     uint32_t bits = (xoshiro_next_u32(s) >> 9) | 0x3F800000u;

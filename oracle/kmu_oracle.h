@@ -55,6 +55,7 @@ uint32_t kmo_minimizer_hash(uint64_t v, int k);
 uint32_t kmo_minimizer_owner(uint64_t v, int k, uint32_t n_parts);
 void kmo_minimizer_owners(const uint64_t *v, uint64_t n, int k, uint32_t n_parts, uint32_t *out);
 uint64_t kmo_superkmer_expand(const uint32_t *recs, uint64_t n_rec, int k, uint64_t *out, int *clean);
+double kmo_unif01_f64(uint64_t s[4]); /* one draw of Uniform::<f64>::new(0., 1.) from a xoshiro256++ state */
 uint64_t kmo_nohash_finish(uint64_t v, int width_bytes);
 uint64_t kmo_fnv1a(uint64_t v, int width_bytes);
 uint64_t kmo_nthash_init_8b(const uint8_t *kmer, int k);

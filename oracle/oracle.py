@@ -12,7 +12,8 @@ import numpy as np
 from kmerutils_amd import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libkmu_oracle.so")
+# KMU_ORACLE_SO: another build of the same source (`make sanitize`: AddressSanitizer + UBSan under the CPU test suite)
+_SO = os.environ.get("KMU_ORACLE_SO") or os.path.join(_HERE, "_build", "libkmu_oracle.so")
 _lib = None
 
 
@@ -24,7 +25,7 @@ def lib():
     global _lib
     if _lib is None:
         src = os.path.join(_HERE, "kmu_oracle.c")
-        if not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
+        if not os.environ.get("KMU_ORACLE_SO") and (not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO))):
             build()
         _lib = C.CDLL(_SO)
         L = _lib
@@ -47,6 +48,7 @@ def lib():
         L.kmo_minimizer_owner.argtypes = [C.c_uint64, C.c_int, C.c_uint32]; L.kmo_minimizer_owner.restype = C.c_uint32
         L.kmo_minimizer_owners.argtypes = [vp, C.c_uint64, C.c_int, C.c_uint32, vp]; L.kmo_minimizer_owners.restype = None
         L.kmo_superkmer_expand.argtypes = [vp, C.c_uint64, C.c_int, vp, C.POINTER(C.c_int)]; L.kmo_superkmer_expand.restype = C.c_uint64
+        L.kmo_unif01_f64.argtypes = [vp]; L.kmo_unif01_f64.restype = C.c_double
         L.kmo_nohash_finish.argtypes = [C.c_uint64, C.c_int]; L.kmo_nohash_finish.restype = C.c_uint64
         L.kmo_fnv1a.argtypes = [C.c_uint64, C.c_int]; L.kmo_fnv1a.restype = C.c_uint64
         L.kmo_nthash_init_8b.argtypes = [vp, C.c_int]; L.kmo_nthash_init_8b.restype = C.c_uint64

@@ -64,9 +64,28 @@ def main():
         json.dump(pmc, open(os.path.join(out_dir, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
         if "--bench" in sys.argv:  # the bench line of the traced run names the workload the counters belong to
             b = json.loads(open(sys.argv[sys.argv.index("--bench") + 1]).readline())
-            json.dump({"round": tag, "source": "scripts/pmc_bench.sh", "workload": b["config"]["workload_name"],
-                       "bases_per_gpu": b["config"]["bases_per_gpu"], "kernels": pmc},
-                      open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+            if "--no-latest" not in sys.argv:  # (pmc_latest.json is the headline workload's: what bench.py reads)
+                json.dump({"round": tag, "source": "scripts/pmc_bench.sh", "workload": b["config"]["workload_name"],
+                           "bases_per_gpu": b["config"]["bases_per_gpu"], "kernels": pmc},
+                          open(os.path.join(out_dir, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+            # a roofline object from THIS run's counters: the units bench.py priced, with the traffic and instruction counts
+            # of the passes above (the bench line itself only knows the committed headline profile)
+            units = {}
+            for name, e in (b.get("kernels") or {}).items():
+                if "alg_bytes" not in e:
+                    continue
+                parts = name.split("+")
+                mult = (e.get("per_step") or {})
+                tr = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in parts]
+                va = [pmc.get(k, {}).get("SQ_INSTS_VALU_per_launch") for k in parts]
+                m = [mult.get(k, 1.0) for k in parts]
+                units[name] = {"bound": "hbm", "achieved": e["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": e["GBps"] / 8000.0,
+                               "avg_launch_ms": e["avg_ms"], "alg_bytes_per_launch": e["alg_bytes"],
+                               "traffic": sum(t * x for t, x in zip(tr, m)) if all(t is not None for t in tr) else None,
+                               "valu_wave_insts": sum(v * x for v, x in zip(va, m)) if all(v is not None for v in va) else None}
+                if units[name]["valu_wave_insts"]:
+                    units[name]["valu_issue_frac"] = units[name]["valu_wave_insts"] / (e["avg_ms"] * 1e-3) / (1.03e9 * 4 * 256)
+            b["roofline_from_this_profile"] = units
             json.dump(b, open(os.path.join(out_dir, "%s_bench.json" % tag), "w"))
     print(open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag)).read())
     print(json.dumps(pmc, indent=1))

@@ -222,3 +222,31 @@ def test_nthash_errors(ctx):
     with pytest.raises(KmuError) as ei:
         ctx.nthash(bases, off, 33)
     assert ei.value.code == A.E_BAD_K
+
+
+def test_device_wang_hashes_against_the_published_inverse(ctx, oracle):
+    """probminhash::invhash::int32_hash / int64_hash on the device (kmu_kmer_hashes, FHASH_INVHASH_RAW / CANON_INVHASH): the
+    published inverse of Thomas Wang's hash64shift (tests/golden/reference_kats.json, public_vectors; restated for 32 bits in
+    tests/test_oracle_kat.py) takes every device value back to the k-mer it was made of, and the device values are the oracle's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kat", os.path.join(os.path.dirname(__file__), "test_oracle_kat.py"))
+    kat = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kat)
+    hv = kat.KAT["public_vectors"]["hash64shift_inverse"]
+    inv21, inv265 = int(hv["inv21"]), int(hv["inv265"])
+    bases, off = synth.ont_reads(4, 50_000, 0xA7)
+    n = int(off[-1])
+    for kmer_type, k in ((A.KMER64BIT, 31), (A.KMER64BIT, 17), (A.KMER32BIT, 12), (A.KMER16B32BIT, 16)):
+        raw = ctx.kmer_hashes(bases, off, kmer_type, k, A.FHASH_IDENTITY_RAW)[:n]
+        hashed = ctx.kmer_hashes(bases, off, kmer_type, k, A.FHASH_INVHASH_RAW)[:n]
+        canon = ctx.kmer_hashes(bases, off, kmer_type, k, A.FHASH_CANON_RAW)[:n]
+        chash = ctx.kmer_hashes(bases, off, kmer_type, k, A.FHASH_CANON_INVHASH)[:n]
+        assert np.array_equal(hashed, oracle.kmer_hashes(bases, off, kmer_type, k, A.FHASH_INVHASH_RAW)[:n])
+        valid = np.zeros(n, bool)
+        for i in range(len(off) - 1):
+            valid[int(off[i]):max(int(off[i]), int(off[i + 1]) - k + 1)] = True
+        idx = np.flatnonzero(valid)[::37]
+        w32 = A.kmer_val_bytes(kmer_type) == 4
+        for i in idx:
+            inv = kat._inv_hash32shift if w32 else (lambda y: kat._inv_hash64shift(y, inv21, inv265))
+            assert inv(int(hashed[i])) == int(raw[i]) and inv(int(chash[i])) == int(canon[i]), (kmer_type, k, i)

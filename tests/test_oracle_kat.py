@@ -344,3 +344,92 @@ def test_seqminhash_reference_tests_on_the_oracle():
         p = A.SketchParams(A.ALGO_SUPER, kmer_type, k, m, A.SIG_F64, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
         r = O.sketch(bases, off, p)
         assert float((r[0] == r[1]).mean()) >= thresh                              # :224, :256
+
+
+# ---- the third-party layers under the sketch arithmetic, against their PUBLISHED vectors (tests/golden/reference_kats.json,
+# "public_vectors"; Cargo.toml:74-89).  What stays unpinned after these is the control flow of probminhash 0.1 alone.
+M64 = (1 << 64) - 1
+
+
+def _inv_hash64shift(key, inv21, inv265):
+    """the published inverse of Thomas Wang's hash64shift (probminhash::invhash::int64_invhash)"""
+    tmp = (key - (key << 31)) & M64
+    key = (key - (tmp << 31)) & M64
+    tmp = key ^ (key >> 28)
+    key = key ^ (tmp >> 28)
+    key = (key * inv21) & M64
+    tmp = key ^ (key >> 14)
+    tmp = key ^ (tmp >> 14)
+    tmp = key ^ (tmp >> 14)
+    key = key ^ (tmp >> 14)
+    key = (key * inv265) & M64
+    tmp = key ^ (key >> 24)
+    key = key ^ (tmp >> 24)
+    tmp = ~key & M64
+    tmp = ~(key - (tmp << 21)) & M64
+    tmp = ~(key - (tmp << 21)) & M64
+    return ~(key - (tmp << 21)) & M64
+
+
+def _inv_hash32shift(y):
+    """inverse of Thomas Wang's hash32shift, step by step (every step of the hash is a bijection of 32 bits)"""
+    m = (1 << 32) - 1
+    y ^= y >> 16
+    y = (y * pow(2057, -1, 1 << 32)) & m
+    x = y
+    for _ in range(8):
+        x = y ^ (x >> 4)
+    y = (x * pow(5, -1, 1 << 32)) & m
+    y = y ^ (y >> 12) ^ (y >> 24)
+    return ((y + 1) * pow(32767, -1, 1 << 32)) & m
+
+
+def test_public_vectors_xoshiro_splitmix(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    pv = KAT["public_vectors"]
+    st = (C.c_uint64 * 4)(*pv["xoshiro256plusplus"]["state"])
+    assert [L.kmo_xoshiro_next(st) for _ in range(10)] == [int(x) for x in pv["xoshiro256plusplus"]["outputs"]]
+    for case in pv["splitmix64"]:
+        # Xoshiro256PlusPlus::seed_from_u64 fills the state with the first four SplitMix64 outputs of the seed; the fifth is
+        # the first output of the stream continued from where the fourth left it
+        seed = int(case["seed"])
+        L.kmo_xoshiro_seed(seed, st)
+        assert list(st) == [int(x) for x in case["outputs"][:4]]
+        L.kmo_xoshiro_seed((seed + 4 * 0x9E3779B97F4A7C15) & M64, st)
+        assert st[0] == int(case["outputs"][4])
+
+
+def test_public_vectors_fnv_and_wang_hashes(oracle):
+    L = oracle.lib()
+    pv = KAT["public_vectors"]
+    for text, want in pv["fnv1a64"]["vectors"]:
+        b = text.encode()
+        assert L.kmo_fnv1a(int.from_bytes(b, "little"), len(b)) == int(want, 16), text
+    hv = pv["hash64shift_inverse"]
+    inv21, inv265 = int(hv["inv21"]), int(hv["inv265"])
+    assert (21 * inv21) & M64 == 1 and (265 * inv265) & M64 == 1
+    rng = np.random.default_rng(1)
+    for x in [int(v) for v in hv["inputs"]] + [int(v) for v in rng.integers(0, 1 << 63, 2000, dtype=np.uint64)]:
+        assert _inv_hash64shift(L.kmo_int64_hash(x), inv21, inv265) == x
+    for x in [0, 1, 2, 255, 65535, 1 << 31, (1 << 32) - 1] + [int(v) for v in rng.integers(0, 1 << 32, 2000, dtype=np.uint64)]:
+        assert _inv_hash32shift(L.kmo_int32_hash(x)) == x
+    # hash64shift(0) by hand: ~0 + 0 = 2^64 - 1, then the six mixing steps of the published function
+    k = M64
+    k ^= k >> 24
+    k = (k + (k << 3) + (k << 8)) & M64
+    k ^= k >> 14
+    k = (k + (k << 2) + (k << 4)) & M64
+    k ^= k >> 28
+    k = (k + (k << 31)) & M64
+    assert L.kmo_int64_hash(0) == k
+
+
+def test_public_vectors_uniform_f64(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    for word, want in KAT["public_vectors"]["uniform_f64"]["vectors"]:
+        w = int(word)
+        # a state whose next output is `w`: s0 = s1 = s2 = 0, rotl(s3, 23) = w
+        st = (C.c_uint64 * 4)(0, 0, 0, ((w >> 23) | (w << 41)) & M64)
+        assert L.kmo_unif01_f64(st) == want, word
