@@ -352,6 +352,9 @@ int kmu_count_nb_distinct(kmu_counter *c, uint64_t *out); /* kmercount.rs:280-28
 int kmu_count_nb_unique(kmu_counter *c, uint64_t *out);   /* kmercount.rs:285-287 */
 /* sum of the (unsaturated) multiplicities held = k-mer occurrences inserted: the conservation check of a build */
 int kmu_count_nb_occurrences(kmu_counter *c, uint64_t *out);
+/* k-mers whose in-table count has reached kmu_count_table_info_t.count_ceiling (a homopolymer in a deep read set): for them the sum
+ * above and a raw export are lower bounds -- an inexact total then reads "saturated", not "k-mers lost" */
+int kmu_count_nb_saturated(kmu_counter *c, uint64_t *out);
 /* The table in HBM (no counterpart upstream: the reference's filters size themselves, kmercount.rs:70-123).  Slots are a power
  * of two >= 1.5 x capacity_hint.  Big tables (>= 2^23 slots with 8-bit counters, >= 2^29 with 16-bit ones) keep ONE 8-byte
  * word per slot -- the bits of the table hash that the slot's position does not already say, and a count field of
@@ -363,6 +366,10 @@ typedef struct kmu_count_table_info_t {
     uint64_t table_bytes;
     uint32_t bytes_per_slot;   /* 8 or 12 */
     uint32_t count_field_bits; /* width of the in-table count */
+    uint64_t count_ceiling;    /* the largest count a slot holds: 2^32 - 1 (12-byte slots), 2^count_field_bits - 1024 (8-byte slots;
+                                  1 024 less with regions of 8 192 slots).  Queries saturate at 2^counter_bits - 1 long before;
+                                  kmu_count_nb_occurrences and the raw counts of kmu_count_export_part are exact while
+                                  kmu_count_nb_saturated is 0 */
 } kmu_count_table_info_t;
 int kmu_count_table_info(const kmu_counter *c, kmu_count_table_info_t *out);
 /* dump of (canonical k-mer, count) for count >= min_count (dump_kmer_counter, kmercount.rs:500-525 uses 2).

@@ -84,7 +84,7 @@ class CommStats(C.Structure):
 class CountTableInfo(C.Structure):
     """kmu_count_table_info_t"""
     _fields_ = [("nslots", C.c_uint64), ("table_bytes", C.c_uint64), ("bytes_per_slot", C.c_uint32),
-                ("count_field_bits", C.c_uint32)]
+                ("count_field_bits", C.c_uint32), ("count_ceiling", C.c_uint64)]
 
 
 ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p,

@@ -431,8 +431,9 @@ __global__ void __launch_bounds__(256) k_count_query(const uint64_t *kmers, uint
 }
 
 // [0] += occupied slots, [1] += slots with count == 1, [3] += sum of the counts (k-mer occurrences held)
-__global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslots, uint64_t *scalars) {
-    uint64_t d = 0, u = 0, tot = 0;
+// scalars[0] distinct, [1] unique, [2] slots whose count sits at (or above) `ceiling`, [3] occurrences
+__global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslots, uint64_t *scalars, uint32_t ceiling) {
+    uint64_t d = 0, u = 0, tot = 0, sat = 0;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         uint64_t key;
         uint32_t c; // 0: an entry that left for its owner (distributed counters)
@@ -440,7 +441,12 @@ __global__ void __launch_bounds__(256) k_count_stats(CountTable t, uint64_t nslo
             d += c != 0u;
             u += c == 1u;
             tot += c;
+            sat += c >= ceiling;
         }
+    }
+    if (__any(sat != 0)) {
+        for (int o = 32; o >= 1; o >>= 1) sat += (uint64_t) (uint32_t) __shfl_xor((int) (uint32_t) sat, o, 64);
+        if (lane_id() == 0) atomicAdd((unsigned long long *) &scalars[2], (unsigned long long) sat);
     }
     for (int o = 32; o >= 1; o >>= 1) {
         d += ((uint64_t) (uint32_t) __shfl_xor((int) (d >> 32), o, 64) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) d, o, 64);
@@ -599,16 +605,16 @@ __global__ void __launch_bounds__(256) k_sample_distinct(const uint64_t *list, u
 // (a zero count is "never seen" for every reader of the table; the key stays as a tombstone of the probe chain)
 __global__ void __launch_bounds__(256) k_owner_census(CountTable t, uint64_t nslots, int w32, uint32_t n_parts,
                                                       unsigned long long *per_owner) {
-    extern __shared__ uint32_t lo[];
-    for (uint32_t b = threadIdx.x; b < n_parts; b += blockDim.x) lo[b] = 0;
+    extern __shared__ uint32_t lo[]; // [n_parts] entries per owner, [n_parts]: tombstones of earlier finalizes (occupied, count zero)
+    for (uint32_t b = threadIdx.x; b <= n_parts; b += blockDim.x) lo[b] = 0;
     __syncthreads();
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (uint64_t) gridDim.x * blockDim.x) {
         uint64_t key;
         uint32_t cnt;
-        if (slot_read<true>(t, i, key, cnt) && cnt != 0u) atomicAdd(&lo[kmer_owner(key, w32, n_parts)], 1u); // (lo[me]: the entries that stay)
+        if (slot_read<true>(t, i, key, cnt)) atomicAdd(&lo[cnt != 0u ? kmer_owner(key, w32, n_parts) : n_parts], 1u); // (lo[me]: the entries that stay)
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_parts; b += blockDim.x)
+    for (uint32_t b = threadIdx.x; b <= n_parts; b += blockDim.x)
         if (lo[b]) atomicAdd(&per_owner[b], (unsigned long long) lo[b]);
 }
 __global__ void __launch_bounds__(256) k_owner_emit(CountTable t, uint64_t nslots, int w32, uint32_t me, uint32_t n_parts,
@@ -2004,7 +2010,7 @@ static bool seg_partition_wanted(uint64_t total_bases) {
     // (round 2: from 2^27 bases on -- the margins of a segment per unit and bin are a small share of the mean only for big batches.
     //  With streams shared by a set's units they are sixteen times smaller, and the route wins wherever a table has two levels:
     //  5.9 / 8.8 / 17.6 / 35 / 70 Mbases: 0.22 / 0.27 / 0.40 / 0.66 / 1.14 ms against 0.65 / 0.70 / 0.83 / 1.14 / 1.68 for the exact levels,
-    //  scripts/r03_segthr.sh.  A partitioned add is a batch of at least a quarter of the table's slots, so this is every one of them.)
+    //  scripts/r03_segthr.sh.  A partitioned add is a batch of at least 1/64 (empty table) or 1/10 of the table's slots -- partitioned_batch_wanted --, so this is nearly every one of them.)
     return total_bases >= (1ull << 22);
 }
 static bool seg_layout_bin() { // A/B runs: level 1's output with the ranges of the bins side by side instead of the units' blocks
@@ -2669,6 +2675,13 @@ static int table_alloc_for(kmu_counter *c, const DevSeqs *ds, uint64_t total_bas
     return table_alloc(c, std::min(distinct, occ));
 }
 
+// Is a batch of n k-mers worth the streaming (partitioned) build?  It rewrites the table image, direct insertion costs ~52 ps per
+// k-mer whatever the table: at the bench table (2^33 slots, scripts/r03_incr.py) a batch of 1/8 of the slots takes 37.8 ms partitioned
+// against 67.6 direct, one of 1/16 33.0 against 28.3; into an EMPTY table (no image to read, and direct insertion has to wipe it
+// first) 19.2 against 36.9 at 1/16 of the slots, 16.0 against 23.4 at 1/32, 13.9 against 18.0 at 1/64.  One rule for every way in
+// (reads, k-mer arrays, super-k-mer records, the chunked host leg).
+static bool partitioned_batch_wanted(const kmu_counter *c, uint64_t n) { return n * (c->empty ? 64u : 10u) >= c->nslots && n >= (1u << 16); }
+
 static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *counts, uint64_t n, int mem);
 static int add_superkmers(kmu_counter *c, const void *recs, uint64_t n_rec, uint64_t n_kmers);
 static int partitioned_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, uint32_t *d_err);
@@ -2681,12 +2694,7 @@ static int local_add(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, ui
     bool partitioned = false;
     const char *force = getenv("KMU_COUNT_PATH"); // "direct" / "partitioned": diagnostics
     if (!ds.packed) {
-        // the streaming build rewrites the table image, direct insertion costs ~52 ps per k-mer whatever the table: at the bench
-        // table (2^33 slots, `scripts/r03_incr.py`) a batch of 1/8 of the slots takes 37.8 ms partitioned against 67.6 direct, one of
-        // 1/16 33.0 against 28.3; into an EMPTY table (no image to read, and direct insertion has to wipe it first) 19.2 against
-        // 36.9 at 1/16 of the slots, 16.0 against 23.4 at 1/32, 13.9 against 18.0 at 1/64.  (Round 2's rule was a quarter of the slots
-        // in either case.)
-        partitioned = total_bases * (c->empty ? 64u : 10u) >= c->nslots && total_bases >= (1u << 16);
+        partitioned = partitioned_batch_wanted(c, total_bases);
         if (force && !strcmp(force, "direct")) partitioned = false;
         if (force && !strcmp(force, "partitioned")) partitioned = total_bases > 0;
     }
@@ -3035,7 +3043,7 @@ int count_chunked_begin(kmu_counter *c, DevSeqs &all, const uint64_t *host_offse
     KMU_TRY(flat_stream_extent(c->ctx, host_offsets, all.n_seq, KMU_MEM_HOST, all, &total_bases));
     KMU_TRY(table_alloc_for(c, nullptr, 0, d_err)); // (the reads are not on the device yet: a table by the hint)
     PartPlan pl;
-    const bool partitioned = total_bases * 4 >= c->nslots && total_bases >= (1u << 16);
+    const bool partitioned = partitioned_batch_wanted(c, total_bases);
     if (!partitioned || !part_plan_for(c, &pl) || !pl.b2 || !seg_partition_wanted(total_bases)) return KMU_OK;
     CountChunked *h = new CountChunked();
     const int rc = seg_begin(c, all, total_bases, pl, d_err, &h->run, true);
@@ -3127,7 +3135,7 @@ static int add_entries(kmu_counter *c, const uint64_t *kmers, const uint32_t *co
     KMU_TRY(table_alloc_for(c, nullptr, 0, d_err, 0.0, std::max<uint64_t>(c->p.capacity_hint, n)));
     {
         const char *force = getenv("KMU_COUNT_PATH");
-        bool partitioned = !counts && n * (c->empty ? 64u : 10u) >= c->nslots && n >= (1u << 16) && c->lg - c->rbits <= 22; // (see local_add)
+        bool partitioned = !counts && partitioned_batch_wanted(c, n) && c->lg - c->rbits <= 22;
         if (force && !strcmp(force, "direct")) partitioned = false;
         if (force && !strcmp(force, "partitioned")) partitioned = !counts;
         if (partitioned) {
@@ -3158,7 +3166,7 @@ static int add_superkmers(kmu_counter *c, const void *recs, uint64_t n_rec, uint
     KMU_TRY(get_err_word(ctx, &d_err));
     KMU_TRY(table_alloc_for(c, nullptr, 0, d_err, 0.0, std::max<uint64_t>(c->p.capacity_hint, n_kmers)));
     const char *force = getenv("KMU_COUNT_PATH");
-    bool partitioned = n_kmers * (c->empty ? 64u : 10u) >= c->nslots && n_kmers >= (1u << 16) && c->lg - c->rbits <= 22; // (see local_add)
+    bool partitioned = partitioned_batch_wanted(c, n_kmers) && c->lg - c->rbits <= 22;
     if (force && !strcmp(force, "direct")) partitioned = false;
     if (force && !strcmp(force, "partitioned")) partitioned = true;
     PartPlan pl;
@@ -3218,16 +3226,24 @@ int kmu_count_query(kmu_counter *c, const uint64_t *canon_kmers, uint64_t n, int
     return finish_call(ctx, mem);
 }
 
-static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique, uint64_t *occurrences = nullptr) {
+// the largest count a slot of this table holds: what a region build may leave (quotient slots: 2^w - 1024, and 1 024 less where
+// the build runs 1 024 threads -- regions of 8 192 slots --: every adder stops there, the plain adds in flight stay below the field)
+static uint64_t count_ceiling(const kmu_counter *c) {
+    if (!c->qw) return 0xFFFFFFFFull;
+    return (1ull << c->qw) - (uint64_t) Q_MARGIN - (c->rbits > 12 ? (uint64_t) Q_MARGIN : 0ull);
+}
+
+static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique, uint64_t *occurrences = nullptr, uint64_t *saturated = nullptr) {
     kmu_ctx *ctx = c->ctx;
     KMU_HIP(ctx, hipSetDevice(ctx->device));
     if (c->empty) {
         if (distinct) *distinct = 0;
         if (unique) *unique = 0;
         if (occurrences) *occurrences = 0;
+        if (saturated) *saturated = 0;
         return KMU_OK;
     }
-    if (c->compact && c->stats_cached) { // the last build left them
+    if (!saturated && c->compact && c->stats_cached) { // the last build left them
         uint64_t h[3];
         KMU_HIP(ctx, hipMemcpyAsync(h, c->scalars + 4, 24, hipMemcpyDeviceToHost, ctx->stream));
         KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -3241,7 +3257,7 @@ static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique, uin
     {
         KernelTimer tm(ctx, "k_count_stats");
         hipLaunchKernelGGL(k_count_stats, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), 0, ctx->stream, table_of(c),
-                           c->nslots, c->scalars);
+                           c->nslots, c->scalars, (uint32_t) std::min<uint64_t>(count_ceiling(c), 0xFFFFFFFFull));
     }
     KMU_HIP(ctx, hipGetLastError());
     uint64_t h[4];
@@ -3250,7 +3266,13 @@ static int count_stats(kmu_counter *c, uint64_t *distinct, uint64_t *unique, uin
     if (distinct) *distinct = h[0];
     if (unique) *unique = h[1];
     if (occurrences) *occurrences = h[3];
+    if (saturated) *saturated = h[2];
     return KMU_OK;
+}
+
+int kmu_count_nb_saturated(kmu_counter *c, uint64_t *out) {
+    if (!c || !out) return KMU_E_BAD_ARG;
+    return count_stats(c, nullptr, nullptr, nullptr, out);
 }
 
 int kmu_count_nb_distinct(kmu_counter *c, uint64_t *out) {
@@ -3271,6 +3293,7 @@ int kmu_count_table_info(const kmu_counter *c, kmu_count_table_info_t *out) {
     out->bytes_per_slot = c->qw ? 8u : 12u;
     out->count_field_bits = c->qw ? (uint32_t) c->qw : 32u;
     out->table_bytes = (uint64_t) table_image_bytes(c);
+    out->count_ceiling = count_ceiling(c);
     return KMU_OK;
 }
 
@@ -3455,13 +3478,14 @@ int kmu_count_finalize(kmu_counter *c) {
     if (have) KMU_TRY(materialize(c)); // (the export probes and rewrites slots)
     if (have) {
         KernelTimer tm(ctx, "k_owner_census");
-        hipLaunchKernelGGL(k_owner_census, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), (size_t) N * 4, ctx->stream, table_of(c),
+        hipLaunchKernelGGL(k_owner_census, dim3(grid_for(ctx, c->nslots, 1024)), dim3(256), ((size_t) N + 1) * 4, ctx->stream, table_of(c),
                            c->nslots, w32, N, (unsigned long long *) po);
     }
     std::vector<uint64_t> mine(N + 1), all((size_t) (N + 1) * N);
-    KMU_HIP(ctx, hipMemcpyAsync(mine.data(), po, (size_t) N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KMU_HIP(ctx, hipMemcpyAsync(mine.data(), po, ((size_t) N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t n_stay = mine[me]; // entries this rank owns itself: they stay
+    const uint64_t n_tomb = mine[N];  // slots still held by entries that left at EARLIER finalizes (they lengthen probe chains like live ones)
     mine[me] = 0;
     mine[N] = c->unmerged ? 1 : 0;
     KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), ((uint64_t) N + 1) * 8));
@@ -3503,7 +3527,8 @@ int kmu_count_finalize(kmu_counter *c) {
     // The entries that left are still in the table as tombstones of their probe chains (key kept, count zero).  Where they
     // and what arrives would crowd the table (a rank whose shard holds as many distinct k-mers as it ends up owning: every
     // k-mer of a noisy long-read set occurs once), the table is rebuilt from the entries that stay before the merge.
-    if (n_send && (double) (n_stay + n_send + n_recv) > 0.55 * (double) c->nslots) {
+    // (a local decision: every rank looks at its own table, nothing collective follows from it)
+    if ((n_send || n_tomb) && (double) (n_stay + n_send + n_tomb + n_recv) > 0.55 * (double) c->nslots) {
         void *kk = nullptr, *kc = nullptr;
         KMU_TRY(dev_buf(ctx, "cnt.keep.k", n_stay * 8 + 8, &kk));
         KMU_TRY(dev_buf(ctx, "cnt.keep.c", n_stay * 4 + 8, &kc));

@@ -31,7 +31,7 @@ SYMBOLS = [
     "kmu_comm_get_id", "kmu_comm_init", "kmu_comm_init_custom", "kmu_comm_destroy", "kmu_comm_rank", "kmu_comm_nranks",
     "kmu_comm_allgather", "kmu_comm_get_stats", "kmu_count_finalize", "kmu_kmer_owner",
     "kmu_sketch_count", "kmu_host_alloc", "kmu_host_free", "kmu_count_nb_occurrences", "kmu_count_table_info",
-    "kmu_kmer_owner_minimizer", "kmu_count_owner_kind", "kmu_count_extract_superkmers", "kmu_count_add_superkmers",
+    "kmu_count_nb_saturated", "kmu_kmer_owner_minimizer", "kmu_count_owner_kind", "kmu_count_extract_superkmers", "kmu_count_add_superkmers",
 ]
 
 
@@ -74,6 +74,7 @@ def load():
     L.kmu_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.kmu_host_free.argtypes = [vp, vp]
     L.kmu_count_nb_occurrences.argtypes = [vp, u64p]
+    L.kmu_count_nb_saturated.argtypes = [vp, u64p]
     L.kmu_count_table_info.argtypes = [vp, C.POINTER(A.CountTableInfo)]
     L.kmu_comm_get_id.argtypes = [C.POINTER(A.CommId)]
     L.kmu_comm_init.argtypes = [vp, C.POINTER(A.CommId), C.c_int, C.c_int]
@@ -728,10 +729,16 @@ class Counter:
         ti = A.CountTableInfo()
         self.ctx._check(self.L.kmu_count_table_info(self.h, C.byref(ti)))
         return {"nslots": ti.nslots, "table_bytes": ti.table_bytes, "bytes_per_slot": ti.bytes_per_slot,
-                "count_field_bits": ti.count_field_bits}
+                "count_field_bits": ti.count_field_bits, "count_ceiling": ti.count_ceiling}
 
     def table_bytes(self):
         return self.table_info()["table_bytes"]
+
+    def nb_saturated(self):
+        """kmu_count_nb_saturated: k-mers whose in-table count reached the table's ceiling (nb_occurrences is then a lower bound)"""
+        n = C.c_uint64(0)
+        self.ctx._check(self.L.kmu_count_nb_saturated(self.h, C.byref(n)))
+        return n.value
 
     def nb_occurrences(self):
         """kmu_count_nb_occurrences: sum of the multiplicities held (= k-mer occurrences inserted)"""

@@ -8,6 +8,8 @@ import pytest
 
 from kmerutils_amd import _abi as A
 from kmerutils_amd import dist as kdist
+
+import host_exchange as hostx  # tests/host_exchange.py
 from kmerutils_amd import synth
 
 
@@ -25,7 +27,7 @@ def test_shard_reads_by_bases():
 
 
 class OracleCounterDouble:
-    """test-only stand-in with the lib.Counter surface used by dist.merge_counters"""
+    """test-only stand-in with the lib.Counter surface used by tests/host_exchange.merge_counters"""
 
     def __init__(self, O, kmer_type, k):
         self.O, self.kt, self.k = O, kmer_type, k
@@ -78,7 +80,7 @@ def _worker(rank, world, port, ret):
         so = (off[r0:r1 + 1] - off[r0]).astype(np.uint64)
         cd = OracleCounterDouble(O, A.KMER64BIT, 21)
         cd.add_reads(sb, so)
-        got = kdist.merge_counters(cd, device=None, chunk_entries=257)  # several exchange rounds
+        got = hostx.merge_counters(cd, device=None, chunk_entries=257)  # several exchange rounds
         # reference result: the global counter restricted to the keys this rank owns
         g = O.Counter(A.KMER64BIT, 21, 16, 1 << 12)
         g.add_reads(bases, off)
@@ -94,7 +96,7 @@ def _worker(rank, world, port, ret):
         ok = ok and allrows.shape[0] == len(lens) and int(allrows[0, 0]) == 0
         # the throughput path: k-mers grouped by owner, one all-to-all, owner builds its table
         cd2 = OracleCounterDouble(O, A.KMER64BIT, 21)
-        nrecv = kdist.count_reads_exchange(cd2, sb, so)
+        nrecv = hostx.count_reads_exchange(cd2, sb, so)
         k2, c2 = cd2.c.dump(1)
         ok = ok and nrecv > 0 and np.array_equal(k2, gk[own]) and np.array_equal(c2, gc[own])
         ret[rank] = bool(ok)

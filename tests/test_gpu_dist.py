@@ -8,6 +8,8 @@ import pytest
 
 from kmerutils_amd import _abi as A
 from kmerutils_amd import dist as kdist
+
+import host_exchange as hostx  # tests/host_exchange.py
 from kmerutils_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -33,7 +35,7 @@ def _worker(rank, world, port, ret):
         os.environ["KMU_PMH_RESERVE_CUS"] = "16"
         p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
         box = {}
-        nrecv = kdist.count_reads_exchange(c, sb, so, overlap=lambda: box.update(sig=ctx.sketch(sb, so, p)))
+        nrecv = hostx.count_reads_exchange(c, sb, so, overlap=lambda: box.update(sig=ctx.sketch(sb, so, p)))
         g = O.Counter(A.KMER64BIT, 31, 8, 1 << 20)
         g.add_reads(bases, off)
         gk, gc = g.dump(1)

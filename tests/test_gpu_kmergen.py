@@ -250,3 +250,27 @@ def test_device_wang_hashes_against_the_published_inverse(ctx, oracle):
         for i in idx:
             inv = kat._inv_hash32shift if w32 else (lambda y: kat._inv_hash64shift(y, inv21, inv265))
             assert inv(int(hashed[i])) == int(raw[i]) and inv(int(chash[i])) == int(canon[i]), (kmer_type, k, i)
+
+
+def test_kmer_hashes_tail_positions_by_memory_kind(ctx, oracle):
+    """include/kmu.h, kmu_kmer_hashes: the positions that start no k-mer (the last k - 1 of a sequence, every position of a
+    sequence shorter than k) come back ZERO in a KMU_MEM_HOST array and are LEFT AS THEY WERE in a KMU_MEM_DEVICE array; the
+    k-mer positions are the oracle's either way (pinned, so that a caller's sentinel means the same tomorrow)."""
+    import torch
+    k = 21
+    seqs = ragged_dna(3, [100, 5, 21, 20, 64, 1, 300])
+    bases, off = oracle.concat(seqs)
+    want = oracle.kmer_hashes(bases, off, A.KMER64BIT, k, A.FHASH_CANON_INVHASH)
+    n = int(off[-1])
+    starts = np.zeros(n, bool)
+    for i in range(len(off) - 1):
+        starts[int(off[i]):max(int(off[i]), int(off[i + 1]) - k + 1)] = True
+    sentinel = 0x5E5E5E5E5E5E5E5E
+    host = np.full(n, sentinel, np.uint64)
+    ctx.kmer_hashes(bases, off, A.KMER64BIT, k, A.FHASH_CANON_INVHASH, out=host)
+    assert np.array_equal(host[starts], want[:n][starts]) and (host[~starts] == 0).all()
+    dev = torch.full((n,), sentinel, dtype=torch.int64, device="cuda")
+    ctx.kmer_hashes(torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), A.KMER64BIT, k, A.FHASH_CANON_INVHASH, out=dev)
+    ctx.synchronize()
+    got = dev.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got[starts], want[:n][starts]) and (got[~starts] == sentinel).all()
