@@ -58,7 +58,8 @@ def test_table_formats(ctx, monkeypatch):
     monkeypatch.setenv("KMU_COUNT_FMT", "quot")
     for bits, lg in ((8, 23), (16, 29)):
         c = ctx.counter(A.KMER64BIT, 31, bits, 1024)
-        assert c.table_info() == {"nslots": 1 << lg, "table_bytes": 8 << lg, "bytes_per_slot": 8, "count_field_bits": lg - 12}
+        assert c.table_info() == {"nslots": 1 << lg, "table_bytes": 8 << lg, "bytes_per_slot": 8, "count_field_bits": lg - 12,
+                                  "count_ceiling": (1 << (lg - 12)) - 1024}  # (2^11 - 1024 = 1 024 for the smallest quotient table)
         c.close()
 
 
@@ -82,6 +83,15 @@ def test_saturation_of_the_count_field(ctx, oracle, quot):
             assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (bits, path)
             assert gc.max() == (1 << bits) - 1
             assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())
+            # an inexact total reads "saturated", not "k-mers lost" (ADVICE r03): the two homopolymers sit at the table's ceiling,
+            # the sum of the counts held is short by exactly what they lost
+            ti = c.table_info()
+            assert ti["count_ceiling"] == (1 << ti["count_field_bits"]) - 1024
+            over = [n for n in (149_970, 69_970) if n >= ti["count_ceiling"]]  # (8-bit counters: both; 16-bit, w = 17: poly-A only)
+            assert c.nb_saturated() == len(over) >= 1
+            lost = sum(n - ti["count_ceiling"] for n in over)
+            nk_all = int(np.maximum(np.diff(alloff.astype(np.int64)) - 30, 0).sum())
+            assert lost > 0 and c.nb_occurrences() == nk_all - lost
             c.add_reads(allb, alloff)  # onto the saturated fields
             o2 = oracle.Counter(A.KMER64BIT, 31, bits, 1 << 22)
             o2.add_reads(allb, alloff)

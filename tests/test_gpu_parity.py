@@ -342,7 +342,8 @@ def _count_parity(ctx, oracle, kmer_type, k):
     # (what an 8-bit counter exports is exact up to the ceiling of its table's count field: 32 bits wide in the 12-byte slot
     #  format, 2^w - 1024 >= 255 in the 8-byte one -- the reference's own 8-bit counters stop at 255, kmercount.rs:1615)
     ti = gc.table_info()
-    ceil = (1 << ti["count_field_bits"]) - 1024 if ti["bytes_per_slot"] == 8 else 1 << 32
+    ceil = ti["count_ceiling"] if ti["bytes_per_slot"] == 8 else 1 << 32
+    assert ti["count_ceiling"] == ((1 << ti["count_field_bits"]) - 1024 if ti["bytes_per_slot"] == 8 else (1 << 32) - 1)
     assert np.array_equal(g2.query(q), np.minimum(o16.query(q), min(ceil, 65535)))
     gc.retain_part(1, 3)
     k1, c1 = g2.export_part(1, 3)
