@@ -34,8 +34,11 @@
 #include "kmu_smer.hpp"
 #include "kmu_stream.h"
 
-#ifndef KMU_STEP_TAB // (A/B builds: 0 = level 1 looks the read of a step up at the top of the step)
-#define KMU_STEP_TAB 1
+// How level 1 of the single-pass partition learns where reads end: 2 = from the "no k-mer" bits of flat_novalid (16 bits per lane,
+// requested with its 16 bases; round 4), 1 = from a table of the wave steps' reads (k_step_table, round 3), 0 = by looking the read
+// of a step up at the top of the step (A/B builds)
+#ifndef KMU_STEP_TAB
+#define KMU_STEP_TAB 2
 #endif
 #ifndef KMU_SCATTER_NT
 #define KMU_SCATTER_NT 0
@@ -1025,6 +1028,7 @@ __device__ __forceinline__ void flat_step_load(const uint8_t *bases, uint64_t to
 struct FlatRaw {
     uint4 c0, cx;
     uint4 tb; // the step's entry of the read table (k_step_table), requested with the chunks
+    uint32_t nv; // KMU_STEP_TAB == 2: the lane's 16 "no k-mer" bits (flat_novalid)
 };
 // The read that holds the first base of every wave step, and where it and the next two reads end, made once per call: x = the
 // read's index, y / z / w = the ends relative to the step's first base (0xFFFFFFFF: more than 4 G bases away).  Level 1 used to
@@ -1055,7 +1059,11 @@ __device__ __forceinline__ void flat_step_fetch(const uint8_t *bases, uint64_t t
                                                 uint64_t last_step = 0) {
     r.c0 = make_uint4(0u, 0u, 0u, 0u);
     r.cx = r.c0;
+#if KMU_STEP_TAB == 2
+    if (TAB) r.nv = reinterpret_cast<const uint16_t *>(tab)[(st < last_step ? st : last_step) * 64 + (uint64_t) lane_id()];
+#else
     if (TAB) r.tb = tab[st < last_step ? st : last_step];
+#endif
     if (total < 16) return; // (wave-uniform; flat_step_words then reads the ragged chunk itself)
     const uint64_t lastc = (total - 16) & ~15ull;
     const uint64_t a0 = (st * 64 + (uint64_t) lane_id()) * 16, ax = (st * 64 + 64 + (uint64_t) (lane_id() & 1)) * 16;
@@ -1162,6 +1170,43 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
     }
 }
 
+// the same from the lane's "no k-mer" bits: no read offsets, no search, no dependent look-up; a wave whose lanes are all-or-nothing
+// (long reads: nearly every wave) skips the per-k-mer tests
+__device__ __forceinline__ void flat_step_items_nv(int k, bool active, uint32_t w0, uint32_t ex, uint32_t nv, uint64_t (&it)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) it[j] = CKEY_EMPTY;
+    if (!active) return; // wave-uniform
+    const int lane = lane_id();
+    uint32_t e0 = bcast_u32(ex, 0), e1 = bcast_u32(ex, 1);
+    uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
+    if (lane == 63) { w1 = e0; w2 = e1; }
+    if (lane == 62) { w2 = e0; }
+    const uint32_t V = ~nv & 0xFFFFu;
+    const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+    const int sh = 64 - 2 * k;
+    if (__all(V == 0xFFFFu || V == 0u)) {
+        if (V) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
+                uint64_t val = v >> sh;
+                uint64_t rc = revcomp_val(val, k);
+                it[j] = rc < val ? rc : val;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if ((V >> j) & 1u) {
+                uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
+                uint64_t val = v >> sh;
+                uint64_t rc = revcomp_val(val, k);
+                it[j] = rc < val ? rc : val;
+            }
+        }
+    }
+}
+
 // level 1, pass 2: scatter the canonical k-mers into their level-1 partitions (private ranges per unit)
 // seg.cap != 0: the single-pass form -- no histogram ran; unit u (= seg.unit_base + blockIdx.x) writes bin b into its own
 // segment [b * seg.bincap + u * seg.cap, + seg.cap) of `out` (offs1 / binstart1 are not read), and validates the bases.
@@ -1236,7 +1281,11 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
         uint64_t it[16];
         if (SEGM) flat_step_words(bases, total, t0 + wave, t0 + wave < s1, raw, w0, ex, bad);
         else flat_step_load(bases, total, t0 + wave, t0 + wave < s1, w0, ex, &bad); // (the exact levels and the owner grouping: the older tile sort leaves no registers for a chunk in flight)
+#if KMU_STEP_TAB == 2
+        if (SEGM) flat_step_items_nv(k, t0 + wave < s1, w0, ex, raw.nv, it);
+#else
         if (SEGM) flat_step_items<KMU_STEP_TAB != 0>(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it, raw.tb);
+#endif
         else flat_step_items(offsets, n_seq, total, start, k, t0 + wave, t0 + wave < s1, w0, ex, r_hint, it);
         // the next step's chunks and its entry of the read table are requested now; they arrive under the tile sort, which waits
         // for them before its write-out
@@ -2124,9 +2173,13 @@ static int seg_begin(kmu_counter *c, const DevSeqs &ds, uint64_t total_bases, co
     } else if (run->rounds) KMU_TRY(dev_buf(ctx, "cnt.seg_state", (size_t) run->sp.units1 * bins1 * 4 + 64, &run->state));
     {
         const uint64_t nsteps = std::max<uint64_t>(1, ((total_bases + 15) / 16 + 63) / 64);
+#if KMU_STEP_TAB == 2
+        KMU_TRY(flat_novalid(ctx, ds, total_bases, c->p.kmer_size, nsteps * 64 + 64, "cnt.novalid", &run->step_tab));
+#else
         KMU_TRY(dev_buf(ctx, "cnt.step_tab", (size_t) nsteps * 16 + 64, &run->step_tab));
         hipLaunchKernelGGL(k_step_table, dim3((unsigned) ((nsteps + 255) / 256)), dim3(256), 0, ctx->stream, ds.offsets, ds.n_seq, nsteps,
                            (uint4 *) run->step_tab);
+#endif
     }
     KMU_TRY(scatter_attrs(ctx));
     return KMU_OK;

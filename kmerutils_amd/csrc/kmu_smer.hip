@@ -531,11 +531,7 @@ int smer_census(kmu_ctx *ctx, const DevSeqs &ds, uint64_t total_bases, int k, ui
     KMU_TRY(dev_buf(ctx, "smer.kmers", (size_t) n_parts * 8 + 64, &g->kmers));
     KMU_HIP(ctx, hipMemsetAsync(g->kmers, 0, (size_t) n_parts * 8, ctx->stream));
     // the positions that start no k-mer: 16 bits per code word of every wave step incl. the last one's halo
-    const uint64_t nwm = nsteps * SMER_STEP_WORDS + 64, mask_bytes = (nwm * 2 + 3) & ~(uint64_t) 3;
-    KMU_TRY(dev_buf(ctx, "smer.novalid", (size_t) mask_bytes + 64, &g->novalid));
-    KMU_HIP(ctx, hipMemsetAsync(g->novalid, 0, (size_t) mask_bytes, ctx->stream));
-    hipLaunchKernelGGL(k_smer_novalid, dim3((unsigned) (((uint64_t) ds.n_seq + 2 + 255) / 256)), dim3(256), 0, ctx->stream, ds.offsets, ds.n_seq, k,
-                       total_bases, (uint64_t) mask_bytes * 8, (uint32_t *) g->novalid);
+    KMU_TRY(flat_novalid(ctx, ds, total_bases, k, nsteps * SMER_STEP_WORDS + 64, "smer.novalid", &g->novalid));
     g->total = total_bases;
     const size_t lds = ((size_t) 2 * n_parts + 4) * 4 + (sa.list ? (size_t) SAMPLE_LDS * 8 : 0);
     const SmerCfg cf = smer_cfg(k);
@@ -553,6 +549,16 @@ int smer_census(kmu_ctx *ctx, const DevSeqs &ds, uint64_t total_bases, int k, ui
                            (uint64_t *) tot);
         hipLaunchKernelGGL(k_smer_scan_b, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t *) tot, n_parts, (uint64_t *) g->binstart);
     }
+    KMU_HIP(ctx, hipGetLastError());
+    return KMU_OK;
+}
+
+int flat_novalid(kmu_ctx *ctx, const DevSeqs &ds, uint64_t total_bases, int k, uint64_t n_words, const char *buf_name, void **out) {
+    const uint64_t mask_bytes = (n_words * 2 + 3) & ~(uint64_t) 3;
+    KMU_TRY(dev_buf(ctx, buf_name, (size_t) mask_bytes + 64, out));
+    KMU_HIP(ctx, hipMemsetAsync(*out, 0, (size_t) mask_bytes, ctx->stream));
+    hipLaunchKernelGGL(k_smer_novalid, dim3((unsigned) (((uint64_t) ds.n_seq + 2 + 255) / 256)), dim3(256), 0, ctx->stream, ds.offsets, ds.n_seq, k,
+                       total_bases, (uint64_t) mask_bytes * 8, (uint32_t *) *out);
     KMU_HIP(ctx, hipGetLastError());
     return KMU_OK;
 }

@@ -31,6 +31,12 @@ struct SmerGroups {
     uint64_t total = 0;       // extent of the flat stream the census walked
 };
 
+// "this position starts no k-mer" for every position of a flat stream of reads, 16 bits per aligned code word (bit j of word i:
+// position 16 i + j): the last k - 1 positions of every read, what lies before the first read and behind the last up to n_words
+// words.  One thread per read; the kernels that walk the stream load a lane's 16 bits next to its 16 bases instead of searching
+// the read offsets.  *out: device buffer `buf_name` of the context.
+int flat_novalid(kmu_ctx *ctx, const DevSeqs &ds, uint64_t total_bases, int k, uint64_t n_words, const char *buf_name, void **out);
+
 // units of the grouping kernels for a flat stream of total_bases bytes (the sample's capacity is sized from it)
 uint32_t smer_units(const kmu_ctx *ctx, uint64_t total_bases);
 // census: records and k-mers per owner, validation of the bases, optional duplication sample
