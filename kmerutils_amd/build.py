@@ -6,9 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkmu.so")
-SOURCES = ["kmu_api.hip", "kmu_sketch.hip", "kmu_sketch_super.hip", "kmu_sketch_dens.hip", "kmu_count.hip", "kmu_smer.hip", "kmu_compare.hip",
+SOURCES = ["kmu_api.hip", "kmu_sketch.hip", "kmu_sketch_super.hip", "kmu_sketch_dens.hip", "kmu_count.hip", "kmu_smer.hip", "kmu_hostpack.hip", "kmu_compare.hip",
            "kmu_ingest.hip", "kmu_kmergen.hip", "kmu_comm.hip"]
-HEADERS = ["kmu_device.h", "kmu_stream.h", "kmu_ctx.hpp", "kmu_comm.hpp", "kmu_flat.h", "kmu_smer.h", "kmu_smer.hpp", os.path.join("..", "..", "include", "kmu.h")]
+HEADERS = ["kmu_device.h", "kmu_stream.h", "kmu_ctx.hpp", "kmu_comm.hpp", "kmu_flat.h", "kmu_smer.h", "kmu_smer.hpp", "kmu_hostpack.hpp", os.path.join("..", "..", "include", "kmu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 
@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % s)
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lpthread"]
     subprocess.check_call(cmd)
     return OUT
 

@@ -13,8 +13,13 @@
 // Integer / f64 ALU + LDS only; HBM traffic = the read's bases in, m signatures out.
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "kmu_ctx.hpp"
+#include "kmu_hostpack.hpp"
 #include "kmu_stream.h"
 
 namespace kmu {
@@ -3180,8 +3185,27 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     // and what is left when the last byte has arrived is the last chunk's sketch + level 1, then level 2 and the region build,
     // which need all of level 1.  Tapering the last chunks (1/2, 1/4, 1/8: KMU_PIPE_TAPER=1) shortens that tail by a chunk's
     // sketch but pays for it in small launches: 149.1 / 149.2 ms against 146.2 / 144.0 without, same box (r03).  Off.
+    // The bases cross PCIe packed (kmu_hostpack.hip): the host's cores pack chunk after chunk ahead of the upload, a quarter of the
+    // bytes travels, a kernel on the upload stream restores the ASCII stream.  KMU_PIPE_PACK=0: the plain upload; small calls keep
+    // it too.  Packed data arrive ~4x as fast as the kernels consume them, so the chunks may GROW: each three times its predecessor
+    // (64 MB, 192 MB, 576 MB, 1.7 GB, the rest: every one is there before the kernels of the one before are through) -- five
+    // launches of the sketch kernels instead of nine, each closer to the batched run's efficiency.  Headline workload, same box
+    // (scripts/r04_hostleg.sh): 114.0 ms with growth 3, 115.3 / 116.0 with 2 / 4, 118.3 with equal chunks (KMU_PIPE_GROWTH=1),
+    // 127.7 with the plain upload (KMU_PIPE_PACK=0); the device-resident step takes 104.5.
+    bool packed_up = n_seq > 0 && total >= (32ull << 20);
+    if (const char *e = getenv("KMU_PIPE_PACK")) packed_up = n_seq > 0 && atoi(e) != 0 && total >= 16;
+    uint64_t growth = packed_up ? 3 : 1;
+    if (const char *e = getenv("KMU_PIPE_GROWTH")) growth = (uint64_t) std::max(1, atoi(e));
     std::vector<uint64_t> plan; // chunk sizes, in order (a chunk ends at the first read boundary at or behind its target)
-    {
+    if (growth > 1) {
+        uint64_t sz = std::min<uint64_t>(std::max<uint64_t>(chunk_bytes / 8, 1), total), left = total;
+        while (left) {
+            const uint64_t take = left <= sz + sz / 2 ? left : sz; // (a remainder of up to half a chunk more rides with the last one)
+            plan.push_back(take);
+            left -= take;
+            sz *= growth;
+        }
+    } else {
         const char *te = getenv("KMU_PIPE_TAPER");
         const bool taper = te && atoi(te) != 0 && total > 3 * chunk_bytes;
         const uint64_t first = std::min<uint64_t>(std::max<uint64_t>(chunk_bytes / 8, 1), total);
@@ -3209,6 +3233,25 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
         if (r < n_seq) cut.push_back(n_seq);
     }
     const size_t n_chunks = cut.size() - 1;
+    // The packed form of chunk c is the stream from the end of chunk c - 1 rounded up to 16 bases to its own end rounded up
+    // likewise (the few bases of its first read before that came with the chunk before).
+    packed_up = packed_up && n_chunks > 0;
+    std::vector<uint64_t> pk_bounds;
+    void *h_packed = nullptr, *d_packed = nullptr;
+    std::unique_ptr<PackPipe> packer;
+    if (packed_up) {
+        pk_bounds.push_back(0);
+        for (size_t c = 0; c < n_chunks; c++) {
+            const uint64_t e = c + 1 == n_chunks ? total : std::min<uint64_t>(total, (h_off[cut[c + 1]] + 15) & ~15ull);
+            pk_bounds.push_back(std::max(e, pk_bounds.back()));
+        }
+        KMU_TRY(host_buf(ctx, "pipe.packed", (size_t) (total / 4 + 64), &h_packed));
+        KMU_TRY(dev_buf(ctx, "pipe.packed_d", (size_t) (total / 4 + 64), &d_packed));
+        int threads = 16;
+        if (const char *e = getenv("KMU_PIPE_PACK_THREADS")) threads = std::max(1, atoi(e));
+        threads = std::min<int>(threads, std::max(1u, std::thread::hardware_concurrency()));
+        packer.reset(new PackPipe(bases + off0, (uint8_t *) h_packed, total, threads));
+    }
     std::vector<hipEvent_t> ev_up(n_chunks), ev_sk(n_chunks);
     for (size_t c = 0; c < n_chunks; c++) {
         KMU_HIP(ctx, hipEventCreateWithFlags(&ev_up[c], hipEventDisableTiming));
@@ -3216,6 +3259,21 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     }
     int rc = KMU_OK;
     auto upload = [&](size_t c) -> int {
+        if (packed_up) {
+            // in pieces of 64 M bases, each as soon as it is packed: the chunk's packing runs under its own upload.  Only copies go
+            // on the upload stream: the kernel that restores the ASCII stream runs on the compute stream in front of the chunk's
+            // kernels (on the upload stream it would wait for a CU that the persistent sketch kernels do not release, and every
+            // copy behind it with it)
+            const uint64_t p0 = pk_bounds[c], p1 = pk_bounds[c + 1], piece = 64ull << 20;
+            for (uint64_t q0 = p0; q0 < p1; q0 += piece) {
+                const uint64_t q1 = std::min(p1, q0 + piece);
+                if (!packer->wait_prefix(q1)) return fail(ctx, KMU_E_NON_ACGT, "pattern not a code in alphabet_2b (non-ACGT byte in a sequence)");
+                KMU_HIP(ctx, hipMemcpyAsync((uint8_t *) d_packed + q0 / 4, (const uint8_t *) h_packed + q0 / 4, (size_t) ((q1 - q0 + 3) / 4), hipMemcpyHostToDevice,
+                                            ctx->pipe_h2d));
+            }
+            KMU_HIP(ctx, hipEventRecord(ev_up[c], ctx->pipe_h2d));
+            return KMU_OK;
+        }
         const uint64_t b0 = h_off[cut[c]], b1 = h_off[cut[c + 1]];
         KMU_HIP(ctx, hipMemcpyAsync((uint8_t *) d_b + b0, bases + off0 + b0, b1 - b0, hipMemcpyHostToDevice, ctx->pipe_h2d));
         KMU_HIP(ctx, hipEventRecord(ev_up[c], ctx->pipe_h2d));
@@ -3233,15 +3291,44 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
         DevSeqs dc = all;
         rc = count_chunked_begin(counter, dc, h_off.data(), d_err, &cc, &cc_on);
     }
-    if (n_chunks && rc == KMU_OK) rc = upload(0);
+    // Packed uploads are enqueued by a thread of their own: an upload waits for the packer, and the thread that launches the
+    // kernels of chunk c must not stand behind the packing of chunk c + 1.  It waits (on the host) only until the upload of ITS
+    // chunk has been enqueued -- an event that has not been recorded yet cannot be waited for on a stream.
+    std::mutex up_mu;
+    std::condition_variable up_cv;
+    size_t up_done = 0; // uploads of chunks [0, up_done) are enqueued
+    int up_rc = KMU_OK;
+    std::thread uploader;
+    if (packed_up && rc == KMU_OK) {
+        uploader = std::thread([&] {
+            (void) hipSetDevice(ctx->device);
+            for (size_t c = 0; c < n_chunks; c++) {
+                const int r = upload(c);
+                std::lock_guard<std::mutex> g(up_mu);
+                if (r != KMU_OK) up_rc = r;
+                up_done = r == KMU_OK ? c + 1 : n_chunks; // (a failure releases every waiter)
+                up_cv.notify_all();
+                if (r != KMU_OK) return;
+            }
+        });
+    } else if (n_chunks && rc == KMU_OK) rc = upload(0);
     for (size_t c = 0; c < n_chunks && rc == KMU_OK; c++) {
-        if (c + 1 < n_chunks) rc = upload(c + 1);
+        if (packed_up) {
+            std::unique_lock<std::mutex> g(up_mu);
+            up_cv.wait(g, [&] { return up_done > c; });
+            rc = up_rc;
+        } else if (c + 1 < n_chunks) rc = upload(c + 1);
         if (rc != KMU_OK) break;
         DevSeqs ds = all;
         ds.offsets = all.offsets + cut[c];
         ds.n_seq = cut[c + 1] - cut[c];
         uint8_t *d_rows = (uint8_t *) d_sig + (size_t) cut[c] * rowb;
         if (hipStreamWaitEvent(ctx->stream, ev_up[c], 0) != hipSuccess) { rc = fail(ctx, KMU_E_HIP, "hipStreamWaitEvent failed"); break; }
+        if (packed_up && pk_bounds[c + 1] > pk_bounds[c]) {
+            KernelTimer tm(ctx, "k_unpack2b");
+            rc = launch_unpack2b(ctx, (const uint8_t *) d_packed + pk_bounds[c] / 4, pk_bounds[c + 1] - pk_bounds[c], (uint8_t *) d_b + pk_bounds[c], ctx->stream);
+            if (rc != KMU_OK) break;
+        }
         rc = sketch_per_seq_device(ctx, p, ds, d_rows, d_err, h_off.data() + cut[c]);
         if (rc != KMU_OK) break;
         if (hipEventRecord(ev_sk[c], ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->pipe_d2h, ev_sk[c], 0) != hipSuccess ||
@@ -3261,6 +3348,8 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
         }
     }
     if (cc) count_chunked_abort(cc);
+    if (uploader.joinable()) uploader.join(); // (a call that failed elsewhere: the uploads still queued are harmless, the buffers stay)
+    packer.reset(); // (joins the workers: a call that ends early stops them at their next slab)
     (void) hipStreamSynchronize(ctx->pipe_h2d);
     (void) hipStreamSynchronize(ctx->pipe_d2h);
     for (size_t c = 0; c < n_chunks; c++) {

@@ -147,7 +147,7 @@ def test_distributed_counter_quot(oracle, quot, owner):
 
 def test_sketch_count_quot(ctx, oracle, quot):
     PIPE = _load("test_gpu_pipeline")
-    PIPE.test_sketch_count_host_and_device(ctx, oracle, quot, "1")
+    PIPE.test_sketch_count_host_and_device(ctx, oracle, quot, "1", "1")
     PIPE.test_sketch_count_host_chunked_level1(ctx, oracle, quot)
 
 

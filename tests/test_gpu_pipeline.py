@@ -28,10 +28,12 @@ def _check_counts(c, oracle, bases, off, k):
     assert c.nb_occurrences() == int(np.maximum(np.diff(off.astype(np.int64)) - k + 1, 0).sum())
 
 
+@pytest.mark.parametrize("pack", ["1", "0"])  # bases cross PCIe packed by the host's cores (the default of big calls) / as they are
 @pytest.mark.parametrize("chunk_mb", ["1", "512"])
-def test_sketch_count_host_and_device(ctx, oracle, monkeypatch, chunk_mb):
+def test_sketch_count_host_and_device(ctx, oracle, monkeypatch, chunk_mb, pack):
     import torch
     monkeypatch.setenv("KMU_PIPE_CHUNK_MB", chunk_mb)
+    monkeypatch.setenv("KMU_PIPE_PACK", pack)
     bases, off = synth.ont_reads(900, 600_000, 0xC3)  # ~5 Mbases: five chunks of 1 MB, reads of 200 .. 60 k bases
     p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 200, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
     want = oracle.sketch(bases, off, p)
@@ -63,14 +65,21 @@ def test_sketch_count_host_and_device(ctx, oracle, monkeypatch, chunk_mb):
     assert np.array_equal(ctx.sketch_count(bases, off, ps).view(np.uint64), oracle.sketch(bases, off, ps).view(np.uint64))
 
 
-def test_sketch_count_errors_and_empty(ctx, oracle):
+@pytest.mark.parametrize("pack", ["1", "0"])
+def test_sketch_count_errors_and_empty(ctx, oracle, monkeypatch, pack):
     from kmerutils_amd.lib import KmuError
+    monkeypatch.setenv("KMU_PIPE_PACK", pack)  # (packed: the host's packer finds the byte; plain: the kernels do)
     p = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
     bases = np.frombuffer(b"ACGT" * 20 + b"ACGTN" * 20, np.uint8).copy()
     off = np.array([0, 80, 180], np.uint64)
     with pytest.raises(KmuError) as ei:
         ctx.sketch_count(bases, off, p)
     assert ei.value.code == A.E_NON_ACGT
+    # lower case is as good as upper case on either path (alphabet.rs:119-127)
+    low = np.frombuffer(bytes(bases[:80]).lower() + bytes(bases[:80]), np.uint8).copy()
+    o2 = np.array([0, 80, 160], np.uint64)
+    rows = ctx.sketch_count(low, o2, p)
+    assert np.array_equal(rows[0], rows[1]) and np.array_equal(rows, oracle.sketch(low, o2, p))
     pb = A.SketchParams(A.ALGO_PROB3A, A.KMER64BIT, 31, 64, A.SIG_U64, 0, A.FHASH_CANON_INVHASH, 10, 0, 0, 0, 0)
     with pytest.raises(KmuError) as ei:
         ctx.sketch_count(bases[:80], off[:2], pb)
@@ -113,6 +122,7 @@ def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
     exact route redoes the whole batch at the end)"""
     import torch
     monkeypatch.setenv("KMU_PIPE_CHUNK_MB", "1")
+    monkeypatch.setenv("KMU_PIPE_GROWTH", "1")  # (equal chunks: the packed upload's growing chunks would make fewer, larger arrivals)
     monkeypatch.setenv("KMU_COUNT_SEG", "2")
     monkeypatch.setenv("KMU_COUNT_SEG_ROUND_MIN", "1")  # (a launch per arrival of >= 1 wave step per unit: 256 KB here, 16 MB by default)
     dev = torch.device("cuda", 0)
