@@ -243,6 +243,8 @@ def main():
         for tr in ([want] if want == "torch" else [want, "torch"]):
             err = None
             try:
+                if os.environ.get("KMU_BENCH_FAIL_TRANSPORT") == tr:  # (rehearsals of the fallback itself)
+                    raise RuntimeError("KMU_BENCH_FAIL_TRANSPORT=%s" % tr)
                 kdist.init_comm(ctx, transport=tr)
                 pn = min(1000, n_reads)
                 pc = ctx.counter(cfg["kmer_type"], cfg["k"], 8, 1 << 22, distributed=True)

@@ -18,8 +18,15 @@ for w in "c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa short_k21_sketc
         print("no line for", w, e); continue
     runs[w] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                "value_host_to_host": d.get("value_host_to_host"), "kernels": {k: v["avg_ms"] for k, v in d["kernels"].items()},
-               "checks": d["checks"], "cpu_baseline": (d.get("cpu_baseline") or {}).get("value")}
+               "checks": d["checks"], "cpu_baseline": (d.get("cpu_baseline") or {}).get("value"),
+               # the HBM roofline of the workload's dominant unit as the line computed it (traffic / instruction counts of the
+               # same workload: profiles/<round>a_<workload>_bench.json, roofline_from_this_profile)
+               "roofline": {k: (d.get("roofline") or {}).get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "alg_bytes_per_launch")}}
 json.dump({"round": "$tag", "source": "scripts/final_round.sh", "runs": runs}, open("gpurun_out/${tag}_workloads.json", "w"), indent=1, sort_keys=True)
 PY
-# the two routes of a distributed add through a communicator of one rank (profiles/<tag>_routes.json is assembled from these)
-ROUTE_WORKLOADS="c4_count ont_k31_count" bash scripts/routes.sh > gpurun_out/routes_$tag.txt 2>&1; tail -6 gpurun_out/routes_$tag.txt
+# the routes of a distributed add through a communicator of one rank (the default owners: minimizer; occurrences = super-k-mer records)
+ROUTE_WORKLOADS="c4_count ont_k31_count" bash scripts/routes.sh > gpurun_out/${tag}_routes.txt 2>&1; tail -6 gpurun_out/${tag}_routes.txt
+# the N-rank code path of the default bench on one rank, minimizer owners against hash owners
+bash scripts/r04_ncomm.sh $tag > gpurun_out/${tag}_ncomm.txt 2>&1; cut -c1-400 gpurun_out/${tag}_ncomm.txt
+# the host-to-host leg: packed upload (default), equal chunks, plain upload
+bash scripts/r04_hostleg.sh "KMU_PIPE_GROWTH=3" "KMU_PIPE_GROWTH=1" "KMU_PIPE_PACK=0" > gpurun_out/${tag}_hostleg.txt 2>&1; cat gpurun_out/${tag}_hostleg.txt

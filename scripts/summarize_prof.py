@@ -76,8 +76,9 @@ def main():
                     continue
                 parts = name.split("+")
                 mult = (e.get("per_step") or {})
-                tr = [pmc.get(k, {}).get("hbm_bytes_per_launch") for k in parts]
-                va = [pmc.get(k, {}).get("SQ_INSTS_VALU_per_launch") for k in parts]
+                alias = {"k_nthash": "k_nthash_flat"}  # (the library's timer name -> the kernel rocprofv3 saw)
+                tr = [pmc.get(alias.get(k, k), {}).get("hbm_bytes_per_launch") for k in parts]
+                va = [pmc.get(alias.get(k, k), {}).get("SQ_INSTS_VALU_per_launch") for k in parts]
                 m = [mult.get(k, 1.0) for k in parts]
                 units[name] = {"bound": "hbm", "achieved": e["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": e["GBps"] / 8000.0,
                                "avg_launch_ms": e["avg_ms"], "alg_bytes_per_launch": e["alg_bytes"],
