@@ -734,9 +734,20 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t item, int region_bits, int
 // Segmented output (the single-pass partition, see partitioned_add): bin b of this unit owns the fixed range
 // [(bin_base + b) * bincap + end_rel - cap, (bin_base + b) * bincap + end_rel) of `out`, sized from the expected number of
 // items with a margin; an item beyond its range is dropped and reported in *ovf (the caller then takes the exact route).
+#ifndef KMU_LEAF6_WIDE // (diagnostic builds: 1 = the second plane of 6-byte leaf items holds 32-bit words)
+#define KMU_LEAF6_WIDE 0
+#endif
+#if KMU_LEAF6_WIDE
+typedef uint32_t leaf_hi_t;
+#else
+typedef uint16_t leaf_hi_t;
+#endif
 struct SegOut {
     uint64_t bin_base, bincap, end_rel, cap;
     uint32_t *ovf;
+    // LEAF6 (tile_scatter_seg): the output holds 6 bytes per item in two planes -- u32 low words of all items, then u16 bits 32..47;
+    // n_total = items in all streams (where the second plane starts)
+    uint64_t n_total = 0;
 };
 
 // it[j] == CKEY_EMPTY marks "no k-mer".  All 1024 threads call this together.  (The exact levels, the owner grouping of a
@@ -882,7 +893,10 @@ __device__ __forceinline__ void seg_spill(uint32_t *ovf, uint64_t item) {
 // 2 048 private streams x 128 bytes = 8 MB of open lines per XCD against 4 MB of L2: the two speeds of level 1, section 3.4).
 // (Round 3, measured and not kept: level 1 taking an item's rank as soon as its hash is made, so that a wave's LDS atomics run
 // under the arithmetic of its next items -- 16.2 / 17.9 / 18.0 ms against 15.7 / 16.2, scripts/r03_prerank.sh.)
-template <bool VMWAIT, bool CUR = false, int THREADS = SCATTER_THREADS>
+// LEAF6: what leaves is bits 47..0 of an item, in two planes (SegOut::n_total): the region build needs the 64 - w hash bits
+// below the region index and knows the rest from where it reads (tables of >= 2^28 slots: w >= 16); 26 instead of 35 GB written
+// by level 2 and read by the build at the bench size.
+template <bool VMWAIT, bool CUR = false, int THREADS = SCATTER_THREADS, bool LEAF6 = false>
 __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLds &l, uint32_t nbins, int region_bits, int shift,
                                                  uint64_t *out, const SegOut &sg, uint32_t (&run)[2], SegClk &clk,
                                                  uint32_t *cursor = nullptr) {
@@ -972,7 +986,11 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
 #if KMU_SCATTER_NT // (A/B builds: non-temporal stores for the partition streams)
                 if (rel[u] < cap) __builtin_nontemporal_store(v[u], &out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])]);
 #else
-                if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
+                if (LEAF6 && rel[u] < cap) {
+                    const uint64_t at = (uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u]);
+                    reinterpret_cast<uint32_t *>(out)[at] = (uint32_t) v[u];
+                    reinterpret_cast<leaf_hi_t *>(reinterpret_cast<uint32_t *>(out) + sg.n_total)[at] = (leaf_hi_t) (v[u] >> 32);
+                } else if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
 #endif
                 else seg_spill(sg.ovf, v[u]);
             }
@@ -1417,7 +1435,7 @@ __global__ void __launch_bounds__(256) k_arr_scan_b(const uint64_t *tot, const u
 // where items went to the spill list: the build clamps it).  The units of a partition are the workgroups 8 apart in the grid:
 // the dispatcher deals workgroups out to the 8 XCDs round robin, so they run at the same time on the same XCD and its L2 sees
 // their runs of a leaf side by side (see tile_scatter_seg).
-template <int IT, bool SEGM, bool SHARED = false, int THREADS = SCATTER_THREADS>
+template <int IT, bool SEGM, bool SHARED = false, int THREADS = SCATTER_THREADS, bool LEAF6 = false>
 __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, const uint64_t *bounds, ArrPlan pl,
                                                       const uint64_t *offs_rel, const uint64_t *outbounds, uint64_t *out,
                                                       uint64_t seg_cap, uint32_t *seg_ovf, uint32_t *leafcnt) {
@@ -1441,6 +1459,7 @@ __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, con
         sg = SegOut{block * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
         cursor = leafcnt + block * pl.bins;
     }
+    if (LEAF6) sg.n_total = (uint64_t) pl.nparts * pl.bins * seg_cap; // (level 2: one set of leaves per input partition)
     uint32_t run[2] = {0u, 0u};
     SegClk clk;
     if (SEGM) {
@@ -1530,7 +1549,7 @@ __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, con
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
         }
-        if (SEGM) tile_scatter_seg<PADDED, SHARED, THREADS>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
+        if (SEGM) tile_scatter_seg<PADDED, SHARED, THREADS, LEAF6>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
         else tile_scatter<IT == IT_KEY_TO_HASH ? IT_HASH : IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
     if (SEGM) {
@@ -1635,11 +1654,16 @@ static constexpr int BUILD_PRE = 6;
 // 4 096 slots: four workgroups of 512 threads per CU; 64 KiB for 8 192 slots: two workgroups of 1 024), a first sighting is
 // one ds_cmpst_rtn_b64, a repeat one more ds_add_u64 (guarded: the count field stops at q_limit), and the LDS image leaves as
 // it is.  in_mode: 0 = the table holds nothing yet, 1 = the slab is read first.  `flags`: A/B runs (KMU_BUILD_ABLATE).
-template <int IT, int THREADS>
+// LEAF6: the leaves hold 6 bytes per item in two planes (tile_scatter_seg): bits 47..0 of the hash are all this kernel uses
+// (hw = h << w, the home slot = the 12 bits below the region index)
+template <int IT, int THREADS, bool LEAF6 = false>
 __global__ void __launch_bounds__(THREADS) k_part_build_q(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
                                                           uint32_t n_regions, CountTable t, int in_mode, int flags, uint32_t *err,
                                                           uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt, int contig) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t *__restrict__ it32 = reinterpret_cast<const uint32_t *>(items);
+    const leaf_hi_t *__restrict__ it16 = reinterpret_cast<const leaf_hi_t *>(it32 + (uint64_t) n_regions * leaf_stride);
+    auto item_at = [&](uint64_t i) -> uint64_t { return LEAF6 ? ((uint64_t) it16[i] << 32) | it32[i] : items[i]; };
     constexpr int BUILD_THREADS = THREADS; // (shadows the wide kernel's constant inside this function)
     const int out_compact = flags;
     const uint32_t R = t.rmask + 1;
@@ -1659,7 +1683,7 @@ __global__ void __launch_bounds__(THREADS) k_part_build_q(const uint64_t *__rest
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++) {
             const uint64_t i = i0 + (uint64_t) q * BUILD_THREADS + tid;
-            pre_it[q] = i < i1 ? items[i] : CKEY_EMPTY;
+            pre_it[q] = i < i1 ? item_at(i) : CKEY_EMPTY;
         }
         uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + (uint64_t) r * R);
         if (in_mode == 1) {
@@ -1724,7 +1748,7 @@ __global__ void __launch_bounds__(THREADS) k_part_build_q(const uint64_t *__rest
                 }
         }
         for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) { // (leaves beyond 3 072 items)
-            const uint64_t item = items[i];
+            const uint64_t item = item_at(i);
             if (item == CKEY_EMPTY) continue;
             const uint64_t h = IT == IT_HASH ? item : khash(item);
             uint32_t off = (uint32_t) (h >> t.shift) & t.rmask, n = 0;
@@ -1915,7 +1939,7 @@ static int grid_for(const kmu_ctx *ctx, uint64_t n, int per_block) {
 static size_t build_lds(const kmu_counter *c) { return c->qw ? (size_t) 8 << c->rbits : ((size_t) 12 << c->rbits) + 64 * 8 + 65 * 4 + 16; }
 template <int IT>
 static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, bool to_compact, uint32_t *d_err,
-                        uint64_t leaf_stride = 0, const uint32_t *leafcnt = nullptr, uint64_t n_items_hint = 0) {
+                        uint64_t leaf_stride = 0, const uint32_t *leafcnt = nullptr, uint64_t n_items_hint = 0, bool leaf6 = false) {
     kmu_ctx *ctx = c->ctx;
     const uint64_t n_regions = c->nslots >> c->rbits;
     const int in_mode = c->empty ? 0 : c->compact ? 2 : 1;
@@ -1942,7 +1966,10 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
             }
             hipLaunchKernelGGL(kq, dim3(grid), dim3(1024), build_lds(c) + pad, ctx->stream, items, leaves, (uint32_t) n_regions, table_of(c), in_mode, abl,
                                d_err, leaf_stride, leafcnt, contig);
-        } else if (c->qw)
+        } else if (c->qw && leaf6)
+            hipLaunchKernelGGL((k_part_build_q<IT, 512, true>), dim3(grid), dim3(512), build_lds(c) + pad, ctx->stream, items, leaves, (uint32_t) n_regions,
+                               table_of(c), in_mode, abl, d_err, leaf_stride, leafcnt, contig);
+        else if (c->qw)
             hipLaunchKernelGGL((k_part_build_q<IT, 512>), dim3(grid), dim3(512), build_lds(c) + pad, ctx->stream, items, leaves, (uint32_t) n_regions,
                                table_of(c), in_mode, abl, d_err, leaf_stride, leafcnt, contig);
         else
@@ -2007,7 +2034,8 @@ static int scatter_attrs(kmu_ctx *ctx) {
                          (const void *) k_arr_scatter<IT_HASH, false>, (const void *) k_arr_scatter<IT_HASH, true>, (const void *) k_arr_scatter<IT_HASH, true, true>, (const void *) k_arr_scatter<IT_HASH, true, true, 512>,
                          (const void *) k_arr_scatter<IT_KEY, false>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, false>,
                          (const void *) k_arr_scatter<IT_KEY_TO_HASH, true>, (const void *) k_arr_scatter<IT_KEY_TO_HASH, true, true>,
-                         (const void *) k_smer_scatter1<false>, (const void *) k_smer_scatter1<true>};
+                         (const void *) k_smer_scatter1<false>, (const void *) k_smer_scatter1<true>,
+                         (const void *) k_arr_scatter<IT_HASH, true, true, SCATTER_THREADS, true>};
     for (const void *f : fns) KMU_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ctx->lds_attr_set |= 1u;
     return KMU_OK;
@@ -2254,8 +2282,18 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
 // phases of the other (thread-0 clocks of the one-workgroup form: rank / scan / place 65 %, loads + stores 35 %, one after the
 // other) -- measured: 19.4-19.6 ms against 16.4-17.8 for one workgroup of 1 024 threads (18.4 / 17.8 with 32 / 64 units per bin):
 // the level runs at 4 TB/s either way, the memory system's rate for this mix; KMU_COUNT_L2_THREADS=512 keeps the A/B
+// leaf items of 6 bytes (two planes) instead of 8: a table whose region index takes w >= 16 hash bits (>= 2^28 slots, quotient
+// slots, regions of 4096), leaves shared through cursors (no tail marks to write), 1 024-thread workgroups.  KMU_COUNT_LEAF6=0/1.
+static bool leaf6_wanted(const kmu_counter *c, bool shared2) {
+    // (same box, alternating processes, scripts/r04_leaf6.sh: the headline's build 23.5 -> 20.2 ms, its level 2 17.4 -> 18.9 -- two
+    //  stores per item --, the count unit 55.3 -> 53.1; config 4's shard 9.26 -> 8.84)
+    bool on = true;
+    if (const char *e = getenv("KMU_COUNT_LEAF6")) on = atoi(e) != 0;
+    const char *te = getenv("KMU_COUNT_L2_THREADS");
+    return on && shared2 && c->qw >= 16 && c->rbits == 12 && !(te && atoi(te) == 512);
+}
 static int seg_launch_level2(kmu_ctx *ctx, const ArrPlan &ap, bool shared, const void *A, const void *bnd, void *B, uint64_t cap2, void *ovf,
-                             void *leafcnt) {
+                             void *leafcnt, bool leaf6 = false) {
     const uint32_t bins2 = ap.bins;
     if (shared) KMU_HIP(ctx, hipMemsetAsync(leafcnt, 0, (size_t) ap.nparts * bins2 * 4, ctx->stream));
     int threads = SCATTER_THREADS;
@@ -2266,6 +2304,7 @@ static int seg_launch_level2(kmu_ctx *ctx, const ArrPlan &ap, bool shared, const
     }
     auto k2 = shared ? k_arr_scatter<IT_HASH, true, true> : k_arr_scatter<IT_HASH, true, false>;
     if (threads == 512) k2 = k_arr_scatter<IT_HASH, true, true, 512>;
+    if (leaf6) k2 = k_arr_scatter<IT_HASH, true, true, SCATTER_THREADS, true>;
     KernelTimer tm(ctx, "k_arr_scatter");
     hipLaunchKernelGGL(k2, dim3(ap.nparts * ap.chunks), dim3(threads), seg_lds_bytes(bins2, 16u * (uint32_t) threads), ctx->stream, (const uint64_t *) A,
                        (const uint64_t *) bnd, ap, (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) B, cap2, (uint32_t *) ovf,
@@ -2282,14 +2321,16 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     {
         ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2, run->sp.sets ? run->sp.sets : run->sp.units1, (uint32_t) run->sp.cap1, bins1};
         if (seg_layout_bin()) { ap.seg_units = 1; ap.seg_cap = (uint32_t) run->sp.bincap1; }
-        KMU_TRY(seg_launch_level2(ctx, ap, run->sp.shared2 != 0, run->A, run->bnd, run->B, run->sp.cap2, run->ovf, run->leafcnt));
+        KMU_TRY(seg_launch_level2(ctx, ap, run->sp.shared2 != 0, run->A, run->bnd, run->B, run->sp.cap2, run->ovf, run->leafcnt,
+                                  leaf6_wanted(c, run->sp.shared2 != 0 && !seg_layout_bin())));
     }
     KMU_HIP(ctx, hipGetLastError());
     uint32_t h_ovf[2] = {0, 0}; // read before the table is touched: a full spill list leaves the call to the exact route
     KMU_HIP(ctx, hipMemcpyAsync(h_ovf, run->ovf, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_ovf[0]) return KMU_OK;
-    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(c), run->d_err, run->sp.leafcap, (const uint32_t *) run->leafcnt));
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) run->B, nullptr, want_compact(c), run->d_err, run->sp.leafcap, (const uint32_t *) run->leafcnt, 0,
+                                  leaf6_wanted(c, run->sp.shared2 != 0 && !seg_layout_bin())));
     KMU_TRY(seg_spill_add(c, run->ovf, h_ovf, run->d_err));
 #if KMU_DIAG
     if (getenv("KMU_DIAG_SEG")) { // thread-0 clocks of the tile sort, summed over the workgroups: [level] between / rank / scan / place / out / finish
@@ -2536,14 +2577,14 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) bnd, (uint64_t) bins1 + 1, bincap1);
     {
         ArrPlan ap{pl.region_bits, 0, bins2, bins1, units2 ? units2 : 1u, pieces, (uint32_t) cap1, bins1, 0u};
-        KMU_TRY(seg_launch_level2(ctx, ap, units2 != 0, A, bnd, B, cap2, ovf, leafcnt));
+        KMU_TRY(seg_launch_level2(ctx, ap, units2 != 0, A, bnd, B, cap2, ovf, leafcnt, leaf6_wanted(c, units2 != 0)));
     }
     KMU_HIP(ctx, hipGetLastError());
     uint32_t h_ovf[2] = {0, 0};
     KMU_HIP(ctx, hipMemcpyAsync(h_ovf, ovf, 8, hipMemcpyDeviceToHost, ctx->stream));
     KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_ovf[0]) return KMU_OK; // the table is untouched: the exact levels take over
-    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(c), d_err, cap2, (const uint32_t *) leafcnt));
+    KMU_TRY(launch_build<IT_HASH>(c, (const uint64_t *) B, nullptr, want_compact(c), d_err, cap2, (const uint32_t *) leafcnt, 0, leaf6_wanted(c, units2 != 0)));
     KMU_TRY(seg_spill_add(c, ovf, h_ovf, d_err));
     *taken = 1;
     return KMU_OK;

@@ -160,10 +160,15 @@ __device__ __forceinline__ void smer_step(const uint8_t *bases, uint64_t total, 
     a.w2 = dpp_shl1(a.w1);
     a.w3 = dpp_shl1(a.w2);
     smer_minwin<W>(a.w0, a.w1, cf.m, mw);
+    // own[j] = smer_owner_of(mw[j], n_parts); 2 / 4 / 8 ranks: the remainder is a mask (a division per k-mer would dominate the
+    // kernel), decided once per step, not per k-mer
+    if ((n_parts & (n_parts - 1u)) == 0u) {
+        const uint32_t nm = n_parts - 1u;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { // (2 / 4 / 8 ranks: the remainder is a mask; a division per k-mer would dominate the kernel)
-        const uint32_t x = (mw[j] * 0xC2B2AE35u) >> 16;
-        own[j] = (n_parts & (n_parts - 1u)) == 0u ? x & (n_parts - 1u) : x % n_parts; // = smer_owner_of(mw[j], n_parts)
+        for (int j = 0; j < 16; j++) own[j] = ((mw[j] * 0xC2B2AE35u) >> 16) & nm;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) own[j] = ((mw[j] * 0xC2B2AE35u) >> 16) % n_parts;
     }
     const uint32_t V = ~raw.nv & 0xFFFFu;
     // ---- boundaries: the first k-mer behind a position without one (every read's first k-mer: the k - 1 positions before it

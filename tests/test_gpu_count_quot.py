@@ -201,3 +201,44 @@ def test_table_sized_from_the_measured_duplication(oracle, genome, n_reads, what
     assert c.table_info()["nslots"] >= 1.5 * wk.size and c.nb_distinct() == wk.size
     c.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("leaf6", ["1", "0"])
+def test_six_byte_leaf_items_of_big_tables(ctx, oracle, monkeypatch, leaf6):
+    """tables of >= 2^28 slots (the region index takes w >= 16 hash bits): level 2 of the partitioned build leaves 6 bytes per item
+    in two planes, the region build reads them back (KMU_COUNT_LEAF6; round 4).  A 2 GB table with a batch the oracle can count,
+    through the reads path, the k-mer array path and the super-k-mer records path."""
+    import torch
+    monkeypatch.setenv("KMU_COUNT_LEAF6", leaf6)
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    bases, off = synth.ont_reads(700, 500_000, 0xCB)
+    poly = np.frombuffer(b"A" * 3000 + b"ACGTTGCA" * 400, np.uint8)
+    allb = np.concatenate([bases, poly])
+    alloff = np.concatenate([off, [off[-1] + 3000, off[-1] + 6200]]).astype(np.uint64)
+    o = oracle.Counter(A.KMER64BIT, 31, 16, 1 << 22)
+    o.add_reads(allb, alloff)
+    wk, wc = o.dump(1)
+    hint = 170_000_000  # x 1.5 -> 2^28 slots of 8 bytes, w = 16
+    c = ctx.counter(A.KMER64BIT, 31, 8, hint)
+    ti = c.table_info()
+    assert ti["nslots"] == 1 << 28 and ti["bytes_per_slot"] == 8 and ti["count_field_bits"] == 16
+    c.add_reads(torch.from_numpy(allb).cuda(), torch.from_numpy(alloff.astype(np.int64)).cuda())
+    gk, gc = c.dump(1)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, np.minimum(wc, 255))
+    c.add_reads(allb, alloff)  # a second batch into the occupied table (the build reads the image first)
+    assert np.array_equal(c.query(wk), np.minimum(2 * wc.astype(np.int64), 255))
+    c.close()
+    c = ctx.counter(A.KMER64BIT, 31, 8, hint)  # explicit k-mers: the array path's two levels
+    c.add_kmers(torch.from_numpy(np.repeat(wk, 2).view(np.int64)).cuda())
+    assert np.array_equal(c.dump(1)[0], wk) and (c.dump(1)[1] == 2).all()
+    c.close()
+    src = ctx.counter(A.KMER64BIT, 31, 8, 1 << 16)  # super-k-mer records: the receiver's level 1
+    rec, bounds, kmers = src.extract_superkmers(allb, alloff, 3)
+    ctx.synchronize()
+    c = ctx.counter(A.KMER64BIT, 31, 8, hint)
+    c.add_superkmers(rec)
+    gk, gc = c.dump(1)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, np.minimum(wc, 255))
+    c.close()
+    src.close()
