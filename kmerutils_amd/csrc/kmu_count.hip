@@ -2834,15 +2834,16 @@ static void route_model(double table_bytes, double gbps, double n, double d, int
     *ms_occ = n * (3.0 + 6.2 + 13.1) * ps + 8.0 * n * f / (gbps * 1e6) + 8.0 * n * (1.0 - f) / 1.2e9;
     *ms_merge = n * (3.0 + 13.5) * ps + (f > 0 ? 2.0 : 1.0) * table_bytes / 4.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
 }
-// The same with minimizer owners: the occurrences travel as `recs` super-k-mer records of 12 bytes (kmu_smer.h).  Per occurrence:
-// census 1.0 ps + record scatter 1.3 ps (neither forms a k-mer), the receiver's build from records 13.3 ps (record expansion inside
-// the first partition level + level 2 + region build); MERGE pays the census, the local build, its table passes and a minimizer per
-// entry in them (r04, scripts/r04_routes.sh).
+// The same with minimizer owners: the occurrences travel as `recs` super-k-mer records of 12 bytes (kmu_smer.h).  Per occurrence
+// (one MI355X, one-rank communicator, profiles/r04b_routes.txt: the headline's 4.36 G k-mers / config 4's 0.75 G): census 1.5 / 2.0
+// ps + record scatter 1.3 / 1.7 ps (neither forms a k-mer), the receiver's build from records 11.4 / 9.3 ps (record expansion inside
+// the first partition level + level 2 + region build); MERGE pays the census, the local build (11.5), two table passes that
+// compute a MINIMIZER per entry (24 ps per entry and pass: k_owner_census 99 ms over 4.05 G entries) and the direct merge.
 static void route_model_smer(double table_bytes, double gbps, double n, double recs, double d, int nranks, double *ms_occ, double *ms_merge) {
     const double f = nranks > 1 ? (double) (nranks - 1) / nranks : 0.0;
     const double ps = 1e-9;
-    *ms_occ = n * (1.0 + 1.3 + 13.3) * ps + 12.0 * recs * f / (gbps * 1e6) + 12.0 * recs * (1.0 - f) / 1.2e9;
-    *ms_merge = n * (1.0 + 13.5) * ps + (f > 0 ? 2.0 : 1.0) * table_bytes / 3.0e9 + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
+    *ms_occ = n * (1.5 + 1.3 + 11.4) * ps + 12.0 * recs * f / (gbps * 1e6) + 12.0 * recs * (1.0 - f) / 1.2e9;
+    *ms_merge = n * (1.5 + 11.5) * ps + (f > 0 ? 2.0 : 1.0) * (table_bytes / 4.0e9 + d * 24.0 * ps) + 12.0 * d * f / (gbps * 1e6) + d * f * 60.0 * ps;
 }
 
 // first half of a distributed add: census of the owners + duplication sample, agreement on the route over all ranks, then

@@ -1,12 +1,22 @@
 #!/bin/bash
 # end-of-round measurement on one GPU box: the full -m gpu suite, the rocprofv3 / PMC passes of the default bench (profiles/<tag>_*),
 # the default bench line with cpu_baseline, the other workloads.  usage: scripts/final_round.sh <tag>
-tag=$1
+# (a gpurun call is at most 20 minutes: `scripts/final_round.sh <tag> 1` = the suite + the headline's profile passes + the default
+#  line, `... <tag> 2` = the other workloads, the routes, the N-rank path on one rank, the host leg)
+tag=$1; stage=${2:-12}
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/t_final_$tag.log 2>&1; echo rc=$? >> gpurun_out/t_final_$tag.log; tail -3 gpurun_out/t_final_$tag.log
+if [[ $stage == *1* ]]; then
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/t_final_$tag.log 2>&1; echo rc=$? >> gpurun_out/t_final_$tag.log; tail -3 gpurun_out/t_final_$tag.log
 grep -q "^rc=0" gpurun_out/t_final_$tag.log || exit 1
 bash scripts/pmc_bench.sh $tag > gpurun_out/pmc_bench_$tag.log 2>&1 || { echo "pmc_bench failed"; tail -5 gpurun_out/pmc_bench_$tag.log; exit 1; }
 timeout -k 10 300 python bench.py > gpurun_out/bench_${tag}_default.json 2> gpurun_out/bench_${tag}_default.err || { echo "bench failed"; exit 1; }
+python3 -c "
+import json; d=json.loads(open('gpurun_out/bench_${tag}_default.json').read().strip().splitlines()[-1])
+print('default line: value', round(d['value'],2), 'ms', round(d['ms_per_step'],2), 'host to host', round(d['host_to_host']['ms_per_step'],2), round(d['metric_value_8d'],2), 'frac', round(d['roofline']['frac'],4), d['roofline']['kernel'])
+print({k: round(v['avg_ms'],2) for k,v in d['kernels'].items()}); print(d['checks']); print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+for n,u in d['roofline']['units'].items(): print(n, 'frac %.4f' % u['frac'], 'traffic', u['traffic'], 'alu', (u.get('alu') or {}).get('frac'))"
+fi
+[[ $stage == *2* ]] || exit 0
 WORKLOADS="c3_k8 c2_count c2_nthash_count c4_count c1_super c5_aa short_k21_sketch" bash scripts/other_workloads.sh
 python3 - <<PY
 import json
