@@ -1234,9 +1234,21 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
 // threads with 20 keys per thread, and TWO workgroups share a CU, so one read's barriers hide under the other's work.
 // Reads with more than UQ_KEYS k-mers (or more than UQ_COLL keys in collision groups) are appended to `redo_list` and taken
 // by the general list-emitting kernel in a second launch.  Output: the lists k_pmh_points reads, as k_sketch_pmh3a<EMIT>.
-// Two shapes: <512 threads, 2^16-bit bitmaps, 2 048 collected keys> for reads of up to 10 240 k-mers, two workgroups per CU;
-// <1024, 2^17, 4 096> for up to 20 480 k-mers, one workgroup per CU, run on the list the first shape leaves behind.
+// Two shapes: <512 threads, 2^17-bit bitmaps, 1 024 collected keys> for reads of up to 10 240 k-mers, two workgroups per CU;
+// <1024, 2^18, 2 048> for up to 20 480 k-mers, one workgroup per CU, run on the list the first shape leaves behind.
 static constexpr int UQ_KREG = 20;
+// The two shapes' bitmap sizes (log2 bits) and collected-key capacities.  Round 4: bitmaps twice as large (nearly every key of a
+// collision group of an ONT read is a false positive of the bitmap: 9 % of the keys at 2^16 bits, 4.5 % at 2^17), collected-key
+// arrays half as large to pay for them in LDS: the sketch unit 50.3 -> 49.6 ms, same rows (A/B builds: -DKMU_UQ1_BM=16
+// -DKMU_UQ1_COLL=2048 -DKMU_UQ2_BM=17 -DKMU_UQ2_COLL=4096 is round 3's form).
+#ifndef KMU_UQ1_BM
+#define KMU_UQ1_BM 17
+#define KMU_UQ1_COLL 1024
+#endif
+#ifndef KMU_UQ2_BM
+#define KMU_UQ2_BM 18
+#define KMU_UQ2_COLL 2048
+#endif
 // every vector-memory request of this wave has completed (the chunks of global_load_lds have landed in LDS)
 __device__ __forceinline__ void vm_wait_lds_loads() {
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0); expcnt / lgkmcnt untouched
@@ -1264,7 +1276,7 @@ template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, int MINW, bool 
 __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) {
     typedef UqShape<UQ_THREADS, UQ_BM_BITS, UQ_COLL, TAB> SH;
     constexpr uint32_t UQ_KEYS = SH::KEYS, UQ_BM_WORDS = SH::BM_WORDS, UQ_BUCKETS = SH::BUCKETS, UQ_TILE = SH::TILE;
-    static_assert(UQ_BM_WORDS / 4 == (uint32_t) UQ_THREADS, "one 16-byte store per thread wipes a bitmap");
+    static_assert((UQ_BM_WORDS / 4) % (uint32_t) UQ_THREADS == 0, "whole 16-byte stores per thread wipe a bitmap");
     static_assert(UQ_COLL % UQ_THREADS == 0 && UQ_COLL / UQ_THREADS <= 4, "collected keys per thread");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *bmA = reinterpret_cast<uint32_t *>(smem);
@@ -1375,8 +1387,11 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                 }
             }
             uint4 *za = reinterpret_cast<uint4 *>(bmA), *zb = reinterpret_cast<uint4 *>(bmB);
-            za[tid] = make_uint4(0u, 0u, 0u, 0u); // 2 048 words = 512 x 16 bytes each
-            zb[tid] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (uint32_t z = 0; z < UQ_BM_WORDS / 4 / (uint32_t) UQ_THREADS; z++) { // (2^16 bits = 512 x 16 bytes)
+                za[tid + z * UQ_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+                zb[tid + z * UQ_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
         phase(0); // queue, staging, wipe
         lds_barrier();
@@ -2695,8 +2710,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         short_route = true;
     } else if (uq) {
         {
-            const auto ka = uq_tab ? k_multiset_uq<512, 16, 2048, 4, true> : k_multiset_uq<512, 16, 2048, 4, false>;
-            const size_t lds_a = uq_tab ? UqShape<512, 16, 2048, true>::LDS : UqShape<512, 16, 2048, false>::LDS;
+            const auto ka = uq_tab ? k_multiset_uq<512, KMU_UQ1_BM, KMU_UQ1_COLL, 4, true> : k_multiset_uq<512, KMU_UQ1_BM, KMU_UQ1_COLL, 4, false>;
+            const size_t lds_a = uq_tab ? UqShape<512, KMU_UQ1_BM, KMU_UQ1_COLL, true>::LDS : UqShape<512, KMU_UQ1_BM, KMU_UQ1_COLL, false>::LDS;
             KMU_HIP(ctx, hipFuncSetAttribute((const void *) ka, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             KernelTimer t(ctx, "k_multiset_uq");
             hipLaunchKernelGGL(ka, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(ds.n_seq, (uint64_t) cus * 2))), dim3(512), lds_a,
@@ -2718,8 +2733,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         }
         const char *uq2_env = getenv("KMU_PMH_UQ2"); // 0: no second shape (A/B)
         if (n_long && !(uq2_env && atoi(uq2_env) == 0)) { // the second shape: reads of up to 20 480 k-mers, from the first one's list
-            const auto kb = uq_tab ? k_multiset_uq<1024, 17, 4096, 4, true> : k_multiset_uq<1024, 17, 4096, 4, false>;
-            const size_t lds_b = uq_tab ? UqShape<1024, 17, 4096, true>::LDS : UqShape<1024, 17, 4096, false>::LDS;
+            const auto kb = uq_tab ? k_multiset_uq<1024, KMU_UQ2_BM, KMU_UQ2_COLL, 4, true> : k_multiset_uq<1024, KMU_UQ2_BM, KMU_UQ2_COLL, 4, false>;
+            const size_t lds_b = uq_tab ? UqShape<1024, KMU_UQ2_BM, KMU_UQ2_COLL, true>::LDS : UqShape<1024, KMU_UQ2_BM, KMU_UQ2_COLL, false>::LDS;
             void *rl2;
             KMU_TRY(dev_buf(ctx, "pmh.redo2", (size_t) ds.n_seq * 4 + 64, &rl2));
             KMU_HIP(ctx, hipFuncSetAttribute((const void *) kb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
