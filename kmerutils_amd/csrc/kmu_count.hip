@@ -737,11 +737,36 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t item, int region_bits, int
 #ifndef KMU_LEAF6_WIDE // (diagnostic builds: 1 = the second plane of 6-byte leaf items holds 32-bit words)
 #define KMU_LEAF6_WIDE 0
 #endif
-#if KMU_LEAF6_WIDE
-typedef uint32_t leaf_hi_t;
-#else
-typedef uint16_t leaf_hi_t;
+// Where the two parts of 6-byte item i of the leaf array live.  KMU_LEAF6_BLOCK = 1: in blocks of eight items, 48 bytes = eight
+// u32 low words then eight u16 high parts, so that the two stores of an item (and of its neighbours in a run) land next to each
+// other; 0: two planes, all low words then all high parts (leaf capacities are multiples of 16 items: a block never straddles leaves).
+#ifndef KMU_LEAF6_BLOCK
+#define KMU_LEAF6_BLOCK 1
 #endif
+__device__ __forceinline__ void leaf6_store(uint64_t *out, uint64_t n_total, uint64_t at, uint64_t v) {
+#if KMU_LEAF6_BLOCK && !KMU_LEAF6_WIDE
+    uint8_t *b = reinterpret_cast<uint8_t *>(out) + (at >> 3) * 48u;
+    reinterpret_cast<uint32_t *>(b)[at & 7u] = (uint32_t) v;
+    reinterpret_cast<uint16_t *>(b + 32)[at & 7u] = (uint16_t) (v >> 32);
+#else
+    reinterpret_cast<uint32_t *>(out)[at] = (uint32_t) v;
+#if KMU_LEAF6_WIDE
+    (reinterpret_cast<uint32_t *>(out) + n_total)[at] = (uint32_t) (v >> 32);
+#else
+    reinterpret_cast<uint16_t *>(reinterpret_cast<uint32_t *>(out) + n_total)[at] = (uint16_t) (v >> 32);
+#endif
+#endif
+}
+__device__ __forceinline__ uint64_t leaf6_load(const uint64_t *items, uint64_t n_total, uint64_t at) {
+#if KMU_LEAF6_BLOCK && !KMU_LEAF6_WIDE
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(items) + (at >> 3) * 48u;
+    return ((uint64_t) reinterpret_cast<const uint16_t *>(b + 32)[at & 7u] << 32) | reinterpret_cast<const uint32_t *>(b)[at & 7u];
+#elif KMU_LEAF6_WIDE
+    return ((uint64_t) (reinterpret_cast<const uint32_t *>(items) + n_total)[at] << 32) | reinterpret_cast<const uint32_t *>(items)[at];
+#else
+    return ((uint64_t) reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint32_t *>(items) + n_total)[at] << 32) | reinterpret_cast<const uint32_t *>(items)[at];
+#endif
+}
 struct SegOut {
     uint64_t bin_base, bincap, end_rel, cap;
     uint32_t *ovf;
@@ -986,11 +1011,8 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
 #if KMU_SCATTER_NT // (A/B builds: non-temporal stores for the partition streams)
                 if (rel[u] < cap) __builtin_nontemporal_store(v[u], &out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])]);
 #else
-                if (LEAF6 && rel[u] < cap) {
-                    const uint64_t at = (uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u]);
-                    reinterpret_cast<uint32_t *>(out)[at] = (uint32_t) v[u];
-                    reinterpret_cast<leaf_hi_t *>(reinterpret_cast<uint32_t *>(out) + sg.n_total)[at] = (leaf_hi_t) (v[u] >> 32);
-                } else if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
+                if (LEAF6 && rel[u] < cap) leaf6_store(out, sg.n_total, (uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u]), v[u]);
+                else if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
 #endif
                 else seg_spill(sg.ovf, v[u]);
             }
@@ -1661,9 +1683,8 @@ __global__ void __launch_bounds__(THREADS) k_part_build_q(const uint64_t *__rest
                                                           uint32_t n_regions, CountTable t, int in_mode, int flags, uint32_t *err,
                                                           uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt, int contig) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t *__restrict__ it32 = reinterpret_cast<const uint32_t *>(items);
-    const leaf_hi_t *__restrict__ it16 = reinterpret_cast<const leaf_hi_t *>(it32 + (uint64_t) n_regions * leaf_stride);
-    auto item_at = [&](uint64_t i) -> uint64_t { return LEAF6 ? ((uint64_t) it16[i] << 32) | it32[i] : items[i]; };
+    const uint64_t n_total6 = (uint64_t) n_regions * leaf_stride;
+    auto item_at = [&](uint64_t i) -> uint64_t { return LEAF6 ? leaf6_load(items, n_total6, i) : items[i]; };
     constexpr int BUILD_THREADS = THREADS; // (shadows the wide kernel's constant inside this function)
     const int out_compact = flags;
     const uint32_t R = t.rmask + 1;
