@@ -84,9 +84,10 @@ def workload_cfg(args):
                    sig=A.SIG_F64, fhash=A.FHASH_VALUE_MASKED, count=False, seed=0xC5, protein=True, strong_total_reads=5_000_000)
     if args.genome:
         cfg["genome"] = args.genome
-    if args.reads:
+    if args.reads:  # (with --scaling strong: the JOB's reads, in place of BASELINE's total)
         cfg["total_bases"] = cfg["total_bases"] * args.reads / cfg["n_reads"]
         cfg["n_reads"] = args.reads
+        cfg.pop("strong_total_reads", None)
     if args.bases:
         cfg["total_bases"] = args.bases
     if args.sketch_size:
