@@ -27,21 +27,51 @@ __device__ __forceinline__ bool is_acgt(uint32_t c) {
     return (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
 }
 // 16 ASCII bytes -> one packed word, first base in bits 31..30 (the MSB-first order of Sequence::new,
-// src/base/sequence.rs:48-73, widened from a byte to a 32-bit word); `bad` gets one bit per invalid byte
+// src/base/sequence.rs:48-73, widened from a byte to a 32-bit word); `bad` gets one bit per invalid byte.
+// Four bytes at a time (the byte-by-byte form -- code2b / is_acgt above -- cost 11 instructions per base, a tenth of the level-1
+// kernel of the count and of the multiset kernels of the sketch; scripts/micro/swar_pack_check.c compares the two forms
+// over every byte value in every position):
+// codes: x ^ (x >> 1) in every byte, then one multiplication moves the four 2-bit fields (bits 0, 8, 16, 24) to bits 30, 28, 26, 24.
+__device__ __forceinline__ uint32_t codes4_ascii(uint32_t c) {
+    uint32_t x = (c >> 1) & 0x03030303u;
+    x ^= (x >> 1) & 0x01010101u;
+    return (x * 0x40100401u) >> 24; // 1 + 2^10 + 2^20 + 2^30: no two partial products share a bit
+}
+// validity: with u = c & 0xDF, bits 1 and 2 of a byte select the one letter of ACGT that has them (A 00, C 01, G 11, T 10:
+// 0x40 | the two bits | 0x10 and not 0x01 for T); the byte is valid iff it IS that letter.  A zero byte of the result = valid.
+__device__ __forceinline__ uint32_t diff4_ascii(uint32_t c) {
+    const uint32_t u = c & 0xDFDFDFDFu;
+    const uint32_t t = (u >> 2) & ~(u >> 1) & 0x01010101u; // T
+    const uint32_t e = 0x40404040u | (u & 0x06060606u) | (t << 4) | (t ^ 0x01010101u);
+    return u ^ e;
+}
+// the non-zero bytes of d as four bits (byte 0 -> bit 0)
+__device__ __forceinline__ uint32_t nonzero4(uint32_t d) {
+    const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+    return (((nz >> 7) * 0x01020408u) >> 24) & 0xFu; // 2^3 + 2^10 + 2^17 + 2^24
+}
+#ifndef KMU_PACK_SWAR // (A/B builds: 0 = byte by byte)
+#define KMU_PACK_SWAR 1
+#endif
 __device__ __forceinline__ uint32_t pack16_ascii(uint4 v, uint32_t &bad) {
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t out = 0;
+#if !KMU_PACK_SWAR
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o = 0;
     bad = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            uint32_t c = (w[i] >> (8 * j)) & 0xFFu;
-            int idx = 4 * i + j;
-            out |= code2b(c) << (30 - 2 * idx);
-            bad |= (is_acgt(c) ? 0u : 1u) << idx;
+            const uint32_t c = (w[i] >> (8 * j)) & 0xFFu;
+            o |= code2b(c) << (30 - 2 * (4 * i + j));
+            bad |= (is_acgt(c) ? 0u : 1u) << (4 * i + j);
         }
-    }
+    return o;
+#endif
+    const uint32_t out = (codes4_ascii(v.x) << 24) | (codes4_ascii(v.y) << 16) | (codes4_ascii(v.z) << 8) | codes4_ascii(v.w);
+    const uint32_t d0 = diff4_ascii(v.x), d1 = diff4_ascii(v.y), d2 = diff4_ascii(v.z), d3 = diff4_ascii(v.w);
+    bad = 0;
+    if (d0 | d1 | d2 | d3) bad = nonzero4(d0) | (nonzero4(d1) << 4) | (nonzero4(d2) << 8) | (nonzero4(d3) << 12);
     return out;
 }
 // amino acids (src/aautils/kmeraa.rs:85-109): 5-bit codes, upper case only, Q = 15, no 14; 0 = invalid
