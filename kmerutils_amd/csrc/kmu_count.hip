@@ -1137,41 +1137,6 @@ __device__ __forceinline__ void flat_step_words(const uint8_t *bases, uint64_t t
     bad_acc |= bad; // (every word is some step's own word: the halo words need no second look)
 }
 
-// A lane's window of a wave step: 48 bases b0 .. b47 (w0, w1, w2; the first base in the top bits) and its reverse complement
-// R = comp(b47) .. comp(b0), taken once per lane (three 16-base words) instead of once per k-mer: k-mer j is bits of the window
-// from base j on, its reverse complement (kmer64bit.rs:83-96) the 2 k bits of R that end 2 j bits above R's bottom.
-struct StepWin {
-    uint64_t hi, rlo, kmask;
-    uint32_t w2, rhi;
-    int sh;
-};
-__device__ __forceinline__ uint32_t revcomp16(uint32_t w) {
-    const uint32_t r = __brev(~w);
-    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
-}
-__device__ __forceinline__ StepWin step_win(uint32_t w0, uint32_t w1, uint32_t w2, int k) {
-    StepWin s;
-    s.hi = ((uint64_t) w0 << 32) | w1;
-    s.w2 = w2;
-    s.rlo = ((uint64_t) revcomp16(w1) << 32) | revcomp16(w0);
-    s.rhi = revcomp16(w2);
-    s.sh = 64 - 2 * k;
-    s.kmask = ~0ull >> (64 - 2 * k);
-    return s;
-}
-#ifndef KMU_STEP_ROLLRC // (A/B builds: 0 = the reverse complement of every k-mer from its value)
-#define KMU_STEP_ROLLRC 1
-#endif
-__device__ __forceinline__ uint64_t step_canonical(const StepWin &s, int j) { // j: 0 .. 15, a constant after unrolling
-    const uint64_t val = ((s.hi << (2 * j)) | (((uint64_t) s.w2 << (2 * j)) >> 32)) >> s.sh;
-#if !KMU_STEP_ROLLRC
-    const uint64_t rc0 = revcomp_val(val, 32 - s.sh / 2);
-    return rc0 < val ? rc0 : val;
-#endif
-    const uint64_t rc = (j ? (s.rlo >> (2 * j)) | ((uint64_t) s.rhi << (64 - 2 * j)) : s.rlo) & s.kmask;
-    return rc < val ? rc : val;
-}
-
 // up to 16 canonical k-mers of this lane for wave step `st` (CKEY_EMPTY where a k-mer would straddle a read end)
 template <bool TAB = false>
 __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_t n_seq, uint64_t total, uint64_t start, int k,

@@ -93,6 +93,47 @@ __device__ __forceinline__ uint64_t revcomp_val(uint64_t val, int k) {
     return rc >> (64 - 2 * k);
 }
 
+// A window of 48 bases b0 .. b47 (three code words; the first base in the top bits) and its reverse complement
+// R = comp(b47) .. comp(b0), taken once per window (three 16-base words) instead of once per k-mer: the k-mer that starts at base j
+// is bits of the window from base j on, its reverse complement (kmer64bit.rs:83-96) the 2 k bits of R that end 2 j bits above
+// R's bottom.  (Level 1 of the count: a lane's window of a wave step; k_multiset_uq: a thread's run of positions.)
+struct StepWin {
+    uint64_t hi, rlo, kmask;
+    uint32_t w2, rhi;
+    int sh;
+};
+__device__ __forceinline__ uint32_t revcomp16(uint32_t w) {
+    const uint32_t r = __brev(~w);
+    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+__device__ __forceinline__ StepWin step_win(uint32_t w0, uint32_t w1, uint32_t w2, int k) {
+    StepWin s;
+    s.hi = ((uint64_t) w0 << 32) | w1;
+    s.w2 = w2;
+    s.rlo = ((uint64_t) revcomp16(w1) << 32) | revcomp16(w0);
+    s.rhi = revcomp16(w2);
+    s.sh = 64 - 2 * k;
+    s.kmask = ~0ull >> (64 - 2 * k);
+    return s;
+}
+#ifndef KMU_STEP_ROLLRC // (A/B builds: 0 = the reverse complement of every k-mer from its value)
+#define KMU_STEP_ROLLRC 1
+#endif
+// the k-mer at base j of the window (0 .. 15; a constant after unrolling, or a lane's own offset) and its reverse complement
+__device__ __forceinline__ void step_val_rc(const StepWin &s, uint32_t j, uint64_t &val, uint64_t &rc) {
+    val = ((s.hi << (2 * j)) | (((uint64_t) s.w2 << (2 * j)) >> 32)) >> s.sh;
+#if !KMU_STEP_ROLLRC
+    rc = revcomp_val(val, 32 - s.sh / 2);
+    return;
+#endif
+    rc = (j ? (s.rlo >> (2 * j)) | ((uint64_t) s.rhi << (64 - 2 * j)) : s.rlo) & s.kmask;
+}
+__device__ __forceinline__ uint64_t step_canonical(const StepWin &s, uint32_t j) {
+    uint64_t val, rc;
+    step_val_rc(s, j, val, rc);
+    return rc < val ? rc : val;
+}
+
 // probminhash::invhash (Thomas Wang hash32shift / hash64shift)
 __device__ __forceinline__ uint32_t int32_hash(uint32_t key) {
     key = ~key + (key << 15);

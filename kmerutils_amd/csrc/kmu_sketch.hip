@@ -1241,6 +1241,9 @@ static constexpr int UQ_KREG = 20;
 // collision group of an ONT read is a false positive of the bitmap: 9 % of the keys at 2^16 bits, 4.5 % at 2^17), collected-key
 // arrays half as large to pay for them in LDS: the sketch unit 50.3 -> 49.6 ms, same rows (A/B builds: -DKMU_UQ1_BM=16
 // -DKMU_UQ1_COLL=2048 -DKMU_UQ2_BM=17 -DKMU_UQ2_COLL=4096 is round 3's form).
+#ifndef KMU_UQ_BMIX // (A/B builds: 0 = round 3's bitmap index)
+#define KMU_UQ_BMIX 1
+#endif
 #ifndef KMU_UQ1_BM
 #define KMU_UQ1_BM 17
 #define KMU_UQ1_COLL 1024
@@ -1332,10 +1335,18 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     SeqView sv;
     sv.base = a.bases; sv.packed = 0; sv.total = total; sv.begin = 0; sv.len = 0;
     if (r < a.n_queue) { sv.begin = uniform_u64(a.offsets[rs]); sv.len = uniform_u64(a.offsets[rs + 1]) - sv.begin; }
+    // A thread's register slots stand for positions in the frame of the staged words (place = position + the place of the read's
+    // first base in its first word, seq_lead): slots 4 i .. 4 i + 3 = the four places of quarter (tid + UQ_THREADS x i) of the
+    // words.  The four k-mers of a quarter come out of ONE window of three words, their reverse complements out of the window's
+    // reverse complement (StepWin: 12 instead of 26 instructions per k-mer for extraction and reverse complement, 0.75 instead
+    // of 3 LDS reads; round 4 -- before, slot q was position q x UQ_THREADS + tid.  Whole words per thread -- constant shifts,
+    // 7 instructions -- leave a quarter of the threads of a typical read without a k-mer: 13.3 against 11.7 ms per launch).
     auto fits = [&](const SeqView &v) -> bool { // a read this shape takes
         const uint32_t Lv = v.len >= 0x80000000ull ? 0xFFFFFFFFu : (uint32_t) v.len;
-        return Lv >= (uint32_t) k && Lv - (uint32_t) k + 1u <= UQ_KEYS;
+        return Lv >= (uint32_t) k && Lv - (uint32_t) k + 1u + seq_lead(v) <= UQ_KEYS;
     };
+    static_assert(UQ_KREG % 4 == 0 && UQ_THREADS % 4 == 0, "quarters of words");
+    auto place_of = [&](int q) -> uint32_t { return 4u * ((uint32_t) tid + (uint32_t) UQ_THREADS * (uint32_t) (q >> 2)) + (uint32_t) (q & 3); };
     // the read after the current one: header known from the start of the current read's turn
     uint32_t r_next = uniform_u32(misc[5]);
     uint32_t rs_next = r_next < a.n_queue ? uniform_u32(seq_of(r_next)) : 0u;
@@ -1367,7 +1378,7 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         }
         const uint32_t L = sv.len >= 0x80000000ull ? 0xFFFFFFFFu : (uint32_t) sv.len;
         const uint32_t nk = L >= (uint32_t) k ? L - (uint32_t) k + 1u : 0u;
-        const bool mine = nk >= 1u && nk <= UQ_KEYS; // else: no k-mer at all (row of zeros), or the general kernel's
+        const bool mine = nk >= 1u && nk + seq_lead(sv) <= UQ_KEYS; // else: no k-mer at all (row of zeros), or the general kernel's
         uint32_t bad = 0;
         if (L == 0 && tid == 0) atomicOr(a.err, DERR_EMPTY_SEQ);
         if (nk == 0) bad |= wave_validate_seq(sv, wave, UQ_THREADS / 64, false);
@@ -1417,28 +1428,33 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         uint64_t rk[UQ_KREG];
         // the bitmap index of a key is a function of the key: computed again where the B bit is looked at instead of kept in
         // twenty registers (the kernel sits at its 128: 33 spilled vector registers with the indices kept)
+        // (one multiplication of the folded key, by another constant than mix32's: the keys that share a bit of the bitmap must not
+        //  share a bucket of the collision groups' sort; round 3's form ran the key through mix32 first: 8 instructions, twice per key)
         auto bm_index = [&](uint64_t key) -> uint32_t {
+#if KMU_UQ_BMIX == 0
             const uint32_t h = mix32(key);
             return ((h ^ (h >> 13)) * 0x85EBCA6Bu) >> (32 - UQ_BM_BITS);
+#endif
+            return (((uint32_t) key ^ (uint32_t) (key >> 32)) * 0x85EBCA6Bu) >> (32 - UQ_BM_BITS);
         };
         bool over = false; // uniform: too many keys in collision groups
         if (mine) {
             // ---- keys: extract, closure, bitmaps; four positions' LDS round trips in flight at a time ----
+            const uint32_t l0 = lead - 16u * wfirst; // place of the read's first base
 #pragma unroll
             for (int q0 = 0; q0 < UQ_KREG; q0 += 4) {
                 uint32_t bit[4], rbi[UQ_KREG];
+                const uint32_t wi = ((uint32_t) tid >> 2) + (uint32_t) (UQ_THREADS / 4) * (uint32_t) (q0 >> 2); // the quarter's word
+                const StepWin sw = step_win(words[wi], words[wi + 1], words[wi + 2], k);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int q = q0 + u;
-                    const uint32_t p = (uint32_t) q * UQ_THREADS + tid;
                     rbi[q] = 0xFFFFFFFFu;
                     rk[q] = 0;
-                    if (p < nk) {
-                        const uint32_t qq = p + lead - 16u * wfirst, idx = qq >> 4, sh = (qq & 15u) * 2u;
-                        const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
-                        const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
-                        const uint64_t val = v >> (64 - 2 * k);
-                        const uint64_t key = apply_fhash(cfg, val, revcomp_val(val, k));
+                    if (place_of(q) - l0 < nk) {
+                        uint64_t val, rc;
+                        step_val_rc(sw, 4u * ((uint32_t) tid & 3u) + (uint32_t) u, val, rc);
+                        const uint64_t key = apply_fhash(cfg, val, rc);
                         rk[q] = key;
                         rbi[q] = bm_index(key);
                     }
@@ -1490,7 +1506,7 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int q = q0 + u;
-                    const bool have = (uint32_t) q * UQ_THREADS + tid < nk;
+                    const bool have = place_of(q) - (lead - 16u * wfirst) < nk;
                     rbi[q] = bm_index(rk[q]);
                     co[u] = have && (bmB[rbi[q] >> 5] & (1u << (rbi[q] & 31u))) != 0u;
                     uq[u] = have && !co[u];
