@@ -861,6 +861,12 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
 // (mod 2^32), so that an item at tile position p goes to slot grel[bin] + p of its segment.  The rank counters are a
 // separate array that the owner zeroes while it scans them, so the ranks of the next tile are taken by the waves that are
 // through with this tile's write-out while the others still store (no barrier behind the write-out).
+#ifndef KMU_TILE_ALLV // (A/B builds: 0 = every item under its own branch)
+#define KMU_TILE_ALLV 1
+#endif
+#ifndef KMU_TILE_ALLV_N
+#define KMU_TILE_ALLV_N 4
+#endif
 struct SegLds {
     uint64_t *stage;  // TILE_ITEMS
     uint32_t *cnt;    // nbins + 1 (+ 1 pad): ranks handed out in this tile; [nbins]: the "no k-mer" marks
@@ -921,7 +927,7 @@ __device__ __forceinline__ void seg_spill(uint32_t *ovf, uint64_t item) {
 // LEAF6: what leaves is bits 47..0 of an item, in two planes (SegOut::n_total): the region build needs the 64 - w hash bits
 // below the region index and knows the rest from where it reads (tables of >= 2^28 slots: w >= 16); 26 instead of 35 GB written
 // by level 2 and read by the build at the bench size.
-template <bool VMWAIT, bool CUR = false, int THREADS = SCATTER_THREADS, bool LEAF6 = false>
+template <bool VMWAIT, bool CUR = false, int THREADS = SCATTER_THREADS, bool LEAF6 = false, bool ALLV = false>
 __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLds &l, uint32_t nbins, int region_bits, int shift,
                                                  uint64_t *out, const SegOut &sg, uint32_t (&run)[2], SegClk &clk,
                                                  uint32_t *cursor = nullptr) {
@@ -932,9 +938,30 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
     uint32_t rk[8]; // ranks (< 16384), two to a register
 #pragma unroll
     for (int j = 0; j < 8; j++) rk[j] = 0;
+    // A wave whose sixteen items per lane are all k-mers (nearly every wave of long reads and of the inner levels) takes its ranks
+    // and stages its items without the per-item branches: the LDS requests of a lane leave back to back and are waited for once,
+    // not one `s_waitcnt` per item inside sixteen EXEC regions.
+    bool allv_lane = true;
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (it[j] != CKEY_EMPTY) rk[j >> 1] |= atomicAdd(&l.cnt[bin_of(it[j])], 1u) << (16 * (j & 1));
+    for (int j = 0; j < 16; j++) allv_lane = allv_lane && it[j] != CKEY_EMPTY;
+    // (ALLV: the callers whose registers have the room -- level 1 from the bases spills 25 with it and takes 18.7 instead of 12.4 ms;
+    //  the array levels: 17.1 -> 16.7 ms on the bench's level 2)
+    const bool allv = ALLV && KMU_TILE_ALLV && __all(allv_lane);
+    if (allv) {
+        constexpr int G = KMU_TILE_ALLV_N; // ranks in flight per lane (8: level 1 spills 25 registers)
+#pragma unroll
+        for (int h = 0; h < 16 / G; h++) {
+            uint32_t r[G];
+#pragma unroll
+            for (int j = 0; j < G; j++) r[j] = atomicAdd(&l.cnt[bin_of(it[G * h + j])], 1u);
+#pragma unroll
+            for (int j = 0; j < G / 2; j++) rk[G / 2 * h + j] = r[2 * j] | (r[2 * j + 1] << 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (it[j] != CKEY_EMPTY) rk[j >> 1] |= atomicAdd(&l.cnt[bin_of(it[j])], 1u) << (16 * (j & 1));
+    }
     lds_barrier(); // (also: every wave is through with the last tile's write-out: stage / lstart / grel are free)
     clk.mark(1);
     const uint32_t b0 = 2u * tid;
@@ -978,9 +1005,21 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
     }
     lds_barrier();
     clk.mark(2);
+    if (allv) {
+        constexpr int G = KMU_TILE_ALLV_N;
 #pragma unroll
-    for (int j = 0; j < 16; j++)
-        if (it[j] != CKEY_EMPTY) l.stage[l.lstart[bin_of(it[j])] + ((rk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu)] = it[j];
+        for (int h = 0; h < 16 / G; h++) {
+            uint32_t at[G];
+#pragma unroll
+            for (int j = 0; j < G; j++) at[j] = l.lstart[bin_of(it[G * h + j])];
+#pragma unroll
+            for (int j = 0; j < G; j++) l.stage[at[j] + ((rk[(G * h + j) >> 1] >> (16 * (j & 1))) & 0xFFFFu)] = it[G * h + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (it[j] != CKEY_EMPTY) l.stage[l.lstart[bin_of(it[j])] + ((rk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu)] = it[j];
+    }
     if (CUR && b0 < nbins) {
         const uint2 ls = *reinterpret_cast<const uint2 *>(&l.lstart[b0]);
         *reinterpret_cast<uint2 *>(&l.grel[b0]) = make_uint2(run[0] - ls.x, run[1] - ls.y);
@@ -1183,12 +1222,14 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
             while (g0 >= rend && r + 1 < n_seq) { r++; rend = offsets[r + 1]; } // the read of this lane's first base
         }
     }
-    const StepWin sw = step_win(w0, w1, w2, k);
+    const uint64_t hi = ((uint64_t) w0 << 32) | w1; // (this form keeps the reverse complement per k-mer: the exact levels' kernel has no registers for the window's)
+    const int sh = 64 - 2 * k;
     if (__all(!in || (g0 >= start && rend - g0 >= (uint64_t) (15 + k)))) { // every lane well inside a read: no per-k-mer boundary tests
         if (in) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                it[j] = step_canonical(sw, j);
+                const uint64_t val = ((hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32)) >> sh, rc = revcomp_val(val, k);
+                it[j] = rc < val ? rc : val;
             }
         }
     } else if (in) {
@@ -1197,7 +1238,8 @@ __device__ __forceinline__ void flat_step_items(const uint64_t *offsets, uint32_
             const uint64_t g = g0 + j;
             while (g >= rend && r + 1 < n_seq) { r++; rend = TAB ? end_of(r) : offsets[r + 1]; }
             if (g >= start && g + k <= rend) {
-                it[j] = step_canonical(sw, j);
+                const uint64_t val = ((hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32)) >> sh, rc = revcomp_val(val, k);
+                it[j] = rc < val ? rc : val;
             }
         }
     }
@@ -1557,7 +1599,7 @@ __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, con
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
         }
-        if (SEGM) tile_scatter_seg<PADDED, SHARED, THREADS, LEAF6>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
+        if (SEGM) tile_scatter_seg<PADDED, SHARED, THREADS, LEAF6, true>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
         else tile_scatter<IT == IT_KEY_TO_HASH ? IT_HASH : IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
     if (SEGM) {
@@ -1590,7 +1632,6 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_smer_scatter1(const uint32_
     for (uint32_t b = threadIdx.x; b <= pl.bins; b += blockDim.x) ls.cnt[b] = 0;
     lds_barrier();
     const uint64_t i0 = n_rec * blockIdx.x / pl.chunks, i1 = n_rec * (blockIdx.x + 1) / pl.chunks;
-    const int sh = 64 - 2 * k;
     uint32_t nx0 = 0, nx1 = 0, nx2 = 0;
     bool nxv = false;
     auto fetch = [&](uint64_t i) {
@@ -1603,13 +1644,10 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_smer_scatter1(const uint32_
         const uint32_t w0 = nx0, w1 = nx1, w2 = nx2, L = nxv ? (nx2 & 15u) + 1u : 0u;
         fetch(t0 + SCATTER_THREADS + threadIdx.x); // the next tile's record arrives under this tile's sort
         uint64_t it[16];
-        const uint64_t hi = ((uint64_t) w0 << 32) | w1;
+        const StepWin sw = step_win(w0, w1, w2 & ~15u, k); // (the low four bits of a record's last word: its k-mer count)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint64_t v = ((hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32)) >> sh;
-            const uint64_t rc = revcomp_val(v, k);
-            it[j] = (uint32_t) j < L ? khash(rc < v ? rc : v) : CKEY_EMPTY; // kmer.reverse_complement().min(kmer), kmercount.rs:938
-        }
+        for (int j = 0; j < 16; j++)
+            it[j] = (uint32_t) j < L ? khash(step_canonical(sw, j)) : CKEY_EMPTY; // kmer.reverse_complement().min(kmer), kmercount.rs:938
         tile_scatter_seg<false, SHARED>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
     }
     if (!SHARED) seg_finish_unit(ls, pl.bins, sg, run, out, true, nullptr);
