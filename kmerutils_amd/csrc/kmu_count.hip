@@ -864,6 +864,9 @@ __device__ __forceinline__ void tile_scatter(uint64_t (&it)[16], const ScatterLd
 #ifndef KMU_TILE_ALLV // (A/B builds: 0 = every item under its own branch)
 #define KMU_TILE_ALLV 1
 #endif
+#ifndef KMU_L1_ALLV // level 1 from the bases: which phases take the branch-free form (0: none)
+#define KMU_L1_ALLV 0
+#endif
 #ifndef KMU_TILE_ALLV_N
 #define KMU_TILE_ALLV_N 4
 #endif
@@ -927,7 +930,7 @@ __device__ __forceinline__ void seg_spill(uint32_t *ovf, uint64_t item) {
 // LEAF6: what leaves is bits 47..0 of an item, in two planes (SegOut::n_total): the region build needs the 64 - w hash bits
 // below the region index and knows the rest from where it reads (tables of >= 2^28 slots: w >= 16); 26 instead of 35 GB written
 // by level 2 and read by the build at the bench size.
-template <bool VMWAIT, bool CUR = false, int THREADS = SCATTER_THREADS, bool LEAF6 = false, bool ALLV = false>
+template <bool VMWAIT, bool CUR = false, int THREADS = SCATTER_THREADS, bool LEAF6 = false, int ALLV = 0>
 __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLds &l, uint32_t nbins, int region_bits, int shift,
                                                  uint64_t *out, const SegOut &sg, uint32_t (&run)[2], SegClk &clk,
                                                  uint32_t *cursor = nullptr) {
@@ -946,8 +949,8 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
     for (int j = 0; j < 16; j++) allv_lane = allv_lane && it[j] != CKEY_EMPTY;
     // (ALLV: the callers whose registers have the room -- level 1 from the bases spills 25 with it and takes 18.7 instead of 12.4 ms;
     //  the array levels: 17.1 -> 16.7 ms on the bench's level 2)
-    const bool allv = ALLV && KMU_TILE_ALLV && __all(allv_lane);
-    if (allv) {
+    const bool allv = ALLV && KMU_TILE_ALLV && __all(allv_lane); // ALLV: bit 0 = the ranks, bit 1 = the staging
+    if ((ALLV & 1) && allv) {
         constexpr int G = KMU_TILE_ALLV_N; // ranks in flight per lane (8: level 1 spills 25 registers)
 #pragma unroll
         for (int h = 0; h < 16 / G; h++) {
@@ -1005,7 +1008,7 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
     }
     lds_barrier();
     clk.mark(2);
-    if (allv) {
+    if ((ALLV & 2) && allv) {
         constexpr int G = KMU_TILE_ALLV_N;
 #pragma unroll
         for (int h = 0; h < 16 / G; h++) {
@@ -1362,7 +1365,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
         else { // from here on the k-mers travel as their table hash
 #pragma unroll
             for (int j = 0; j < 16; j++) it[j] = khash(it[j]); // (khash keeps the "no k-mer" mark)
-            if (SEGM) tile_scatter_seg<true, SHARED>(it, ls, bins1, pl.region_bits, pl.b2, out, sg, run, clk, cursor);
+            if (SEGM) tile_scatter_seg<true, SHARED, SCATTER_THREADS, false, KMU_L1_ALLV>(it, ls, bins1, pl.region_bits, pl.b2, out, sg, run, clk, cursor);
             else tile_scatter<IT_HASH>(it, l, bins1, pl.region_bits, pl.b2, bins1 - 1, out);
         }
     }
@@ -1599,7 +1602,7 @@ __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, con
             for (int j = 0; j < 16; j++)
                 if (it[j] != CKEY_EMPTY) it[j] = khash(it[j]);
         }
-        if (SEGM) tile_scatter_seg<PADDED, SHARED, THREADS, LEAF6, true>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
+        if (SEGM) tile_scatter_seg<PADDED, SHARED, THREADS, LEAF6, 3>(it, ls, pl.bins, pl.region_bits, pl.shift, out, sg, run, clk, cursor);
         else tile_scatter<IT == IT_KEY_TO_HASH ? IT_HASH : IT>(it, l, pl.bins, pl.region_bits, pl.shift, pl.bins - 1, out);
     }
     if (SEGM) {

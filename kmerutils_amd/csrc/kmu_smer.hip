@@ -49,9 +49,15 @@ __device__ __forceinline__ void smer_minwin(uint32_t w0, uint32_t w1, int m, uin
     const uint64_t hi = ((uint64_t) w0 << 32) | w1;
     const uint32_t mask = (1u << (2 * m)) - 1u;
     const int sh0 = 64 - 2 * m;
+    // (smer_hash of every m-mer, with the reverse complements taken out of the reverse complement of the two words: the m-mer at
+    //  offset i ends 2 i bits above its bottom -- StepWin's form, kmu_device.h)
+    const uint64_t R = ((uint64_t) revcomp16(w1) << 32) | revcomp16(w0);
     uint32_t h[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) h[i] = smer_hash((uint32_t) (hi >> (sh0 - 2 * i)) & mask, m);
+    for (int i = 0; i < 16; i++) {
+        const uint32_t f = (uint32_t) (hi >> (sh0 - 2 * i)) & mask, r = (uint32_t) (R >> (2 * i)) & mask;
+        h[i] = smer_mix(r < f ? r : f);
+    }
     uint32_t P[16], S[16]; // prefix / suffix minima of the own word
     P[0] = h[0];
 #pragma unroll
