@@ -274,3 +274,43 @@ def test_kmer_hashes_tail_positions_by_memory_kind(ctx, oracle):
     ctx.synchronize()
     got = dev.cpu().numpy().view(np.uint64)
     assert np.array_equal(got[starts], want[:n][starts]) and (got[~starts] == sentinel).all()
+
+
+def test_every_byte_value_at_every_place_of_a_chunk(ctx, oracle, monkeypatch):
+    """The kernels turn 16 ASCII bytes into a code word four bytes at a time (pack16_ascii, kmu_device.h): every byte value in
+    each of the sixteen places of a chunk must give what the byte-wise rule of alphabet.rs:119-127 gives -- the code of
+    ACGTacgt (the oracle's hashes), the reference's panic (KMU_E_NON_ACGT) for the 248 other values."""
+    from kmerutils_amd.lib import KmuError
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACGTacgt", np.uint8)
+    base = letters[rng.integers(0, 8, 96)].copy()
+    off = np.array([0, 96], np.uint64)
+    valid = set(b"ACGTacgt")
+    refused = 0
+    for place in range(16):
+        for b in range(256):
+            seq = base.copy()
+            seq[32 + place] = b
+            if b in valid:
+                want = oracle.kmer_hashes(seq, off, A.KMER64BIT, 21, A.FHASH_CANON_INVHASH)
+                assert np.array_equal(ctx.kmer_hashes(seq, off, A.KMER64BIT, 21, A.FHASH_CANON_INVHASH), want), (place, b)
+            else:
+                with pytest.raises(KmuError) as ei:
+                    ctx.kmer_hashes(seq, off, A.KMER64BIT, 21, A.FHASH_CANON_INVHASH)
+                assert ei.value.code == A.E_NON_ACGT, (place, b)
+                refused += 1
+    assert refused == 16 * 248
+    # ... and through the count's level 1 (flat_step_words) and the sketch's staged words: one bad byte anywhere refuses the batch
+    from kmerutils_amd import lib
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    seqs = [bytes(synth.ACGT[rng.integers(0, 4, 3000)]) for _ in range(40)]
+    bases, offs = oracle.concat(seqs)
+    for pos in (0, 1, 15, 16, 17, 2999, 3000, 40 * 3000 - 1, 77777):
+        for b in (ord("N"), 0, 0x40, 0x42, 0x55, 0x61 ^ 0x80, 0xFF):
+            bad = bases.copy()
+            bad[pos] = b
+            c = lib.Counter(ctx, A.KMER64BIT, 31, capacity_hint=200000)
+            with pytest.raises(KmuError) as ei:
+                c.add_reads(bad, offs)
+            assert ei.value.code == A.E_NON_ACGT, (pos, b)
+            c.close()
