@@ -1241,6 +1241,9 @@ static constexpr int UQ_KREG = 20;
 // collision group of an ONT read is a false positive of the bitmap: 9 % of the keys at 2^16 bits, 4.5 % at 2^17), collected-key
 // arrays half as large to pay for them in LDS: the sketch unit 50.3 -> 49.6 ms, same rows (A/B builds: -DKMU_UQ1_BM=16
 // -DKMU_UQ1_COLL=2048 -DKMU_UQ2_BM=17 -DKMU_UQ2_COLL=4096 is round 3's form).
+#ifndef KMU_UQ_FASTKEY // (A/B builds: 0 = every key through apply_fhash)
+#define KMU_UQ_FASTKEY 1
+#endif
 #ifndef KMU_UQ_BMIX // (A/B builds: 0 = round 3's bitmap index)
 #define KMU_UQ_BMIX 1
 #endif
@@ -1440,38 +1443,48 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         bool over = false; // uniform: too many keys in collision groups
         if (mine) {
             // ---- keys: extract, closure, bitmaps; four positions' LDS round trips in flight at a time ----
+            // (FAST: the closure of the headline -- canonical Kmer64bit through int64_hash, datasketcher.rs:225 -- without the
+            //  per-key walk through apply_fhash's cases: the mode is the same for every key of the launch, and a chain of scalar
+            //  compares and taken branches per key costs a workgroup of four waves per SIMD more than the arithmetic it selects)
             const uint32_t l0 = lead - 16u * wfirst; // place of the read's first base
+            auto key_phase = [&](auto fast_tag) __attribute__((always_inline)) {
+                constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-            for (int q0 = 0; q0 < UQ_KREG; q0 += 4) {
-                uint32_t bit[4], rbi[UQ_KREG];
-                const uint32_t wi = ((uint32_t) tid >> 2) + (uint32_t) (UQ_THREADS / 4) * (uint32_t) (q0 >> 2); // the quarter's word
-                const StepWin sw = step_win(words[wi], words[wi + 1], words[wi + 2], k);
+                for (int q0 = 0; q0 < UQ_KREG; q0 += 4) {
+                    uint32_t bit[4], rbi[UQ_KREG];
+                    const uint32_t wi = ((uint32_t) tid >> 2) + (uint32_t) (UQ_THREADS / 4) * (uint32_t) (q0 >> 2); // the quarter's word
+                    const StepWin sw = step_win(words[wi], words[wi + 1], words[wi + 2], k);
+                    // (round 4, measured and not kept: a branch-free form for the waves whose quarters are whole -- 10.6 against 10.1 ms
+                    //  per launch, 19 instead of 15 spilled registers)
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = q0 + u;
-                    rbi[q] = 0xFFFFFFFFu;
-                    rk[q] = 0;
-                    if (place_of(q) - l0 < nk) {
-                        uint64_t val, rc;
-                        step_val_rc(sw, 4u * ((uint32_t) tid & 3u) + (uint32_t) u, val, rc);
-                        const uint64_t key = apply_fhash(cfg, val, rc);
-                        rk[q] = key;
-                        rbi[q] = bm_index(key);
+                    for (int u = 0; u < 4; u++) {
+                        const int q = q0 + u;
+                        rbi[q] = 0xFFFFFFFFu;
+                        rk[q] = 0;
+                        if (place_of(q) - l0 < nk) {
+                            uint64_t val, rc;
+                            step_val_rc(sw, 4u * ((uint32_t) tid & 3u) + (uint32_t) u, val, rc);
+                            const uint64_t key = FAST ? int64_hash(rc < val ? rc : val) : apply_fhash(cfg, val, rc);
+                            rk[q] = key;
+                            rbi[q] = bm_index(key);
+                        }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = q0 + u;
-                    bit[u] = 0;
-                    if (rbi[q] != 0xFFFFFFFFu) {
-                        const uint32_t b = 1u << (rbi[q] & 31u);
-                        bit[u] = atomicOr(&bmA[rbi[q] >> 5], b) & b;
+                    for (int u = 0; u < 4; u++) {
+                        const int q = q0 + u;
+                        bit[u] = 0;
+                        if (rbi[q] != 0xFFFFFFFFu) {
+                            const uint32_t b = 1u << (rbi[q] & 31u);
+                            bit[u] = atomicOr(&bmA[rbi[q] >> 5], b) & b;
+                        }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (bit[u]) atomicOr(&bmB[rbi[q0 + u] >> 5], bit[u]);
-            }
+                    for (int u = 0; u < 4; u++)
+                        if (bit[u]) atomicOr(&bmB[rbi[q0 + u] >> 5], bit[u]);
+                }
+            };
+            if (KMU_UQ_FASTKEY && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT) key_phase(std::true_type{});
+            else key_phase(std::false_type{});
             phase(2); // keys, closure, bitmaps
             lds_barrier();
             phase(3);
