@@ -103,6 +103,9 @@ static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions 
 static constexpr uint32_t DEF_PARTS = 32;           //   one sub-list of DEF_CAP / DEF_PARTS keys per later partition
 static constexpr uint32_t DEF_SEG = DEF_CAP / DEF_PARTS;
 #define ABL(bits) (KMU_DIAG && (a.ablate & (bits)))
+#ifndef KMU_UQ_FASTKEY // (A/B builds: 0 = every key through apply_fhash)
+#define KMU_UQ_FASTKEY 1
+#endif
 #ifndef KMU_PTS_UNITW // (A/B builds: 0 = the cheap test of k_pmh_points looks 1 / w up for every chunk)
 #define KMU_PTS_UNITW 1
 #endif
@@ -388,6 +391,8 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     }
     const KmerCfg cfg = a.cfg;
     const bool sig32 = a.sig_bytes == 4;
+    // the headline's closure (canonical Kmer64bit through int64_hash) without the walk through apply_fhash's cases per key (see k_multiset_uq)
+    const bool fast64 = KMU_UQ_FASTKEY && !AA && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t cap = a.cap;
     uint64_t *dk = reinterpret_cast<uint64_t *>(smem); // dense keys of the current pass, grouped by bucket
@@ -653,7 +658,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
                                             uint64_t key = 0;
                                             uint32_t h = 0;
                                             if (go) {
-                                                key = (AA && a.hashed_bytes) ? val : apply_fhash(cfg, val, rc);
+                                                key = (AA && a.hashed_bytes) ? val : fast64 ? int64_hash(rc < val ? rc : val) : apply_fhash(cfg, val, rc);
                                                 if (BOTTOMK) key = hasher_finish(a.hasher, key, sig32);
                                                 h = mix32(key);
                                                 if (ABL(2u)) go = false;
@@ -1241,9 +1246,6 @@ static constexpr int UQ_KREG = 20;
 // collision group of an ONT read is a false positive of the bitmap: 9 % of the keys at 2^16 bits, 4.5 % at 2^17), collected-key
 // arrays half as large to pay for them in LDS: the sketch unit 50.3 -> 49.6 ms, same rows (A/B builds: -DKMU_UQ1_BM=16
 // -DKMU_UQ1_COLL=2048 -DKMU_UQ2_BM=17 -DKMU_UQ2_COLL=4096 is round 3's form).
-#ifndef KMU_UQ_FASTKEY // (A/B builds: 0 = every key through apply_fhash)
-#define KMU_UQ_FASTKEY 1
-#endif
 #ifndef KMU_UQ_BMIX // (A/B builds: 0 = round 3's bitmap index)
 #define KMU_UQ_BMIX 1
 #endif
@@ -1727,6 +1729,7 @@ __global__ void __launch_bounds__(256) k_multiset_short(SketchArgs a) {
     uint32_t *words = tc + SHORT_SLOTS;
     const KmerCfg cfg = a.cfg;
     const int k = cfg.k;
+    const bool fast64 = KMU_UQ_FASTKEY && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT; // (see k_multiset_uq)
     for (uint32_t t = (uint32_t) lane; t < SHORT_SLOTS; t += 64u) { tk[t] = ~0ull; tc[t] = 0u; }
     const uint64_t off_first = uniform_u64(a.offsets[0]);
     const uint64_t total = a.total_bytes ? a.total_bytes : uniform_u64(a.offsets[a.n_seq]);
@@ -1778,7 +1781,8 @@ __global__ void __launch_bounds__(256) k_multiset_short(SketchArgs a) {
                 const uint64_t hi = ((uint64_t) words[idx] << 32) | words[idx + 1];
                 const uint64_t v = (hi << sh) | (((uint64_t) words[idx + 2] << sh) >> 32);
                 const uint64_t val = v >> (64 - 2 * k);
-                key = apply_fhash(cfg, val, revcomp_val(val, k));
+                const uint64_t rc = revcomp_val(val, k);
+                key = fast64 ? int64_hash(rc < val ? rc : val) : apply_fhash(cfg, val, rc);
             }
             const bool odd = have && key == ~0ull;
             n_free_key += (uint32_t) __popcll(__ballot(odd));
@@ -1994,7 +1998,13 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
         }
     };
     // the key of histogram index `idx` (a k-mer value): the closure on that k-mer
-    auto key_of = [&](uint32_t idx) -> uint64_t { return apply_fhash(cfg, (uint64_t) idx, (uint64_t) revcomp32(idx, k)); };
+    // (the README's closure -- canonical Kmer32bit through int32_hash, datasketcher.rs:225 -- without the walk through apply_fhash's cases)
+    const bool fast32 = KMU_UQ_FASTKEY && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER32BIT;
+    auto key_of = [&](uint32_t idx) -> uint64_t {
+        const uint32_t rc = revcomp32(idx, k);
+        if (fast32) return (uint64_t) int32_hash((rc < idx ? rc : idx) | ((uint32_t) k << 28));
+        return apply_fhash(cfg, (uint64_t) idx, (uint64_t) rc);
+    };
     auto view_of = [&](uint32_t q) {
         SeqView v;
         v.base = a.bases;
