@@ -18,6 +18,10 @@
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
+#ifndef KMU_SUPER_TMODE // (A/B builds: 0 = mode and index draw looked up per step)
+#define KMU_SUPER_TMODE 1
+#endif
+
 namespace kmu {
 
 struct SuperArgs {
@@ -64,8 +68,13 @@ __device__ __forceinline__ uint32_t super_floor(uint64_t bits, int mode, int m, 
     return f;
 }
 
-template <typename PT>
+// MODE (the signature type: 0 f64, 1 f32, 2 u64, 3 u32) and RAND08 (the index draw of rand 0.8) are template constants: the step
+// loop below runs ~10 times per item and looked both up in `a` on every step -- two four-way switches and a flag, i.e. chains of
+// scalar compares and taken branches around ~110 vector instructions (round 4: config 5's shard 8.4 -> see DESIGN.md 3.3).
+template <typename PT, int MODE, bool RAND08>
 __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
+#define SUPER_MODE (KMU_SUPER_TMODE ? MODE : a.mode) // (A/B builds read the arguments as before)
+#define SUPER_R08 (KMU_SUPER_TMODE ? RAND08 : a.rand08 != 0)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
@@ -79,7 +88,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
     PT *perm = reinterpret_cast<PT *>(misc + 4);                  // [m][ncol]
     constexpr uint32_t LOG_BITS = 8 * sizeof(PT), LOG_PER = 64 / LOG_BITS, LOG_STEPS = 2 * LOG_PER; // swap partners kept in registers
     const bool aa = a.cfg.kmer_type == KMU_KMERAA32BIT || a.cfg.kmer_type == KMU_KMERAA64BIT;
-    const uint64_t init_bits = super_init_bits(a.mode);
+    const uint64_t init_bits = super_init_bits(SUPER_MODE);
 
     if (tid < ncol)
         for (int e = 0; e < m; e++) perm[(size_t) e * ncol + tid] = (PT) e;
@@ -154,13 +163,13 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         double rd = 0.0;
                         float rf = 0.f;
                         uint64_t ri = 0;
-                        switch (a.mode) {
+                        switch (SUPER_MODE) {
                         case 0: rd = rng.unif01(); break;
                         case 1: rf = rng.unif01_f32(); break;
                         case 2: ri = rng.next(); break;
                         default: ri = rng.next_u32(); break;
                         }
-                        uint32_t k = rng.unif_index(j, (uint32_t) m, a.rand08 != 0);
+                        uint32_t k = rng.unif_index(j, (uint32_t) m, SUPER_R08);
                         PT pj = perm[(size_t) j * ncol + tid];
                         PT pk = perm[(size_t) k * ncol + tid];
                         perm[(size_t) j * ncol + tid] = pk;
@@ -168,7 +177,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         if (j < LOG_PER) slog0 |= (uint64_t) k << (LOG_BITS * j);
                         else if (j < LOG_STEPS) slog1 |= (uint64_t) k << (LOG_BITS * (j - LOG_PER));
                         uint64_t bits;
-                        switch (a.mode) {
+                        switch (SUPER_MODE) {
                         case 0: bits = (uint64_t) __double_as_longlong(rd + (double) j); break;
                         case 1: bits = (uint64_t) __float_as_uint(rf + (float) j); break;
                         case 2: bits = a.lg ? (((uint64_t) j << (64 - a.lg)) | (ri >> a.lg)) : ri; break;
@@ -181,7 +190,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                     if ((round & 3u) == 0u || round == 1u) { // refresh a_upper = max_s min(floor(hs[s]), m-1)
                         uint32_t mx = 0;
                         for (int s = lane_id(); s < m; s += 64) {
-                            uint32_t f = super_floor(*(volatile uint64_t *) &hs[s], a.mode, m, a.lg);
+                            uint32_t f = super_floor(*(volatile uint64_t *) &hs[s], SUPER_MODE, m, a.lg);
                             mx = f > mx ? f : mx;
                         }
                         mx = (uint32_t) wave_max_u64(mx);
@@ -199,13 +208,13 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                     Xoshiro r2;
                     r2.seed(items[b0 + tid]);
                     for (uint32_t jj = 0; jj < j; jj++) {
-                        switch (a.mode) {
+                        switch (SUPER_MODE) {
                         case 0: (void) r2.unif01(); break;
                         case 1: (void) r2.unif01_f32(); break;
                         case 2: (void) r2.next(); break;
                         default: (void) r2.next_u32(); break;
                         }
-                        const PT k = (PT) r2.unif_index(jj, (uint32_t) m, a.rand08 != 0);
+                        const PT k = (PT) r2.unif_index(jj, (uint32_t) m, SUPER_R08);
                         perm[(size_t) jj * ncol + tid] = (PT) jj;
                         perm[(size_t) k * ncol + tid] = k;
                     }
@@ -221,7 +230,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                 hs[t] = init_bits;
                 continue;
             }
-            switch (a.mode) {
+            switch (SUPER_MODE) {
             case 0: reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * m + t] = v; break;
             case 2: reinterpret_cast<uint64_t *>(a.sig_out)[(uint64_t) r * m + t] = v; break;
             default: reinterpret_cast<uint32_t *>(a.sig_out)[(uint64_t) r * m + t] = (uint32_t) v; break;
@@ -232,6 +241,8 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
         __syncthreads();
     }
 }
+#undef SUPER_MODE
+#undef SUPER_R08
 
 // element-wise minimum of the partial slot arrays (order-preserving bit patterns); one thread per slot
 // (raw_out: leave the 64-bit slot patterns there instead of a signature)
@@ -293,7 +304,18 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     const bool wide = a.m > 256;
     const size_t pt = wide ? 2 : 1;
     const size_t lds_max = 160 * 1024;
-    auto fn = wide ? (const void *) k_sketch_super<uint16_t> : (const void *) k_sketch_super<uint8_t>;
+    typedef void (*super_kernel_t)(SuperArgs);
+    super_kernel_t kern = nullptr;
+#define KMU_SUPER_PICK(PT_) \
+    switch (a.mode * 2 + a.rand08) { \
+    case 0: kern = k_sketch_super<PT_, 0, false>; break; case 1: kern = k_sketch_super<PT_, 0, true>; break; \
+    case 2: kern = k_sketch_super<PT_, 1, false>; break; case 3: kern = k_sketch_super<PT_, 1, true>; break; \
+    case 4: kern = k_sketch_super<PT_, 2, false>; break; case 5: kern = k_sketch_super<PT_, 2, true>; break; \
+    case 6: kern = k_sketch_super<PT_, 3, false>; break; default: kern = k_sketch_super<PT_, 3, true>; break; \
+    }
+    if (wide) { KMU_SUPER_PICK(uint16_t) } else { KMU_SUPER_PICK(uint8_t) }
+#undef KMU_SUPER_PICK
+    auto fn = (const void *) kern;
     // the per-lane permutation columns dominate the LDS footprint: shrink the workgroup for large m
     int threads = 64;
     if (const char *e = getenv("KMU_SUPER_THREADS")) threads = std::max(64, std::min(256, atoi(e) & ~63));
@@ -323,8 +345,7 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     if (grid < 1) grid = 1;
     {
         KernelTimer t(ctx, "k_sketch_super");
-        if (wide) hipLaunchKernelGGL(k_sketch_super<uint16_t>, dim3(grid), dim3(threads), lds, ctx->stream, a);
-        else hipLaunchKernelGGL(k_sketch_super<uint8_t>, dim3(grid), dim3(threads), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ctx->stream, a);
     }
     KMU_HIP(ctx, hipGetLastError());
     return KMU_OK;
