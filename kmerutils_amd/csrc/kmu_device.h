@@ -299,6 +299,25 @@ struct Xoshiro {
             if ((uint32_t) m >= thresh) return low + (uint32_t) (m >> 32);
         }
     }
+    // the same draw with the rejection bound of `range` taken from a table (index_bound(range, rand08)): it depends on the range alone
+    __device__ static __forceinline__ uint64_t index_bound(uint32_t range, bool rand08) {
+        if (rand08) return 0xFFFFFFFFFFFFFFFFull - (0xFFFFFFFFFFFFFFFFull - (uint64_t) range + 1ull) % (uint64_t) range; // zone
+        return (uint64_t) ((0u - range) % range);                                                                       // thresh
+    }
+    __device__ __forceinline__ uint32_t unif_index_bound(uint32_t low, uint32_t high, uint64_t bound, bool rand08) {
+        const uint32_t range = high - low;
+        if (rand08) {
+            for (;;) {
+                const uint64_t v = next();
+                const uint64_t hi = __umul64hi(v, (uint64_t) range), lo = v * (uint64_t) range;
+                if (lo <= bound) return low + (uint32_t) hi;
+            }
+        }
+        for (;;) {
+            const uint64_t m = (uint64_t) next_u32() * range;
+            if ((uint32_t) m >= (uint32_t) bound) return low + (uint32_t) (m >> 32);
+        }
+    }
 };
 
 // exp(x) - 1 on [0, ln 2]: the same fixed 22-term Horner as the oracle's expm1_small (no fused operations)

@@ -128,7 +128,7 @@ __device__ __forceinline__ double kmu_log(double x) {
 __device__ __forceinline__ void hll_refresh_klow(const DensArgs &a, const uint64_t *hs, uint32_t *klow) {
     uint64_t mn = ~0ull;
     for (int i = lane_id(); i < a.m; i += 64) {
-        const uint64_t v = *(volatile const uint64_t *) &hs[i];
+        const uint64_t v = __hip_atomic_load(&hs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (not volatile: that becomes a FLAT load)
         mn = v < mn ? v : mn;
     }
     mn = ~wave_max_u64(~mn);
@@ -154,7 +154,7 @@ __device__ __forceinline__ void hll_wave_items(const DensArgs &a, uint64_t *hs, 
             uint32_t k = 0;
             if (t >= (double) a.q + 1.0) k = a.q + 1u;
             else if (t > 0.0) k = (uint32_t) t;
-            if (k <= *(volatile const uint32_t *) klow) active = false;
+            if (k <= __hip_atomic_load(klow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) active = false;
             else {
                 const uint32_t i = dens_draw_bin(a, rng);
                 atomicMax((unsigned long long *) &hs[i], (unsigned long long) k);

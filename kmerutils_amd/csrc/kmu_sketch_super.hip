@@ -18,6 +18,12 @@
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
+#ifndef KMU_SUPER_VOL // (A/B builds: 1 = the volatile loads of rounds 1-3)
+#define KMU_SUPER_VOL 0
+#endif
+#ifndef KMU_SUPER_ZTAB // (A/B builds: 0 = the rejection bound of the index draw computed in every step)
+#define KMU_SUPER_ZTAB 1
+#endif
 #ifndef KMU_SUPER_TMODE // (A/B builds: 0 = mode and index draw looked up per step)
 #define KMU_SUPER_TMODE 1
 #endif
@@ -81,7 +87,10 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
     const int m = a.m;
     uint64_t *hs = reinterpret_cast<uint64_t *>(smem);          // m slot minima
     uint64_t *items = hs + m;                                     // a.chunk staged RNG seeds
-    uint32_t *misc = reinterpret_cast<uint32_t *>(items + a.chunk); // [0] read, [1] a_upper
+    // step j draws an index in [j, m): the rejection bound of that draw (rand's Uniform: `(0 - range) % range`, or 0.8's zone)
+    // depends on j alone -- a table, filled once, instead of an integer division (~20 instructions) in every step
+    uint64_t *ztab = items + a.chunk;                             // m bounds
+    uint32_t *misc = reinterpret_cast<uint32_t *>(ztab + m);      // [0] read, [1] a_upper
     // one permutation column + swap log per item lane; ncol = nthreads unless the sketch is so large that only some
     // lanes of a single wave get a column
     const int ncol = a.ncol;
@@ -93,6 +102,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
     if (tid < ncol)
         for (int e = 0; e < m; e++) perm[(size_t) e * ncol + tid] = (PT) e;
     for (int s = tid; s < m; s += nthreads) hs[s] = init_bits;
+    for (int s = tid; s < m; s += nthreads) ztab[s] = Xoshiro::index_bound((uint32_t) (m - s), SUPER_R08);
     if (tid == 0) misc[1] = (uint32_t) (m - 1);
     __syncthreads();
 
@@ -156,7 +166,9 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                 uint64_t slog0 = 0, slog1 = 0; // the swap partners of steps 0 .. LOG_STEPS - 1
                 bool active = have;
                 for (;;) {
-                    uint32_t a_upper = *(volatile uint32_t *) &misc[1];
+                    // (a relaxed atomic load, not a volatile one: the compiler turns a volatile access through a derived pointer into a FLAT load
+                    //  with a full vmcnt / lgkmcnt wait -- the step loop had one per step)
+                    uint32_t a_upper = KMU_SUPER_VOL ? *(volatile uint32_t *) &misc[1] : __hip_atomic_load(&misc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (active && j > a_upper) active = false;
                     if (!__any(active)) break;
                     if (active) {
@@ -169,7 +181,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         case 2: ri = rng.next(); break;
                         default: ri = rng.next_u32(); break;
                         }
-                        uint32_t k = rng.unif_index(j, (uint32_t) m, SUPER_R08);
+                        uint32_t k = KMU_SUPER_ZTAB ? rng.unif_index_bound(j, (uint32_t) m, ztab[j], SUPER_R08) : rng.unif_index(j, (uint32_t) m, SUPER_R08);
                         PT pj = perm[(size_t) j * ncol + tid];
                         PT pk = perm[(size_t) k * ncol + tid];
                         perm[(size_t) j * ncol + tid] = pk;
@@ -190,7 +202,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                     if ((round & 3u) == 0u || round == 1u) { // refresh a_upper = max_s min(floor(hs[s]), m-1)
                         uint32_t mx = 0;
                         for (int s = lane_id(); s < m; s += 64) {
-                            uint32_t f = super_floor(*(volatile uint64_t *) &hs[s], SUPER_MODE, m, a.lg);
+                            uint32_t f = super_floor(KMU_SUPER_VOL ? *(volatile uint64_t *) &hs[s] : __hip_atomic_load(&hs[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), SUPER_MODE, m, a.lg);
                             mx = f > mx ? f : mx;
                         }
                         mx = (uint32_t) wave_max_u64(mx);
@@ -214,7 +226,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         case 2: (void) r2.next(); break;
                         default: (void) r2.next_u32(); break;
                         }
-                        const PT k = (PT) r2.unif_index(jj, (uint32_t) m, SUPER_R08);
+                        const PT k = (PT) r2.unif_index_bound(jj, (uint32_t) m, ztab[jj], SUPER_R08);
                         perm[(size_t) jj * ncol + tid] = (PT) jj;
                         perm[(size_t) k * ncol + tid] = k;
                     }
@@ -322,13 +334,13 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     size_t lds = 0;
     int ncol = 0;
     for (; threads >= 64; threads -= 64) {
-        lds = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + pt * a.m * threads;
+        lds = (size_t) 16 * a.m + (size_t) 8 * a.chunk + 16 + pt * a.m * threads;
         lds = (lds + 15) & ~(size_t) 15;
         if (lds <= lds_max) { ncol = threads; break; }
     }
     if (!ncol) { // very large sketches: one wave, as many item lanes as columns fit
         threads = 64;
-        const size_t fixed = (size_t) 8 * a.m + (size_t) 8 * a.chunk + 16 + 16;
+        const size_t fixed = (size_t) 16 * a.m + (size_t) 8 * a.chunk + 16 + 16;
         if (fixed < lds_max) ncol = (int) std::min<size_t>(64, (lds_max - fixed) / (pt * (size_t) a.m));
         lds = (fixed + pt * (size_t) a.m * ncol + 15) & ~(size_t) 15;
     }

@@ -3,5 +3,5 @@
 # (libkmu_t0.so: scripts/build_variant.sh t0 "-DKMU_SUPER_TMODE=0" kmu_sketch_super)
 cd $GRAFT_REPO_ROOT
 for wl in c5_aa c1_super; do
-  AB_LIBS="h t0 h t0" AB_WORKLOAD=$wl bash scripts/r04_swar.sh | sed "s/^/$wl /"
+  AB_LIBS="${SUPER_LIBS:-h t0 h t0}" AB_WORKLOAD=$wl bash scripts/r04_swar.sh | sed "s/^/$wl /"
 done
