@@ -18,6 +18,9 @@
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
+#ifndef KMU_SUPER_IDX32
+#define KMU_SUPER_IDX32 0
+#endif
 #ifndef KMU_SUPER_VOL // (A/B builds: 1 = the volatile loads of rounds 1-3)
 #define KMU_SUPER_VOL 0
 #endif
@@ -182,10 +185,15 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         default: ri = rng.next_u32(); break;
                         }
                         uint32_t k = KMU_SUPER_ZTAB ? rng.unif_index_bound(j, (uint32_t) m, ztab[j], SUPER_R08) : rng.unif_index(j, (uint32_t) m, SUPER_R08);
-                        PT pj = perm[(size_t) j * ncol + tid];
-                        PT pk = perm[(size_t) k * ncol + tid];
-                        perm[(size_t) j * ncol + tid] = pk;
-                        perm[(size_t) k * ncol + tid] = pj;
+#if KMU_SUPER_IDX32
+                        const uint32_t ij = j * (uint32_t) ncol + (uint32_t) tid, ik = k * (uint32_t) ncol + (uint32_t) tid;
+#else
+                        const size_t ij = (size_t) j * ncol + tid, ik = (size_t) k * ncol + tid;
+#endif
+                        PT pj = perm[ij];
+                        PT pk = perm[ik];
+                        perm[ij] = pk;
+                        perm[ik] = pj;
                         if (j < LOG_PER) slog0 |= (uint64_t) k << (LOG_BITS * j);
                         else if (j < LOG_STEPS) slog1 |= (uint64_t) k << (LOG_BITS * (j - LOG_PER));
                         uint64_t bits;
