@@ -1262,11 +1262,14 @@ __device__ __forceinline__ void vm_wait_lds_loads() {
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0); expcnt / lgkmcnt untouched
     asm volatile("" ::: "memory");
 }
-// TAB (round 3; opt-in with KMU_PMH_UQTAB=1, measured slower: 18.8 against 13.0 ms per launch of the first shape): the keys of the collision groups are not collected and counting-
-// sorted (rank / scan / place / walk: five barriers) but meet in an open-addressing table of 2 x UQ_COLL slots in LDS
-// (ds_cmpst_rtn_b64 claims a slot, ds_add counts: the table of k_multiset_short, workgroup-wide) straight from the registers;
-// after ONE barrier the occupied slots leave as (key, weight) pairs and the table is free again: four barriers per read
-// instead of nine, and the list holds no zero-weight repeats.
+// TAB: the keys of the collision groups are collected as before, but then they are not counting-sorted (rank / scan / place /
+// walk: five barriers, a fixed cost per read for a few hundred keys) -- they meet in an open-addressing table of 2 x UQ_COLL
+// slots in LDS (ds_cmpst_rtn_b64 claims a slot, ds_add counts: the table of k_multiset_short, workgroup-wide), at most
+// UQ_COLL / UQ_THREADS inserts per thread; after ONE barrier the occupied slots leave as (key, weight) pairs and the table is
+// free again, and the list holds no zero-weight repeats.  (Round 3 inserted straight from the registers inside the sort-out
+// loop -- twenty probe loops per wave, each as long as its unluckiest lane's: 18.8 against 13.0 ms per launch.  This form, round 4:
+// 10.13 against 10.10 ms per launch -- the same as the counting sort: with two workgroups per CU the barriers of one hide under the
+// other's key phase, the kernel is bound by the instructions of the key and sort-out phases.  Opt-in: KMU_PMH_UQTAB=1.)
 template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, bool TAB = false>
 struct UqShape {
     static constexpr uint32_t KEYS = (uint32_t) UQ_THREADS * UQ_KREG;
@@ -1275,7 +1278,7 @@ struct UqShape {
     static constexpr uint32_t TILE = (KEYS + 32 + 15) / 16 + 3; // staged code words of a read
     static constexpr uint32_t TABS = 2u * UQ_COLL;         // slots of the collision table (TAB)
     static constexpr uint32_t RAW_WAVES = (TILE + 63) / 64; // landing area of the next read's 16-byte chunks: 1 KiB per wave instruction
-    static constexpr size_t LDS = (TAB ? (size_t) BM_WORDS * 8 + (size_t) TABS * 12 + ((size_t) TILE + 16) * 4 + 64
+    static constexpr size_t LDS = (TAB ? (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 8 + (size_t) TABS * 12 + ((size_t) TILE + 16) * 4 + 64
                                        : (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64) +
                                   (size_t) RAW_WAVES * 1024 + 16;
 };
@@ -1293,9 +1296,9 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     uint64_t *dk = ck + UQ_COLL;                                     // ... grouped by bucket
     uint32_t *dw = reinterpret_cast<uint32_t *>(dk + UQ_COLL);
     uint32_t *bst = dw + UQ_COLL;          // UQ_BUCKETS + 1
-    // TAB: the collision table in place of ck / dk / dw / bst / wtot
+    // TAB: the collision table in place of dk / dw / bst / wtot
     constexpr uint32_t UQ_TABS = SH::TABS;
-    uint64_t *tk = ck;                                         // UQ_TABS keys, all-ones = free
+    uint64_t *tk = ck + UQ_COLL;                               // UQ_TABS keys, all-ones = free
     uint32_t *tc = reinterpret_cast<uint32_t *>(tk + UQ_TABS); // their multiplicities
     uint32_t *words = TAB ? tc + UQ_TABS : bst + UQ_BUCKETS + 1; // UQ_TILE
     uint32_t *wtot = words + UQ_TILE;       // one per wave (not TAB)
@@ -1548,23 +1551,8 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                         a.lst_keys[at] = rk[q0 + u]; // (weight 1, implied: lst_nu)
                     }
                     if (co[u]) {
-                        if (TAB) {
-                            const uint64_t key = rk[q0 + u];
-                            if (key == ~0ull) atomicAdd(&misc[2], 1u); // (the value that marks a free slot: counted aside)
-                            else {
-                                uint32_t sl = rbi[q0 + u] >> (UQ_BM_BITS - (31 - __builtin_clz(UQ_TABS)));
-                                bool done = false;
-                                for (int pr = 0; pr < 64; pr++) {
-                                    const unsigned long long old = atomicCAS((unsigned long long *) &tk[sl], ~0ull, (unsigned long long) key);
-                                    if (old == ~0ull || old == key) { atomicAdd(&tc[sl], 1u); done = true; break; }
-                                    sl = (sl + 1u) & (UQ_TABS - 1u);
-                                }
-                                if (!done) misc[3] = 1u; // (a crowded table: the read goes to the general kernel)
-                            }
-                        } else {
-                            const uint32_t at = cb + (uint32_t) __popcll(cm[u] & below);
-                            if (at < UQ_COLL) ck[at] = rk[q0 + u];
-                        }
+                        const uint32_t at = cb + (uint32_t) __popcll(cm[u] & below);
+                        if (at < UQ_COLL) ck[at] = rk[q0 + u];
                     }
                     ub += (uint32_t) __popcll(um[u]);
                     cb += (uint32_t) __popcll(cm[u]);
@@ -1576,8 +1564,29 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             const uint32_t n_u = uniform_u32(misc[0]), n_c = uniform_u32(misc[1]);
             over = n_c > UQ_COLL;
             if (TAB) {
-                over = over || uniform_u32(misc[3]) != 0u;
-                if (n_c) { // the occupied slots leave as (key, weight) pairs behind the unique entries; the table is wiped
+                if (!over && n_c) { // the collected keys meet in the table
+#pragma unroll
+                    for (int j = 0; j < (int) (UQ_COLL / UQ_THREADS); j++) {
+                        const uint32_t i = (uint32_t) j * UQ_THREADS + tid;
+                        if (i < n_c) {
+                            const uint64_t key = ck[i];
+                            if (key == ~0ull) atomicAdd(&misc[2], 1u); // (the value that marks a free slot: counted aside)
+                            else {
+                                uint32_t sl = mix32(key) >> (32 - (31 - __builtin_clz(UQ_TABS)));
+                                bool done = false;
+                                for (int pr = 0; pr < 64; pr++) {
+                                    const unsigned long long old = atomicCAS((unsigned long long *) &tk[sl], ~0ull, (unsigned long long) key);
+                                    if (old == ~0ull || old == key) { atomicAdd(&tc[sl], 1u); done = true; break; }
+                                    sl = (sl + 1u) & (UQ_TABS - 1u);
+                                }
+                                if (!done) misc[3] = 1u; // (a crowded table: the read goes to the general kernel)
+                            }
+                        }
+                    }
+                    lds_barrier();
+                    over = uniform_u32(misc[3]) != 0u;
+                }
+                if (n_c && n_c <= UQ_COLL) { // the occupied slots leave as (key, weight) pairs behind the unique entries; the table is wiped
                     constexpr int PER = (int) (UQ_TABS / UQ_THREADS);
                     uint64_t key[PER];
                     uint32_t cnt[PER];
@@ -2733,7 +2742,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     const char *uq_env = getenv("KMU_PMH_UQ"); // 0: every read through the counting-sort kernel (A/B)
     const bool uq = split && plain && !(uq_env && atoi(uq_env) == 0);
     const char *uqt_env = getenv("KMU_PMH_UQTAB"); // 0: the collision groups through the counting sort (A/B)
-    const bool uq_tab = uqt_env && atoi(uqt_env) != 0; // (measured r03: 18.8 against 13.0 ms per launch -- opt-in)
+    const bool uq_tab = uqt_env && atoi(uqt_env) != 0; // (opt-in: as fast as the counting sort, scripts/r04_uqtab.sh)
     bool main_launched = false, short_route = false;
     const char *sh_env = getenv("KMU_PMH_SHORT"); // 0: short reads through k_multiset_uq like the others (A/B)
     if (uq && len_stats && len_stats[0] < (uint64_t) SHORT_KEYS + (uint64_t) p->kmer_size && !(sh_env && atoi(sh_env) == 0)) {
