@@ -317,9 +317,12 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     KMU_TRY(dev_buf(ctx, "queue", 64, &q));
     KMU_HIP(ctx, hipMemsetAsync(q, 0, 64, ctx->stream));
     a.queue = (uint32_t *) q;
-    // One wave per workgroup and a small staging chunk: the kernel is latency-bound (LDS atomics, queue, row output),
-    // so many small workgroups per CU beat one large one (config 5: 27.6 -> 12.8 ms; scripts/dbg_super.sh).
-    a.chunk = 256;
+    // Round 1 chose one wave per workgroup and a staging chunk of 256 items (config 5: 27.6 -> 12.8 ms, scripts/dbg_super.sh: the
+    // step loop then waited on FLAT loads and divisions).  Round 4: the items of a batch advance j in lock step against ONE bound
+    // (a_upper falls with every offer of every lane), so the more items of a read are in flight together the fewer rounds the
+    // read takes -- four waves and 512 staged items: 7.93 -> 7.25 ms on config 5's shard (scripts/r04_superthreads.sh; 1 024
+    // staged items: 8.7).
+    a.chunk = 512;
     if (const char *e = getenv("KMU_SUPER_CHUNK")) a.chunk = (uint32_t) std::max(64, atoi(e));
     const bool wide = a.m > 256;
     const size_t pt = wide ? 2 : 1;
@@ -337,7 +340,7 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
 #undef KMU_SUPER_PICK
     auto fn = (const void *) kern;
     // the per-lane permutation columns dominate the LDS footprint: shrink the workgroup for large m
-    int threads = 64;
+    int threads = 256;
     if (const char *e = getenv("KMU_SUPER_THREADS")) threads = std::max(64, std::min(256, atoi(e) & ~63));
     size_t lds = 0;
     int ncol = 0;
