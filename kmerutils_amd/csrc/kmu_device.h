@@ -375,6 +375,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t shfl_down_u32(uint32_t v, int d) { return (uint32_t) __shfl_down((int) v, d, 64); }
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, 64); }
+// maximum of a 32-bit value over the 64 lanes, in every lane: DPP row shifts / broadcasts (the inclusive max scan of kmu_smer.hip)
+// and one readlane -- no LDS round trips (wave_max_u64 below makes twelve: ds_bpermute)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false)); // row_shr:1
+    v = mx(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false)); // row_shr:2
+    v = mx(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false)); // row_shr:4
+    v = mx(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false)); // row_shr:8
+    v = mx(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false)); // row_bcast:15
+    v = mx(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false)); // row_bcast:31
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {

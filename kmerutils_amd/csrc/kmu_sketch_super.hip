@@ -18,6 +18,12 @@
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
+#ifndef KMU_SUPER_DPPMAX // (A/B builds: 0 = the maximum over the wave through ds_bpermute)
+#define KMU_SUPER_DPPMAX 1
+#endif
+#ifndef KMU_SUPER_RMASK
+#define KMU_SUPER_RMASK 3u
+#endif
 #ifndef KMU_SUPER_IDX32
 #define KMU_SUPER_IDX32 0
 #endif
@@ -207,13 +213,15 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         j++;
                     }
                     round++; // wave-uniform (all lanes of the wave run this loop together)
-                    if ((round & 3u) == 0u || round == 1u) { // refresh a_upper = max_s min(floor(hs[s]), m-1)
+                    // (round 4: the waves of a workgroup taking turns at the refresh -- 7.46 against 7.22 ms on config 5's shard: a staler
+                    //  bound costs more steps than the refresh saves; KMU_SUPER_RMASK: the period, A/B builds)
+                    if ((round & KMU_SUPER_RMASK) == 0u || round == 1u) { // refresh a_upper = max_s min(floor(hs[s]), m-1)
                         uint32_t mx = 0;
                         for (int s = lane_id(); s < m; s += 64) {
                             uint32_t f = super_floor(KMU_SUPER_VOL ? *(volatile uint64_t *) &hs[s] : __hip_atomic_load(&hs[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), SUPER_MODE, m, a.lg);
                             mx = f > mx ? f : mx;
                         }
-                        mx = (uint32_t) wave_max_u64(mx);
+                        mx = KMU_SUPER_DPPMAX ? wave_max_u32(mx) : (uint32_t) wave_max_u64(mx);
                         if (lane_id() == 0) atomicMin(&misc[1], mx);
                     }
                 }
