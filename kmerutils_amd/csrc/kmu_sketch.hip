@@ -84,6 +84,9 @@ struct SketchArgs {
     uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
     uint32_t ablate;      // diagnostics only (KMU_PMH_ABLATE): 1 skip pass B math, 2 skip table insert, 4 skip hashing
     Exp01 e01;
+    // k <= 8 (k_sketch_smallk<EMIT>): the first point of every possible key, made once per call (k_pts_table): x = the key's Exp01
+    // sample, y = its slot, w = the key itself; the lists then hold the k-mer VALUE (the index of this table) instead of the key
+    const uint4 *pts_tab;
     void *sig_out;
     uint32_t *queue; // atomic read counter
     uint32_t *err;
@@ -1077,7 +1080,19 @@ __device__ __forceinline__ uint64_t wg4_qmax(const uint64_t *arrays, size_t wave
 
 // one read's points.  WG = false: by this wave alone (chunks 0, 64, 128, ...).  WG = true: by the four waves of the workgroup,
 // wave w on chunks 64 w, 64 w + 256, ... with slot arrays of its own, the row = per-slot minimum of the four.
-template <bool SIG32, bool WG>
+// a queued first point of the table form: x = the sample's bits, slot from the table
+__device__ __forceinline__ void pts_tab_point(uint64_t *hmin, uint64_t *sig, const uint64_t *qmax_sh, bool have, uint64_t key, uint32_t w,
+                                              uint64_t xbits, uint64_t slot, const double *winv_lut) {
+    const uint64_t qb = __hip_atomic_load(qmax_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (have) {
+        const double h = winv_of(winv_lut, w) * __longlong_as_double((long long) xbits);
+        if (h < __longlong_as_double((long long) qb)) slot_update_wave(hmin, sig, (uint32_t) slot, h, key); // (q_max may have fallen since the key was queued)
+    }
+}
+// TAB8 (k <= 8): a list entry is the k-mer value; the first point of a key -- its Exp01 sample, whichever branch of the sampler made
+// it, and its slot -- comes out of a.pts_tab: no generator runs in pass 1, and the test against q_max also prunes the 42 % of the
+// keys whose first draw falls into the rejection branch (their sample is known here; from the seed it is not before the full state is).
+template <bool SIG32, bool WG, bool TAB8 = false>
 __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, uint8_t *smem, size_t wave_words, const double *winv_lut) {
     const int wave = threadIdx.x >> 6, lane = lane_id();
     constexpr bool sig32 = SIG32;
@@ -1123,13 +1138,24 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
             qb = WG ? wg4_qmax(arrays, wave_words, a.m) : wave_qmax(hmin, a.m);
             if (lane == 0) *qmax_sh = qb;
         }
-        uint64_t s0 = 0, s3 = 0;
-        const bool pass = KMU_PTS_UNITW && c + 64u <= n_u ? have && pmh3a_first_point_may_matter<true>(a, sig32, qb, key, w, winv_lut, s0, s3) // (uniform)
-                                         : have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
+        uint64_t s0 = 0, s3 = 0, qkey = key;
+        bool pass;
+        if (TAB8) { // s0: the bits of the sample, s3: the slot
+            pass = false;
+            if (have) {
+                const uint4 e = a.pts_tab[(uint32_t) key];
+                s0 = ((uint64_t) e.y << 32) | e.x;
+                s3 = e.z;
+                qkey = e.w;
+                pass = winv_of(winv_lut, w) * __longlong_as_double((long long) s0) < __longlong_as_double((long long) qb);
+            }
+        } else
+            pass = KMU_PTS_UNITW && c + 64u <= n_u ? have && pmh3a_first_point_may_matter<true>(a, sig32, qb, key, w, winv_lut, s0, s3) // (uniform)
+                                                 : have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
         const uint64_t pm = __ballot(pass);
         if (pass) {
             const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));
-            qk[pos] = key;
+            qk[pos] = qkey;
             qw[pos] = w;
             qs0[pos] = s0;
             qs3[pos] = s3;
@@ -1137,12 +1163,16 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
         qn += (uint32_t) __popcll(pm);
         if (qn >= 64u) { // the newest 64
             qn -= 64u;
+            if (TAB8) pts_tab_point(hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane], qs3[qn + lane], winv_lut);
+            else
             pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane], qs3[qn + lane],
                                    winv_lut);
         }
     }
     if (qn) {
         const bool have = (uint32_t) lane < qn;
+        if (TAB8) pts_tab_point(hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u, have ? qs0[lane] : 0ull, have ? qs3[lane] : 0ull, winv_lut);
+        else
         pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u, have ? qs0[lane] : 0ull,
                                have ? qs3[lane] : 0ull, winv_lut);
     }
@@ -1169,7 +1199,7 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
                 winv = winv_of(winv_lut, w);
                 alive = w != 0u && winv < __longlong_as_double((long long) qb);
             }
-            if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
+            if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, !alive ? 0ull : TAB8 ? (uint64_t) a.pts_tab[(uint32_t) a.lst_keys[base + i]].w : a.lst_keys[base + i], winv);
         }
     }
     // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
@@ -1196,7 +1226,7 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
     }
 }
 
-template <bool SIG32>
+template <bool SIG32, bool TAB8 = false>
 __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = lane_id();
@@ -1211,7 +1241,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     //  as single waves' reads, and the workgroup form costs more per key -- three barriers per read, q_max over four arrays)
     uint32_t n_long = a.pts_long ? a.pts_long[0] : 0u;
     if (n_long > 4u * gridDim.x) n_long = 0u;
-    for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) pts_one_read<SIG32, true>(a, a.pts_long[2 + li], smem, wave_words, winv_lut);
+    for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) pts_one_read<SIG32, true, TAB8>(a, a.pts_long[2 + li], smem, wave_words, winv_lut);
     uint32_t q_next = 0, q_end = 0; // lane 0: reads are taken QCHUNK at a time
     for (;;) {
         uint32_t r = 0;
@@ -1225,7 +1255,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         r = uniform_u32(r);
         if (r >= a.n_seq) break;
         if (n_long && uniform_u32(a.lst_n[r]) > a.pts_long_t) continue; // (taken by a workgroup above)
-        pts_one_read<SIG32, false>(a, r, smem, wave_words, winv_lut);
+        pts_one_read<SIG32, false, TAB8>(a, r, smem, wave_words, winv_lut);
     }
 }
 
@@ -1957,6 +1987,20 @@ __device__ __forceinline__ uint32_t revcomp32(uint32_t val, int k) {
     return rc >> (32 - 2 * k);
 }
 
+// the first point of every k-mer value of k <= 8 bases (a.pts_tab; SketchArgs): what pmh3a_first_point draws for the key of that value
+__global__ void __launch_bounds__(256) k_pts_table(SketchArgs a, uint4 *tab, uint32_t n) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const bool sig32 = a.sig_bytes == 4;
+    const uint64_t key = apply_fhash(a.cfg, (uint64_t) idx, (uint64_t) revcomp32(idx, a.cfg.k));
+    Xoshiro rng;
+    rng.seed(hasher_finish(KMU_HASHER_NOHASH, key, sig32));
+    const double x = exp01_sample(a.e01, rng);
+    const uint32_t slot = draw_slot(a, rng);
+    const uint64_t xb = (uint64_t) __double_as_longlong(x);
+    tab[idx] = make_uint4((uint32_t) xb, (uint32_t) (xb >> 32), slot, (uint32_t) key);
+}
+
 // EMIT: the (key, weight) pairs of the distinct k-mers leave for k_pmh_points (one wave per read, 95 % VALU busy) instead of
 // being turned into points here by a workgroup that has to meet at barriers.
 template <bool EMIT>
@@ -2161,7 +2205,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
                 for (uint32_t i = tid; i < n_list && !ABL(2u); i += nthreads) {
                     const uint32_t idx = list[i];
                     const uint32_t c = cnt[idx >> 1];
-                    a.lst_keys[lbase + i] = key_of(idx);
+                    a.lst_keys[lbase + i] = a.pts_tab ? (uint64_t) idx : key_of(idx);
                     a.lst_w[lbase + i] = (idx & 1u) ? c >> 16 : c & 0xFFFFu;
                     atomicAnd(&cnt[idx >> 1], (idx & 1u) ? 0x0000FFFFu : 0xFFFF0000u);
                 }
@@ -2203,7 +2247,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
                         for (uint32_t i = tid; i < n_list && !ABL(2u); i += nthreads) {
                             const uint32_t idx = list[i];
                             const uint32_t c = wide ? cnt[idx & 0x7FFFu] : cnt[idx >> 1];
-                            a.lst_keys[lbase + i] = key_of(idx);
+                            a.lst_keys[lbase + i] = a.pts_tab ? (uint64_t) idx : key_of(idx);
                             a.lst_w[lbase + i] = wide ? c : ((idx & 1u) ? c >> 16 : c & 0xFFFFu);
                         }
                         emit_n += n_list;
@@ -2465,7 +2509,8 @@ static bool smallk_route(const kmu_sketch_params *p, int hashed_bytes, bool part
 // k_pmh_points over the lists of a.n_seq reads; reads with more than KMU_PMH_PTS_LONG list entries (default 32 768; 0: none)
 // are listed first (k_pts_long_list) and taken by whole workgroups
 static int launch_points(kmu_ctx *ctx, SketchArgs a, int cus) {
-    void (*const kpts)(SketchArgs) = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
+    void (*const kpts)(SketchArgs) = a.pts_tab ? (a.sig_bytes == 4 ? k_pmh_points<true, true> : k_pmh_points<false, true>)
+                                               : a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
     const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
     if (lds2 > 64 * 1024)
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2565,6 +2610,20 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
                 a.lst_nu = a.lst_n + ds.n_seq;
                 KMU_HIP(ctx, hipMemsetAsync(a.lst_nu, 0, (size_t) ds.n_seq * 4, ctx->stream));
             }
+        }
+        // KMU_PMH_K8TAB=1 (opt-in; round 4, measured slower): the first point of every one of the 4^k possible keys from a table made
+        // once per call.  No generator runs in pass 1 and the 42 % of the keys in the sampler's rejection branch are pruned like the
+        // others -- but 4e9 gathers of 16 bytes out of a 1 MB table are 4e9 lines from L2 (the table does not fit a CU's 32 KB of L1):
+        // k_pmh_points 26.1 against 18.9 ms on config 3 (scripts/r04_k8tab.sh; same rows).  A bound small enough for LDS in front
+        // of the gather would be the next step.
+        const char *k8t = getenv("KMU_PMH_K8TAB");
+        if (emit && k8t && atoi(k8t) != 0) {
+            void *pt;
+            const uint32_t nv = 1u << (2 * p->kmer_size);
+            KMU_TRY(dev_buf(ctx, "pts.tab", (size_t) nv * 16 + 64, &pt));
+            hipLaunchKernelGGL(k_pts_table, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, a, (uint4 *) pt, nv);
+            KMU_HIP(ctx, hipGetLastError());
+            a.pts_tab = (const uint4 *) pt;
         }
         const sketch_kernel_t kern = emit ? k_sketch_smallk<true> : k_sketch_smallk<false>;
         // LDS: histogram | slot minima (only when the kernel makes the points itself) | list of u16 indices | staged words
