@@ -2614,8 +2614,9 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         // KMU_PMH_K8TAB=1 (opt-in; round 4, measured slower): the first point of every one of the 4^k possible keys from a table made
         // once per call.  No generator runs in pass 1 and the 42 % of the keys in the sampler's rejection branch are pruned like the
         // others -- but 4e9 gathers of 16 bytes out of a 1 MB table are 4e9 lines from L2 (the table does not fit a CU's 32 KB of L1):
-        // k_pmh_points 26.1 against 18.9 ms on config 3 (scripts/r04_k8tab.sh; same rows).  A bound small enough for LDS in front
-        // of the gather would be the next step.
+        // k_pmh_points 26.1 against 18.9 ms on config 3 (scripts/r04_k8tab.sh; same rows).  16-bit lower bounds of the samples in LDS
+        // in front of the gather (128 KB: one workgroup of four waves per CU) were slower still -- 52 ms: one wave per SIMD hides
+        // neither the LDS nor the L2 round trips of a chunk.
         const char *k8t = getenv("KMU_PMH_K8TAB");
         if (emit && k8t && atoi(k8t) != 0) {
             void *pt;
