@@ -767,9 +767,18 @@ __device__ __forceinline__ uint64_t leaf6_load(const uint64_t *items, uint64_t n
     return ((uint64_t) reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint32_t *>(items) + n_total)[at] << 32) | reinterpret_cast<const uint32_t *>(items)[at];
 #endif
 }
+// CHUNKED streams (the shared level-1 streams): stream (block, bin) of `cap` items is not contiguous -- it is cut into chunks of
+// 2^lc items, and chunk c of all the bins of a block lie side by side: item `rel` of the stream sits at
+// ((block * cap / 2^lc + rel / 2^lc) * bins + bin) * 2^lc + rel % 2^lc.  The cursors of a block's 2 048 streams advance at the
+// same pace, so what a workgroup writes at any time lies within two or three chunk rows (16 - 50 MB: a handful of pages) instead
+// of 2 048 places a megabyte apart (2.2 GB: a page each).  Opt-in (KMU_COUNT_SEG_CHUNK): see seg_chunk_log.
+__host__ __device__ __forceinline__ uint64_t seg_chunked_index(uint32_t block, uint32_t nbins, uint32_t bin, uint32_t cap, uint32_t rel, uint32_t lc) {
+    return ((((uint64_t) block * (cap >> lc) + (rel >> lc)) * nbins + bin) << lc) | (rel & ((1u << lc) - 1u));
+}
 struct SegOut {
     uint64_t bin_base, bincap, end_rel, cap;
     uint32_t *ovf;
+    uint32_t lc = 0, cblock = 0, cbins = 0; // lc != 0: CHUNKED -- the streams of block `cblock` of `cbins` bins (bin_base / bincap / end_rel unused)
     // LEAF6 (tile_scatter_seg): the output holds 6 bytes per item in two planes -- u32 low words of all items, then u16 bits 32..47;
     // n_total = items in all streams (where the second plane starts)
     uint64_t n_total = 0;
@@ -1032,6 +1041,7 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
     if (VMWAIT) vm_wait_all(); // the next tile's requests (in flight since before the ranks) and the last tile's stores: nothing younger
     const uint64_t seg0 = sg.end_rel - sg.cap; // start of this unit's segment inside a bin's range
     const uint32_t bb = (uint32_t) sg.bin_base, bc = (uint32_t) sg.bincap, cap = (uint32_t) sg.cap;
+    const uint32_t clc = LEAF6 ? 0u : (uint32_t) __builtin_amdgcn_readfirstlane((int) sg.lc); // (uniform)
     for (uint32_t p0 = 0; p0 < total; p0 += 8u * nthreads) {
         uint64_t v[8];
         uint32_t rel[8], bin[8];
@@ -1054,7 +1064,7 @@ __device__ __forceinline__ void tile_scatter_seg(uint64_t (&it)[16], const SegLd
                 if (rel[u] < cap) __builtin_nontemporal_store(v[u], &out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])]);
 #else
                 if (LEAF6 && rel[u] < cap) leaf6_store(out, sg.n_total, (uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u]), v[u]);
-                else if (rel[u] < cap) out[(uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
+                else if (rel[u] < cap) out[clc ? seg_chunked_index(sg.cblock, sg.cbins, bin[u], cap, rel[u], clc) : (uint64_t) (bb + bin[u]) * bc + (seg0 + rel[u])] = v[u];
 #endif
                 else seg_spill(sg.ovf, v[u]);
             }
@@ -1295,6 +1305,7 @@ struct SegPlan1 {
     // loaded, stored or marked by the kernel (k_seg_tails marks the tails behind the last launch)
     uint32_t sets;
     const uint4 *step_tab; // k_step_table's entries of all wave steps of the stream (single-pass form)
+    uint32_t lc = 0;       // sets != 0: the streams are CHUNKED (SegOut)
 };
 template <bool SEGM, bool SHARED = false>
 __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seq,
@@ -1315,6 +1326,7 @@ __global__ void __launch_bounds__(1024) k_part_scatter1(const uint8_t *bases, co
     if (SEGM && SHARED) {
         const uint32_t set = seg.first & 2 ? blockIdx.x / ((gridDim.x + seg.sets - 1) / seg.sets) : blockIdx.x % seg.sets; // (A/B: bit 1 of first = sets of consecutive workgroups)
         sg = SegOut{(uint64_t) set * bins1, seg.cap, seg.cap, seg.cap, seg.ovf};
+        sg.lc = seg.lc; sg.cblock = set; sg.cbins = bins1;
         cursor = seg.state + (size_t) set * bins1;
     }
     uint32_t run[2] = {0u, 0u};
@@ -1402,6 +1414,8 @@ struct ArrPlan {
     // k_arr_scatter<.., SHARED>: > 1 = that many sets of shared output streams per partition, a unit writes set blockIdx.x % out_sets
     // (level 1 of an array: [set][bin][seg_cap], cursors in the same order); 0 / 1: one set (level 2: the leaves)
     uint32_t out_sets;
+    uint32_t seg_lc = 0; // the input streams are CHUNKED (SegOut)
+    uint32_t out_lc = 0; // out_sets > 1: so are the output streams
 };
 
 __device__ __forceinline__ void arr_unit_range(const uint64_t *bounds, const ArrPlan &pl, uint32_t unit, uint64_t *i0,
@@ -1510,6 +1524,7 @@ __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, con
         const uint32_t nsets = pl.out_sets > 1u ? pl.out_sets : 1u;
         const uint64_t block = sp * nsets + (nsets > 1u ? blockIdx.x % nsets : 0u);
         sg = SegOut{block * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
+        if (nsets > 1u && pl.out_lc) { sg.lc = pl.out_lc; sg.cblock = (uint32_t) block; sg.cbins = pl.bins; }
         cursor = leafcnt + block * pl.bins;
     }
     if (LEAF6) sg.n_total = (uint64_t) pl.nparts * pl.bins * seg_cap; // (level 2: one set of leaves per input partition)
@@ -1558,10 +1573,11 @@ __global__ void __launch_bounds__(THREADS) k_arr_scatter(const uint64_t *in, con
 #pragma unroll
             for (int j2 = 0; j2 < 8; j2++) {
                 const uint32_t uu = u < pl.seg_units ? u : pl.seg_units - 1; // (beyond the partition: anything readable)
+                const uint64_t at = pl.seg_lc ? seg_chunked_index(uu, pl.seg_bins, sp, pl.seg_cap, o, pl.seg_lc) : (uint64_t) uu * seg_stride + seg_base + o;
 #if KMU_SCATTER_NTLOAD >= 1
-                const u64x2 q = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + (uint64_t) uu * seg_stride + seg_base + o));
+                const u64x2 q = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + at));
 #else
-                const u64x2 q = *reinterpret_cast<const u64x2 *>(in + (uint64_t) uu * seg_stride + seg_base + o);
+                const u64x2 q = *reinterpret_cast<const u64x2 *>(in + at);
 #endif
                 nxt[2 * j2] = q.x;
                 nxt[2 * j2 + 1] = q.y;
@@ -1628,6 +1644,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_smer_scatter1(const uint32_
         const uint32_t nsets = pl.out_sets > 1u ? pl.out_sets : 1u;
         const uint64_t block = nsets > 1u ? blockIdx.x % nsets : 0u;
         sg = SegOut{block * pl.bins, seg_cap, seg_cap, seg_cap, seg_ovf};
+        if (nsets > 1u && pl.out_lc) { sg.lc = pl.out_lc; sg.cblock = (uint32_t) block; sg.cbins = pl.bins; }
         cursor = cursors + block * pl.bins;
     }
     uint32_t run[2] = {0u, 0u};
@@ -1669,9 +1686,10 @@ __global__ void __launch_bounds__(64) k_spill_header(uint32_t *ovf, uint32_t cap
 }
 
 // shared segments (SegPlan1::sets): "no k-mer" marks from the fill of every (set, bin) stream to its capacity
-__global__ void __launch_bounds__(256) k_seg_tails(const uint32_t *cursor, uint32_t cap, uint64_t *out) {
+__global__ void __launch_bounds__(256) k_seg_tails(const uint32_t *cursor, uint32_t cap, uint64_t *out, uint32_t lc, uint32_t nbins) {
     const uint32_t n = cursor[blockIdx.x] < cap ? cursor[blockIdx.x] : cap;
-    for (uint32_t i = n + threadIdx.x; i < cap; i += blockDim.x) out[(uint64_t) blockIdx.x * cap + i] = CKEY_EMPTY;
+    for (uint32_t i = n + threadIdx.x; i < cap; i += blockDim.x)
+        out[lc ? seg_chunked_index(blockIdx.x / nbins, nbins, blockIdx.x % nbins, cap, i, lc) : (uint64_t) blockIdx.x * cap + i] = CKEY_EMPTY;
 }
 
 // the spill list of a single-pass partition (khash values) into the finished table, by direct insertion
@@ -2142,6 +2160,17 @@ static bool seg_layout_bin() { // A/B runs: level 1's output with the ranges of 
     const char *e = getenv("KMU_COUNT_SEG_LAYOUT");
     return e && e[0] == 'b';
 }
+// log2 of the chunk of the CHUNKED level-1 streams (SegOut), 0 = contiguous streams (the default); KMU_COUNT_SEG_CHUNK (A/B runs).
+// Round 4, one box: level 1 12.3 (contiguous) / 12.6 (chunks of 2^10 or 2^12 items) / 12.7 ms (2^8), level 2 17.0 / 17.0 / 17.2 / 18.1:
+// where the address translation is not the bound, the index arithmetic of the chunks is all that shows (scripts/r04_segchunk.sh).
+// Kept behind the switch for the boxes on which level 1 runs 15 % slower in every launch (profiles/r04f_*), where it could not be tried.
+static uint32_t seg_chunk_log(uint64_t cap) {
+    uint32_t lc = 0;
+    if (const char *e = getenv("KMU_COUNT_SEG_CHUNK")) lc = (uint32_t) std::max(0, std::min(16, atoi(e)));
+    if (lc && lc < 4) lc = 4;             // (a pair of items, 16 bytes, never straddles chunks; capacities are multiples of 16)
+    while (lc && (cap >> lc) < 8) lc--;   // small streams: a chunk row would be most of the stream
+    return lc < 4 ? 0 : lc;
+}
 static uint64_t seg_cap_for(double mean) {
     double pct = 1.0;
     if (const char *e = getenv("KMU_COUNT_SEG_PCT")) pct = std::max(0.01, atof(e) / 100.0); // tests: force overflows
@@ -2158,6 +2187,7 @@ struct SegPlan {
     uint32_t chunks2;
     uint32_t shared2; // level 2: the chunks2 units of a bin share its leaves (cursors in leafcnt)
     uint32_t sets; // level 1 with shared segments: one stream per (set, bin), cap1 items each (0: a segment per unit and bin)
+    uint32_t lc1 = 0; // ... CHUNKED (SegOut): cap1 is a multiple of 2^lc1
 };
 // shared segments (tile_scatter_seg with cursors).  Level 1: sets of streams, two per XCD (bench workload, same box: 15.8-16.1 ms;
 // one per XCD 18.5, four 15.9-16.7, eight 20.3, one for the whole chip 19.8-20.1, a unit's own segments 17.6-21.5 in two states).
@@ -2194,6 +2224,8 @@ static SegPlan seg_plan(const kmu_ctx *ctx, uint64_t total_bases, const PartPlan
         sp.sets = std::min(want_sets, sp.units1);
         const uint64_t units_per_set = (sp.units1 + sp.sets - 1) / sp.sets;
         sp.cap1 = seg_cap_for((double) units_per_set * sp.steps_per_unit * 1024.0 / bins1);
+        sp.lc1 = seg_layout_bin() ? 0u : seg_chunk_log(sp.cap1);
+        if (sp.lc1) sp.cap1 = (sp.cap1 + (1ull << sp.lc1) - 1) >> sp.lc1 << sp.lc1;
         sp.bincap1 = (uint64_t) sp.sets * sp.cap1;
     }
     sp.chunks2 = 1; // a leaf has ONE capacity, whoever fills it: a unit per level-1 bin, or (shared2) several through the leaf's cursor
@@ -2286,7 +2318,7 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                                (uint64_t *) run->A,
                                SegPlan1{run->sp.cap1, 0, 0, run->steps_done, (uint32_t *) run->ovf, run->d_err, run->steps_done + n_new,
                                         (uint32_t *) run->state, (run->steps_done == 0 ? 1 : 0) | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), last ? 1 : 0, run->sp.sets,
-                                        (const uint4 *) run->step_tab});
+                                        (const uint4 *) run->step_tab, run->sp.lc1});
         }
         KMU_HIP(ctx, hipGetLastError());
         run->steps_done += n_new;
@@ -2294,7 +2326,7 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
             run->units_done = run->sp.units1;
             if (run->sp.sets)
                 hipLaunchKernelGGL(k_seg_tails, dim3(run->sp.sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) run->state,
-                                   (uint32_t) run->sp.cap1, (uint64_t *) run->A);
+                                   (uint32_t) run->sp.cap1, (uint64_t *) run->A, run->sp.lc1, bins1);
         }
         return KMU_OK;
     }
@@ -2315,13 +2347,13 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
                            (const uint64_t *) nullptr, (uint64_t *) run->A,
                            SegPlan1{run->sp.cap1, seg_layout_bin() ? run->sp.bincap1 : 0, run->units_done, (uint64_t) run->units_done * run->sp.steps_per_unit,
                                     (uint32_t *) run->ovf, run->d_err, 0, (uint32_t *) run->state, 1 | (getenv("KMU_COUNT_SEG_SETMAP") ? 2 : 0), 1, run->sp.sets,
-                                    (const uint4 *) run->step_tab});
+                                    (const uint4 *) run->step_tab, run->sp.lc1});
     }
     KMU_HIP(ctx, hipGetLastError());
     run->units_done = upto;
     if (run->sp.sets && upto == run->sp.units1)
         hipLaunchKernelGGL(k_seg_tails, dim3(run->sp.sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) run->state,
-                           (uint32_t) run->sp.cap1, (uint64_t *) run->A);
+                           (uint32_t) run->sp.cap1, (uint64_t *) run->A, run->sp.lc1, bins1);
     return KMU_OK;
 }
 // level 2 of a single-pass partition: A (level 1's segments: ap.seg_*) -> the leaves in B; shared: ap.chunks units per bin share
@@ -2369,6 +2401,7 @@ static int seg_finish(kmu_counter *c, SegRun *run, int *taken) {
     {
         ArrPlan ap{run->pl.region_bits, 0, bins2, bins1, run->sp.chunks2, run->sp.sets ? run->sp.sets : run->sp.units1, (uint32_t) run->sp.cap1, bins1};
         if (seg_layout_bin()) { ap.seg_units = 1; ap.seg_cap = (uint32_t) run->sp.bincap1; }
+        if (run->sp.sets) ap.seg_lc = run->sp.lc1;
         KMU_TRY(seg_launch_level2(ctx, ap, run->sp.shared2 != 0, run->A, run->bnd, run->B, run->sp.cap2, run->ovf, run->leafcnt,
                                   leaf6_wanted(c, run->sp.shared2 != 0 && !seg_layout_bin())));
     }
@@ -2592,7 +2625,10 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     // (shared segments as in the read path: sets of level-1 streams with cursors, the leaves of a bin shared by level 2's units)
     const uint32_t sets = std::min(seg_sets_wanted(), chunks1), units2 = seg_l2_units_wanted();
     const uint32_t pieces = sets ? sets : chunks1;
-    const uint64_t cap1 = seg_cap_for((double) n / pieces / bins1), bincap1 = (uint64_t) pieces * cap1;
+    uint64_t cap1 = seg_cap_for((double) n / pieces / bins1);
+    const uint32_t lc1 = sets ? seg_chunk_log(cap1) : 0u; // (CHUNKED streams, SegOut)
+    if (lc1) cap1 = (cap1 + (1ull << lc1) - 1) >> lc1 << lc1;
+    const uint64_t bincap1 = (uint64_t) pieces * cap1;
     const uint64_t cap2 = seg_cap_for((double) n / bins1 / bins2);
     void *A, *B, *ovf, *bnd, *b0, *leafcnt, *cur1 = nullptr;
     KMU_TRY(dev_buf(ctx, "cnt.partA", (size_t) bins1 * bincap1 * 8 + (size_t) 2 * TILE_ITEMS * 8 + 64, &A));
@@ -2609,22 +2645,25 @@ static int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, ui
     KMU_TRY(scatter_attrs(ctx));
     if (recs) {
         ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1, 0u, 0u, 0u, sets};
+        ap.out_lc = lc1;
         const auto k1 = sets ? k_smer_scatter1<true> : k_smer_scatter1<false>;
         KernelTimer tm(ctx, "k_smer_scatter1");
         hipLaunchKernelGGL(k1, dim3(chunks1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, (const uint32_t *) recs, n_rec, c->p.kmer_size,
                            ap, (uint64_t *) A, cap1, (uint32_t *) ovf, (uint32_t *) cur1);
     } else {
         ArrPlan ap{pl.region_bits, pl.b2, bins1, 1u, chunks1, 0u, 0u, 0u, sets};
+        ap.out_lc = lc1;
         const auto k1 = sets ? k_arr_scatter<IT_KEY_TO_HASH, true, true> : k_arr_scatter<IT_KEY_TO_HASH, true, false>;
         KernelTimer tm(ctx, "k_arr_scatter");
         hipLaunchKernelGGL(k1, dim3(chunks1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, d_kmers, (const uint64_t *) b0, ap,
                            (const uint64_t *) nullptr, (const uint64_t *) nullptr, (uint64_t *) A, cap1, (uint32_t *) ovf, (uint32_t *) cur1);
     }
     if (sets)
-        hipLaunchKernelGGL(k_seg_tails, dim3(sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) cur1, (uint32_t) cap1, (uint64_t *) A);
+        hipLaunchKernelGGL(k_seg_tails, dim3(sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) cur1, (uint32_t) cap1, (uint64_t *) A, lc1, bins1);
     hipLaunchKernelGGL(k_fill_linear, dim3(8), dim3(256), 0, ctx->stream, (uint64_t *) bnd, (uint64_t) bins1 + 1, bincap1);
     {
         ArrPlan ap{pl.region_bits, 0, bins2, bins1, units2 ? units2 : 1u, pieces, (uint32_t) cap1, bins1, 0u};
+        ap.seg_lc = lc1;
         KMU_TRY(seg_launch_level2(ctx, ap, units2 != 0, A, bnd, B, cap2, ovf, leafcnt, leaf6_wanted(c, units2 != 0)));
     }
     KMU_HIP(ctx, hipGetLastError());
