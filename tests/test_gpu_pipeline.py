@@ -156,11 +156,13 @@ def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
 @pytest.mark.parametrize("switches", [{"KMU_COUNT_SEG_SHARED": "0", "KMU_COUNT_L2_SHARED": "0"},  # a segment per unit, a leaf set per unit (round 2's form)
                                       {"KMU_COUNT_SEG_SHARED": "0"}, {"KMU_COUNT_L2_SHARED": "0"},
                                       {"KMU_COUNT_SEG_SHARED": "3", "KMU_COUNT_L2_SHARED": "5"},  # set / unit counts that divide nothing
-                                      {"KMU_COUNT_L2_THREADS": "512"}, {"KMU_COUNT_SEG_ROUNDS": "0"}, {"KMU_PIPE_TAPER": "1"}],
+                                      {"KMU_COUNT_L2_THREADS": "512"}, {"KMU_COUNT_SEG_ROUNDS": "0"}, {"KMU_PIPE_TAPER": "1"},
+                                      {"KMU_COUNT_SEG_CHUNK": "4"}, {"KMU_COUNT_SEG_CHUNK": "6", "KMU_COUNT_SEG_SHARED": "3"}],  # level-1 streams in chunks
                          ids=lambda d: ",".join("%s=%s" % (k.replace("KMU_COUNT_", "").replace("KMU_", ""), v) for k, v in d.items()))
 def test_single_pass_partition_switches(ctx, oracle, monkeypatch, switches):
     """the A/B switches of the single-pass partition still give the oracle's table: private segments and
-    leaves, odd set / unit counts, level 2 on 512-thread workgroups, the host leg's level 1 in launches of finished units"""
+    leaves, odd set / unit counts, level 2 on 512-thread workgroups, the host leg's level 1 in launches of finished units, the
+    shared level-1 streams cut into chunks (small ones: the test's streams hold a few hundred items)"""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("_sw_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
