@@ -332,8 +332,8 @@ int kmu_sketch_merge_partials(kmu_ctx *ctx, const kmu_sketch_params *p, const ui
  * count_kmer_threaded_one_to_many :881-974, KmerCounterPool :424-565 --------------------------------- */
 /* KMU_COUNT_HINT_OCCURRENCES (kmu_count_params.flags): capacity_hint counts the k-mer OCCURRENCES the caller is going to add (what
  * a caller knows: the bases of its reads), not distinct k-mers.  The table is then allocated by the first add and sized from the
- * duplication that add measures on a key sample of its batch (one extra pass over those reads, once per counter): 1.5 x
- * occurrences / ratio slots.  The reference's filters are sized the same blind way -- capacity 3e9 / n whatever the reads,
+ * duplication that add measures on a key sample of its batch (one extra pass over those reads, once per counter): occurrences /
+ * ratio / 0.70 slots.  The reference's filters are sized the same blind way -- capacity 3e9 / n whatever the reads,
  * src/base/kmercount.rs:888-892 --; a table nine tenths empty costs nothing there, here every partitioned build writes the image.
  * Batches added later must fit the table the first one made (KMU_E_TABLE_FULL otherwise): give a distinct-k-mer hint where the
  * first batch is not representative.  Until that add kmu_count_table_info reports nslots = 0. */
@@ -355,9 +355,10 @@ int kmu_count_nb_occurrences(kmu_counter *c, uint64_t *out);
 /* k-mers whose in-table count has reached kmu_count_table_info_t.count_ceiling (a homopolymer in a deep read set): for them the sum
  * above and a raw export are lower bounds -- an inexact total then reads "saturated", not "k-mers lost" */
 int kmu_count_nb_saturated(kmu_counter *c, uint64_t *out);
-/* The table in HBM (no counterpart upstream: the reference's filters size themselves, kmercount.rs:70-123).  Slots are a power
- * of two >= 1.5 x capacity_hint.  Big tables (>= 2^23 slots with 8-bit counters, >= 2^29 with 16-bit ones) keep ONE 8-byte
- * word per slot -- the bits of the table hash that the slot's position does not already say, and a count field of
+/* The table in HBM (no counterpart upstream: the reference's filters size themselves, kmercount.rs:70-123).  Slots: whole regions
+ * of 4096 -- capacity_hint / 0.70 of them, NOT rounded to a power of two (round 5: the image of a big table is written by every
+ * partitioned build).  Big tables (more than 2048 regions whose index is worth >= 11 bits with 8-bit counters, >= 17 with 16-bit
+ * ones) keep ONE 8-byte word per slot -- the bits of the table hash that the slot's position does not already say, and a count field of
  * count_field_bits that stops a little below its maximum (every reader saturates at 2^counter_bits - 1 like
  * kmercount.rs:1615; kmu_count_nb_occurrences is exact while no k-mer occurs 2^count_field_bits - 1024 times) --, small ones
  * a 64-bit key + a 32-bit count. */
@@ -366,8 +367,7 @@ typedef struct kmu_count_table_info_t {
     uint64_t table_bytes;
     uint32_t bytes_per_slot;   /* 8 or 12 */
     uint32_t count_field_bits; /* width of the in-table count */
-    uint64_t count_ceiling;    /* the largest count a slot holds: 2^32 - 1 (12-byte slots), 2^count_field_bits - 1024 (8-byte slots;
-                                  1 024 less with regions of 8 192 slots).  Queries saturate at 2^counter_bits - 1 long before;
+    uint64_t count_ceiling;    /* the largest count a slot holds: 2^32 - 1 (12-byte slots), 2^count_field_bits - 1024 (8-byte slots).  Queries saturate at 2^counter_bits - 1 long before;
                                   kmu_count_nb_occurrences and the raw counts of kmu_count_export_part are exact while
                                   kmu_count_nb_saturated is 0 */
 } kmu_count_table_info_t;

@@ -29,8 +29,8 @@ __device__ __forceinline__ bool is_acgt(uint32_t c) {
 // 16 ASCII bytes -> one packed word, first base in bits 31..30 (the MSB-first order of Sequence::new,
 // src/base/sequence.rs:48-73, widened from a byte to a 32-bit word); `bad` gets one bit per invalid byte.
 // Four bytes at a time (the byte-by-byte form -- code2b / is_acgt above -- cost 11 instructions per base, a tenth of the level-1
-// kernel of the count and of the multiset kernels of the sketch; scripts/micro/swar_pack_check.c compares the two forms
-// over every byte value in every position):
+// kernel of the count and of the multiset kernels of the sketch; scripts/micro/swar_pack_check.c compares this form with the
+// byte-wise rule over every byte value in every position):
 // codes: x ^ (x >> 1) in every byte, then one multiplication moves the four 2-bit fields (bits 0, 8, 16, 24) to bits 30, 28, 26, 24.
 __device__ __forceinline__ uint32_t codes4_ascii(uint32_t c) {
     uint32_t x = (c >> 1) & 0x03030303u;
@@ -50,24 +50,7 @@ __device__ __forceinline__ uint32_t nonzero4(uint32_t d) {
     const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
     return (((nz >> 7) * 0x01020408u) >> 24) & 0xFu; // 2^3 + 2^10 + 2^17 + 2^24
 }
-#ifndef KMU_PACK_SWAR // (A/B builds: 0 = byte by byte)
-#define KMU_PACK_SWAR 1
-#endif
 __device__ __forceinline__ uint32_t pack16_ascii(uint4 v, uint32_t &bad) {
-#if !KMU_PACK_SWAR
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t o = 0;
-    bad = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t c = (w[i] >> (8 * j)) & 0xFFu;
-            o |= code2b(c) << (30 - 2 * (4 * i + j));
-            bad |= (is_acgt(c) ? 0u : 1u) << (4 * i + j);
-        }
-    return o;
-#endif
     const uint32_t out = (codes4_ascii(v.x) << 24) | (codes4_ascii(v.y) << 16) | (codes4_ascii(v.z) << 8) | codes4_ascii(v.w);
     const uint32_t d0 = diff4_ascii(v.x), d1 = diff4_ascii(v.y), d2 = diff4_ascii(v.z), d3 = diff4_ascii(v.w);
     bad = 0;
@@ -116,16 +99,9 @@ __device__ __forceinline__ StepWin step_win(uint32_t w0, uint32_t w1, uint32_t w
     s.kmask = ~0ull >> (64 - 2 * k);
     return s;
 }
-#ifndef KMU_STEP_ROLLRC // (A/B builds: 0 = the reverse complement of every k-mer from its value)
-#define KMU_STEP_ROLLRC 1
-#endif
 // the k-mer at base j of the window (0 .. 15; a constant after unrolling, or a lane's own offset) and its reverse complement
 __device__ __forceinline__ void step_val_rc(const StepWin &s, uint32_t j, uint64_t &val, uint64_t &rc) {
     val = ((s.hi << (2 * j)) | (((uint64_t) s.w2 << (2 * j)) >> 32)) >> s.sh;
-#if !KMU_STEP_ROLLRC
-    rc = revcomp_val(val, 32 - s.sh / 2);
-    return;
-#endif
     rc = (j ? (s.rlo >> (2 * j)) | ((uint64_t) s.rhi << (64 - 2 * j)) : s.rlo) & s.kmask;
 }
 __device__ __forceinline__ uint64_t step_canonical(const StepWin &s, uint32_t j) {

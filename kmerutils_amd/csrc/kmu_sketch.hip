@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 
 #include "kmu_ctx.hpp"
@@ -3306,8 +3307,8 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     // Chunk sizes: the first one is an eighth of the others (the kernels start after 1 ms of upload instead of 9).  The upload
     // (4.38 GB at ~55 GB/s = 80 ms) is what the first phase is bound by -- a chunk's sketch + level 1 take 8 ms, its upload 9.3 --
     // and what is left when the last byte has arrived is the last chunk's sketch + level 1, then level 2 and the region build,
-    // which need all of level 1.  Tapering the last chunks (1/2, 1/4, 1/8: KMU_PIPE_TAPER=1) shortens that tail by a chunk's
-    // sketch but pays for it in small launches: 149.1 / 149.2 ms against 146.2 / 144.0 without, same box (r03).  Off.
+    // which need all of level 1.  (Tapering the last chunks shortens that tail by a chunk's sketch but pays for it in small
+    // launches: 149.1 / 149.2 ms against 146.2 / 144.0 without, same box, r03: not kept.)
     // The bases cross PCIe packed (kmu_hostpack.hip): the host's cores pack chunk after chunk ahead of the upload, a quarter of the
     // bytes travels, a kernel on the upload stream restores the ASCII stream.  KMU_PIPE_PACK=0: the plain upload; small calls keep
     // it too.  Packed data arrive ~4x as fast as the kernels consume them, so the chunks may GROW: each three times its predecessor
@@ -3317,6 +3318,7 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     // 127.7 with the plain upload (KMU_PIPE_PACK=0); the device-resident step takes 104.5.
     bool packed_up = n_seq > 0 && total >= (32ull << 20);
     if (const char *e = getenv("KMU_PIPE_PACK")) packed_up = n_seq > 0 && atoi(e) != 0 && total >= 16;
+    if (kmer_is_aa(p->kmer_type)) packed_up = false; // (residues are no bases: the 2-bit packer would reject every byte outside ACGT)
     uint64_t growth = packed_up ? 3 : 1;
     if (const char *e = getenv("KMU_PIPE_GROWTH")) growth = (uint64_t) std::max(1, atoi(e));
     std::vector<uint64_t> plan; // chunk sizes, in order (a chunk ends at the first read boundary at or behind its target)
@@ -3329,18 +3331,11 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
             sz *= growth;
         }
     } else {
-        const char *te = getenv("KMU_PIPE_TAPER");
-        const bool taper = te && atoi(te) != 0 && total > 3 * chunk_bytes;
         const uint64_t first = std::min<uint64_t>(std::max<uint64_t>(chunk_bytes / 8, 1), total);
-        uint64_t tail_sum = 0;
-        std::vector<uint64_t> tail;
-        if (taper)
-            for (uint64_t d = 2; d <= 8; d *= 2) { tail.push_back(std::max<uint64_t>(chunk_bytes / d, 1)); tail_sum += tail.back(); }
         plan.push_back(first);
-        const uint64_t body = total - first - tail_sum; // (taper: total > 3 chunks, so the body is more than two)
+        const uint64_t body = total - first;
         const uint64_t n_body = std::max<uint64_t>(1, (body + chunk_bytes / 2) / chunk_bytes);
         for (uint64_t i = 0; i < n_body && body; i++) plan.push_back(body / n_body + 1);
-        for (uint64_t t : tail) plan.push_back(t);
     }
     {
         uint64_t target = 0;
@@ -3373,7 +3368,12 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
         int threads = 16;
         if (const char *e = getenv("KMU_PIPE_PACK_THREADS")) threads = std::max(1, atoi(e));
         threads = std::min<int>(threads, std::max(1u, std::thread::hardware_concurrency()));
-        packer.reset(new PackPipe(bases + off0, (uint8_t *) h_packed, total, threads));
+        try {
+            packer.reset(new PackPipe(bases + off0, (uint8_t *) h_packed, total, threads));
+        } catch (const std::exception &) { // (no threads to be had: the plain upload, same chunks)
+            packer.reset();
+            packed_up = false;
+        }
     }
     std::vector<hipEvent_t> ev_up(n_chunks), ev_sk(n_chunks);
     for (size_t c = 0; c < n_chunks; c++) {
@@ -3381,7 +3381,14 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
         KMU_HIP(ctx, hipEventCreateWithFlags(&ev_sk[c], hipEventDisableTiming));
     }
     int rc = KMU_OK;
-    auto upload = [&](size_t c) -> int {
+    // (the uploads of the packed form are enqueued by a thread of their own: nothing in here touches the context's error state --
+    //  a failure comes back as a code and a text, and the calling thread reports it)
+    auto upload = [&](size_t c, std::string *msg) -> int {
+        auto hip_ok = [&](hipError_t e, const char *what) {
+            if (e == hipSuccess) return true;
+            *msg = std::string(what) + ": " + hipGetErrorString(e);
+            return false;
+        };
         if (packed_up) {
             // in pieces of 64 M bases, each as soon as it is packed: the chunk's packing runs under its own upload.  Only copies go
             // on the upload stream: the kernel that restores the ASCII stream runs on the compute stream in front of the chunk's
@@ -3390,17 +3397,18 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
             const uint64_t p0 = pk_bounds[c], p1 = pk_bounds[c + 1], piece = 64ull << 20;
             for (uint64_t q0 = p0; q0 < p1; q0 += piece) {
                 const uint64_t q1 = std::min(p1, q0 + piece);
-                if (!packer->wait_prefix(q1)) return fail(ctx, KMU_E_NON_ACGT, "pattern not a code in alphabet_2b (non-ACGT byte in a sequence)");
-                KMU_HIP(ctx, hipMemcpyAsync((uint8_t *) d_packed + q0 / 4, (const uint8_t *) h_packed + q0 / 4, (size_t) ((q1 - q0 + 3) / 4), hipMemcpyHostToDevice,
-                                            ctx->pipe_h2d));
+                if (!packer->wait_prefix(q1)) {
+                    *msg = "pattern not a code in alphabet_2b (non-ACGT byte in a sequence)";
+                    return KMU_E_NON_ACGT;
+                }
+                if (!hip_ok(hipMemcpyAsync((uint8_t *) d_packed + q0 / 4, (const uint8_t *) h_packed + q0 / 4, (size_t) ((q1 - q0 + 3) / 4), hipMemcpyHostToDevice,
+                                           ctx->pipe_h2d), "upload of a packed chunk")) return KMU_E_HIP;
             }
-            KMU_HIP(ctx, hipEventRecord(ev_up[c], ctx->pipe_h2d));
-            return KMU_OK;
+            return hip_ok(hipEventRecord(ev_up[c], ctx->pipe_h2d), "hipEventRecord") ? KMU_OK : KMU_E_HIP;
         }
         const uint64_t b0 = h_off[cut[c]], b1 = h_off[cut[c + 1]];
-        KMU_HIP(ctx, hipMemcpyAsync((uint8_t *) d_b + b0, bases + off0 + b0, b1 - b0, hipMemcpyHostToDevice, ctx->pipe_h2d));
-        KMU_HIP(ctx, hipEventRecord(ev_up[c], ctx->pipe_h2d));
-        return KMU_OK;
+        if (!hip_ok(hipMemcpyAsync((uint8_t *) d_b + b0, bases + off0 + b0, b1 - b0, hipMemcpyHostToDevice, ctx->pipe_h2d), "upload of a chunk")) return KMU_E_HIP;
+        return hip_ok(hipEventRecord(ev_up[c], ctx->pipe_h2d), "hipEventRecord") ? KMU_OK : KMU_E_HIP;
     };
     DevSeqs all;
     all.bases = (const uint8_t *) d_b;
@@ -3421,26 +3429,37 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
     std::condition_variable up_cv;
     size_t up_done = 0; // uploads of chunks [0, up_done) are enqueued
     int up_rc = KMU_OK;
+    std::string up_msg, my_msg;
     std::thread uploader;
     if (packed_up && rc == KMU_OK) {
-        uploader = std::thread([&] {
-            (void) hipSetDevice(ctx->device);
-            for (size_t c = 0; c < n_chunks; c++) {
-                const int r = upload(c);
-                std::lock_guard<std::mutex> g(up_mu);
-                if (r != KMU_OK) up_rc = r;
-                up_done = r == KMU_OK ? c + 1 : n_chunks; // (a failure releases every waiter)
-                up_cv.notify_all();
-                if (r != KMU_OK) return;
-            }
-        });
-    } else if (n_chunks && rc == KMU_OK) rc = upload(0);
+        try {
+            uploader = std::thread([&] {
+                (void) hipSetDevice(ctx->device);
+                for (size_t c = 0; c < n_chunks; c++) {
+                    std::string m;
+                    const int r = upload(c, &m);
+                    std::lock_guard<std::mutex> g(up_mu);
+                    if (r != KMU_OK) { up_rc = r; up_msg = m; }
+                    up_done = r == KMU_OK ? c + 1 : n_chunks; // (a failure releases every waiter)
+                    up_cv.notify_all();
+                    if (r != KMU_OK) return;
+                }
+            });
+        } catch (const std::exception &) { rc = fail(ctx, KMU_E_HIP, "kmu_sketch_count: cannot start the upload thread"); }
+    } else if (n_chunks && rc == KMU_OK) {
+        rc = upload(0, &my_msg);
+        if (rc != KMU_OK) (void) fail(ctx, rc, "%s", my_msg.c_str());
+    }
     for (size_t c = 0; c < n_chunks && rc == KMU_OK; c++) {
         if (packed_up) {
             std::unique_lock<std::mutex> g(up_mu);
             up_cv.wait(g, [&] { return up_done > c; });
             rc = up_rc;
-        } else if (c + 1 < n_chunks) rc = upload(c + 1);
+            if (rc != KMU_OK) (void) fail(ctx, rc, "%s", up_msg.c_str());
+        } else if (c + 1 < n_chunks) {
+            rc = upload(c + 1, &my_msg);
+            if (rc != KMU_OK) (void) fail(ctx, rc, "%s", my_msg.c_str());
+        }
         if (rc != KMU_OK) break;
         DevSeqs ds = all;
         ds.offsets = all.offsets + cut[c];

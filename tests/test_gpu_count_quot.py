@@ -1,7 +1,7 @@
 """The count table's 8-byte-per-slot (quotient) format.
 
-Big tables take it by themselves (>= 2^23 slots with 8-bit counters, >= 2^29 with 16-bit ones: the bench's table, and every
-count test of the suite whose capacity hint is >= 5.6 M with 8-bit counters); here it is FORCED (`KMU_COUNT_FMT=quot` raises a
+Big tables take it by themselves (more than 2048 regions with 8-bit counters, >= 2^17 with 16-bit ones: the bench's table, and
+every count test of the suite whose capacity hint is >= 5.9 M with 8-bit counters); here it is FORCED (`KMU_COUNT_FMT=quot` raises a
 small table to the size the format starts at) on the count tests of the other files, so that every reader and writer of a slot
 -- direct insertion, the LDS region build on empty and on occupied tables, spill list, query, statistics, dump, export /
 merge / retain, eliminate-once, once-positions, the MERGE finalize with its tombstones -- runs on quotient slots against the
@@ -41,18 +41,20 @@ def quot(monkeypatch):
 
 
 def test_table_formats(ctx, monkeypatch):
-    """which table gets which format, and what kmu_count_table_info says"""
-    for bits, hint, want in ((8, 1 << 16, 12), (8, 5_600_000, 8), (16, 12_000_000, 12), (16, 400_000_000, 8)):
+    """which table gets which format, and what kmu_count_table_info says: whole regions of 4096 slots at a load of 0.70 at the
+    hint (not a power of two), 8-byte slots where the region index is worth the count field"""
+    for bits, hint, want in ((8, 1 << 16, 12), (8, 5_600_000, 12), (8, 6_000_000, 8), (16, 12_000_000, 12), (16, 400_000_000, 8)):
         c = ctx.counter(A.KMER64BIT, 31, bits, hint)
         ti = c.table_info()
         assert ti["bytes_per_slot"] == want and ti["table_bytes"] == ti["nslots"] * want, (bits, hint, ti)
-        assert ti["nslots"] >= 1.5 * hint and ti["nslots"] & (ti["nslots"] - 1) == 0
-        if want == 8:  # the count field: the region bits of the table; its ceiling is above what the counter reports
-            assert ti["count_field_bits"] == ti["nslots"].bit_length() - 1 - 12
+        assert hint / 0.70 <= ti["nslots"] <= hint / 0.70 * 1.11 + 4096 and ti["nslots"] % 4096 == 0, (bits, hint, ti)
+        if want == 8:  # the count field: the bits the region index saves; its ceiling is above what the counter reports
+            n_regions = ti["nslots"] // 4096
+            assert (1 << ti["count_field_bits"]) <= n_regions < (4 << ti["count_field_bits"])
             assert (1 << ti["count_field_bits"]) - 1024 >= (1 << bits) - 1
         c.close()
     monkeypatch.setenv("KMU_COUNT_FMT", "wide")
-    c = ctx.counter(A.KMER64BIT, 31, 8, 5_600_000)
+    c = ctx.counter(A.KMER64BIT, 31, 8, 6_000_000)
     assert c.table_info()["bytes_per_slot"] == 12
     c.close()
     monkeypatch.setenv("KMU_COUNT_FMT", "quot")
@@ -60,6 +62,89 @@ def test_table_formats(ctx, monkeypatch):
         c = ctx.counter(A.KMER64BIT, 31, bits, 1024)
         assert c.table_info() == {"nslots": 1 << lg, "table_bytes": 8 << lg, "bytes_per_slot": 8, "count_field_bits": lg - 12,
                                   "count_ceiling": (1 << (lg - 12)) - 1024}  # (2^11 - 1024 = 1 024 for the smallest quotient table)
+        c.close()
+
+
+# region maps that are not powers of two (round 5): (KMU_COUNT_REGIONS, what it exercises)
+REGION_MAPS = [("1", "one region"), ("3", "three regions, one level"), ("1021", "a prime, one level"), ("2048", "the largest single level"),
+               ("6144", "3 x 2^11: 128 groups of 48"), ("2052", "just over one level: 64 groups of 36"), ("33000", "256 groups of 132"),
+               ("66000", "512 groups of 132: 6-byte leaves"), ("300000", "1024 groups of 296: 9.9 GB")]
+
+
+@pytest.mark.parametrize("regions,what", REGION_MAPS, ids=[r for r, _ in REGION_MAPS])
+def test_region_maps_that_are_no_powers_of_two(ctx, oracle, monkeypatch, regions, what):
+    """KMU_COUNT_REGIONS forces the table's region count whatever the hint: every way into the table and out of it on maps of 1 .. 3e5
+    regions -- single-pass partition, exact levels, direct insertion, a second batch onto the occupied image, query, dump,
+    statistics, export_part / merge, saturation of the count field, the spill list of overflowing streams -- gives the oracle's
+    counts (kmercount.rs:241-287).  Tables of more than 2048 regions are quotient tables here (8-bit counters: w >= 11)."""
+    import torch
+    monkeypatch.setenv("KMU_COUNT_REGIONS", regions)
+    n_regions = int(regions)
+    # (a table of few regions only holds so much: reads for ~1/3 of its slots, at most ~1.2 M k-mers for the oracle)
+    n_kmers = min(1_200_000, max(600, n_regions * 4096 // 3))
+    bases, off = synth.ont_reads(max(2, n_kmers // 3000), n_kmers + 30 * max(2, n_kmers // 3000), 0xD7)
+    poly = np.frombuffer(b"A" * 2500, np.uint8)  # 2 470 x poly-A: beyond 2^11 - 1024 of the smallest quotient tables, and beyond 255
+    if n_regions > 1:
+        bases = np.concatenate([bases, poly])
+        off = np.concatenate([off, [off[-1] + poly.size]]).astype(np.uint64)
+    o = oracle.Counter(A.KMER64BIT, 31, 16, 1 << 22)
+    o.add_reads(bases, off)
+    wk, wc = o.dump(1)
+    want8 = np.minimum(wc, 255)
+    d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    for path, seg, pct in (("partitioned", "2", "100"), ("partitioned", "2", "60"), ("partitioned", "0", "100"), ("direct", "1", "100")):
+        monkeypatch.setenv("KMU_COUNT_PATH", path)
+        monkeypatch.setenv("KMU_COUNT_SEG", seg)
+        monkeypatch.setenv("KMU_COUNT_SEG_PCT", pct)
+        c = ctx.counter(A.KMER64BIT, 31, 8, 1024)
+        ti = c.table_info()
+        rounded = ti["nslots"] // 4096
+        assert n_regions <= rounded <= n_regions + 4 * 2048 and (n_regions <= 2048) == (rounded == n_regions), (ti, what)
+        assert ti["bytes_per_slot"] == (8 if n_regions > 2048 else 12), (ti, what)
+        c.add_reads(d_b, d_o)
+        gk, gc = c.dump(1)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, want8), (what, path, seg, pct)
+        assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())
+        c.add_reads(bases, off)  # a second batch: onto the occupied image (the build reads the regions first) / direct insertion
+        assert np.array_equal(c.query(wk), np.minimum(2 * wc.astype(np.int64), 255)), (what, path, seg, pct)
+        # export by key partition and merge into a table with ANOTHER map: the keys come back out of the quotients
+        monkeypatch.setenv("KMU_COUNT_REGIONS", "5000")  # (128 groups of 40)
+        c2 = ctx.counter(A.KMER64BIT, 31, 8, 1024)
+        monkeypatch.setenv("KMU_COUNT_REGIONS", regions)
+        tot = 0
+        for part in range(3):
+            kk, cc = c.export_part(part, 3)
+            tot += kk.size
+            c2.merge_entries(kk, cc)
+        assert tot == wk.size and np.array_equal(c2.dump(1)[0], wk)
+        ceil = ti["count_ceiling"] if ti["bytes_per_slot"] == 8 else 1 << 32
+        assert np.array_equal(c2.query(wk), np.minimum(np.minimum(2 * wc.astype(np.int64), ceil), 255))
+        c2.close()
+        c.close()
+    # explicit k-mers (the array path's levels) into the same map
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    monkeypatch.setenv("KMU_COUNT_SEG", "2")
+    c = ctx.counter(A.KMER64BIT, 31, 8, 1024)
+    c.add_kmers(torch.from_numpy(np.repeat(wk, 3).view(np.int64)).cuda())
+    gk, gc = c.dump(1)
+    assert np.array_equal(gk, wk) and (gc == 3).all()
+    c.close()
+
+
+def test_table_load_factor_switch(ctx, oracle, monkeypatch):
+    """KMU_COUNT_LOAD (per cent; A/B runs of the region build): the same counts from a table at a load of 0.85 at the hint"""
+    bases, off = synth.ont_reads(400, 1_500_000, 0xD8)
+    o = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 22)
+    o.add_reads(bases, off)
+    wk, wc = o.dump(1)
+    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
+    for load in ("85", "40"):
+        monkeypatch.setenv("KMU_COUNT_LOAD", load)
+        c = ctx.counter(A.KMER64BIT, 31, 8, wk.size)
+        assert abs(c.table_info()["nslots"] - wk.size / (int(load) / 100)) <= 4096
+        c.add_reads(bases, off)
+        gk, gc = c.dump(1)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
         c.close()
 
 
@@ -161,7 +246,7 @@ def test_counter_usage_sweep_quot(ctx, oracle, quot, seed):
 @pytest.mark.parametrize("genome,n_reads,what", [(4_000_000, 4000, "ratio ~1"), (150_000, 4000, "ratio ~3.6"), (10_000, 4000, "ratio ~50")])
 def test_table_sized_from_the_measured_duplication(oracle, genome, n_reads, what):
     """KMU_COUNT_HINT_OCCURRENCES: the hint counts k-mer occurrences, the first add measures occurrences / distinct on a key
-    sample of its batch and allocates 1.5 x occurrences / ratio slots (config 4's shard: 2^29 instead of 2^31).  The reference
+    sample of its batch and allocates occurrences / ratio / 0.70 slots (config 4's shard: a quarter of what the occurrences ask for).  The reference
     sizes its filters blind (capacity 3e9 / n, src/base/kmercount.rs:888-892); counts are the same whatever the size."""
     import torch
     from kmerutils_amd import lib
@@ -184,8 +269,8 @@ def test_table_sized_from_the_measured_duplication(oracle, genome, n_reads, what
         slots = c.table_info()["nslots"]
         gk, gc = c.dump(1)
         assert np.array_equal(gk, wk) and np.array_equal(gc, wc), what
-        # load <= 2/3, and no more than the power of two that 1.5 x 1.1 x distinct asks for
-        assert 1.5 * wk.size <= slots <= max(1024, 2 * 1.5 * 1.1 * wk.size + 2048), (what, slots, wk.size, nk / wk.size)
+        # a load of <= 0.70, and no more than the sample's error and the rounding to whole regions add
+        assert wk.size / 0.70 <= slots <= max(1024, (1.16 * wk.size + 1024) / 0.70 + 4096 * 260), (what, slots, wk.size, nk / wk.size)
         assert slots <= blind_slots
         # a second batch goes into the table the first one made
         c.add_reads(bases, off)
@@ -198,15 +283,16 @@ def test_table_sized_from_the_measured_duplication(oracle, genome, n_reads, what
     c.close()
     c = ctx.counter(A.KMER64BIT, 31, 16, 16, hint_occurrences=True)
     c.add_kmers(wk)
-    assert c.table_info()["nslots"] >= 1.5 * wk.size and c.nb_distinct() == wk.size
+    assert c.table_info()["nslots"] >= wk.size / 0.70 and c.nb_distinct() == wk.size
     c.close()
     ctx.close()
 
 
 @pytest.mark.parametrize("leaf6", ["1", "0"])
 def test_six_byte_leaf_items_of_big_tables(ctx, oracle, monkeypatch, leaf6):
-    """tables of >= 2^28 slots (the region index takes w >= 16 hash bits): level 2 of the partitioned build leaves 6 bytes per item
-    in two planes, the region build reads them back (KMU_COUNT_LEAF6; round 4).  A 2 GB table with a batch the oracle can count,
+    """tables whose region index is worth w >= 16 hash bits: level 2 of the partitioned build leaves the <= 48 bits a slot keeps of
+    an item (6 bytes, blocks of eight), the region build reads them back (KMU_COUNT_LEAF6; round 4).  A 2.3 GB table -- 512 groups of
+    140 regions: no power of two -- with a batch the oracle can count,
     through the reads path, the k-mer array path and the super-k-mer records path."""
     import torch
     monkeypatch.setenv("KMU_COUNT_LEAF6", leaf6)
@@ -219,10 +305,10 @@ def test_six_byte_leaf_items_of_big_tables(ctx, oracle, monkeypatch, leaf6):
     o = oracle.Counter(A.KMER64BIT, 31, 16, 1 << 22)
     o.add_reads(allb, alloff)
     wk, wc = o.dump(1)
-    hint = 170_000_000  # x 1.5 -> 2^28 slots of 8 bytes, w = 16
+    hint = 200_000_000  # / 0.70 -> 69 755 regions -> 512 groups of 140: slots of 8 bytes, w = 9 + 7 = 16
     c = ctx.counter(A.KMER64BIT, 31, 8, hint)
     ti = c.table_info()
-    assert ti["nslots"] == 1 << 28 and ti["bytes_per_slot"] == 8 and ti["count_field_bits"] == 16
+    assert ti["nslots"] == 512 * 140 * 4096 and ti["bytes_per_slot"] == 8 and ti["count_field_bits"] == 16
     c.add_reads(torch.from_numpy(allb).cuda(), torch.from_numpy(alloff.astype(np.int64)).cuda())
     gk, gc = c.dump(1)
     assert np.array_equal(gk, wk) and np.array_equal(gc, np.minimum(wc, 255))

@@ -1168,37 +1168,6 @@ def test_smallk_histogram_route(ctx, oracle, monkeypatch, split):
     assert np.array_equal(np.asarray(ctx.sketch(bases, off, p)), want)
 
 
-def test_count_compact_state(ctx, oracle, monkeypatch):
-    """KMU_COUNT_COMPACT=1: the partitioned build leaves every region as its (key, count) pairs + a per-region length; the
-    statistics come from the build, a second batch re-inserts the pairs, and whatever probes slots expands the table first"""
-    monkeypatch.setenv("KMU_COUNT_COMPACT", "1")
-    monkeypatch.setenv("KMU_COUNT_FMT", "wide")  # (the compact state belongs to the 12-byte slot format; this table would take the 8-byte one)
-    monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
-    bases, off = synth.ont_reads(500, 300_000, 0xC3)
-    half = 250
-    o = oracle.Counter(A.KMER64BIT, 31, 8, 1 << 20)
-    c = ctx.counter(A.KMER64BIT, 31, 8, int(off[-1]))
-    ctx.profile_reset()
-    ctx.profile_enable(True)
-    c.add_reads(bases[:int(off[half])], off[:half + 1])            # fresh -> compact
-    o.add_reads(bases[:int(off[half])], off[:half + 1])
-    assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())  # (cached by the build: no table pass)
-    assert "k_count_stats" not in ctx.profile_get()
-    c.add_reads(bases[int(off[half]):], off[half:] - off[half])    # compact -> compact: the pairs are re-inserted
-    o.add_reads(bases[int(off[half]):], off[half:] - off[half])
-    assert (c.nb_distinct(), c.nb_unique(), c.nb_occurrences()) == (o.nb_distinct(), o.nb_unique(), int(np.maximum(np.diff(off.astype(np.int64)) - 30, 0).sum()))
-    wk, wc = o.dump(1)
-    assert np.array_equal(c.query(wk), wc)                         # expands (k_part_expand), then probes
-    ctx.profile_enable(False)
-    assert "k_part_expand" in ctx.profile_get()
-    gk, gc = c.dump(1)
-    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
-    monkeypatch.setenv("KMU_COUNT_PATH", "direct")
-    c.add_kmers(wk[:100])                                          # direct insertion on the open image
-    assert np.array_equal(c.query(wk[:200]), np.minimum(wc[:200].astype(np.int64) + (np.arange(200) < 100), 255))
-    c.close()
-
-
 def test_count_single_pass_overflow_on_a_fresh_context(oracle, monkeypatch):
     """The fall-back of the single-pass partition on a context whose scratch buffers do not exist yet: the attempt
     allocates "cnt.partA" / "cnt.partB" in its own sizes, the exact levels that take over allocate them anew (a route that

@@ -144,32 +144,9 @@ def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
         assert ("k_part_hist1" in prof) == (pct == "60")  # the histogram passes only run when the exact route takes over
         # (overflowing segments: the chunked attempt, then the exact levels -- no second attempt on the same k-mers)
         assert prof["k_arr_scatter"][0] == (1 if pct == "100" else 2)
-        if os.environ.get("KMU_COUNT_SEG_ROUNDS") != "0":
-            assert prof["k_part_scatter1"][0] >= 5  # the level-1 units took their slices of the stream in rounds, chunk by chunk
+        assert prof["k_part_scatter1"][0] >= 5  # the level-1 units took their slices of the stream in rounds, chunk by chunk
         assert np.array_equal(got, want)
         assert (c.nb_distinct(), c.nb_unique()) == (o.nb_distinct(), o.nb_unique())
         gk, gc = c.dump(2)
         assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
         c.close()
-
-
-@pytest.mark.parametrize("switches", [{"KMU_COUNT_SEG_SHARED": "0", "KMU_COUNT_L2_SHARED": "0"},  # a segment per unit, a leaf set per unit (round 2's form)
-                                      {"KMU_COUNT_SEG_SHARED": "0"}, {"KMU_COUNT_L2_SHARED": "0"},
-                                      {"KMU_COUNT_SEG_SHARED": "3", "KMU_COUNT_L2_SHARED": "5"},  # set / unit counts that divide nothing
-                                      {"KMU_COUNT_L2_THREADS": "512"}, {"KMU_COUNT_SEG_ROUNDS": "0"}, {"KMU_PIPE_TAPER": "1"},
-                                      {"KMU_COUNT_SEG_CHUNK": "4"}, {"KMU_COUNT_SEG_CHUNK": "6", "KMU_COUNT_SEG_SHARED": "3"}],  # level-1 streams in chunks
-                         ids=lambda d: ",".join("%s=%s" % (k.replace("KMU_COUNT_", "").replace("KMU_", ""), v) for k, v in d.items()))
-def test_single_pass_partition_switches(ctx, oracle, monkeypatch, switches):
-    """the A/B switches of the single-pass partition still give the oracle's table: private segments and
-    leaves, odd set / unit counts, level 2 on 512-thread workgroups, the host leg's level 1 in launches of finished units, the
-    shared level-1 streams cut into chunks (small ones: the test's streams hold a few hundred items)"""
-    import importlib.util
-    import os
-    spec = importlib.util.spec_from_file_location("_sw_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_parity.py"))
-    parity = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(parity)
-    for k, v in switches.items():
-        monkeypatch.setenv(k, v)
-    parity.test_count_single_pass_partition(ctx, oracle, monkeypatch, "100")
-    parity.test_count_single_pass_spill_list(ctx, oracle, monkeypatch)
-    test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch)
