@@ -1039,8 +1039,8 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
                 if (have) {
                     if (probe(hw, off)) have = false;
                     else {
-                        off = (off + 1) & t.rmask;
-                        if (++guard >= R) { full = 1; have = false; }
+                        off = (off + ++guard) & t.rmask; // (the triangular sequence of kmu_count_table.h)
+                        if (guard >= R) { full = 1; have = false; }
                     }
                 }
             }
@@ -1052,8 +1052,8 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
             uint32_t off, n = 0;
             locate(item, hw, off);
             while (!probe(hw, off)) {
-                off = (off + 1) & t.rmask;
-                if (++n >= R) { full = 1; break; }
+                off = (off + ++n) & t.rmask;
+                if (n >= R) { full = 1; break; }
             }
         }
         lds_barrier();
@@ -1106,7 +1106,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
                     done = true;
                     break;
                 }
-                off = (off + 1) & t.rmask;
+                off = (off + probes + 1u) & t.rmask;
             }
             if (!done) full = 1;
         };

@@ -5,8 +5,12 @@
 // Reference (src/base/kmercount.rs:241-277): a cuckoo filter holds k-mers seen once, a counting Bloom filter the counts >= 2;
 // both are randomised per process, so the observable contract is "exact multiplicity of the canonical k-mer, reported
 // saturated at 2^bits - 1" (plus ~3 % false positives the reference itself treats as noise).  Here: one exact table in HBM,
-// cut into REGIONS of 4096 slots; a key lives in ONE region, named by its table hash, and is probed linearly inside it
-// (wrapping at the region end), so a region is an independent little hash table that fits LDS.
+// cut into REGIONS of 4096 slots; a key lives in ONE region, named by its table hash, and is probed inside it along the
+// TRIANGULAR sequence home, +1, +3, +6, ... (mod the region size: a permutation of a power of two of slots), so a region is an
+// independent little hash table that fits LDS.  (Round 5: linear probing until then.  A region build is paced by the longest
+// probe chain among a wave's lanes, and at the load of 0.66 the bench's table now has the clusters of linear probing make that
+// 41 trips per region against 25 for the triangular sequence -- 14 / 11 at the old load of 0.44; scripts/sim_region_build.py.
+// The first two steps of a chain stay inside the home slot's 128-byte line in HBM.)
 //
 // Which region (round 5: the number of regions is no longer a power of two).  h = khash(key), a bijection of 64 bits:
 //   h = [ g : b1 bits ][ x : 32 bits ][ low : 32 - b1 bits ]
@@ -204,7 +208,7 @@ __device__ __forceinline__ bool count_insert_h(const CountTable &t, uint64_t v, 
                     cur = prev;
                 }
             }
-            off = (off + 1) & t.rmask;
+            off = (off + probes + 1u) & t.rmask;
         }
         return false;
     }
@@ -219,7 +223,7 @@ __device__ __forceinline__ bool count_insert_h(const CountTable &t, uint64_t v, 
             atomicAdd(&t.counts[idx], add);
             return true;
         }
-        off = (off + 1) & t.rmask;
+        off = (off + probes + 1u) & t.rmask;
     }
     return false;
 }
@@ -240,7 +244,7 @@ __device__ __forceinline__ uint32_t count_lookup(const CountTable &t, uint64_t v
                 return (uint32_t) (f < lim ? f : lim);
             }
         } else if (cur == v) return t.counts[idx];
-        off = (off + 1) & t.rmask;
+        off = (off + probes + 1u) & t.rmask;
     }
     return 0;
 }

@@ -82,7 +82,8 @@ def test_region_maps_that_are_no_powers_of_two(ctx, oracle, monkeypatch, regions
     n_regions = int(regions)
     # (a table of few regions only holds so much: reads for ~1/3 of its slots, at most ~1.2 M k-mers for the oracle)
     n_kmers = min(1_200_000, max(600, n_regions * 4096 // 3))
-    bases, off = synth.ont_reads(max(2, n_kmers // 3000), n_kmers + 30 * max(2, n_kmers // 3000), 0xD7)
+    n_reads = max(2, n_kmers // 3000)
+    bases, off = synth.genome_reads(n_reads, np.full(n_reads, n_kmers // n_reads + 30, np.int64), 4_000_000, 0xD7, sub=0.01)
     poly = np.frombuffer(b"A" * 2500, np.uint8)  # 2 470 x poly-A: beyond 2^11 - 1024 of the smallest quotient tables, and beyond 255
     if n_regions > 1:
         bases = np.concatenate([bases, poly])
