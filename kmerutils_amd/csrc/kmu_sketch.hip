@@ -85,9 +85,6 @@ struct SketchArgs {
     uint64_t idx_zone;    // rand 0.8 Uniform<usize>(0, m): accept while lo <= zone
     uint32_t ablate;      // diagnostics only (KMU_PMH_ABLATE): 1 skip pass B math, 2 skip table insert, 4 skip hashing
     Exp01 e01;
-    // k <= 8 (k_sketch_smallk<EMIT>): the first point of every possible key, made once per call (k_pts_table): x = the key's Exp01
-    // sample, y = its slot, w = the key itself; the lists then hold the k-mer VALUE (the index of this table) instead of the key
-    const uint4 *pts_tab;
     void *sig_out;
     uint32_t *queue; // atomic read counter
     uint32_t *err;
@@ -107,12 +104,6 @@ static constexpr uint32_t DEF_CAP = 1u << 20;       // keys of later partitions 
 static constexpr uint32_t DEF_PARTS = 32;           //   one sub-list of DEF_CAP / DEF_PARTS keys per later partition
 static constexpr uint32_t DEF_SEG = DEF_CAP / DEF_PARTS;
 #define ABL(bits) (KMU_DIAG && (a.ablate & (bits)))
-#ifndef KMU_UQ_FASTKEY // (A/B builds: 0 = every key through apply_fhash)
-#define KMU_UQ_FASTKEY 1
-#endif
-#ifndef KMU_PTS_UNITW // (A/B builds: 0 = the cheap test of k_pmh_points looks 1 / w up for every chunk)
-#define KMU_PTS_UNITW 1
-#endif
 
 static constexpr uint32_t LONG_SEQ_KMERS = 1u << 18; // longer sequences take the global partitioned route (kmu_sketch)
 static constexpr int BUCKET_BITS = 12;               // counting-sort buckets
@@ -396,7 +387,7 @@ __global__ void __launch_bounds__(1024) k_sketch_pmh3a(SketchArgs a) {
     const KmerCfg cfg = a.cfg;
     const bool sig32 = a.sig_bytes == 4;
     // the headline's closure (canonical Kmer64bit through int64_hash) without the walk through apply_fhash's cases per key (see k_multiset_uq)
-    const bool fast64 = KMU_UQ_FASTKEY && !AA && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT;
+    const bool fast64 = !AA && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t cap = a.cap;
     uint64_t *dk = reinterpret_cast<uint64_t *>(smem); // dense keys of the current pass, grouped by bucket
@@ -1081,19 +1072,7 @@ __device__ __forceinline__ uint64_t wg4_qmax(const uint64_t *arrays, size_t wave
 
 // one read's points.  WG = false: by this wave alone (chunks 0, 64, 128, ...).  WG = true: by the four waves of the workgroup,
 // wave w on chunks 64 w, 64 w + 256, ... with slot arrays of its own, the row = per-slot minimum of the four.
-// a queued first point of the table form: x = the sample's bits, slot from the table
-__device__ __forceinline__ void pts_tab_point(uint64_t *hmin, uint64_t *sig, const uint64_t *qmax_sh, bool have, uint64_t key, uint32_t w,
-                                              uint64_t xbits, uint64_t slot, const double *winv_lut) {
-    const uint64_t qb = __hip_atomic_load(qmax_sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (have) {
-        const double h = winv_of(winv_lut, w) * __longlong_as_double((long long) xbits);
-        if (h < __longlong_as_double((long long) qb)) slot_update_wave(hmin, sig, (uint32_t) slot, h, key); // (q_max may have fallen since the key was queued)
-    }
-}
-// TAB8 (k <= 8): a list entry is the k-mer value; the first point of a key -- its Exp01 sample, whichever branch of the sampler made
-// it, and its slot -- comes out of a.pts_tab: no generator runs in pass 1, and the test against q_max also prunes the 42 % of the
-// keys whose first draw falls into the rejection branch (their sample is known here; from the seed it is not before the full state is).
-template <bool SIG32, bool WG, bool TAB8 = false>
+template <bool SIG32, bool WG>
 __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, uint8_t *smem, size_t wave_words, const double *winv_lut) {
     const int wave = threadIdx.x >> 6, lane = lane_id();
     constexpr bool sig32 = SIG32;
@@ -1139,24 +1118,13 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
             qb = WG ? wg4_qmax(arrays, wave_words, a.m) : wave_qmax(hmin, a.m);
             if (lane == 0) *qmax_sh = qb;
         }
-        uint64_t s0 = 0, s3 = 0, qkey = key;
-        bool pass;
-        if (TAB8) { // s0: the bits of the sample, s3: the slot
-            pass = false;
-            if (have) {
-                const uint4 e = a.pts_tab[(uint32_t) key];
-                s0 = ((uint64_t) e.y << 32) | e.x;
-                s3 = e.z;
-                qkey = e.w;
-                pass = winv_of(winv_lut, w) * __longlong_as_double((long long) s0) < __longlong_as_double((long long) qb);
-            }
-        } else
-            pass = KMU_PTS_UNITW && c + 64u <= n_u ? have && pmh3a_first_point_may_matter<true>(a, sig32, qb, key, w, winv_lut, s0, s3) // (uniform)
-                                                 : have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
+        uint64_t s0 = 0, s3 = 0;
+        const bool pass = c + 64u <= n_u ? have && pmh3a_first_point_may_matter<true>(a, sig32, qb, key, w, winv_lut, s0, s3) // (uniform)
+                                         : have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
         const uint64_t pm = __ballot(pass);
         if (pass) {
             const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));
-            qk[pos] = qkey;
+            qk[pos] = key;
             qw[pos] = w;
             qs0[pos] = s0;
             qs3[pos] = s3;
@@ -1164,16 +1132,12 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
         qn += (uint32_t) __popcll(pm);
         if (qn >= 64u) { // the newest 64
             qn -= 64u;
-            if (TAB8) pts_tab_point(hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane], qs3[qn + lane], winv_lut);
-            else
             pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane], qs3[qn + lane],
                                    winv_lut);
         }
     }
     if (qn) {
         const bool have = (uint32_t) lane < qn;
-        if (TAB8) pts_tab_point(hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u, have ? qs0[lane] : 0ull, have ? qs3[lane] : 0ull, winv_lut);
-        else
         pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u, have ? qs0[lane] : 0ull,
                                have ? qs3[lane] : 0ull, winv_lut);
     }
@@ -1200,7 +1164,7 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
                 winv = winv_of(winv_lut, w);
                 alive = w != 0u && winv < __longlong_as_double((long long) qb);
             }
-            if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, !alive ? 0ull : TAB8 ? (uint64_t) a.pts_tab[(uint32_t) a.lst_keys[base + i]].w : a.lst_keys[base + i], winv);
+            if (__any(alive)) pmh3a_more_points<true>(a, sig32, hmin, sig, qb, alive, alive ? a.lst_keys[base + i] : 0ull, winv);
         }
     }
     // ---- signature row: arg-min key per slot, initobj (0) for an empty multiset ----
@@ -1227,7 +1191,7 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
     }
 }
 
-template <bool SIG32, bool TAB8 = false>
+template <bool SIG32>
 __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = lane_id();
@@ -1242,7 +1206,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
     //  as single waves' reads, and the workgroup form costs more per key -- three barriers per read, q_max over four arrays)
     uint32_t n_long = a.pts_long ? a.pts_long[0] : 0u;
     if (n_long > 4u * gridDim.x) n_long = 0u;
-    for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) pts_one_read<SIG32, true, TAB8>(a, a.pts_long[2 + li], smem, wave_words, winv_lut);
+    for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) pts_one_read<SIG32, true>(a, a.pts_long[2 + li], smem, wave_words, winv_lut);
     uint32_t q_next = 0, q_end = 0; // lane 0: reads are taken QCHUNK at a time
     for (;;) {
         uint32_t r = 0;
@@ -1256,7 +1220,7 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
         r = uniform_u32(r);
         if (r >= a.n_seq) break;
         if (n_long && uniform_u32(a.lst_n[r]) > a.pts_long_t) continue; // (taken by a workgroup above)
-        pts_one_read<SIG32, false, TAB8>(a, r, smem, wave_words, winv_lut);
+        pts_one_read<SIG32, false>(a, r, smem, wave_words, winv_lut);
     }
 }
 
@@ -1275,48 +1239,29 @@ __global__ void __launch_bounds__(256) k_pmh_points(SketchArgs a) {
 static constexpr int UQ_KREG = 20;
 // The two shapes' bitmap sizes (log2 bits) and collected-key capacities.  Round 4: bitmaps twice as large (nearly every key of a
 // collision group of an ONT read is a false positive of the bitmap: 9 % of the keys at 2^16 bits, 4.5 % at 2^17), collected-key
-// arrays half as large to pay for them in LDS: the sketch unit 50.3 -> 49.6 ms, same rows (A/B builds: -DKMU_UQ1_BM=16
-// -DKMU_UQ1_COLL=2048 -DKMU_UQ2_BM=17 -DKMU_UQ2_COLL=4096 is round 3's form).
-#ifndef KMU_UQ_BMIX // (A/B builds: 0 = round 3's bitmap index)
-#define KMU_UQ_BMIX 1
-#endif
-#ifndef KMU_UQ1_BM
-#define KMU_UQ1_BM 17
-#define KMU_UQ1_COLL 1024
-#endif
-#ifndef KMU_UQ2_BM
-#define KMU_UQ2_BM 18
-#define KMU_UQ2_COLL 2048
-#endif
+// arrays half as large to pay for them in LDS: the sketch unit 50.3 -> 49.6 ms, same rows.
+static constexpr uint32_t UQ1_BM = 17, UQ1_COLL = 1024, UQ2_BM = 18, UQ2_COLL = 2048;
 // every vector-memory request of this wave has completed (the chunks of global_load_lds have landed in LDS)
 __device__ __forceinline__ void vm_wait_lds_loads() {
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0); expcnt / lgkmcnt untouched
     asm volatile("" ::: "memory");
 }
-// TAB: the keys of the collision groups are collected as before, but then they are not counting-sorted (rank / scan / place /
-// walk: five barriers, a fixed cost per read for a few hundred keys) -- they meet in an open-addressing table of 2 x UQ_COLL
-// slots in LDS (ds_cmpst_rtn_b64 claims a slot, ds_add counts: the table of k_multiset_short, workgroup-wide), at most
-// UQ_COLL / UQ_THREADS inserts per thread; after ONE barrier the occupied slots leave as (key, weight) pairs and the table is
-// free again, and the list holds no zero-weight repeats.  (Round 3 inserted straight from the registers inside the sort-out
-// loop -- twenty probe loops per wave, each as long as its unluckiest lane's: 18.8 against 13.0 ms per launch.  This form, round 4:
-// 10.13 against 10.10 ms per launch -- the same as the counting sort: with two workgroups per CU the barriers of one hide under the
-// other's key phase, the kernel is bound by the instructions of the key and sort-out phases.  Opt-in: KMU_PMH_UQTAB=1.)
-template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, bool TAB = false>
+// (Round 4, measured and not kept: the collision groups through an open-addressing table in LDS instead of the counting sort --
+// 10.13 against 10.10 ms per launch: with two workgroups per CU the barriers of one hide under the other's key phase.)
+template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL>
 struct UqShape {
     static constexpr uint32_t KEYS = (uint32_t) UQ_THREADS * UQ_KREG;
     static constexpr uint32_t BM_WORDS = (1u << UQ_BM_BITS) / 32;
     static constexpr uint32_t BUCKETS = 2u * UQ_THREADS; // of the collision groups' counting sort: two per thread
     static constexpr uint32_t TILE = (KEYS + 32 + 15) / 16 + 3; // staged code words of a read
-    static constexpr uint32_t TABS = 2u * UQ_COLL;         // slots of the collision table (TAB)
     static constexpr uint32_t RAW_WAVES = (TILE + 63) / 64; // landing area of the next read's 16-byte chunks: 1 KiB per wave instruction
-    static constexpr size_t LDS = (TAB ? (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 8 + (size_t) TABS * 12 + ((size_t) TILE + 16) * 4 + 64
-                                       : (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64) +
+    static constexpr size_t LDS = (size_t) BM_WORDS * 8 + (size_t) UQ_COLL * 20 + ((size_t) BUCKETS + 1 + TILE + UQ_THREADS / 64 + 8 + 8) * 4 + 64 +
                                   (size_t) RAW_WAVES * 1024 + 16;
 };
 
-template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, int MINW, bool TAB = false>
+template <int UQ_THREADS, uint32_t UQ_BM_BITS, uint32_t UQ_COLL, int MINW>
 __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) {
-    typedef UqShape<UQ_THREADS, UQ_BM_BITS, UQ_COLL, TAB> SH;
+    typedef UqShape<UQ_THREADS, UQ_BM_BITS, UQ_COLL> SH;
     constexpr uint32_t UQ_KEYS = SH::KEYS, UQ_BM_WORDS = SH::BM_WORDS, UQ_BUCKETS = SH::BUCKETS, UQ_TILE = SH::TILE;
     static_assert((UQ_BM_WORDS / 4) % (uint32_t) UQ_THREADS == 0, "whole 16-byte stores per thread wipe a bitmap");
     static_assert(UQ_COLL % UQ_THREADS == 0 && UQ_COLL / UQ_THREADS <= 4, "collected keys per thread");
@@ -1327,26 +1272,16 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     uint64_t *dk = ck + UQ_COLL;                                     // ... grouped by bucket
     uint32_t *dw = reinterpret_cast<uint32_t *>(dk + UQ_COLL);
     uint32_t *bst = dw + UQ_COLL;          // UQ_BUCKETS + 1
-    // TAB: the collision table in place of dk / dw / bst / wtot
-    constexpr uint32_t UQ_TABS = SH::TABS;
-    uint64_t *tk = ck + UQ_COLL;                               // UQ_TABS keys, all-ones = free
-    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + UQ_TABS); // their multiplicities
-    uint32_t *words = TAB ? tc + UQ_TABS : bst + UQ_BUCKETS + 1; // UQ_TILE
-    uint32_t *wtot = words + UQ_TILE;       // one per wave (not TAB)
-    // [0] unique entries, [1] keys in collision groups, [2] (TAB) occurrences of the all-ones key among them, [3] (TAB) table
-    // overflow, [4] first read, [5] the read after the current one, [6] (TAB) pairs that left the table
-    uint32_t *misc = TAB ? words + UQ_TILE : wtot + UQ_THREADS / 64;
+    uint32_t *words = bst + UQ_BUCKETS + 1; // UQ_TILE
+    uint32_t *wtot = words + UQ_TILE;       // one per wave
+    // [0] unique entries, [1] keys in collision groups, [4] first read, [5] the read after the current one
+    uint32_t *misc = wtot + UQ_THREADS / 64;
     // the next read's chunks land here straight from HBM (global_load_lds: no register is held while they are in flight):
     // chunk t of the read at byte 16 t, i.e. lane l of the wave instruction that fetches chunks 64 j .. 64 j + 63 at 1024 j + 16 l
     uint8_t *rawp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(misc + 16) + 15) & ~(uintptr_t) 15);
     const KmerCfg cfg = a.cfg;
     const int k = cfg.k, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    if (TAB) {
-        for (uint32_t i = tid; i < UQ_TABS; i += UQ_THREADS) { tk[i] = ~0ull; tc[i] = 0u; }
-        if (tid == 0) { misc[2] = 0; misc[3] = 0; misc[6] = 0; }
-    } else {
-        for (uint32_t i = tid; i < UQ_BUCKETS + 1; i += UQ_THREADS) bst[i] = 0;
-    }
+    for (uint32_t i = tid; i < UQ_BUCKETS + 1; i += UQ_THREADS) bst[i] = 0;
     uint32_t q_next = 0, q_end = 0, q_pend = 0;
     bool q_pending = false;
     auto take = [&]() -> uint32_t { // thread 0: the next queue entry (the queue is asked a read before the chunk runs out)
@@ -1470,10 +1405,6 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
         // (one multiplication of the folded key, by another constant than mix32's: the keys that share a bit of the bitmap must not
         //  share a bucket of the collision groups' sort; round 3's form ran the key through mix32 first: 8 instructions, twice per key)
         auto bm_index = [&](uint64_t key) -> uint32_t {
-#if KMU_UQ_BMIX == 0
-            const uint32_t h = mix32(key);
-            return ((h ^ (h >> 13)) * 0x85EBCA6Bu) >> (32 - UQ_BM_BITS);
-#endif
             return (((uint32_t) key ^ (uint32_t) (key >> 32)) * 0x85EBCA6Bu) >> (32 - UQ_BM_BITS);
         };
         bool over = false; // uniform: too many keys in collision groups
@@ -1519,7 +1450,7 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                         if (bit[u]) atomicOr(&bmB[rbi[q0 + u] >> 5], bit[u]);
                 }
             };
-            if (KMU_UQ_FASTKEY && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT) key_phase(std::true_type{});
+            if (cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT) key_phase(std::true_type{});
             else key_phase(std::false_type{});
             phase(2); // keys, closure, bitmaps
             lds_barrier();
@@ -1594,65 +1525,7 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             phase(6);
             const uint32_t n_u = uniform_u32(misc[0]), n_c = uniform_u32(misc[1]);
             over = n_c > UQ_COLL;
-            if (TAB) {
-                if (!over && n_c) { // the collected keys meet in the table
-#pragma unroll
-                    for (int j = 0; j < (int) (UQ_COLL / UQ_THREADS); j++) {
-                        const uint32_t i = (uint32_t) j * UQ_THREADS + tid;
-                        if (i < n_c) {
-                            const uint64_t key = ck[i];
-                            if (key == ~0ull) atomicAdd(&misc[2], 1u); // (the value that marks a free slot: counted aside)
-                            else {
-                                uint32_t sl = mix32(key) >> (32 - (31 - __builtin_clz(UQ_TABS)));
-                                bool done = false;
-                                for (int pr = 0; pr < 64; pr++) {
-                                    const unsigned long long old = atomicCAS((unsigned long long *) &tk[sl], ~0ull, (unsigned long long) key);
-                                    if (old == ~0ull || old == key) { atomicAdd(&tc[sl], 1u); done = true; break; }
-                                    sl = (sl + 1u) & (UQ_TABS - 1u);
-                                }
-                                if (!done) misc[3] = 1u; // (a crowded table: the read goes to the general kernel)
-                            }
-                        }
-                    }
-                    lds_barrier();
-                    over = uniform_u32(misc[3]) != 0u;
-                }
-                if (n_c && n_c <= UQ_COLL) { // the occupied slots leave as (key, weight) pairs behind the unique entries; the table is wiped
-                    constexpr int PER = (int) (UQ_TABS / UQ_THREADS);
-                    uint64_t key[PER];
-                    uint32_t cnt[PER];
-                    uint64_t om[PER];
-                    uint32_t tot = 0;
-#pragma unroll
-                    for (int j = 0; j < PER; j++) key[j] = tk[(uint32_t) j * UQ_THREADS + tid];
-#pragma unroll
-                    for (int j = 0; j < PER; j++) {
-                        const bool occ = key[j] != ~0ull;
-                        cnt[j] = 0;
-                        if (occ) {
-                            cnt[j] = tc[(uint32_t) j * UQ_THREADS + tid];
-                            tk[(uint32_t) j * UQ_THREADS + tid] = ~0ull;
-                            tc[(uint32_t) j * UQ_THREADS + tid] = 0u;
-                        }
-                        om[j] = __ballot(occ);
-                        tot += (uint32_t) __popcll(om[j]);
-                    }
-                    uint32_t ob = 0; // one atomic per wave
-                    if (lane == 0 && tot) ob = atomicAdd(&misc[6], tot);
-                    ob = bcast_u32(ob, 0);
-                    if (!over) {
-#pragma unroll
-                        for (int j = 0; j < PER; j++) {
-                            if (key[j] != ~0ull) {
-                                const uint64_t at = lb + n_u + ob + (uint32_t) __popcll(om[j] & ((1ull << lane) - 1ull));
-                                a.lst_keys[at] = key[j];
-                                a.lst_w[at] = cnt[j];
-                            }
-                            ob += (uint32_t) __popcll(om[j]);
-                        }
-                    }
-                }
-            } else if (!over && n_c) {
+            if (!over && n_c) {
                 // ---- the collision groups: counting sort on 10 hash bits, equal keys hand their weight to the first ----
                 uint64_t key[UQ_COLL / UQ_THREADS];
                 uint32_t rb[UQ_COLL / UQ_THREADS];
@@ -1708,27 +1581,15 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
                 bst[2 * tid] = 0;
                 bst[2 * tid + 1] = 0;
             }
-            if (!TAB && tid == 0 && !over) { a.lst_n[rs] = n_u + n_c; a.lst_nu[rs] = n_u; }
+            if (tid == 0 && !over) { a.lst_n[rs] = n_u + n_c; a.lst_nu[rs] = n_u; }
         }
         phase(7); // collision groups
-        if (TAB) lds_barrier(); // (the pairs of the table are out and counted)
         if (tid == 0) {
             if (nk == 0) a.lst_n[rs] = 0u; // no k-mer: k_pmh_points writes the row of an empty multiset
             else if (!mine || over) {       // the next kernel's: longer than the registers, or too repetitive
                 a.lst_n[rs] = 0u;
                 a.redo_list[atomicAdd(a.queue + 56, 1u)] = rs;
-            } else if (TAB) {
-                const uint32_t n_u = misc[0];
-                uint32_t n_t = misc[6];
-                if (misc[2]) { // the all-ones key, met more than once
-                    a.lst_keys[lb + n_u + n_t] = ~0ull;
-                    a.lst_w[lb + n_u + n_t] = misc[2];
-                    n_t++;
-                }
-                a.lst_n[rs] = n_u + n_t;
-                a.lst_nu[rs] = n_u;
             }
-            if (TAB) { misc[2] = 0; misc[3] = 0; misc[6] = 0; }
         }
         if (bad) atomicOr(a.err, DERR_NON_ACGT);
         pf_valid = nv_mine;
@@ -1743,7 +1604,7 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
             nv.len = uniform_u64(nn_o1) - nv.begin;
             nv_mine = fits(nv);
         }
-        if (!TAB) lds_barrier();
+        lds_barrier();
         phase(8); // end of the read's turn
     }
     if (ph_on)
@@ -1769,7 +1630,7 @@ __global__ void __launch_bounds__(256) k_multiset_short(SketchArgs a) {
     uint32_t *words = tc + SHORT_SLOTS;
     const KmerCfg cfg = a.cfg;
     const int k = cfg.k;
-    const bool fast64 = KMU_UQ_FASTKEY && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT; // (see k_multiset_uq)
+    const bool fast64 = cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER64BIT; // (see k_multiset_uq)
     for (uint32_t t = (uint32_t) lane; t < SHORT_SLOTS; t += 64u) { tk[t] = ~0ull; tc[t] = 0u; }
     const uint64_t off_first = uniform_u64(a.offsets[0]);
     const uint64_t total = a.total_bytes ? a.total_bytes : uniform_u64(a.offsets[a.n_seq]);
@@ -1988,20 +1849,6 @@ __device__ __forceinline__ uint32_t revcomp32(uint32_t val, int k) {
     return rc >> (32 - 2 * k);
 }
 
-// the first point of every k-mer value of k <= 8 bases (a.pts_tab; SketchArgs): what pmh3a_first_point draws for the key of that value
-__global__ void __launch_bounds__(256) k_pts_table(SketchArgs a, uint4 *tab, uint32_t n) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const bool sig32 = a.sig_bytes == 4;
-    const uint64_t key = apply_fhash(a.cfg, (uint64_t) idx, (uint64_t) revcomp32(idx, a.cfg.k));
-    Xoshiro rng;
-    rng.seed(hasher_finish(KMU_HASHER_NOHASH, key, sig32));
-    const double x = exp01_sample(a.e01, rng);
-    const uint32_t slot = draw_slot(a, rng);
-    const uint64_t xb = (uint64_t) __double_as_longlong(x);
-    tab[idx] = make_uint4((uint32_t) xb, (uint32_t) (xb >> 32), slot, (uint32_t) key);
-}
-
 // EMIT: the (key, weight) pairs of the distinct k-mers leave for k_pmh_points (one wave per read, 95 % VALU busy) instead of
 // being turned into points here by a workgroup that has to meet at barriers.
 template <bool EMIT>
@@ -2053,7 +1900,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
     };
     // the key of histogram index `idx` (a k-mer value): the closure on that k-mer
     // (the README's closure -- canonical Kmer32bit through int32_hash, datasketcher.rs:225 -- without the walk through apply_fhash's cases)
-    const bool fast32 = KMU_UQ_FASTKEY && cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER32BIT;
+    const bool fast32 = cfg.fhash == KMU_FHASH_CANON_INVHASH && cfg.kmer_type == KMU_KMER32BIT;
     auto key_of = [&](uint32_t idx) -> uint64_t {
         const uint32_t rc = revcomp32(idx, k);
         if (fast32) return (uint64_t) int32_hash((rc < idx ? rc : idx) | ((uint32_t) k << 28));
@@ -2206,7 +2053,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
                 for (uint32_t i = tid; i < n_list && !ABL(2u); i += nthreads) {
                     const uint32_t idx = list[i];
                     const uint32_t c = cnt[idx >> 1];
-                    a.lst_keys[lbase + i] = a.pts_tab ? (uint64_t) idx : key_of(idx);
+                    a.lst_keys[lbase + i] = key_of(idx);
                     a.lst_w[lbase + i] = (idx & 1u) ? c >> 16 : c & 0xFFFFu;
                     atomicAnd(&cnt[idx >> 1], (idx & 1u) ? 0x0000FFFFu : 0xFFFF0000u);
                 }
@@ -2248,7 +2095,7 @@ __global__ void __launch_bounds__(1024) k_sketch_smallk(SketchArgs a) {
                         for (uint32_t i = tid; i < n_list && !ABL(2u); i += nthreads) {
                             const uint32_t idx = list[i];
                             const uint32_t c = wide ? cnt[idx & 0x7FFFu] : cnt[idx >> 1];
-                            a.lst_keys[lbase + i] = a.pts_tab ? (uint64_t) idx : key_of(idx);
+                            a.lst_keys[lbase + i] = key_of(idx);
                             a.lst_w[lbase + i] = wide ? c : ((idx & 1u) ? c >> 16 : c & 0xFFFFu);
                         }
                         emit_n += n_list;
@@ -2510,8 +2357,7 @@ static bool smallk_route(const kmu_sketch_params *p, int hashed_bytes, bool part
 // k_pmh_points over the lists of a.n_seq reads; reads with more than KMU_PMH_PTS_LONG list entries (default 32 768; 0: none)
 // are listed first (k_pts_long_list) and taken by whole workgroups
 static int launch_points(kmu_ctx *ctx, SketchArgs a, int cus) {
-    void (*const kpts)(SketchArgs) = a.pts_tab ? (a.sig_bytes == 4 ? k_pmh_points<true, true> : k_pmh_points<false, true>)
-                                               : a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
+    void (*const kpts)(SketchArgs) = a.sig_bytes == 4 ? k_pmh_points<true> : k_pmh_points<false>;
     const size_t lds2 = (size_t) 4 * (2 * (size_t) a.m + PTS_WAVE_WORDS) * 8 + WINV_LUT * 8;
     if (lds2 > 64 * 1024)
         KMU_HIP(ctx, hipFuncSetAttribute((const void *) kpts, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2612,21 +2458,9 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
                 KMU_HIP(ctx, hipMemsetAsync(a.lst_nu, 0, (size_t) ds.n_seq * 4, ctx->stream));
             }
         }
-        // KMU_PMH_K8TAB=1 (opt-in; round 4, measured slower): the first point of every one of the 4^k possible keys from a table made
-        // once per call.  No generator runs in pass 1 and the 42 % of the keys in the sampler's rejection branch are pruned like the
-        // others -- but 4e9 gathers of 16 bytes out of a 1 MB table are 4e9 lines from L2 (the table does not fit a CU's 32 KB of L1):
-        // k_pmh_points 26.1 against 18.9 ms on config 3 (scripts/r04_k8tab.sh; same rows).  16-bit lower bounds of the samples in LDS
-        // in front of the gather (128 KB: one workgroup of four waves per CU) were slower still -- 52 ms: one wave per SIMD hides
-        // neither the LDS nor the L2 round trips of a chunk.
-        const char *k8t = getenv("KMU_PMH_K8TAB");
-        if (emit && k8t && atoi(k8t) != 0) {
-            void *pt;
-            const uint32_t nv = 1u << (2 * p->kmer_size);
-            KMU_TRY(dev_buf(ctx, "pts.tab", (size_t) nv * 16 + 64, &pt));
-            hipLaunchKernelGGL(k_pts_table, dim3((nv + 255) / 256), dim3(256), 0, ctx->stream, a, (uint4 *) pt, nv);
-            KMU_HIP(ctx, hipGetLastError());
-            a.pts_tab = (const uint4 *) pt;
-        }
+        // (Round 4, measured and not kept: the first point of every one of the 4^k possible keys from a table made once per call -- no
+        //  generator in pass 1 -- but 4e9 gathers of 16 bytes out of a 1 MB table are 4e9 lines from L2: k_pmh_points 26.1 against 18.9 ms
+        //  on config 3; 16-bit lower bounds of the samples in LDS in front of the gather: 52 ms.)
         const sketch_kernel_t kern = emit ? k_sketch_smallk<true> : k_sketch_smallk<false>;
         // LDS: histogram | slot minima (only when the kernel makes the points itself) | list of u16 indices | staged words
         const size_t lds_fixed = (size_t) SMALLK_WORDS * 4 + (emit ? 0 : (size_t) 16 * a.m) + ((size_t) SMALLK_TILE + 2) * 4 + 64;
@@ -2802,8 +2636,6 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     // longer ones (and the rare read with too many repeated keys) are handed to the general list-emitting kernel.
     const char *uq_env = getenv("KMU_PMH_UQ"); // 0: every read through the counting-sort kernel (A/B)
     const bool uq = split && plain && !(uq_env && atoi(uq_env) == 0);
-    const char *uqt_env = getenv("KMU_PMH_UQTAB"); // 0: the collision groups through the counting sort (A/B)
-    const bool uq_tab = uqt_env && atoi(uqt_env) != 0; // (opt-in: as fast as the counting sort, scripts/r04_uqtab.sh)
     bool main_launched = false, short_route = false;
     const char *sh_env = getenv("KMU_PMH_SHORT"); // 0: short reads through k_multiset_uq like the others (A/B)
     if (uq && len_stats && len_stats[0] < (uint64_t) SHORT_KEYS + (uint64_t) p->kmer_size && !(sh_env && atoi(sh_env) == 0)) {
@@ -2819,8 +2651,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         short_route = true;
     } else if (uq) {
         {
-            const auto ka = uq_tab ? k_multiset_uq<512, KMU_UQ1_BM, KMU_UQ1_COLL, 4, true> : k_multiset_uq<512, KMU_UQ1_BM, KMU_UQ1_COLL, 4, false>;
-            const size_t lds_a = uq_tab ? UqShape<512, KMU_UQ1_BM, KMU_UQ1_COLL, true>::LDS : UqShape<512, KMU_UQ1_BM, KMU_UQ1_COLL, false>::LDS;
+            const auto ka = k_multiset_uq<512, UQ1_BM, UQ1_COLL, 4>;
+            const size_t lds_a = UqShape<512, UQ1_BM, UQ1_COLL>::LDS;
             KMU_HIP(ctx, hipFuncSetAttribute((const void *) ka, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             KernelTimer t(ctx, "k_multiset_uq");
             hipLaunchKernelGGL(ka, dim3((unsigned) std::max<uint64_t>(1, std::min<uint64_t>(ds.n_seq, (uint64_t) cus * 2))), dim3(512), lds_a,
@@ -2842,8 +2674,8 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
         }
         const char *uq2_env = getenv("KMU_PMH_UQ2"); // 0: no second shape (A/B)
         if (n_long && !(uq2_env && atoi(uq2_env) == 0)) { // the second shape: reads of up to 20 480 k-mers, from the first one's list
-            const auto kb = uq_tab ? k_multiset_uq<1024, KMU_UQ2_BM, KMU_UQ2_COLL, 4, true> : k_multiset_uq<1024, KMU_UQ2_BM, KMU_UQ2_COLL, 4, false>;
-            const size_t lds_b = uq_tab ? UqShape<1024, KMU_UQ2_BM, KMU_UQ2_COLL, true>::LDS : UqShape<1024, KMU_UQ2_BM, KMU_UQ2_COLL, false>::LDS;
+            const auto kb = k_multiset_uq<1024, UQ2_BM, UQ2_COLL, 4>;
+            const size_t lds_b = UqShape<1024, UQ2_BM, UQ2_COLL>::LDS;
             void *rl2;
             KMU_TRY(dev_buf(ctx, "pmh.redo2", (size_t) ds.n_seq * 4 + 64, &rl2));
             KMU_HIP(ctx, hipFuncSetAttribute((const void *) kb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

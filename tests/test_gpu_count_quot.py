@@ -76,7 +76,7 @@ def test_region_maps_that_are_no_powers_of_two(ctx, oracle, monkeypatch, regions
     """KMU_COUNT_REGIONS forces the table's region count whatever the hint: every way into the table and out of it on maps of 1 .. 3e5
     regions -- single-pass partition, exact levels, direct insertion, a second batch onto the occupied image, query, dump,
     statistics, export_part / merge, saturation of the count field, the spill list of overflowing streams -- gives the oracle's
-    counts (kmercount.rs:241-287).  Tables of more than 2048 regions are quotient tables here (8-bit counters: w >= 11)."""
+    counts (kmercount.rs:241-287).  Tables of >= 2048 regions are quotient tables here (8-bit counters: w >= 11)."""
     import torch
     monkeypatch.setenv("KMU_COUNT_REGIONS", regions)
     n_regions = int(regions)
@@ -100,8 +100,8 @@ def test_region_maps_that_are_no_powers_of_two(ctx, oracle, monkeypatch, regions
         c = ctx.counter(A.KMER64BIT, 31, 8, 1024)
         ti = c.table_info()
         rounded = ti["nslots"] // 4096
-        assert n_regions <= rounded <= n_regions + 4 * 2048 and (n_regions <= 2048) == (rounded == n_regions), (ti, what)
-        assert ti["bytes_per_slot"] == (8 if n_regions > 2048 else 12), (ti, what)
+        assert n_regions <= rounded <= n_regions + 4 * 2048 and (rounded == n_regions if n_regions <= 2048 else rounded % 4 == 0), (ti, what)
+        assert ti["bytes_per_slot"] == (8 if n_regions >= 2048 else 12), (ti, what)
         c.add_reads(d_b, d_o)
         gk, gc = c.dump(1)
         assert np.array_equal(gk, wk) and np.array_equal(gc, want8), (what, path, seg, pct)
@@ -272,7 +272,7 @@ def test_table_sized_from_the_measured_duplication(oracle, genome, n_reads, what
         assert np.array_equal(gk, wk) and np.array_equal(gc, wc), what
         # a load of <= 0.70, and no more than the sample's error and the rounding to whole regions add
         assert wk.size / 0.70 <= slots <= max(1024, (1.16 * wk.size + 1024) / 0.70 + 4096 * 260), (what, slots, wk.size, nk / wk.size)
-        assert slots <= blind_slots
+        assert slots <= max(blind_slots, int(off[-1]) / 0.70 + 2 * 4096)  # (no duplication to speak of: the bases of the batch bound its k-mers)
         # a second batch goes into the table the first one made
         c.add_reads(bases, off)
         assert c.table_info()["nslots"] == slots

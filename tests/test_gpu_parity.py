@@ -695,20 +695,17 @@ def test_probminhash3_depth_first_oracle(ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("uqtab", ["0", "1"])
-def test_two_kernel_probminhash_path(ctx, oracle, monkeypatch, uqtab):
+def test_two_kernel_probminhash_path(ctx, oracle, monkeypatch):
     """KMU_PMH_SPLIT=1: multiset kernel -> (key, weight) lists -> k_pmh_points; same rows as the oracle, including
-    reads that need several partition passes, tandem repeats and a read shorter than k.  uqtab = 1: the collision groups of
-    k_multiset_uq through its LDS table instead of the counting sort (opt-in, KMU_PMH_UQTAB)."""
+    reads that need several partition passes, tandem repeats and a read shorter than k."""
     monkeypatch.setenv("KMU_PMH_SPLIT", "1")
-    monkeypatch.setenv("KMU_PMH_UQTAB", uqtab)
     monkeypatch.setenv("KMU_PMH_SMALLK", "0")  # (k = 8 has a route of its own: test_smallk_histogram_route)
     rng = np.random.default_rng(21)
     seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in (12, 300, 7000, 45000, 9000)]
     seqs.append(b"ACGGT" * 3000)
     seqs.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=900).tobytes() * 9)  # every k-mer nine times: all keys in collision groups
     seqs.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=4000).tobytes() + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=150).tobytes() * 20)
-    seqs.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=6000).tobytes() + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=100).tobytes() * 3)  # a few hundred keys of weight 3 among the false positives: the groups the table / the counting sort merge
+    seqs.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=6000).tobytes() + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=100).tobytes() * 3)  # a few hundred keys of weight 3 among the false positives: the groups the counting sort merges
     bases, off = oracle.concat(seqs)
     for kmer_type, k, sig, m in ((A.KMER64BIT, 31, A.SIG_U64, 200), (A.KMER32BIT, 8, A.SIG_U32, 64)):
         p = A.SketchParams(A.ALGO_PROB3A, kmer_type, k, m, sig, A.HASHER_NOHASH, A.FHASH_CANON_INVHASH, 0, 0, 0, 0, 0)
@@ -1134,16 +1131,12 @@ def test_probminhash_many_reads_default_route(ctx, oracle, monkeypatch):
     assert got2.tobytes() == np.asarray(want2).tobytes()
 
 
-@pytest.mark.parametrize("split", ["1", "0", "1+table"])
+@pytest.mark.parametrize("split", ["1", "0"])
 def test_smallk_histogram_route(ctx, oracle, monkeypatch, split):
     """k <= 8: the multiset as a direct-indexed histogram in LDS (k_sketch_smallk), with the points made by k_pmh_points
     (KMU_PMH_SPLIT=1) or by the histogram kernel itself (=0).  Reads of every regime: shorter than k, listed first touches
     (<= 8192 k-mers), scanned histogram, 32-bit counters in two halves (> 65535 k-mers), poly-A (one counter takes it all),
-    tandem repeats; every closure the route accepts; packed input; against the oracle and against the general kernels.
-    "1+table": the opt-in form in which k_pmh_points takes every key's first point from a table of all 4^k keys (KMU_PMH_K8TAB=1)."""
-    if split == "1+table":
-        monkeypatch.setenv("KMU_PMH_K8TAB", "1")
-        split = "1"
+    tandem repeats; every closure the route accepts; packed input; against the oracle and against the general kernels."""
     monkeypatch.setenv("KMU_PMH_SPLIT", split)
     rng = np.random.default_rng(88)
     seqs = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(n)).tobytes() for n in (5, 8, 9, 300, 8199, 8200, 30000, 65542, 65543, 150000)]

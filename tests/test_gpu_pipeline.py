@@ -116,6 +116,22 @@ def test_sketch_count_distributed_world1(oracle, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("pack", ["1", "0"])
+def test_sketch_count_host_amino_acids(ctx, oracle, monkeypatch, pack):
+    """signatures-only kmu_sketch_count of protein sequences from HOST buffers: the packed upload packs 2-bit bases
+    and would reject every residue outside ACGT -- amino-acid k-mers keep the plain upload, whatever KMU_PIPE_PACK says; the
+    rows equal the oracle's (aautils path: src/aautils/setsketchert.rs:247-289)"""
+    monkeypatch.setenv("KMU_PIPE_PACK", pack)
+    monkeypatch.setenv("KMU_PIPE_CHUNK_MB", "1")
+    res, off = synth.protein_seqs(6000, 0xA5)  # ~2 M residues: two chunks
+    off = off.astype(np.uint64)
+    for algo, sig, m in ((A.ALGO_SUPER, A.SIG_F64, 128), (A.ALGO_PROB3A, A.SIG_U64, 64)):
+        p = A.SketchParams(algo, A.KMERAA64BIT, 12, m, sig, A.HASHER_NOHASH, A.FHASH_VALUE_MASKED, 0, 0, 0, 0, 0)
+        want = oracle.sketch(res, off, p)
+        got = np.asarray(ctx.sketch_count(res, off, p))
+        assert np.array_equal(got.view(np.uint8), np.ascontiguousarray(want).view(np.uint8)), (algo, pack)
+
+
 def test_sketch_count_host_chunked_level1(ctx, oracle, monkeypatch):
     """host form with the count's level-1 partition running chunk by chunk under the upload (the single-pass partition,
     forced on a batch the oracle can count: KMU_COUNT_SEG=2), nine 1 MB chunks; also with segments that overflow (the

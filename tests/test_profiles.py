@@ -113,6 +113,8 @@ def test_bench_falls_back_to_a_fresh_child_when_the_first_contact_fails(capsys):
     line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert line["value"] == 2.0 and [f["exit_code"] for f in line["fallback_from"]] == [134, 0]
     assert line["fallback_from"][1]["json_line"] is False and "no collective" in line["attempt"]
+    # a substituted workload is no headline: the metric of the line says so
+    assert line["workload_substituted"] == {"asked": "ont_k31", "ran": "ont_k31_sketch"} and "SUBSTITUTED" in line["metric"]
     # every attempt fails: a non-zero exit code, no line
     rc = bench.launch_ranks(args, argv=["--gpus", "8"], runner=lambda c, e: (9, ""), environ={"PATH": os.environ["PATH"]})
     assert rc == 9 and capsys.readouterr().out.strip() == ""
@@ -121,3 +123,35 @@ def test_bench_falls_back_to_a_fresh_child_when_the_first_contact_fails(capsys):
     args2 = bench.argparse.Namespace(gpus=4, workload="c5_aa")
     assert bench.launch_ranks(args2, argv=["--gpus", "4", "--workload", "c5_aa"], runner=lambda c, e: (calls.append(1), (1, ""))[1],
                               environ={"PATH": os.environ["PATH"], "KMU_BENCH_TRANSPORT": "torch"}) == 1 and len(calls) == 1
+
+
+def test_the_default_run_times_every_baseline_configuration():
+    """`configs` of the default one-GPU line: one child `python bench.py --workload <w>` per BASELINE
+    configuration, each relayed as ms per step, throughput, roofline fraction of its dominant unit and oracle parity of its timed
+    output; a child that fails leaves an `error` entry, not a missing key and not a dead headline."""
+    import bench
+    seen = []
+
+    def runner(cmd, env):
+        w = cmd[cmd.index("--workload") + 1]
+        seen.append(cmd)
+        if w == "c4_count":
+            return 1, "boom\n"
+        line = {"metric": "m", "value": 100.0, "ms_per_step": 7.5, "steps": 5, "warmup": 3,
+                "config": {"workload": "%s: %s" % (w, "625000 protein sequences" if w == "c5_aa" else "1000000 x 150 bp reads")},
+                "roofline": {"frac": 0.2, "kernel": "k_x", "avg_launch_ms": 7.0},
+                "checks": {"parity_reads": 1000, "parity_rows_ok": True, "parity_counts_ok": w != "c2_nthash_count", "count_conservation_ok": True}}
+        return 0, "noise\n" + json.dumps(line) + "\n"
+
+    out = bench.run_configs(runner=runner, environ={"PATH": os.environ["PATH"]})
+    assert set(out) == set(bench.CONFIG_WORKLOADS) == {"c1_super", "c2_nthash_count", "c3_k8", "c4_count", "c5_aa"}
+    for cmd in seen:  # a plain one-GPU child each: no cpu baseline, no nested configs, 3 warm-up + 5 steps
+        assert cmd[1].endswith("bench.py") and "--no-configs" in cmd and "--no-cpu-baseline" in cmd
+        assert cmd[cmd.index("--steps") + 1] == "5" and cmd[cmd.index("--warmup") + 1] == "3" and cmd[cmd.index("--gpus") + 1] == "1"
+    assert "error" in out["c4_count"] and "exit code 1" in out["c4_count"]["error"]
+    for w in ("c1_super", "c3_k8", "c5_aa", "c2_nthash_count"):
+        e = out[w]
+        assert {"workload", "ms_per_step", "value", "unit", "roofline_frac", "parity_ok", "steps", "warmup"} <= set(e)
+        assert e["ms_per_step"] == 7.5 and e["roofline_frac"] == 0.2 and e["steps"] == 5 and e["warmup"] == 3
+    assert out["c5_aa"]["unit"] == "Gresidues/s" and out["c3_k8"]["unit"] == "Gbases/s"
+    assert out["c1_super"]["parity_ok"] is True and out["c2_nthash_count"]["parity_ok"] is False  # every parity_* check must hold
