@@ -117,22 +117,42 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
         return e;
     };
     hipEvent_t t_a = take_event(), t_b = take_event();
+    auto give_back = [&]() { // (every way out that does not hand the pair to `timed`)
+        if (t_a) c->ev_pool.push_back(t_a);
+        if (t_b) c->ev_pool.push_back(t_b);
+        t_a = t_b = nullptr;
+    };
     if (t_a) (void) hipEventRecord(t_a, s);
+    const uint8_t *sb = (const uint8_t *) send_dev;
+    uint8_t *rb = (uint8_t *) recv_dev;
+    // what a rank keeps does not travel: one device-to-device copy (no RCCL channel, no peer).  KMU_COMM_SELF_RCCL=1 sends it to
+    // self through RCCL like a peer's share (tests and measurements on one GPU: the only RCCL data path there is)
+    const char *sr = getenv("KMU_COMM_SELF_RCCL");
+    const bool self_rccl = sr && atoi(sr) != 0;
+    if (!self_rccl && send_counts[c->rank] && hipMemcpyAsync(rb + recv_displs[c->rank] * elem_bytes, sb + send_displs[c->rank] * elem_bytes,
+                                               (size_t) send_counts[c->rank] * elem_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        give_back();
+        return fail(ctx, KMU_E_HIP, "the copy of a rank's own share of an exchange failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     // every pair of ranks exchanges one message per round: xGMI is point to point, all seven links of a GPU carry traffic at
     // once.  A message is at most KMU_COMM_CHUNK_MB (default 1024) long: rounds of grouped sends / receives until every
     // pair is through (sizes are known on both sides, so both sides run the same number of rounds for a pair).
-    const uint8_t *sb = (const uint8_t *) send_dev;
-    uint8_t *rb = (uint8_t *) recv_dev;
     uint64_t chunk = 1024ull << 20;
     if (const char *e = getenv("KMU_COMM_CHUNK_MB")) chunk = (uint64_t) std::max(1, atoi(e)) << 20;
     uint64_t longest = 0;
-    for (int p = 0; p < c->nranks; p++) longest = std::max(longest, std::max(send_counts[p], recv_counts[p]) * elem_bytes);
+    for (int p = 0; p < c->nranks; p++)
+        if (p != c->rank || self_rccl) longest = std::max(longest, std::max(send_counts[p], recv_counts[p]) * elem_bytes);
     for (uint64_t o = 0; o < longest; o += chunk) {
-        KMU_NCCL(ctx, rccl()->GroupStart());
+        const ncclResult_t gs = rccl()->GroupStart();
+        if (gs != ncclSuccess) {
+            give_back();
+            return fail(ctx, KMU_E_RCCL, "ncclGroupStart: %s", rccl()->GetErrorString(gs));
+        }
         // a failing send / receive must not leave the group open (every later RCCL call of this thread would queue into it and
         // the peers that have posted their side would wait): the first error is kept, the group is always closed
         ncclResult_t first = ncclSuccess;
         for (int p = 0; p < c->nranks && first == ncclSuccess; p++) {
+            if (p == c->rank && !self_rccl) continue;
             const uint64_t sbytes = send_counts[p] * elem_bytes, rbytes = recv_counts[p] * elem_bytes;
             if (o < sbytes)
                 first = rccl()->Send(sb + send_displs[p] * elem_bytes + o, (size_t) std::min(chunk, sbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s);
@@ -140,26 +160,32 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
                 first = rccl()->Recv(rb + recv_displs[p] * elem_bytes + o, (size_t) std::min(chunk, rbytes - o), ncclUint8, p, (ncclComm_t) c->nccl, s);
         }
         const ncclResult_t ge = rccl()->GroupEnd();
-        if (first != ncclSuccess) return fail(ctx, KMU_E_RCCL, "ncclSend / ncclRecv in the all-to-all: %s", rccl()->GetErrorString(first));
-        if (ge != ncclSuccess) return fail(ctx, KMU_E_RCCL, "ncclGroupEnd: %s", rccl()->GetErrorString(ge));
+        if (first != ncclSuccess || ge != ncclSuccess) {
+            give_back();
+            if (first != ncclSuccess) return fail(ctx, KMU_E_RCCL, "ncclSend / ncclRecv in the all-to-all: %s", rccl()->GetErrorString(first));
+            return fail(ctx, KMU_E_RCCL, "ncclGroupEnd: %s", rccl()->GetErrorString(ge));
+        }
     }
     if (t_a && t_b) {
         (void) hipEventRecord(t_b, s);
         c->timed.emplace_back(t_a, t_b);
-    }
+    } else give_back();
     if (getenv("KMU_COMM_SYNC")) KMU_HIP(ctx, hipStreamSynchronize(s)); // diagnostics
     return KMU_OK;
 }
 
-// the event pairs of finished exchanges -> stats.exchange_ms (waits for the ones still running)
+// the event pairs of FINISHED exchanges -> stats.exchange_ms; one still in flight stays queued for the next query (a statistics
+// call never stalls the host on the exchange stream)
 static void comm_collect_timed(kmu_comm *c) {
+    size_t kept = 0;
     for (auto &pr : c->timed) {
+        if (hipEventQuery(pr.second) == hipErrorNotReady) { c->timed[kept++] = pr; continue; }
         float ms = 0;
-        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->stats.exchange_ms += ms;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->stats.exchange_ms += ms;
         c->ev_pool.push_back(pr.first);
         c->ev_pool.push_back(pr.second);
     }
-    c->timed.clear();
+    c->timed.resize(kept);
     (void) hipGetLastError();
 }
 
@@ -181,7 +207,11 @@ static int comm_new(kmu_ctx *ctx, int rank, int nranks) {
     kmu_comm *c = new kmu_comm();
     c->rank = rank;
     c->nranks = nranks;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
+    // the exchange stream at the device's highest priority: its kernels (RCCL's copies, a blit of the rank's own share) compete for
+    // CUs with the sketch kernels that run under the exchange -- at every kernel boundary of the other stream they go first
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail(ctx, KMU_E_HIP, "cannot create the exchange stream");

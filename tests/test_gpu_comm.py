@@ -268,6 +268,7 @@ def test_rccl_many_rounds_to_self(oracle, monkeypatch, owner):
     from kmerutils_amd import lib
     monkeypatch.setenv("NCCL_SOCKET_IFNAME", os.environ.get("NCCL_SOCKET_IFNAME", "lo"))
     monkeypatch.setenv("KMU_COMM_CHUNK_MB", "1")
+    monkeypatch.setenv("KMU_COMM_SELF_RCCL", "1")  # (a rank's own share is a plain device copy by default: here it goes through RCCL like a peer's)
     monkeypatch.setenv("KMU_COUNT_OWNER", owner)
     ctx = lib.Context(0)
     ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
