@@ -6,7 +6,7 @@ CC       ?= gcc
 HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function
 CSRC     := kmerutils_amd/csrc
 OBJDIR   := kmerutils_amd/build
-SOURCES  := kmu_api kmu_sketch kmu_sketch_super kmu_sketch_dens kmu_count kmu_count_part kmu_count_dist kmu_smer kmu_hostpack kmu_compare kmu_ingest kmu_kmergen kmu_comm
+SOURCES  := kmu_api kmu_sketch kmu_sketch_kernels kmu_sketch_super kmu_sketch_dens kmu_count kmu_count_part kmu_count_dist kmu_smer kmu_hostpack kmu_compare kmu_ingest kmu_kmergen kmu_comm
 OBJS     := $(SOURCES:%=$(OBJDIR)/%.o)
 LIB      := kmerutils_amd/libkmu.so
 BIN      := kmerutils_amd/bin
@@ -14,7 +14,7 @@ LINK     := -Lkmerutils_amd -lkmu -Wl,-rpath-link,/opt/rocm/lib
 
 all: $(LIB) $(BIN)/datasketcher $(BIN)/parsefastq examples/sketch_c
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/kmu_device.h $(CSRC)/kmu_stream.h $(CSRC)/kmu_ctx.hpp $(CSRC)/kmu_comm.hpp $(CSRC)/kmu_flat.h $(CSRC)/kmu_count_table.h $(CSRC)/kmu_smer.h $(CSRC)/kmu_smer.hpp $(CSRC)/kmu_hostpack.hpp include/kmu.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/kmu_device.h $(CSRC)/kmu_stream.h $(CSRC)/kmu_ctx.hpp $(CSRC)/kmu_comm.hpp $(CSRC)/kmu_flat.h $(CSRC)/kmu_count_table.h $(CSRC)/kmu_sketch_kernels.h $(CSRC)/kmu_smer.h $(CSRC)/kmu_smer.hpp $(CSRC)/kmu_hostpack.hpp include/kmu.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

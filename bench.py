@@ -287,8 +287,9 @@ def main():
                     raise RuntimeError("KMU_BENCH_FAIL_TRANSPORT=%s" % tr)
                 kdist.init_comm(ctx, transport=tr)
                 pn = min(1000, n_reads)
-                pc = ctx.counter(cfg["kmer_type"], cfg["k"], 8, 1 << 22, distributed=True)
-                pc.add_reads(bases[:int(offsets[pn].item())], offsets[:pn + 1])
+                pb = int(offsets[pn].item())  # (the probe's table: room for every k-mer of its reads -- the hint counts distinct k-mers)
+                pc = ctx.counter(cfg["kmer_type"], cfg["k"], 8, max(1 << 20, pb), distributed=True)
+                pc.add_reads(bases[:pb], offsets[:pn + 1])
                 pc.finalize()
                 ctx.synchronize()
                 pc.close()
@@ -470,6 +471,16 @@ def main():
             cpu = cpu_baseline(cfg, bases, offsets, lens, args.cpu_sample_reads, args.cpu_threads)
         configs = None
         if world == 1 and cfg["name"] == "ont_k31" and not args.no_configs and not (args.reads or args.bases or args.genome):
+            # the children get the whole card: this process first gives its device memory back (a child that finds the card half
+            # full takes other routes -- config 3's list-emitting route wants 52 GB of scratch -- and would not be the workload)
+            if counter is not None:
+                counter.close()
+                counter = None
+            ctx.close()
+            del bases, offsets, sig, nth
+            if host is not None:
+                del h_bases, h_sig, h_off
+            torch.cuda.empty_cache()
             configs = run_configs()
         out = {
             "metric": "Gbases/sec k-mer+sketch throughput, k=31, 200 sketches/read",

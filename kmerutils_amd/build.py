@@ -6,9 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkmu.so")
-SOURCES = ["kmu_api.hip", "kmu_sketch.hip", "kmu_sketch_super.hip", "kmu_sketch_dens.hip", "kmu_count.hip", "kmu_count_part.hip", "kmu_count_dist.hip", "kmu_smer.hip", "kmu_hostpack.hip", "kmu_compare.hip",
+SOURCES = ["kmu_api.hip", "kmu_sketch.hip", "kmu_sketch_kernels.hip", "kmu_sketch_super.hip", "kmu_sketch_dens.hip", "kmu_count.hip", "kmu_count_part.hip", "kmu_count_dist.hip", "kmu_smer.hip", "kmu_hostpack.hip", "kmu_compare.hip",
            "kmu_ingest.hip", "kmu_kmergen.hip", "kmu_comm.hip"]
-HEADERS = ["kmu_device.h", "kmu_stream.h", "kmu_ctx.hpp", "kmu_comm.hpp", "kmu_flat.h", "kmu_count_table.h", "kmu_smer.h", "kmu_smer.hpp", "kmu_hostpack.hpp", os.path.join("..", "..", "include", "kmu.h")]
+HEADERS = ["kmu_device.h", "kmu_stream.h", "kmu_ctx.hpp", "kmu_comm.hpp", "kmu_flat.h", "kmu_count_table.h", "kmu_sketch_kernels.h", "kmu_smer.h", "kmu_smer.hpp", "kmu_hostpack.hpp", os.path.join("..", "..", "include", "kmu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 
