@@ -97,11 +97,32 @@ def workload_cfg(args):
     return cfg
 
 
-def _run_child(cmd, env):
-    """one attempt: the child's exit code and what it wrote to stdout (its stderr goes straight through)"""
+def _run_child(cmd, env, timeout=None):
+    """one attempt: the child's exit code and what it wrote to stdout (its stderr goes straight through).  A child that is still
+    running after `timeout` seconds is ended with its whole process group (the ranks are grandchildren) and counts as failed:
+    exit code 124, like timeout(1)."""
+    import signal
     import subprocess
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    return p.returncode, p.stdout.decode(errors="replace")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        return p.returncode, out.decode(errors="replace")
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)  # (the group this child leads: start_new_session above -- nothing of the caller's is in it)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            out, _ = p.communicate(timeout=15)  # (what it had written before it was ended)
+        except Exception:  # noqa: BLE001
+            out = b""
+        return 124, (out or b"").decode(errors="replace")
 
 
 def _last_json_line(text):
@@ -124,15 +145,24 @@ def launch_ranks(args, argv=None, runner=_run_child, environ=None):
     torch import yet), and every child is a child -- never an exec of a process that holds the device.
 
     The first contact with N real GPUs must not be wasted: if the child exits non-zero or prints no JSON line, a FRESH child
-    runs with the library's exchange carried by torch's process group instead of the library's own RCCL communicator
-    (KMU_BENCH_TRANSPORT=torch), then one with the sketch-only workload (no collective at all); the line that comes out says
-    which attempt it is (`fallback_from`)."""
+    runs with the next transport of the exchange -- the library's COPY transport first, then its RCCL all-to-all, then torch's
+    process group as carrier (KMU_BENCH_TRANSPORT = copy | rccl | torch names where the chain starts) --, and last one with the
+    sketch-only workload (no collective at all); the line that comes out says which attempt it is (`fallback_from`).  An attempt
+    that is still running after KMU_BENCH_ATTEMPT_TIMEOUT seconds (default 900) is ended and counts as failed."""
     import socket
     argv = list(sys.argv[1:] if argv is None else argv)
     environ = dict(os.environ if environ is None else environ)
-    attempts = [({}, None, "rccl: the library's communicator")]
-    if environ.get("KMU_BENCH_TRANSPORT", "rccl") != "torch" and environ.get("KMU_BENCH_BACKEND", "nccl") == "nccl":
-        attempts.append(({"KMU_BENCH_TRANSPORT": "torch"}, None, "torch: the process group carries the exchange"))
+    # the transports of the exchange, in the order they are tried (VERDICT r04 next #4): the library's COPY transport (device copies
+    # into the peers' IPC-mapped receive buffers: no kernel has to find a CU under the sketch kernels), its RCCL all-to-all, the
+    # process group as carrier, and last the step without a collective.  KMU_BENCH_TRANSPORT names where to start.
+    order = [("copy", "copy: the library's communicator, the all-to-all as device copies into the peers' IPC-mapped buffers"),
+             ("rccl", "rccl: the library's communicator"), ("torch", "torch: the process group carries the exchange")]
+    first = environ.get("KMU_BENCH_TRANSPORT", "copy")
+    if environ.get("KMU_BENCH_BACKEND", "nccl") != "nccl":
+        first = "torch"  # (gloo rehearsals: the ranks share devices, the process group is the only carrier)
+    names = [n for n, _ in order]
+    order = order[names.index(first):] if first in names else order
+    attempts = [({"KMU_BENCH_TRANSPORT": n}, None, what) for n, what in order]
     if args.workload in SKETCH_ONLY:
         attempts.append(({}, SKETCH_ONLY[args.workload], "no collective: %s" % SKETCH_ONLY[args.workload]))
     failed = []
@@ -152,7 +182,11 @@ def launch_ranks(args, argv=None, runner=_run_child, environ=None):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "4")
         env.update(envo)
-        rc, out = runner(cmd, env)
+        # (an attempt that hangs -- a transport that has never met this hardware -- must not take the others with it)
+        try:
+            rc, out = runner(cmd, env, timeout=float(environ.get("KMU_BENCH_ATTEMPT_TIMEOUT", "900")))
+        except TypeError:  # (a runner without a timeout of its own: the tests' stand-ins)
+            rc, out = runner(cmd, env)
         line = _last_json_line(out)
         if rc == 0 and line is not None:
             if failed:
@@ -279,8 +313,9 @@ def main():
         # distributed count before anything is timed; if any rank fails there, EVERY rank drops it and the process group
         # carries the exchange instead (KMU_BENCH_TRANSPORT=torch asks for that from the start); if that fails too the
         # step loses its collective (sketch only) -- and the line says so
-        want = os.environ.get("KMU_BENCH_TRANSPORT", "rccl" if backend == "nccl" else "torch")
-        for tr in ([want] if want == "torch" else [want, "torch"]):
+        want = os.environ.get("KMU_BENCH_TRANSPORT", "copy" if backend == "nccl" else "torch")
+        chain = ["copy", "rccl", "torch"] if backend == "nccl" else ["torch"]
+        for tr in (chain[chain.index(want):] if want in chain else [want]):
             err = None
             try:
                 if os.environ.get("KMU_BENCH_FAIL_TRANSPORT") == tr:  # (rehearsals of the fallback itself)

@@ -414,7 +414,7 @@ typedef struct kmu_comm_id { char bytes[KMU_COMM_ID_BYTES]; } kmu_comm_id; /* an
 int kmu_comm_get_id(kmu_comm_id *out);
 int kmu_comm_init(kmu_ctx *ctx, const kmu_comm_id *id, int rank, int nranks);
 /* A transport supplied by the host instead (a host that owns a communicator already; tests with more ranks than GPUs).
- * alltoallv: device pointers; counts and displacements per peer in elements of elem_bytes; the library has synchronised
+ * alltoallv (may be NULL: the library's COPY transport, below): device pointers; counts and displacements per peer in elements of elem_bytes; the library has synchronised
  * `stream` before the call and expects the received data to be visible to the device at return.  allgather: host memory,
  * `bytes` from every rank, rank order.  Both return 0 on success. */
 typedef int (*kmu_alltoallv_fn)(void *user, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs,
@@ -422,6 +422,16 @@ typedef int (*kmu_alltoallv_fn)(void *user, const void *send_dev, const uint64_t
                                 void *stream);
 typedef int (*kmu_allgather_fn)(void *user, const void *send_host, void *recv_host, uint64_t bytes);
 int kmu_comm_init_custom(kmu_ctx *ctx, int rank, int nranks, kmu_alltoallv_fn alltoallv, kmu_allgather_fn allgather, void *user);
+/* The COPY transport (round 5): the all-to-all of a distributed add as N - 1 device-to-device copies straight into the peers' receive
+ * buffers -- mapped through HIP IPC (hipIpcGetMemHandle / hipIpcOpenMemHandle) when the peer is another process of this node, used as
+ * they are when it is a thread of this one -- on the communicator's exchange stream.  No kernel of a collective library has to find
+ * a CU under the persistent sketch kernels a step runs the exchange under (RCCL's send / receive kernels do: measured on one GPU,
+ * profiles/r05_reserve.txt).  The communicator's all-gather (RCCL's, or the host's) carries the handles and closes the exchange with
+ * a host barrier.  One node only.  kmu_comm_set_transport(ctx, KMU_TRANSPORT_COPY) switches an existing communicator over (every
+ * rank alike, between exchanges); kmu_comm_init_custom with alltoallv == NULL creates one that has only this transport. */
+typedef enum kmu_transport { KMU_TRANSPORT_DEFAULT = 0 /* RCCL, or the host's all-to-all function */, KMU_TRANSPORT_COPY = 1 } kmu_transport;
+int kmu_comm_set_transport(kmu_ctx *ctx, int transport);
+int kmu_comm_transport(const kmu_ctx *ctx); /* kmu_transport of the context's communicator */
 int kmu_comm_destroy(kmu_ctx *ctx); /* also done by kmu_destroy */
 int kmu_comm_rank(const kmu_ctx *ctx);   /* -1 without a communicator */
 int kmu_comm_nranks(const kmu_ctx *ctx); /* 0 without a communicator */
@@ -470,7 +480,7 @@ typedef struct kmu_comm_stats {
     int32_t exchanges;             /* all-to-alls of the last add + its finalize */
     uint64_t records_local;        /* super-k-mer records of this rank's shard (0 with hash owners) */
     double exchange_ms;            /* MEASURED duration of those all-to-alls: events around them on the exchange stream (RCCL), wall
-                                      time of the host's function (kmu_comm_init_custom).  kmu_comm_get_stats waits for them. */
+                                      time of the host's function (kmu_comm_init_custom).  An exchange still in flight is counted by the next query. */
     double exchange_gbps_out;      /* bytes_sent / exchange_ms and bytes_received / exchange_ms, in GB/s: the link rate the route */
     double exchange_gbps_in;       /* model assumes as KMU_XGMI_GBPS */
 } kmu_comm_stats;

@@ -117,3 +117,6 @@ class NthashParams(C.Structure):
     """kmu_nthash_params"""
     _fields_ = [("kmer_size", C.c_int32), ("table", C.c_int32), ("mode", C.c_int32), ("n_hashes", C.c_int32),
                 ("input_kind", C.c_int32), ("mem", C.c_int32)]
+
+# kmu_transport
+TRANSPORT_DEFAULT, TRANSPORT_COPY = 0, 1

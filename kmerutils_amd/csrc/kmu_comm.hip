@@ -91,6 +91,108 @@ int comm_allgather_host(kmu_ctx *ctx, const void *send, void *recv, uint64_t byt
     return KMU_OK;
 }
 
+// The COPY transport's all-to-all (kmu_comm::copy).  Every rank publishes where its receive buffer is -- an IPC handle of the
+// allocation, its process id and address for peers that are threads of the same process -- and where every peer's share starts
+// in it; the all-gather that carries this is also the point at which every rank's earlier work on both buffers is known to be
+// finished (each rank drains its stream before it publishes: a peer writes into memory this rank may still have been reading).
+// Then N - 1 device-to-device copies on the exchange stream (+ the rank's own share), closed by comm_wait's barrier.
+#include <unistd.h>
+static int copy_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
+                          const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s) {
+    kmu_comm *c = ctx->comm;
+    const int N = c->nranks;
+    if (c->copy_pending) KMU_TRY(comm_wait(ctx)); // (an exchange nobody waited for: its barrier first)
+    c->peers.resize((size_t) N);
+    uint64_t n_in = 0;
+    for (int p = 0; p < N; p++)
+        if (p != c->rank) n_in += recv_counts[p];
+    // row of a rank: [0] pid, [1] address of its receive buffer, [2] 1 = the handle is valid, [3 .. 3 + N) where peer p's share starts
+    // in it (bytes), then the 64 bytes of the handle
+    const size_t row_words = 3 + (size_t) N + sizeof(hipIpcMemHandle_t) / 8;
+    static_assert(sizeof(hipIpcMemHandle_t) % 8 == 0, "the handle travels as 64-bit words");
+    std::vector<uint64_t> mine(row_words, 0), all(row_words * (size_t) N, 0);
+    KMU_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the send buffer is complete, the receive buffer no longer in use
+    KMU_HIP(ctx, hipStreamSynchronize(s));
+    mine[0] = (uint64_t) getpid();
+    mine[1] = (uint64_t) (uintptr_t) recv_dev;
+    if (n_in && recv_dev) {
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, recv_dev) == hipSuccess) {
+            mine[2] = 1;
+            memcpy(&mine[3 + N], &h, sizeof h);
+        } else (void) hipGetLastError(); // (peers in this process need no handle; the others will report it)
+    }
+    for (int p = 0; p < N; p++) mine[3 + p] = recv_displs[p] * elem_bytes;
+    KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), (uint64_t) row_words * 8));
+    hipEvent_t t_a = nullptr, t_b = nullptr;
+    auto take_event = [&]() -> hipEvent_t {
+        hipEvent_t e = nullptr;
+        if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    };
+    t_a = take_event();
+    t_b = take_event();
+    auto give_back = [&]() {
+        if (t_a) c->ev_pool.push_back(t_a);
+        if (t_b) c->ev_pool.push_back(t_b);
+    };
+    if (t_a) (void) hipEventRecord(t_a, s);
+    const uint8_t *sb = (const uint8_t *) send_dev;
+    for (int q = 0; q < N; q++) {
+        const uint64_t bytes = send_counts[q] * elem_bytes;
+        if (!bytes) continue;
+        const uint64_t *row = &all[row_words * (size_t) q];
+        uint8_t *dst = nullptr;
+        if (q == c->rank) dst = (uint8_t *) recv_dev;
+        else if (row[0] == mine[0]) dst = (uint8_t *) (uintptr_t) row[1]; // a thread of this process: its pointer is good here
+        else {
+            kmu_comm::Peer &pe = c->peers[(size_t) q];
+            if (!row[2]) { give_back(); return fail(ctx, KMU_E_RCCL, "rank %d could not export its receive buffer (hipIpcGetMemHandle)", q); }
+            if (!pe.opened || memcmp(&pe.handle, &row[3 + N], sizeof pe.handle) != 0) { // the peer's buffer is new (or has grown)
+                if (pe.opened) (void) hipIpcCloseMemHandle(pe.base);
+                pe.opened = false;
+                memcpy(&pe.handle, &row[3 + N], sizeof pe.handle);
+                const hipError_t e = hipIpcOpenMemHandle(&pe.base, pe.handle, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) {
+                    (void) hipGetLastError();
+                    give_back();
+                    return fail(ctx, KMU_E_RCCL, "hipIpcOpenMemHandle of rank %d's receive buffer: %s", q, hipGetErrorString(e));
+                }
+                pe.opened = true;
+            }
+            dst = (uint8_t *) pe.base;
+        }
+        const hipError_t e = hipMemcpyAsync(dst + row[3 + c->rank], sb + send_displs[q] * elem_bytes, (size_t) bytes, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            give_back();
+            return fail(ctx, KMU_E_HIP, "the copy of rank %d's share of an exchange failed: %s", q, hipGetErrorString(e));
+        }
+    }
+    if (t_a && t_b) {
+        (void) hipEventRecord(t_b, s);
+        c->timed.emplace_back(t_a, t_b);
+    } else give_back();
+    c->copy_pending = true;
+    return KMU_OK;
+}
+
+int comm_wait(kmu_ctx *ctx) {
+    kmu_comm *c = ctx->comm;
+    if (!c) return fail(ctx, KMU_E_BAD_ARG, "the context has no communicator (kmu_comm_init)");
+    if (c->copy) {
+        if (!c->copy_pending) return KMU_OK;
+        c->copy_pending = false;
+        KMU_HIP(ctx, hipStreamSynchronize(c->stream)); // this rank's copies have landed at its peers ...
+        uint64_t one = 1;
+        std::vector<uint64_t> all((size_t) c->nranks);
+        return comm_allgather_host(ctx, &one, all.data(), 8); // ... and everybody else's here, once every rank has said so
+    }
+    if (!c->a2a) KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_b, 0));
+    return KMU_OK;
+}
+
 int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
                    const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s) {
     kmu_comm *c = ctx->comm;
@@ -101,6 +203,7 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
     c->stats.bytes_sent += out;
     c->stats.bytes_received += in;
     c->stats.exchanges++;
+    if (c->copy) return copy_alltoallv(ctx, send_dev, send_counts, send_displs, recv_dev, recv_counts, recv_displs, elem_bytes, s);
     if (c->a2a) {
         KMU_HIP(ctx, hipStreamSynchronize(s));
         const auto t0 = std::chrono::steady_clock::now();
@@ -226,6 +329,8 @@ void comm_free(kmu_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
+    for (auto &pe : c->peers)
+        if (pe.opened) (void) hipIpcCloseMemHandle(pe.base);
     if (c->nccl) (void) rccl()->CommDestroy((ncclComm_t) c->nccl);
     for (auto &pr : c->timed) { (void) hipEventDestroy(pr.first); (void) hipEventDestroy(pr.second); }
     for (hipEvent_t e : c->ev_pool) (void) hipEventDestroy(e);
@@ -271,13 +376,26 @@ int kmu_comm_init(kmu_ctx *ctx, const kmu_comm_id *id, int rank, int nranks) {
 }
 
 int kmu_comm_init_custom(kmu_ctx *ctx, int rank, int nranks, kmu_alltoallv_fn alltoallv, kmu_allgather_fn allgather, void *user) {
-    if (!ctx || !alltoallv || !allgather) return KMU_E_BAD_ARG;
+    if (!ctx || !allgather) return KMU_E_BAD_ARG;
     KMU_TRY(comm_new(ctx, rank, nranks));
     ctx->comm->a2a = alltoallv;
     ctx->comm->ag = allgather;
     ctx->comm->user = user;
+    ctx->comm->copy = alltoallv == nullptr; // no all-to-all of the host's: the library's COPY transport over the host's all-gather
     return KMU_OK;
 }
+
+int kmu_comm_set_transport(kmu_ctx *ctx, int transport) {
+    if (!ctx || !ctx->comm) return KMU_E_BAD_ARG;
+    kmu_comm *c = ctx->comm;
+    if (transport != KMU_TRANSPORT_DEFAULT && transport != KMU_TRANSPORT_COPY) return fail(ctx, KMU_E_BAD_ARG, "unknown transport %d", transport);
+    if (c->copy_pending) KMU_TRY(comm_wait(ctx));
+    if (transport == KMU_TRANSPORT_DEFAULT && !c->nccl && !c->a2a)
+        return fail(ctx, KMU_E_BAD_ARG, "this communicator has no all-to-all but the COPY transport's");
+    c->copy = transport == KMU_TRANSPORT_COPY;
+    return KMU_OK;
+}
+int kmu_comm_transport(const kmu_ctx *ctx) { return ctx && ctx->comm && ctx->comm->copy ? KMU_TRANSPORT_COPY : KMU_TRANSPORT_DEFAULT; }
 
 int kmu_comm_destroy(kmu_ctx *ctx) {
     if (!ctx) return KMU_E_BAD_ARG;

@@ -592,8 +592,7 @@ extern "C" {
 
 int kmu_count_reset(kmu_counter *c) {
     if (!c) return KMU_E_BAD_ARG;
-    if (c->pending && c->ctx->comm) // an exchange left open: what it writes ("cnt.recv") is dropped, but not under later work
-        (void) hipStreamWaitEvent(c->ctx->stream, c->ctx->comm->ev_b, 0);
+    if (c->pending && c->ctx->comm) (void) comm_wait(c->ctx); // an exchange left open: what it writes ("cnt.recv") is dropped, but not under later work
     c->pending = false;
     c->pend_recv = 0;
     c->pend_kmers = 0;

@@ -257,7 +257,7 @@ int dist_add_end(kmu_counter *c) {
     if (!c->pending) return KMU_OK;
     c->pending = false;
     if (!ctx->comm) return fail(ctx, KMU_E_BAD_ARG, "the communicator went away under an exchange of this counter (kmu_comm_destroy)");
-    KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm->ev_b, 0));
+    KMU_TRY(comm_wait(ctx));
     if (c->pend_recv == 0) return KMU_OK;
     if (c->okind == 1) return add_superkmers(c, ctx->bufs["cnt.recv"].p, c->pend_recv, c->pend_kmers);
     return add_entries(c, (const uint64_t *) ctx->bufs["cnt.recv"].p, nullptr, c->pend_recv, KMU_MEM_DEVICE);
@@ -343,7 +343,7 @@ int kmu_count_finalize(kmu_counter *c) {
     KMU_TRY(comm_alltoallv(ctx, sk, scnt.data(), sdis.data(), rk, rcnt.data(), rdis.data(), 8, cm->stream));
     KMU_TRY(comm_alltoallv(ctx, sc, scnt.data(), sdis.data(), rc, rcnt.data(), rdis.data(), 4, cm->stream));
     KMU_HIP(ctx, hipEventRecord(cm->ev_b, cm->stream));
-    KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, cm->ev_b, 0));
+    KMU_TRY(comm_wait(ctx));
     cm->stats.bytes_merge = cm->stats.bytes_sent - sent0; // exact now
     // The entries that left are still in the table as tombstones of their probe chains (key kept, count zero).  Where they
     // and what arrives would crowd the table (a rank whose shard holds as many distinct k-mers as it ends up owning: every

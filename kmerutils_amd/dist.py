@@ -271,12 +271,13 @@ class ThreadTransport:
         return out
 
 
-def init_comm_threads(ctx, group, rank):
-    """communicator of rank `rank` of a ThreadGroup on `ctx` (kmu_comm_init_custom)"""
+def init_comm_threads(ctx, group, rank, copy=False):
+    """communicator of rank `rank` of a ThreadGroup on `ctx` (kmu_comm_init_custom); copy: the library's COPY transport carries
+    the all-to-all (the ranks are threads of one process: a peer's receive buffer is used through its own address)"""
     import torch
     tt = ThreadTransport(group, rank, torch.device("cuda", ctx.device_id))
     ctx._transport = tt
-    ctx.comm_init_custom(rank, group.world, tt.alltoallv, tt.allgather)
+    ctx.comm_init_custom(rank, group.world, None if copy else tt.alltoallv, tt.allgather)
     return tt
 
 
@@ -286,20 +287,33 @@ def init_comm(ctx, group=None, transport=None):
     transport "rccl" (the default whenever the group's backend is nccl, or there is no group): the library's own RCCL
     communicator -- rank 0 makes the id (kmu_comm_get_id), the 128 bytes travel over the process group, every rank calls
     kmu_comm_init; from then on the exchanges of distributed counters run inside libkmu.so, which is what a Rust host
-    gets.  transport "torch": the process group carries the exchanges (TorchTransport; gloo rehearsals)."""
+    gets.  transport "copy": the same communicator with the library's COPY transport (kmu_comm_set_transport: the all-to-all as
+    device copies into the peers' IPC-mapped receive buffers; one node).  transport "torch": the process group carries the
+    exchanges (TorchTransport; gloo rehearsals); "copy+torch": the COPY transport with the process group's all-gather."""
     import torch
     import torch.distributed as dist
     from . import lib
     if not dist.is_initialized():
         ctx.comm_init(lib.Context.comm_get_id(), 0, 1)
+        if transport == "copy":
+            from . import _abi as A
+            ctx.comm_set_transport(A.TRANSPORT_COPY)
+            return "copy"
         return "rccl"
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if transport is None:
         transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
-    if transport == "rccl":
+    if transport in ("rccl", "copy"):
         box = [lib.Context.comm_get_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         ctx.comm_init(box[0], rank, world)
+        if transport == "copy":  # the library's copy transport: RCCL carries the handles and the closing barrier, the copy engines the data
+            from . import _abi as A
+            ctx.comm_set_transport(A.TRANSPORT_COPY)
+    elif transport == "copy+torch":  # the copy transport over the process group's all-gather (ranks that share a GPU: RCCL refuses those)
+        tt = TorchTransport(group, torch.device("cuda", ctx.device_id))
+        ctx._transport = tt
+        ctx.comm_init_custom(rank, world, None, tt.allgather)
     else:
         tt = TorchTransport(group, torch.device("cuda", ctx.device_id))
         ctx._transport = tt

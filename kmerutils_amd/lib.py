@@ -28,7 +28,7 @@ SYMBOLS = [
     "kmu_copy_to_device", "kmu_copy_to_host", "kmu_count_once_positions", "kmu_count_eliminate_once", "kmu_sketch_partial_words",
     "kmu_sketch_partial", "kmu_sketch_hashed_partial", "kmu_sketch_merge_partials", "kmu_kmer_hashes_compact", "kmu_set_hll_params",
     "kmu_kmer_hashes_range", "kmu_kmer_distribution", "kmu_nthash",
-    "kmu_comm_get_id", "kmu_comm_init", "kmu_comm_init_custom", "kmu_comm_destroy", "kmu_comm_rank", "kmu_comm_nranks",
+    "kmu_comm_get_id", "kmu_comm_init", "kmu_comm_init_custom", "kmu_comm_set_transport", "kmu_comm_transport", "kmu_comm_destroy", "kmu_comm_rank", "kmu_comm_nranks",
     "kmu_comm_allgather", "kmu_comm_get_stats", "kmu_count_finalize", "kmu_kmer_owner",
     "kmu_sketch_count", "kmu_host_alloc", "kmu_host_free", "kmu_count_nb_occurrences", "kmu_count_table_info",
     "kmu_count_nb_saturated", "kmu_kmer_owner_minimizer", "kmu_count_owner_kind", "kmu_count_extract_superkmers", "kmu_count_add_superkmers",
@@ -258,8 +258,17 @@ class Context:
                 traceback.print_exc()
                 return 1
 
-        self._comm_cbs = (A.ALLTOALLV_FN(a2a), A.ALLGATHER_FN(ag))  # keep the trampolines alive
+        # alltoallv None: the library's COPY transport (device copies into the peers' receive buffers) over the caller's all-gather
+        self._comm_cbs = (A.ALLTOALLV_FN(a2a) if alltoallv is not None else C.cast(None, A.ALLTOALLV_FN), A.ALLGATHER_FN(ag))  # keep the trampolines alive
         self._check(self.L.kmu_comm_init_custom(self.h, rank, nranks, self._comm_cbs[0], self._comm_cbs[1], None))
+
+    def comm_set_transport(self, transport):
+        """kmu_comm_set_transport: A.TRANSPORT_DEFAULT (RCCL / the host's all-to-all) or A.TRANSPORT_COPY (IPC-mapped device copies)"""
+        self._check(self.L.kmu_comm_set_transport(self.h, int(transport)))
+
+    @property
+    def comm_transport(self):
+        return self.L.kmu_comm_transport(self.h)
 
     def comm_destroy(self):
         self._check(self.L.kmu_comm_destroy(self.h))

@@ -13,6 +13,16 @@ import os
 import sys
 
 
+# the kernels whose library timer (what bench.py groups into units) carries another name than the function rocprofv3 sees
+TIMER_OF = {"k_arr_scatter_seg": "k_arr_scatter", "k_arr_scatter_exact": "k_arr_scatter", "k_part_scatter1_exact": "k_part_scatter1"}
+
+
+def timer_name(kernel_name):
+    """"void kmu::k_sketch_pmh3a<false, false>(kmu::SketchArgs)" -> "k_sketch_pmh3a" """
+    k = kernel_name.split("(")[0].split("<")[0].replace("void ", "").replace("kmu::", "").strip()
+    return TIMER_OF.get(k, k)
+
+
 def main():
     tag, trace = sys.argv[1], sys.argv[2]
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
@@ -36,7 +46,7 @@ def main():
             for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
                 if r["Counter_Name"] == name and "kmu::" in r["Kernel_Name"].split("(")[0]:
                     # "void kmu::k_sketch_pmh3a<false, false>(kmu::SketchArgs)" -> "k_sketch_pmh3a"
-                    k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kmu::", "").strip()
+                    k = timer_name(r["Kernel_Name"])
                     acc[k] += float(r["Counter_Value"])
                     cnt[k] += 1
             for k in acc:
@@ -55,7 +65,7 @@ def main():
             cnt = collections.defaultdict(collections.Counter)
             for r in csv.DictReader(open(glob.glob(os.path.join(sys.argv[5], "*", "*_counter_collection.csv"))[0])):
                 if "kmu::" in r["Kernel_Name"].split("(")[0]:
-                    k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kmu::", "").strip()
+                    k = timer_name(r["Kernel_Name"])
                     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
                     cnt[k][r["Counter_Name"]] += 1
             for k in acc:

@@ -92,7 +92,8 @@ def test_bench_starts_its_ranks_as_a_child_process(monkeypatch, capsys):
 
 def test_bench_falls_back_to_a_fresh_child_when_the_first_contact_fails(capsys):
     """the first N-GPU run must leave a record: a child that dies (or prints no JSON line) is followed by a FRESH child with the
-    torch transport, then by one without a collective; the line names what failed (VERDICT r03 next #2b)"""
+    next transport of the chain copy -> rccl -> torch, then by one without a collective; the line names what failed
+    (VERDICT r03 next #2b, r04 next #4)"""
     import bench
     args = bench.argparse.Namespace(gpus=8, workload="ont_k31")
     calls = []
@@ -100,30 +101,46 @@ def test_bench_falls_back_to_a_fresh_child_when_the_first_contact_fails(capsys):
     def runner(cmd, env):
         calls.append((cmd, env.get("KMU_BENCH_TRANSPORT")))
         if len(calls) == 1:
-            return 134, "RCCL blew up\n"  # killed: no JSON
+            return 134, "the copy transport blew up\n"  # killed: no JSON
         if len(calls) == 2:
+            return 124, ""  # hung, ended by the attempt's timeout
+        if len(calls) == 3:
             return 0, "partial output, no json\n"  # exits 0 but printed nothing usable
         return 0, '{"metric": "m", "value": 2.0, "n_gpus": 8, "config": {"workload_name": "ont_k31_sketch"}}\n'
 
     rc = bench.launch_ranks(args, argv=["--gpus", "8", "--workload", "ont_k31", "--steps", "2"], runner=runner, environ={"PATH": os.environ["PATH"]})
-    assert rc == 0 and len(calls) == 3
-    assert [t for _, t in calls] == [None, "torch", None]
+    assert rc == 0 and len(calls) == 4
+    assert [t for _, t in calls] == ["copy", "rccl", "torch", None]
     assert calls[0][0][-6:] == ["--gpus", "8", "--workload", "ont_k31", "--steps", "2"]
-    assert calls[2][0][-2:] == ["--workload", "ont_k31_sketch"] and calls[2][0].count("--workload") == 1
+    assert calls[3][0][-2:] == ["--workload", "ont_k31_sketch"] and calls[3][0].count("--workload") == 1
     line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert line["value"] == 2.0 and [f["exit_code"] for f in line["fallback_from"]] == [134, 0]
-    assert line["fallback_from"][1]["json_line"] is False and "no collective" in line["attempt"]
+    assert line["value"] == 2.0 and [f["exit_code"] for f in line["fallback_from"]] == [134, 124, 0]
+    assert line["fallback_from"][2]["json_line"] is False and "no collective" in line["attempt"]
     # a substituted workload is no headline: the metric of the line says so
     assert line["workload_substituted"] == {"asked": "ont_k31", "ran": "ont_k31_sketch"} and "SUBSTITUTED" in line["metric"]
     # every attempt fails: a non-zero exit code, no line
     rc = bench.launch_ranks(args, argv=["--gpus", "8"], runner=lambda c, e: (9, ""), environ={"PATH": os.environ["PATH"]})
     assert rc == 9 and capsys.readouterr().out.strip() == ""
-    # a workload without a collective has nothing to fall back from but the transport
+    # KMU_BENCH_TRANSPORT names where the chain starts; a workload without a collective has nothing to fall back from but the transport
     calls.clear()
     args2 = bench.argparse.Namespace(gpus=4, workload="c5_aa")
-    assert bench.launch_ranks(args2, argv=["--gpus", "4", "--workload", "c5_aa"], runner=lambda c, e: (calls.append(1), (1, ""))[1],
-                              environ={"PATH": os.environ["PATH"], "KMU_BENCH_TRANSPORT": "torch"}) == 1 and len(calls) == 1
+    assert bench.launch_ranks(args2, argv=["--gpus", "4", "--workload", "c5_aa"], runner=lambda c, e: (calls.append(e.get("KMU_BENCH_TRANSPORT")), (1, ""))[1],
+                              environ={"PATH": os.environ["PATH"], "KMU_BENCH_TRANSPORT": "torch"}) == 1 and calls == ["torch"]
+    calls.clear()
+    assert bench.launch_ranks(args2, argv=["--gpus", "4", "--workload", "c5_aa"], runner=lambda c, e: (calls.append(e.get("KMU_BENCH_TRANSPORT")), (1, ""))[1],
+                              environ={"PATH": os.environ["PATH"], "KMU_BENCH_TRANSPORT": "rccl"}) == 1 and calls == ["rccl", "torch"]
 
+
+def test_a_hung_attempt_is_ended_with_its_process_group():
+    """bench._run_child with a timeout: the child (and what it started) is gone afterwards, the attempt reads as failed (124)"""
+    import bench
+    import time
+    t0 = time.time()
+    rc, out = bench._run_child([sys.executable, "-c", "import subprocess, sys, time; print('started', flush=True); subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)']); time.sleep(60)"],
+                               dict(os.environ), timeout=2.0)
+    assert rc == 124 and "started" in out and time.time() - t0 < 30
+    rc, out = bench._run_child([sys.executable, "-c", "print('{\"a\": 1}')"], dict(os.environ), timeout=30.0)
+    assert rc == 0 and bench._last_json_line(out) == {"a": 1}
 
 def test_the_default_run_times_every_baseline_configuration():
     """`configs` of the default one-GPU line: one child `python bench.py --workload <w>` per BASELINE
