@@ -945,6 +945,9 @@ __global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, 
 // initialised, so their HBM latency hides under the LDS fill; the workgroups of a CU overlap each other's phases.
 static constexpr int BUILD_THREADS = 512;
 static constexpr int BUILD_PRE = 6;
+#ifndef KMU_BUILD_AHEAD // (A/B builds of round 5)
+#define KMU_BUILD_AHEAD 1
+#endif
 
 // where the items of region r lie: [leafstart[r], leafstart[r + 1]) (exact route), or a fixed-size leaf with its fill in leafcnt
 // (single-pass route: the fill may exceed the capacity where items went to the spill list)
@@ -973,15 +976,44 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
     uint32_t full = 0;
     const int w = t.w, xs = 32 - t.b1, os = 32 - t.rbits;
     const uint64_t cmask = q_cmask(w), add_limit = q_limit(w), lowmask = (1ull << xs) - 1ull;
-    for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-        uint64_t i0, i1;
-        leaf_range(r, leafstart, leaf_stride, leafcnt, i0, i1);
-        auto item_at = [&](uint64_t i) -> uint64_t { return LEAF6 ? leaf6_load(items, i) : items[i]; };
-        uint64_t pre_it[BUILD_PRE];
+    auto item_at = [&](uint64_t i) -> uint64_t { return LEAF6 ? leaf6_load(items, i) : items[i]; };
+    // where the items of region rr lie (nothing for a region beyond the table), and the first BUILD_PRE of them of this thread
+    auto range = [&](uint32_t rr, uint64_t &a0, uint64_t &a1) {
+        a0 = a1 = 0;
+        if (rr < n_regions) leaf_range(rr, leafstart, leaf_stride, leafcnt, a0, a1);
+    };
+    auto request = [&](uint64_t a0, uint64_t a1, uint64_t (&it)[BUILD_PRE]) {
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++) {
-            const uint64_t i = i0 + (uint64_t) q * BUILD_THREADS + tid;
-            pre_it[q] = i < i1 ? item_at(i) : CKEY_EMPTY;
+            const uint64_t i = a0 + (uint64_t) q * BUILD_THREADS + tid;
+            it[q] = i < a1 ? item_at(i) : CKEY_EMPTY;
+        }
+    };
+    // AHEAD (round 5): the items of a workgroup's NEXT region are requested before this region is built, and the bounds of the one
+    // after that with them -- a leaf's items come from HBM at the latency of a memory system that the builds themselves keep at
+    // 3.5 TB/s, and a workgroup that asks at the top of its region (first for the leaf's fill, then for the items) waits for them
+    // behind the LDS fill with only the three other workgroups of its CU to cover for it
+    uint64_t nxt_it[BUILD_PRE], n0 = 0, n1 = 0, m0 = 0, m1 = 0;
+    if (KMU_BUILD_AHEAD) {
+        range(blockIdx.x, n0, n1);
+        request(n0, n1, nxt_it);
+        range(blockIdx.x + gridDim.x, m0, m1);
+    }
+    for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        uint64_t i0, i1;
+        uint64_t pre_it[BUILD_PRE];
+        if (KMU_BUILD_AHEAD) {
+            i0 = n0;
+            i1 = n1;
+#pragma unroll
+            for (int q = 0; q < BUILD_PRE; q++) pre_it[q] = nxt_it[q];
+            n0 = m0;
+            n1 = m1;
+            request(n0, n1, nxt_it);                 // region r + grid: its bounds have been here since the last turn
+            range(r + 2u * gridDim.x, m0, m1);       // region r + 2 grid: looked at in the next turn
+        } else {
+            range(r, i0, i1);
+            request(i0, i1, pre_it);
         }
         const uint32_t lox_s = t.lox[r % t.n2]; // (workgroup-uniform: the sub-region of this region)
         uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + (uint64_t) r * R);

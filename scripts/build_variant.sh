@@ -8,7 +8,7 @@ tag=$1; flags=$2; shift 2
 python kmerutils_amd/build.py > /dev/null
 mkdir -p kmerutils_amd/build_$tag
 objs=""
-for s in kmu_api kmu_sketch kmu_sketch_super kmu_sketch_dens kmu_count kmu_smer kmu_hostpack kmu_compare kmu_ingest kmu_kmergen kmu_comm; do
+for s in kmu_api kmu_sketch kmu_sketch_kernels kmu_sketch_super kmu_sketch_dens kmu_count kmu_count_part kmu_count_dist kmu_smer kmu_hostpack kmu_compare kmu_ingest kmu_kmergen kmu_comm; do
   if [[ " $* " == *" $s "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $flags \
       -c kmerutils_amd/csrc/$s.hip -o kmerutils_amd/build_$tag/$s.o &
