@@ -943,14 +943,12 @@ __global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, 
 // The region lives in LDS while its k-mers are inserted, then it leaves for HBM.  in_mode: 0 = the table holds nothing yet (no
 // region is read), 1 = the slab is read first.  The first BUILD_PRE items of every thread are requested before the region is
 // initialised, so their HBM latency hides under the LDS fill; the workgroups of a CU overlap each other's phases.
-static constexpr int BUILD_THREADS = 512;
+static constexpr int BUILD_THREADS = 1 << (REGION_BITS_MAX - 3); // 512 threads for regions of 4096 slots
 static constexpr int BUILD_PRE = 6;
 #ifndef KMU_BUILD_AHEAD // (A/B builds of round 5)
 #define KMU_BUILD_AHEAD 1
 #endif
-#ifndef KMU_BUILD_BALANCE
-#define KMU_BUILD_BALANCE 1
-#endif
+
 
 // where the items of region r lie: [leafstart[r], leafstart[r + 1]) (exact route), or a fixed-size leaf with its fill in leafcnt
 // (single-pass route: the fill may exceed the capacity where items went to the spill list)
@@ -1048,65 +1046,13 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
             if ((old & cmask) < add_limit) atomicAdd((unsigned long long *) &lk[off], 1ull);
             return true;
         };
-        if (KMU_BUILD_BALANCE) {
-            // Every LANE walks through its prefetched items at its own pace (a lane whose item is in takes its next one in the next
-            // trip), and -- round 5 -- a lane that has run out of items takes one from a lane of its wave that still has some
-            // queued.  A wave leaves the loop when its LAST lane is through, and probe chains are unequal: at the load of 0.66 the
-            // bench's table has now the slowest of 64 lanes needs ~25 trips where the average lane needs ~11
-            // (scripts/sim_region_build.py).  Every other trip the idle lanes and the lanes with queued items are counted (two
-            // ballots); the k-th idle lane gets the LAST queued item of the k-th such lane through the wave's 64 words of LDS.
-            static_assert(BUILD_PRE == 6, "the item queue of a lane is written out by hand");
-            uint64_t *xch = lk + R + (tid >> 6) * 64u;
-            uint64_t q0 = pre_it[0], q1 = pre_it[1], q2 = pre_it[2], q3 = pre_it[3], q4 = pre_it[4], q5 = pre_it[5];
-            // queued slots of this lane: those that lie inside the leaf (a "no k-mer" mark among them is skipped when its turn comes)
-            uint32_t nq = 0;
-            if (i0 + tid < i1) {
-                const uint64_t mine = (i1 - i0 - tid + BUILD_THREADS - 1) / BUILD_THREADS;
-                nq = mine < (uint64_t) BUILD_PRE ? (uint32_t) mine : (uint32_t) BUILD_PRE;
-            }
-            uint32_t guard = 0, off = 0;
-            uint64_t hw = 0;
-            bool have = false; // this lane is probing for an item
-            for (uint32_t trip = 0;; trip++) {
-                if (!have && nq) { // the lane's next item
-                    const uint64_t item = q0;
-                    q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = CKEY_EMPTY;
-                    nq--;
-                    if (item != CKEY_EMPTY) {
-                        locate(item, hw, off);
-                        guard = 0;
-                        have = true;
-                    }
-                }
-                if (have) {
-                    if (probe(hw, off)) have = false;
-                    else {
-                        off = (off + ++guard) & t.rmask; // (the triangular sequence of kmu_count_table.h)
-                        if (guard >= R) { full = 1; have = false; }
-                    }
-                }
-                const uint64_t busy = __ballot(have || nq != 0u);
-                if (!busy) break;
-                if (trip & 1u) {
-                    const uint64_t idle_m = ~busy, rich_m = __ballot(nq >= (have ? 1u : 2u)); // (a lane keeps the item it will take itself next trip)
-                    if (idle_m && rich_m) { // (wave-uniform)
-                        const uint32_t n_i = (uint32_t) __popcll(idle_m), n_r = (uint32_t) __popcll(rich_m), np = n_i < n_r ? n_i : n_r;
-                        const uint32_t ki = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle_m, 0u));
-                        const uint32_t kr = __builtin_amdgcn_mbcnt_hi((uint32_t) (rich_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) rich_m, 0u));
-                        const bool rich = nq >= (have ? 1u : 2u), idle = !have && nq == 0u;
-                        if (rich && kr < np) { // give the last queued item away
-                            const uint64_t g = nq == 6u ? q5 : nq == 5u ? q4 : nq == 4u ? q3 : nq == 3u ? q2 : nq == 2u ? q1 : q0;
-                            xch[kr] = g;
-                            nq--;
-                        }
-                        if (idle && ki < np) { // (the same wave's LDS operations complete in order: the word is there)
-                            q0 = xch[ki];
-                            nq = 1u;
-                        }
-                    }
-                }
-            }
-        } else {
+        {
+            // Every LANE walks through its prefetched items at its own pace: a lane whose item is in takes its next one in the
+            // next trip of the loop.  (Item by item, a wave repeats the probe loop until the unluckiest of its 64 lanes is through,
+            // while the lanes' SUMS of probes over their items lie closer together.  Round 5, measured and not kept: idle lanes
+            // taking queued items from busy lanes of their wave through 64 words of LDS -- the simulation halves the trips of a
+            // wave, the kernel took 25.2 instead of 21.4 ms: two ballots and the bookkeeping per trip cost more than the trips
+            // they save, in a loop that is bound by the instructions of a trip.)
             static_assert(BUILD_PRE == 6, "the item queue of a lane is written out by hand");
             uint64_t q0 = pre_it[0], q1 = pre_it[1], q2 = pre_it[2], q3 = pre_it[3], q4 = pre_it[4], q5 = pre_it[5];
             uint32_t left = BUILD_PRE + 1, guard = 0, off = 0;
@@ -1215,7 +1161,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static size_t build_lds(const kmu_counter *c) { return c->qw ? ((size_t) 8 << c->rbits) + (BUILD_THREADS / 64) * 64 * 8 : (size_t) 12 << c->rbits; } // (quotient: + a wave's 64 words of exchange each)
+static size_t build_lds(const kmu_counter *c) { return c->qw ? (size_t) 8 << c->rbits : (size_t) 12 << c->rbits; }
 // the items of every region (leaves: the regions' bounds; or leaf_stride / leafcnt: fixed-size leaves with their fills) into the table
 template <int IT>
 static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, uint32_t *d_err,
@@ -1223,7 +1169,7 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     kmu_ctx *ctx = c->ctx;
     const uint64_t n_regions = table_regions(c);
     const int in_mode = c->empty ? 0 : 1;
-    const int per_cu = c->qw ? 4 : 3;
+    const int per_cu = c->qw ? std::min(32 / (BUILD_THREADS / 64), (int) ((160 * 1024) / build_lds(c))) : 3;
     const int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * per_cu * 8);
     {
         KernelTimer tm(ctx, c->qw ? "k_part_build_q" : "k_part_build"); // (the kernels' own names)
