@@ -533,6 +533,10 @@ def main():
             # device); `value` is the bench contract's device-resident figure.  Quote THIS one as the 8(d) number.
             "metric_value_8d": host["value"] if host else None,
             "kernels": kern, "device_ms_per_step": dev_ms / args.steps,
+            # for whoever samples the card from outside (a sampler that saw 0 % busy): the launches the library timed
+            # inside the timed region, their summed device time (hipEvents), and the region's wall time
+            "gpu_work": {"timed_kernel_launches": int(sum(ln for ln, _ in stats.values())), "timed_kernel_ms": float(sum(ms for _, ms in stats.values())),
+                         "timed_region_wall_ms": elapsed * 1e3, "timed_region_device_ms": dev_ms},
             "checks": checks, "comm": _comm_summary(comm_stats, transport, comm_fallbacks, comm_ranks), "gen_seconds": t_gen,
             # the other BASELINE configurations on this GPU (configs 4 / 5: one GPU's shard), each timed by a child of this run
             "configs": configs,

@@ -1037,8 +1037,11 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
             if (lane == 0) *qmax_sh = qb;
         }
         uint64_t s0 = 0, s3 = 0;
-        const bool pass = c + 64u <= n_u ? have && pmh3a_first_point_may_matter<true>(a, sig32, qb, key, w, winv_lut, s0, s3) // (uniform)
-                                         : have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
+        // (diagnostic builds, KMU_PMH_ABLATE: 16384 = no key passes and the test is not computed -- the list walk alone; 8192 = the
+        //  keys that pass are queued but not worked off -- walk + cheap test; wrong rows, the parts' share of the instructions)
+        const bool pass = ABL(16384u) ? false
+                          : c + 64u <= n_u ? have && pmh3a_first_point_may_matter<true>(a, sig32, qb, key, w, winv_lut, s0, s3) // (uniform)
+                                           : have && pmh3a_first_point_may_matter(a, sig32, qb, key, w, winv_lut, s0, s3);
         const uint64_t pm = __ballot(pass);
         if (pass) {
             const uint32_t pos = qn + (uint32_t) __popcll(pm & ((1ull << lane) - 1ull));
@@ -1050,12 +1053,14 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
         qn += (uint32_t) __popcll(pm);
         if (qn >= 64u) { // the newest 64
             qn -= 64u;
+            if (!ABL(8192u))
             pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, true, qk[qn + lane], qw[qn + lane], qs0[qn + lane], qs3[qn + lane],
                                    winv_lut);
         }
     }
     if (qn) {
         const bool have = (uint32_t) lane < qn;
+        if (!ABL(8192u))
         pmh3a_first_point_rest(a, sig32, hmin, sig, qmax_sh, have, have ? qk[lane] : 0ull, have ? qw[lane] : 1u, have ? qs0[lane] : 0ull,
                                have ? qs3[lane] : 0ull, winv_lut);
     }
