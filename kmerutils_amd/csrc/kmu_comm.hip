@@ -273,7 +273,6 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
         (void) hipEventRecord(t_b, s);
         c->timed.emplace_back(t_a, t_b);
     } else give_back();
-    if (getenv("KMU_COMM_SYNC")) KMU_HIP(ctx, hipStreamSynchronize(s)); // diagnostics
     return KMU_OK;
 }
 

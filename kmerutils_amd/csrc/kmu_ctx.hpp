@@ -99,7 +99,6 @@ inline int dev_buf(kmu_ctx *ctx, const char *name, size_t bytes, void **out) {
         size_t want = bytes + bytes / 8 + 256;
         KMU_HIP(ctx, hipMalloc(&b.p, want));
         b.bytes = want;
-        if (getenv("KMU_DIAG_BUFS")) fprintf(stderr, "kmu dev_buf %-16s %p  %zu bytes\n", name, b.p, want); // (diagnostics: where the driver put it)
     }
     *out = b.p;
     return KMU_OK;

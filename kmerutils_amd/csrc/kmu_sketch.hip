@@ -147,7 +147,10 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     a.e01.c3 = (1.0 - std::exp(-lambda)) / lambda;
     a.sig_out = d_sig;
     a.err = d_err;
-    { const char *ab = getenv("KMU_PMH_ABLATE"); a.ablate = ab ? (uint32_t) atoi(ab) : 0u; }
+    a.ablate = 0u;
+#if KMU_DIAG // (diagnostic builds: parts of the kernels switched off / clocked, scripts/r05_pts_parts.sh)
+    if (const char *ab = getenv("KMU_PMH_ABLATE")) a.ablate = (uint32_t) atoi(ab);
+#endif
     const bool aa = kmer_is_aa(p->kmer_type) || hashed_bytes != 0; // pre-hashed values use the byte-stream instantiation
     typedef void (*sketch_kernel_t)(SketchArgs);
     if (smallk_route(p, hashed_bytes, part_h != nullptr, d_block_rows != nullptr)) { // k <= 8: direct-indexed histogram
@@ -276,7 +279,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     }
     const char *plain_env = getenv("KMU_PMH_PLAIN"); // diagnostics: 0 = always the general instantiation
     const bool plain = !bottomk && !aa && !part_h && !d_block_rows && p->block_size == 0 && !ds.packed &&
-                 !(plain_env && atoi(plain_env) == 0) && !getenv("KMU_PMH_THREADS"); // (1024 threads: see part_target below)
+                 !(plain_env && atoi(plain_env) == 0);
     const sketch_kernel_t kern = bottomk ? (aa ? k_sketch_pmh3a<true, true> : k_sketch_pmh3a<false, true>)
                                  : aa    ? k_sketch_pmh3a<true, false>
                                  : split ? (plain ? k_sketch_pmh3a<false, false, true, true> : k_sketch_pmh3a<false, false, true>)
@@ -309,8 +312,6 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     uint32_t cap = (uint32_t) ((lds_max - fixed) / 12);
     cap &= ~63u;
     if (cap > 65472) cap = 65472; // positions are stored in 16 bits
-    const char *env = getenv("KMU_PMH_SLOTS");
-    if (env && atoi(env) >= 256) cap = std::min<uint32_t>(cap, (uint32_t) atoi(env) & ~63u);
     a.cap = cap;
     a.part_target = cap - cap / 10;
     a.inv_part_target = 1.0 / (double) a.part_target;
@@ -327,9 +328,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
     KMU_TRY(dev_buf(ctx, "queue", 256, &q)); // [0] read cursor; u64 words 8..23: phase clocks (diagnostics)
     KMU_HIP(ctx, hipMemsetAsync(q, 0, 256, ctx->stream));
     a.queue = (uint32_t *) q;
-    int threads = 1024;
-    const char *tenv = getenv("KMU_PMH_THREADS");
-    if (tenv && atoi(tenv) >= 512) threads = std::min(1024, atoi(tenv) & ~63); // bucket_scan: <= 8 buckets per thread
+    const int threads = 1024;
     int blocks_per_cu = std::max<int>(1, (int) (lds_max / lds));
     int cus = ctx->num_cus;
     if (const char *rs = getenv("KMU_PMH_RESERVE_CUS")) // CUs left to concurrent work (RCCL kernels of an exchange in flight)
@@ -923,7 +922,6 @@ extern "C" int kmu_sketch_count(kmu_ctx *ctx, const kmu_sketch_params *p_in, kmu
         KMU_TRY(host_buf(ctx, "pipe.packed", (size_t) (total / 4 + 64), &h_packed));
         KMU_TRY(dev_buf(ctx, "pipe.packed_d", (size_t) (total / 4 + 64), &d_packed));
         int threads = 16;
-        if (const char *e = getenv("KMU_PIPE_PACK_THREADS")) threads = std::max(1, atoi(e));
         threads = std::min<int>(threads, std::max(1u, std::thread::hardware_concurrency()));
         try {
             packer.reset(new PackPipe(bases + off0, (uint8_t *) h_packed, total, threads));

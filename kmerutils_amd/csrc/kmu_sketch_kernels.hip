@@ -1013,6 +1013,10 @@ __device__ __forceinline__ void pts_one_read(const SketchArgs &a, uint32_t r, ui
     uint32_t chunk = 0, qn = 0; // qn: queued pairs (uniform)
     uint32_t wmax = 0;          // largest weight this lane saw
     uint64_t qb = H_INIT;
+    // (Round 5, measured and not kept: the keys of 2 / 4 / 8 chunks in flight instead of one -- 18.40 / 18.42 / 19.60 against 18.38 ms,
+    //  profiles/r05_pts_ahead.txt.  With everything but the list walk switched off the kernel takes 9.3 ms -- 38 GB of lists at
+    //  4.1 TB/s -- but the whole kernel is bound by instruction issue: 1.008e10 vector wave-instructions at the half-rate peak are
+    //  18 ms, the walk's loads are under them already; profiles/r05_pts_parts.txt.)
     uint64_t key_nx = 0; // the next chunk's pair is requested one iteration ahead
     uint32_t w_nx = 1;
     {

@@ -18,25 +18,6 @@
 #include "kmu_ctx.hpp"
 #include "kmu_stream.h"
 
-#ifndef KMU_SUPER_DPPMAX // (A/B builds: 0 = the maximum over the wave through ds_bpermute)
-#define KMU_SUPER_DPPMAX 1
-#endif
-#ifndef KMU_SUPER_RMASK
-#define KMU_SUPER_RMASK 3u
-#endif
-#ifndef KMU_SUPER_IDX32
-#define KMU_SUPER_IDX32 0
-#endif
-#ifndef KMU_SUPER_VOL // (A/B builds: 1 = the volatile loads of rounds 1-3)
-#define KMU_SUPER_VOL 0
-#endif
-#ifndef KMU_SUPER_ZTAB // (A/B builds: 0 = the rejection bound of the index draw computed in every step)
-#define KMU_SUPER_ZTAB 1
-#endif
-#ifndef KMU_SUPER_TMODE // (A/B builds: 0 = mode and index draw looked up per step)
-#define KMU_SUPER_TMODE 1
-#endif
-
 namespace kmu {
 
 struct SuperArgs {
@@ -88,8 +69,8 @@ __device__ __forceinline__ uint32_t super_floor(uint64_t bits, int mode, int m, 
 // scalar compares and taken branches around ~110 vector instructions (round 4: config 5's shard 8.4 -> see DESIGN.md 3.3).
 template <typename PT, int MODE, bool RAND08>
 __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
-#define SUPER_MODE (KMU_SUPER_TMODE ? MODE : a.mode) // (A/B builds read the arguments as before)
-#define SUPER_R08 (KMU_SUPER_TMODE ? RAND08 : a.rand08 != 0)
+#define SUPER_MODE MODE
+#define SUPER_R08 RAND08
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int wave = tid >> 6, nwaves = nthreads >> 6;
@@ -177,7 +158,7 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                 for (;;) {
                     // (a relaxed atomic load, not a volatile one: the compiler turns a volatile access through a derived pointer into a FLAT load
                     //  with a full vmcnt / lgkmcnt wait -- the step loop had one per step)
-                    uint32_t a_upper = KMU_SUPER_VOL ? *(volatile uint32_t *) &misc[1] : __hip_atomic_load(&misc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t a_upper = __hip_atomic_load(&misc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (active && j > a_upper) active = false;
                     if (!__any(active)) break;
                     if (active) {
@@ -190,12 +171,8 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                         case 2: ri = rng.next(); break;
                         default: ri = rng.next_u32(); break;
                         }
-                        uint32_t k = KMU_SUPER_ZTAB ? rng.unif_index_bound(j, (uint32_t) m, ztab[j], SUPER_R08) : rng.unif_index(j, (uint32_t) m, SUPER_R08);
-#if KMU_SUPER_IDX32
-                        const uint32_t ij = j * (uint32_t) ncol + (uint32_t) tid, ik = k * (uint32_t) ncol + (uint32_t) tid;
-#else
+                        uint32_t k = rng.unif_index_bound(j, (uint32_t) m, ztab[j], SUPER_R08);
                         const size_t ij = (size_t) j * ncol + tid, ik = (size_t) k * ncol + tid;
-#endif
                         PT pj = perm[ij];
                         PT pk = perm[ik];
                         perm[ij] = pk;
@@ -214,14 +191,14 @@ __global__ void __launch_bounds__(256) k_sketch_super(SuperArgs a) {
                     }
                     round++; // wave-uniform (all lanes of the wave run this loop together)
                     // (round 4: the waves of a workgroup taking turns at the refresh -- 7.46 against 7.22 ms on config 5's shard: a staler
-                    //  bound costs more steps than the refresh saves; KMU_SUPER_RMASK: the period, A/B builds)
-                    if ((round & KMU_SUPER_RMASK) == 0u || round == 1u) { // refresh a_upper = max_s min(floor(hs[s]), m-1)
+                    //  bound costs more steps than the refresh saves; every 2 / 8 rounds instead of 4: 7.36 / 7.82 against 7.22)
+                    if ((round & 3u) == 0u || round == 1u) { // refresh a_upper = max_s min(floor(hs[s]), m-1)
                         uint32_t mx = 0;
                         for (int s = lane_id(); s < m; s += 64) {
-                            uint32_t f = super_floor(KMU_SUPER_VOL ? *(volatile uint64_t *) &hs[s] : __hip_atomic_load(&hs[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), SUPER_MODE, m, a.lg);
+                            uint32_t f = super_floor(__hip_atomic_load(&hs[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), SUPER_MODE, m, a.lg);
                             mx = f > mx ? f : mx;
                         }
-                        mx = KMU_SUPER_DPPMAX ? wave_max_u32(mx) : (uint32_t) wave_max_u64(mx);
+                        mx = wave_max_u32(mx);
                         if (lane_id() == 0) atomicMin(&misc[1], mx);
                     }
                 }
@@ -331,7 +308,6 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     // read takes -- four waves and 512 staged items: 7.93 -> 7.25 ms on config 5's shard (scripts/r04_superthreads.sh; 1 024
     // staged items: 8.7).
     a.chunk = 512;
-    if (const char *e = getenv("KMU_SUPER_CHUNK")) a.chunk = (uint32_t) std::max(64, atoi(e));
     const bool wide = a.m > 256;
     const size_t pt = wide ? 2 : 1;
     const size_t lds_max = 160 * 1024;
@@ -349,7 +325,6 @@ int launch_super(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs &ds, vo
     auto fn = (const void *) kern;
     // the per-lane permutation columns dominate the LDS footprint: shrink the workgroup for large m
     int threads = 256;
-    if (const char *e = getenv("KMU_SUPER_THREADS")) threads = std::max(64, std::min(256, atoi(e) & ~63));
     size_t lds = 0;
     int ncol = 0;
     for (; threads >= 64; threads -= 64) {
