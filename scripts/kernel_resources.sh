@@ -16,7 +16,7 @@ for line in sys.stdin:
         k, v = t.rsplit(":", 1); cur[k.strip()] = v.strip()
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 for r in rows:
-    try: name = subprocess.run(["/opt/rocm/llvm/bin/llvm-cxxfilt", r["name"]], capture_output=True, text=True).stdout.strip()
+    try: name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", r["name"]], capture_output=True, text=True).stdout.strip()
     except Exception: name = r["name"]
     name = re.sub(r"\(.*", "", name)
     if flt and flt not in name: continue
