@@ -835,8 +835,10 @@ __global__ void __launch_bounds__(SCATTER_THREADS) k_arr_scatter_seg(const uint6
         uint32_t u = i / pl.seg_cap, o = i - u * pl.seg_cap;
 #pragma unroll
         for (int j2 = 0; j2 < 8; j2++) {
-            const uint32_t uu = u < pl.seg_units ? u : pl.seg_units - 1; // (beyond the partition: anything readable)
-            const u64x2 q = *reinterpret_cast<const u64x2 *>(in + ((uint64_t) uu * seg_stride + seg_base + o));
+            // a pair beyond the unit's slice is not looked at: its lanes ask for the partition's first pair, one line that the
+            // vector cache holds (requested as whole tiles a unit of 8.3 tiles fetched 10: 42.7 GB for the bench's 35.6)
+            const bool mine = t + (uint64_t) j2 * (2u * THREADS) + 2u * threadIdx.x < i1;
+            const u64x2 q = *reinterpret_cast<const u64x2 *>(in + (mine ? (uint64_t) u * seg_stride + seg_base + o : seg_base));
             nxt[2 * j2] = q.x;
             nxt[2 * j2 + 1] = q.y;
             o += 2u * THREADS;
@@ -945,10 +947,10 @@ __global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, 
 // initialised, so their HBM latency hides under the LDS fill; the workgroups of a CU overlap each other's phases.
 static constexpr int BUILD_THREADS = 1 << (REGION_BITS_MAX - 3); // 512 threads for regions of 4096 slots
 static constexpr int BUILD_PRE = 6;
-#ifndef KMU_BUILD_AHEAD // (A/B builds of round 5)
-#define KMU_BUILD_AHEAD 1
-#endif
-
+// batched form of the quotient build: entries of the per-wave pool of items that two probes did not place (8 bytes each, behind the
+// region in LDS: 32 + 6 KiB per workgroup, four workgroups per CU as before), and the ceiling of a count field while up to
+// BUILD_PRE adds per thread are in flight behind a count that was seen below it
+static constexpr uint32_t BUILD_POOL = 96, BUILD_BATCH_MARGIN = 4096;
 
 // where the items of region r lie: [leafstart[r], leafstart[r + 1]) (exact route), or a fixed-size leaf with its fill in leafcnt
 // (single-pass route: the fill may exceed the capacity where items went to the spill list)
@@ -963,20 +965,27 @@ __device__ __forceinline__ void leaf_range(uint32_t r, const uint64_t *leafstart
 }
 
 // Quotient slots: the region is 4 096 8-byte words in LDS (32 KiB: four workgroups of 512 threads per CU), a first sighting is
-// one ds_cmpst_rtn_b64, a repeat one more ds_add_u64 (guarded: the count field stops at q_limit), and the LDS image leaves as
+// one ds_cmpst_rtn_b64, a repeat one more ds_add_u64 (guarded: the count field stops short of its width), and the LDS image leaves as
 // it is.  LEAF6: the leaves hold the <= 48 bits a slot keeps of an item (tile_scatter_seg) instead of its hash.
+// The items of a workgroup's NEXT region are requested before this region is built, and the bounds of the one after that with
+// them (round 5): a leaf's items come from HBM at the latency of a memory system that the builds themselves keep busy, and a
+// workgroup that asks at the top of its region (first for the leaf's fill, then for the items) waits for them behind the LDS fill
+// with only the three other workgroups of its CU to cover for it.
+// batched (the host sets it where the count field has the room, w >= 13 / 17): see the comment in the body.
 template <int IT, bool LEAF6>
 __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
                                                                 uint32_t n_regions, CountTable t, int in_mode, uint32_t *err,
-                                                                uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt) {
+                                                                uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt, int batched) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t R = t.rmask + 1;
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
     uint4 *lk4 = reinterpret_cast<uint4 *>(lk);
     const uint32_t tid = threadIdx.x;
+    uint64_t *pool = lk + R + (tid >> 6) * BUILD_POOL; // this wave's (batched form only: the launch asks for the room)
     uint32_t full = 0;
     const int w = t.w, xs = 32 - t.b1, os = 32 - t.rbits;
-    const uint64_t cmask = q_cmask(w), add_limit = q_limit(w), lowmask = (1ull << xs) - 1ull;
+    const uint64_t cmask = q_cmask(w), lowmask = (1ull << xs) - 1ull;
+    const uint64_t add_limit = batched ? (1ull << w) - BUILD_BATCH_MARGIN : q_limit(w);
     auto item_at = [&](uint64_t i) -> uint64_t { return LEAF6 ? leaf6_load(items, i) : items[i]; };
     // where the items of region rr lie (nothing for a region beyond the table), and the first BUILD_PRE of them of this thread
     auto range = [&](uint32_t rr, uint64_t &a0, uint64_t &a1) {
@@ -990,32 +999,19 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
             it[q] = i < a1 ? item_at(i) : CKEY_EMPTY;
         }
     };
-    // AHEAD (round 5): the items of a workgroup's NEXT region are requested before this region is built, and the bounds of the one
-    // after that with them -- a leaf's items come from HBM at the latency of a memory system that the builds themselves keep at
-    // 3.5 TB/s, and a workgroup that asks at the top of its region (first for the leaf's fill, then for the items) waits for them
-    // behind the LDS fill with only the three other workgroups of its CU to cover for it
     uint64_t nxt_it[BUILD_PRE], n0 = 0, n1 = 0, m0 = 0, m1 = 0;
-    if (KMU_BUILD_AHEAD) {
-        range(blockIdx.x, n0, n1);
-        request(n0, n1, nxt_it);
-        range(blockIdx.x + gridDim.x, m0, m1);
-    }
+    range(blockIdx.x, n0, n1);
+    request(n0, n1, nxt_it);
+    range(blockIdx.x + gridDim.x, m0, m1);
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-        uint64_t i0, i1;
         uint64_t pre_it[BUILD_PRE];
-        if (KMU_BUILD_AHEAD) {
-            i0 = n0;
-            i1 = n1;
+        const uint64_t i0 = n0, i1 = n1;
 #pragma unroll
-            for (int q = 0; q < BUILD_PRE; q++) pre_it[q] = nxt_it[q];
-            n0 = m0;
-            n1 = m1;
-            request(n0, n1, nxt_it);                 // region r + grid: its bounds have been here since the last turn
-            range(r + 2u * gridDim.x, m0, m1);       // region r + 2 grid: looked at in the next turn
-        } else {
-            range(r, i0, i1);
-            request(i0, i1, pre_it);
-        }
+        for (int q = 0; q < BUILD_PRE; q++) pre_it[q] = nxt_it[q];
+        n0 = m0;
+        n1 = m1;
+        request(n0, n1, nxt_it);                 // region r + grid: its bounds have been here since the last turn
+        range(r + 2u * gridDim.x, m0, m1);       // region r + 2 grid: looked at in the next turn
         const uint32_t lox_s = t.lox[r % t.n2]; // (workgroup-uniform: the sub-region of this region)
         uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + (uint64_t) r * R);
         if (in_mode == 1) {
@@ -1042,11 +1038,69 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
             const unsigned long long old = atomicCAS((unsigned long long *) &lk[off], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw | 1ull));
             if (old == CKEY_EMPTY) return true;
             if (!q_same(old, hw, w)) return false;
-            // fewer than BUILD_THREADS adds are in flight behind a count seen below the limit: no carry into the key bits
+            // the adds in flight behind a count seen below the limit are fewer than the margin: no carry into the key bits
             if ((old & cmask) < add_limit) atomicAdd((unsigned long long *) &lk[off], 1ull);
             return true;
         };
-        {
+        // the rest of an item's probe sequence from its n-th probe at `off` on
+        auto walk = [&](uint64_t hw, uint32_t off, uint32_t n) {
+            do {
+                off = (off + ++n) & t.rmask;
+                if (n >= R) { full = 1; break; }
+            } while (!probe(hw, off));
+        };
+        if (batched) {
+            // BATCHED: item by item a wave repeats "probe, wait for the answer, branch" until the unluckiest of its lanes is through
+            // -- ~31 trips of ~55 instructions for the six items of a lane where the average item needs 1.6 probes.  Here the first
+            // probes of a thread's six items leave back to back without a branch (a lane without an item compares against 0, which no
+            // slot holds, so nothing is written) and are waited for once; so do the second probes (the next slot) of the items that
+            // failed; what is left -- one item in seven -- is pooled per WAVE in LDS and the lanes take the pool's entries, one each:
+            // the walk of the remaining probe sequences is as long as the longest of them, not as the unluckiest lane's sum.
+            uint64_t hw[BUILD_PRE];
+            uint32_t off[BUILD_PRE];
+            bool todo[BUILD_PRE];
+#pragma unroll
+            for (int q = 0; q < BUILD_PRE; q++) {
+                locate(pre_it[q], hw[q], off[q]);
+                todo[q] = pre_it[q] != CKEY_EMPTY;
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                unsigned long long old[BUILD_PRE];
+#pragma unroll
+                for (int q = 0; q < BUILD_PRE; q++) {
+                    if (pass) off[q] = (off[q] + 1u) & t.rmask;
+                    old[q] = atomicCAS((unsigned long long *) &lk[off[q]], todo[q] ? (unsigned long long) CKEY_EMPTY : 0ull, (unsigned long long) (hw[q] | 1ull));
+                }
+#pragma unroll
+                for (int q = 0; q < BUILD_PRE; q++) {
+                    const bool claimed = old[q] == CKEY_EMPTY, same = !claimed && q_same(old[q], hw[q], w);
+                    if (todo[q] && same && (old[q] & cmask) < add_limit) atomicAdd((unsigned long long *) &lk[off[q]], 1ull);
+                    todo[q] = todo[q] && !claimed && !same;
+                }
+            }
+            uint32_t n_pool = 0; // (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < BUILD_PRE; q++) {
+                const uint64_t m = __ballot(todo[q]);
+                const uint32_t at = n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+                if (todo[q]) {
+                    if (at < BUILD_POOL) pool[at] = hw[q];
+                    else walk(hw[q], off[q], 1u); // (a wave with more than 96 of 384 items left after two probes: a table that is filling up)
+                }
+                n_pool += (uint32_t) __popcll(m);
+            }
+            n_pool = n_pool < BUILD_POOL ? n_pool : BUILD_POOL;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t e = tid & 63u; e < n_pool; e += 64u) {
+                const uint64_t h = pool[e];
+                const uint32_t x = lox_s + (uint32_t) ((h >> w) >> xs);
+                walk(h, (((x * t.n2) >> os) + 1u) & t.rmask, 1u); // (its second probe was at home + 1)
+            }
+            __builtin_amdgcn_wave_barrier(); // (the pool is this wave's alone: the next region's entries come behind two workgroup barriers)
+        } else {
             // Every LANE walks through its prefetched items at its own pace: a lane whose item is in takes its next one in the
             // next trip of the loop.  (Item by item, a wave repeats the probe loop until the unluckiest of its 64 lanes is through,
             // while the lanes' SUMS of probes over their items lie closer together.  Round 5, measured and not kept: idle lanes
@@ -1082,12 +1136,9 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
             const uint64_t item = item_at(i);
             if (item == CKEY_EMPTY) continue;
             uint64_t hw;
-            uint32_t off, n = 0;
+            uint32_t off;
             locate(item, hw, off);
-            while (!probe(hw, off)) {
-                off = (off + ++n) & t.rmask;
-                if (n >= R) { full = 1; break; }
-            }
+            if (!probe(hw, off)) walk(hw, off, 0u);
         }
         lds_barrier();
         for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
@@ -1162,6 +1213,9 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t build_lds(const kmu_counter *c) { return c->qw ? (size_t) 8 << c->rbits : (size_t) 12 << c->rbits; }
+// the batched form of the quotient build (k_part_build_q): where the count field keeps its ceiling with six adds per thread in flight
+static bool build_batched(const kmu_counter *c) { return c->qw && (1ull << c->qw) >= (uint64_t) BUILD_BATCH_MARGIN + max_count(c); }
+static size_t build_pool_lds(const kmu_counter *c) { return build_batched(c) ? (size_t) (BUILD_THREADS / 64) * BUILD_POOL * 8 : 0; }
 // the items of every region (leaves: the regions' bounds; or leaf_stride / leafcnt: fixed-size leaves with their fills) into the table
 template <int IT>
 static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, uint32_t *d_err,
@@ -1169,18 +1223,19 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     kmu_ctx *ctx = c->ctx;
     const uint64_t n_regions = table_regions(c);
     const int in_mode = c->empty ? 0 : 1;
-    const int per_cu = c->qw ? std::min(32 / (BUILD_THREADS / 64), (int) ((160 * 1024) / build_lds(c))) : 3;
+    const size_t lds = build_lds(c) + build_pool_lds(c);
+    const int per_cu = c->qw ? std::min(32 / (BUILD_THREADS / 64), (int) ((160 * 1024) / lds)) : 3;
     const int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * per_cu * 8);
     {
         KernelTimer tm(ctx, c->qw ? "k_part_build_q" : "k_part_build"); // (the kernels' own names)
         if (c->qw && leaf6)
-            hipLaunchKernelGGL((k_part_build_q<IT_HASH, true>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
-                               table_of(c), in_mode, d_err, leaf_stride, leafcnt);
+            hipLaunchKernelGGL((k_part_build_q<IT_HASH, true>), dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
+                               table_of(c), in_mode, d_err, leaf_stride, leafcnt, (int) build_batched(c));
         else if (c->qw)
-            hipLaunchKernelGGL((k_part_build_q<IT, false>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
-                               table_of(c), in_mode, d_err, leaf_stride, leafcnt);
+            hipLaunchKernelGGL((k_part_build_q<IT, false>), dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
+                               table_of(c), in_mode, d_err, leaf_stride, leafcnt, (int) build_batched(c));
         else
-            hipLaunchKernelGGL((k_part_build<IT>), dim3(grid), dim3(BUILD_THREADS), build_lds(c), ctx->stream, items, leaves, (uint32_t) n_regions,
+            hipLaunchKernelGGL((k_part_build<IT>), dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
                                table_of(c), in_mode, d_err, leaf_stride, leafcnt);
     }
     KMU_HIP(ctx, hipGetLastError());
