@@ -948,9 +948,8 @@ __global__ void __launch_bounds__(256) k_fill_linear(uint64_t *out, uint64_t n, 
 static constexpr int BUILD_THREADS = 1 << (REGION_BITS_MAX - 3); // 512 threads for regions of 4096 slots
 static constexpr int BUILD_PRE = 6;
 // batched form of the quotient build: entries of the per-wave pool of items that two probes did not place (8 bytes each, behind the
-// region in LDS: 32 + 6 KiB per workgroup, four workgroups per CU as before), and the ceiling of a count field while up to
-// BUILD_PRE adds per thread are in flight behind a count that was seen below it
-static constexpr uint32_t BUILD_POOL = 96, BUILD_BATCH_MARGIN = 4096;
+// region in LDS: 32 + 6 KiB per workgroup, four workgroups per CU as before)
+static constexpr uint32_t BUILD_POOL = 96;
 
 // where the items of region r lie: [leafstart[r], leafstart[r + 1]) (exact route), or a fixed-size leaf with its fill in leafcnt
 // (single-pass route: the fill may exceed the capacity where items went to the spill list)
@@ -971,35 +970,54 @@ __device__ __forceinline__ void leaf_range(uint32_t r, const uint64_t *leafstart
 // them (round 5): a leaf's items come from HBM at the latency of a memory system that the builds themselves keep busy, and a
 // workgroup that asks at the top of its region (first for the leaf's fill, then for the items) waits for them behind the LDS fill
 // with only the three other workgroups of its CU to cover for it.
-// batched (the host sets it where the count field has the room, w >= 13 / 17): see the comment in the body.
 template <int IT, bool LEAF6>
-__global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
+__global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_t *__restrict__ items, const uint64_t *__restrict__ leafstart,
                                                                 uint32_t n_regions, CountTable t, int in_mode, uint32_t *err,
-                                                                uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt, int batched) {
+                                                                uint64_t leaf_stride, const uint32_t *__restrict__ leafcnt) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t R = t.rmask + 1;
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
     uint4 *lk4 = reinterpret_cast<uint4 *>(lk);
     const uint32_t tid = threadIdx.x;
-    uint64_t *pool = lk + R + (tid >> 6) * BUILD_POOL; // this wave's (batched form only: the launch asks for the room)
+    uint64_t *pool = lk + R + (tid >> 6) * BUILD_POOL; // this wave's
     uint32_t full = 0;
     const int w = t.w, xs = 32 - t.b1, os = 32 - t.rbits;
     const uint64_t cmask = q_cmask(w), lowmask = (1ull << xs) - 1ull;
-    const uint64_t add_limit = batched ? (1ull << w) - BUILD_BATCH_MARGIN : q_limit(w);
+    const uint64_t add_limit = q_limit(w);
     auto item_at = [&](uint64_t i) -> uint64_t { return LEAF6 ? leaf6_load(items, i) : items[i]; };
     // where the items of region rr lie (nothing for a region beyond the table), and the first BUILD_PRE of them of this thread
     auto range = [&](uint32_t rr, uint64_t &a0, uint64_t &a1) {
         a0 = a1 = 0;
         if (rr < n_regions) leaf_range(rr, leafstart, leaf_stride, leafcnt, a0, a1);
     };
-    auto request = [&](uint64_t a0, uint64_t a1, uint64_t (&it)[BUILD_PRE]) {
+    // the requested items wait a region long in registers: as nine words where they are 48-bit leaves (twelve otherwise)
+    struct Ahead {
+        uint32_t lo[BUILD_PRE], hi[LEAF6 ? BUILD_PRE / 2 : BUILD_PRE];
+    };
+    auto request = [&](uint64_t a0, uint64_t a1, Ahead &it) {
 #pragma unroll
         for (int q = 0; q < BUILD_PRE; q++) {
             const uint64_t i = a0 + (uint64_t) q * BUILD_THREADS + tid;
-            it[q] = i < a1 ? item_at(i) : CKEY_EMPTY;
+            if (LEAF6) {
+                const uint8_t *b = reinterpret_cast<const uint8_t *>(items) + (i >> 3) * 48u;
+                it.lo[q] = i < a1 ? reinterpret_cast<const uint32_t *>(b)[i & 7u] : ~0u;
+                const uint32_t h = i < a1 ? (uint32_t) reinterpret_cast<const uint16_t *>(b + 32)[i & 7u] : 0xFFFFu;
+                it.hi[q >> 1] = (q & 1) ? it.hi[q >> 1] | (h << 16) : h;
+            } else {
+                const uint64_t v = i < a1 ? items[i] : CKEY_EMPTY;
+                it.lo[q] = (uint32_t) v;
+                it.hi[q] = (uint32_t) (v >> 32);
+            }
         }
     };
-    uint64_t nxt_it[BUILD_PRE], n0 = 0, n1 = 0, m0 = 0, m1 = 0;
+    // (a 48-bit leaf item is never all ones: the "no item" mark of a lane beyond the leaf's fill is 2^48 - 1)
+    auto unpack = [&](const Ahead &it, int q) -> uint64_t {
+        if (!LEAF6) return ((uint64_t) it.hi[q] << 32) | it.lo[q];
+        const uint64_t v = ((uint64_t) ((it.hi[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) << 32) | it.lo[q];
+        return v == 0xFFFFFFFFFFFFull ? CKEY_EMPTY : v;
+    };
+    Ahead nxt_it;
+    uint64_t n0 = 0, n1 = 0, m0 = 0, m1 = 0;
     range(blockIdx.x, n0, n1);
     request(n0, n1, nxt_it);
     range(blockIdx.x + gridDim.x, m0, m1);
@@ -1007,7 +1025,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
         uint64_t pre_it[BUILD_PRE];
         const uint64_t i0 = n0, i1 = n1;
 #pragma unroll
-        for (int q = 0; q < BUILD_PRE; q++) pre_it[q] = nxt_it[q];
+        for (int q = 0; q < BUILD_PRE; q++) pre_it[q] = unpack(nxt_it, q);
         n0 = m0;
         n1 = m1;
         request(n0, n1, nxt_it);                 // region r + grid: its bounds have been here since the last turn
@@ -1049,46 +1067,55 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
                 if (n >= R) { full = 1; break; }
             } while (!probe(hw, off));
         };
-        if (batched) {
-            // BATCHED: item by item a wave repeats "probe, wait for the answer, branch" until the unluckiest of its lanes is through
-            // -- ~31 trips of ~55 instructions for the six items of a lane where the average item needs 1.6 probes.  Here the first
+        {
+            // Item by item (rounds 2-4: every lane walking through its six items at its own pace) a wave repeats "probe, wait for the
+            // answer, branch" until the unluckiest of its lanes is through -- ~31 trips of ~55 instructions where the average item
+            // needs 1.6 probes; 21.3 ms for the bench's table where this form takes 20.3 (9.4 -> 7.2e9 vector, 8.2 -> 5.6e9 scalar
+            // wave-instructions).  Here the first
             // probes of a thread's six items leave back to back without a branch (a lane without an item compares against 0, which no
             // slot holds, so nothing is written) and are waited for once; so do the second probes (the next slot) of the items that
             // failed; what is left -- one item in seven -- is pooled per WAVE in LDS and the lanes take the pool's entries, one each:
             // the walk of the remaining probe sequences is as long as the longest of them, not as the unluckiest lane's sum.
-            uint64_t hw[BUILD_PRE];
-            uint32_t off[BUILD_PRE];
-            bool todo[BUILD_PRE];
-#pragma unroll
-            for (int q = 0; q < BUILD_PRE; q++) {
-                locate(pre_it[q], hw[q], off[q]);
-                todo[q] = pre_it[q] != CKEY_EMPTY;
-            }
-#pragma unroll
-            for (int pass = 0; pass < 2; pass++) {
-                unsigned long long old[BUILD_PRE];
-#pragma unroll
-                for (int q = 0; q < BUILD_PRE; q++) {
-                    if (pass) off[q] = (off[q] + 1u) & t.rmask;
-                    old[q] = atomicCAS((unsigned long long *) &lk[off[q]], todo[q] ? (unsigned long long) CKEY_EMPTY : 0ull, (unsigned long long) (hw[q] | 1ull));
-                }
-#pragma unroll
-                for (int q = 0; q < BUILD_PRE; q++) {
-                    const bool claimed = old[q] == CKEY_EMPTY, same = !claimed && q_same(old[q], hw[q], w);
-                    if (todo[q] && same && (old[q] & cmask) < add_limit) atomicAdd((unsigned long long *) &lk[off[q]], 1ull);
-                    todo[q] = todo[q] && !claimed && !same;
-                }
-            }
+            // Two items at a time: a thread that has seen counts below the ceiling has at most two adds in flight behind them, the 512
+            // threads 1024 = Q_MARGIN -- a field stops at 2^w - 1 at the latest, as with the item-by-item loop.
+            constexpr int H = 2;
+            static_assert(BUILD_THREADS * H <= (int) Q_MARGIN && BUILD_PRE % H == 0, "adds in flight against the margin of a count field");
             uint32_t n_pool = 0; // (wave-uniform)
 #pragma unroll
-            for (int q = 0; q < BUILD_PRE; q++) {
-                const uint64_t m = __ballot(todo[q]);
-                const uint32_t at = n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-                if (todo[q]) {
-                    if (at < BUILD_POOL) pool[at] = hw[q];
-                    else walk(hw[q], off[q], 1u); // (a wave with more than 96 of 384 items left after two probes: a table that is filling up)
+            for (int h = 0; h < BUILD_PRE / H; h++) {
+                uint64_t hw[H];
+                uint32_t off[H];
+                bool todo[H];
+#pragma unroll
+                for (int q = 0; q < H; q++) {
+                    locate(pre_it[H * h + q], hw[q], off[q]);
+                    todo[q] = pre_it[H * h + q] != CKEY_EMPTY;
                 }
-                n_pool += (uint32_t) __popcll(m);
+#pragma unroll
+                for (int pass = 0; pass < 2; pass++) {
+                    unsigned long long old[H];
+#pragma unroll
+                    for (int q = 0; q < H; q++) {
+                        if (pass) off[q] = (off[q] + 1u) & t.rmask;
+                        old[q] = atomicCAS((unsigned long long *) &lk[off[q]], todo[q] ? (unsigned long long) CKEY_EMPTY : 0ull, (unsigned long long) (hw[q] | 1ull));
+                    }
+#pragma unroll
+                    for (int q = 0; q < H; q++) {
+                        const bool claimed = old[q] == CKEY_EMPTY, same = !claimed && q_same(old[q], hw[q], w);
+                        if (todo[q] && same && (old[q] & cmask) < add_limit) atomicAdd((unsigned long long *) &lk[off[q]], 1ull);
+                        todo[q] = todo[q] && !claimed && !same;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < H; q++) {
+                    const uint64_t m = __ballot(todo[q]);
+                    const uint32_t at = n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+                    if (todo[q]) {
+                        if (at < BUILD_POOL) pool[at] = hw[q];
+                        else walk(hw[q], off[q], 1u); // (a wave with more than 96 of 384 items left after two probes: a table that is filling up)
+                    }
+                    n_pool += (uint32_t) __popcll(m);
+                }
             }
             n_pool = n_pool < BUILD_POOL ? n_pool : BUILD_POOL;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1100,37 +1127,6 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build_q(const uint64_t *
                 walk(h, (((x * t.n2) >> os) + 1u) & t.rmask, 1u); // (its second probe was at home + 1)
             }
             __builtin_amdgcn_wave_barrier(); // (the pool is this wave's alone: the next region's entries come behind two workgroup barriers)
-        } else {
-            // Every LANE walks through its prefetched items at its own pace: a lane whose item is in takes its next one in the
-            // next trip of the loop.  (Item by item, a wave repeats the probe loop until the unluckiest of its 64 lanes is through,
-            // while the lanes' SUMS of probes over their items lie closer together.  Round 5, measured and not kept: idle lanes
-            // taking queued items from busy lanes of their wave through 64 words of LDS -- the simulation halves the trips of a
-            // wave, the kernel took 25.2 instead of 21.4 ms: two ballots and the bookkeeping per trip cost more than the trips
-            // they save, in a loop that is bound by the instructions of a trip.)
-            static_assert(BUILD_PRE == 6, "the item queue of a lane is written out by hand");
-            uint64_t q0 = pre_it[0], q1 = pre_it[1], q2 = pre_it[2], q3 = pre_it[3], q4 = pre_it[4], q5 = pre_it[5];
-            uint32_t left = BUILD_PRE + 1, guard = 0, off = 0;
-            uint64_t hw = 0;
-            bool have = false; // this lane is probing for an item
-            while (left) {
-                if (!have) { // the lane's next item, if any ("no k-mer" marks are skipped a trip at a time)
-                    const uint64_t item = q0;
-                    q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = CKEY_EMPTY;
-                    left--;
-                    if (left && item != CKEY_EMPTY) {
-                        locate(item, hw, off);
-                        guard = 0;
-                        have = true;
-                    }
-                }
-                if (have) {
-                    if (probe(hw, off)) have = false;
-                    else {
-                        off = (off + ++guard) & t.rmask;
-                        if (guard >= R) { full = 1; have = false; }
-                    }
-                }
-            }
         }
         for (uint64_t i = i0 + (uint64_t) BUILD_PRE * BUILD_THREADS + tid; i < i1; i += BUILD_THREADS) { // (leaves beyond 3 072 items)
             const uint64_t item = item_at(i);
@@ -1213,9 +1209,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) k_part_build(const uint64_t *__
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t build_lds(const kmu_counter *c) { return c->qw ? (size_t) 8 << c->rbits : (size_t) 12 << c->rbits; }
-// the batched form of the quotient build (k_part_build_q): where the count field keeps its ceiling with six adds per thread in flight
-static bool build_batched(const kmu_counter *c) { return c->qw && (1ull << c->qw) >= (uint64_t) BUILD_BATCH_MARGIN + max_count(c); }
-static size_t build_pool_lds(const kmu_counter *c) { return build_batched(c) ? (size_t) (BUILD_THREADS / 64) * BUILD_POOL * 8 : 0; }
+static size_t build_pool_lds(const kmu_counter *c) { return c->qw ? (size_t) (BUILD_THREADS / 64) * BUILD_POOL * 8 : 0; } // (k_part_build_q's pools)
 // the items of every region (leaves: the regions' bounds; or leaf_stride / leafcnt: fixed-size leaves with their fills) into the table
 template <int IT>
 static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *leaves, uint32_t *d_err,
@@ -1228,12 +1222,11 @@ static int launch_build(kmu_counter *c, const uint64_t *items, const uint64_t *l
     const int grid = (int) std::min<uint64_t>(n_regions, (uint64_t) ctx->num_cus * per_cu * 8);
     {
         KernelTimer tm(ctx, c->qw ? "k_part_build_q" : "k_part_build"); // (the kernels' own names)
-        if (c->qw && leaf6)
-            hipLaunchKernelGGL((k_part_build_q<IT_HASH, true>), dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
-                               table_of(c), in_mode, d_err, leaf_stride, leafcnt, (int) build_batched(c));
-        else if (c->qw)
-            hipLaunchKernelGGL((k_part_build_q<IT, false>), dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
-                               table_of(c), in_mode, d_err, leaf_stride, leafcnt, (int) build_batched(c));
+        if (c->qw) {
+            const auto kern = leaf6 ? k_part_build_q<IT_HASH, true> : k_part_build_q<IT, false>;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves, (uint32_t) n_regions, table_of(c), in_mode, d_err,
+                               leaf_stride, leafcnt);
+        }
         else
             hipLaunchKernelGGL((k_part_build<IT>), dim3(grid), dim3(BUILD_THREADS), lds, ctx->stream, items, leaves, (uint32_t) n_regions,
                                table_of(c), in_mode, d_err, leaf_stride, leafcnt);

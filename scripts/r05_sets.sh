@@ -1,0 +1,12 @@
+#!/bin/bash
+# level 1's sets of shared streams: 16 (two per XCD) against 8, same box, alternating processes; count-only headline
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05sets
+for v in "" sets8 "" sets8; do
+  lib=$PWD/kmerutils_amd/libkmu${v:+_$v}.so
+  KMU_LIB=$lib timeout -k 10 120 python bench.py --workload ont_k31_count --steps 4 --warmup 1 --no-cpu-baseline --no-parity > gpurun_out/r05sets/a$v.json 2> gpurun_out/r05sets/a$v.err || { echo "run $v failed"; tail -3 gpurun_out/r05sets/a$v.err; continue; }
+  python3 - "$v" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/r05sets/a%s.json'%sys.argv[1]).read().strip().splitlines()[-1]); k=d['kernels']
+print('variant %-6s: step %.2f ms  l1 %.2f  l2 %.2f  build %.2f' % (sys.argv[1] or 'sets16', d['ms_per_step'], k['k_part_scatter1']['avg_ms'], k['k_arr_scatter']['avg_ms'], k['k_part_build_q']['avg_ms']))
+PY
+done
