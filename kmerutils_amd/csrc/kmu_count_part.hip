@@ -1021,6 +1021,10 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
     range(blockIdx.x, n0, n1);
     request(n0, n1, nxt_it);
     range(blockIdx.x + gridDim.x, m0, m1);
+    if (in_mode != 1) {
+        for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        lds_barrier();
+    }
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
         uint64_t pre_it[BUILD_PRE];
         const uint64_t i0 = n0, i1 = n1;
@@ -1032,12 +1036,10 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
         range(r + 2u * gridDim.x, m0, m1);       // region r + 2 grid: looked at in the next turn
         const uint32_t lox_s = t.lox[r % t.n2]; // (workgroup-uniform: the sub-region of this region)
         uint4 *gk4 = reinterpret_cast<uint4 *>(t.keys + (uint64_t) r * R);
-        if (in_mode == 1) {
+        if (in_mode == 1) { // (an empty table: the region in LDS is empty already -- the copy-out of the last one left it so)
             for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = gk4[s];
-        } else {
-            for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            lds_barrier();
         }
-        lds_barrier();
         // an item -> the slot word it would claim (count 0) and its home slot
         auto locate = [&](uint64_t item, uint64_t &hw, uint32_t &off) {
             if (LEAF6) {
@@ -1096,8 +1098,13 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
                     unsigned long long old[H];
 #pragma unroll
                     for (int q = 0; q < H; q++) {
-                        if (pass) off[q] = (off[q] + 1u) & t.rmask;
-                        old[q] = atomicCAS((unsigned long long *) &lk[off[q]], todo[q] ? (unsigned long long) CKEY_EMPTY : 0ull, (unsigned long long) (hw[q] | 1ull));
+                        if (pass == 0) // (nearly every lane has an item)
+                            old[q] = atomicCAS((unsigned long long *) &lk[off[q]], todo[q] ? (unsigned long long) CKEY_EMPTY : 0ull, (unsigned long long) (hw[q] | 1ull));
+                        else {         // (one lane in three)
+                            off[q] = (off[q] + 1u) & t.rmask;
+                            old[q] = 0ull;
+                            if (todo[q]) old[q] = atomicCAS((unsigned long long *) &lk[off[q]], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw[q] | 1ull));
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < H; q++) {
@@ -1137,7 +1144,10 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
             if (!probe(hw, off)) walk(hw, off, 0u);
         }
         lds_barrier();
-        for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) gk4[s] = lk4[s];
+        for (uint32_t s = tid; s < R / 2; s += BUILD_THREADS) {
+            gk4[s] = lk4[s];
+            if (in_mode != 1) lk4[s] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
         lds_barrier();
     }
     if (full) atomicOr(err, DERR_TABLE_FULL);
