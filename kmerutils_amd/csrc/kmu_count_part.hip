@@ -949,7 +949,7 @@ static constexpr int BUILD_THREADS = 1 << (REGION_BITS_MAX - 3); // 512 threads 
 static constexpr int BUILD_PRE = 6;
 // batched form of the quotient build: entries of the per-wave pool of items that two probes did not place (8 bytes each, behind the
 // region in LDS: 32 + 6 KiB per workgroup, four workgroups per CU as before)
-static constexpr uint32_t BUILD_POOL = 96;
+static constexpr uint32_t BUILD_POOL = 96, BUILD_PASSES = 3; // batched probes of an item before it goes to the pool (1 / 2 / 3: 21.1 / 18.8 / 18.4 ms)
 
 // where the items of region r lie: [leafstart[r], leafstart[r + 1]) (exact route), or a fixed-size leaf with its fill in leafcnt
 // (single-pass route: the fill may exceed the capacity where items went to the spill list)
@@ -1094,14 +1094,14 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
                     todo[q] = pre_it[H * h + q] != CKEY_EMPTY;
                 }
 #pragma unroll
-                for (int pass = 0; pass < 2; pass++) {
+                for (int pass = 0; pass < BUILD_PASSES; pass++) {
                     unsigned long long old[H];
 #pragma unroll
                     for (int q = 0; q < H; q++) {
                         if (pass == 0) // (nearly every lane has an item)
                             old[q] = atomicCAS((unsigned long long *) &lk[off[q]], todo[q] ? (unsigned long long) CKEY_EMPTY : 0ull, (unsigned long long) (hw[q] | 1ull));
                         else {         // (one lane in three)
-                            off[q] = (off[q] + 1u) & t.rmask;
+                            off[q] = (off[q] + (uint32_t) pass) & t.rmask;
                             old[q] = 0ull;
                             if (todo[q]) old[q] = atomicCAS((unsigned long long *) &lk[off[q]], (unsigned long long) CKEY_EMPTY, (unsigned long long) (hw[q] | 1ull));
                         }
@@ -1119,7 +1119,7 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
                     const uint32_t at = n_pool + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
                     if (todo[q]) {
                         if (at < BUILD_POOL) pool[at] = hw[q];
-                        else walk(hw[q], off[q], 1u); // (a wave with more than 96 of 384 items left after two probes: a table that is filling up)
+                        else walk(hw[q], off[q], BUILD_PASSES - 1u); // (a wave with more than 96 of 384 items left after the batched probes: a table that is filling up)
                     }
                     n_pool += (uint32_t) __popcll(m);
                 }
@@ -1131,7 +1131,7 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
             for (uint32_t e = tid & 63u; e < n_pool; e += 64u) {
                 const uint64_t h = pool[e];
                 const uint32_t x = lox_s + (uint32_t) ((h >> w) >> xs);
-                walk(h, (((x * t.n2) >> os) + 1u) & t.rmask, 1u); // (its second probe was at home + 1)
+                walk(h, (((x * t.n2) >> os) + (BUILD_PASSES - 1u) * BUILD_PASSES / 2u) & t.rmask, BUILD_PASSES - 1u); // (its last probe: the triangular number)
             }
             __builtin_amdgcn_wave_barrier(); // (the pool is this wave's alone: the next region's entries come behind two workgroup barriers)
         }
