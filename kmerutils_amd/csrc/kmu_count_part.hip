@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(BUILD_THREADS, 8) k_part_build_q(const uint64_
     uint64_t *lk = reinterpret_cast<uint64_t *>(smem);
     uint4 *lk4 = reinterpret_cast<uint4 *>(lk);
     const uint32_t tid = threadIdx.x;
-    uint64_t *pool = lk + R + (tid >> 6) * BUILD_POOL; // this wave's
+    uint64_t *pool = lk + R + (uint32_t) __builtin_amdgcn_readfirstlane((int) (tid >> 6)) * BUILD_POOL; // this wave's
     uint32_t full = 0;
     const int w = t.w, xs = 32 - t.b1, os = 32 - t.rbits;
     const uint64_t cmask = q_cmask(w), lowmask = (1ull << xs) - 1ull;
