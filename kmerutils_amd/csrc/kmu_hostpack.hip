@@ -135,22 +135,40 @@ PackPipe::~PackPipe() {
 }
 
 // ---- device: 4 packed bytes -> 16 ASCII bases ----
+__device__ __forceinline__ uint4 unpack16(uint32_t w) { // bytes in memory order: byte b holds bases 4 b .. 4 b + 3, the first in bits 7..6
+    uint32_t o[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const uint32_t by = (w >> (8 * b)) & 0xFFu;
+        uint32_t r = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) r |= ((0x54474341u >> (8u * ((by >> (6 - 2 * j)) & 3u))) & 0xFFu) << (8 * j); // "ACGT"[code]
+        o[b] = r;
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// four words per thread and turn, their loads in flight together (one word per turn: 2.0 TB/s for the 5.5 GB of a 4.38 G base stream)
 __global__ void __launch_bounds__(256) k_unpack2b(const uint32_t *packed, uint64_t n_bases, uint8_t *out) {
-    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x, nw = (n_bases + 15) / 16;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) {
-        const uint32_t w = packed[i]; // bytes in memory order: byte b holds bases 4 b .. 4 b + 3, the first in bits 7..6
-        uint32_t o[4];
+    constexpr int U = 4;
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x, nw = (n_bases + 15) / 16, whole = n_bases / 16;
+    for (uint64_t i0 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i0 < nw; i0 += stride * U) {
+        uint32_t w[U];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const uint32_t by = (w >> (8 * b)) & 0xFFu;
-            uint32_t r = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) r |= ((0x54474341u >> (8u * ((by >> (6 - 2 * j)) & 3u))) & 0xFFu) << (8 * j); // "ACGT"[code]
-            o[b] = r;
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = i0 + (uint64_t) u * stride;
+            w[u] = i < nw ? packed[i] : 0u;
         }
-        if (i * 16 + 16 <= n_bases) *reinterpret_cast<uint4 *>(out + i * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-        else
-            for (uint64_t t = i * 16; t < n_bases; t++) out[t] = (uint8_t) (o[(t >> 2) & 3] >> (8 * (t & 3)));
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t i = i0 + (uint64_t) u * stride;
+            if (i >= nw) break;
+            const uint4 o4 = unpack16(w[u]);
+            if (i < whole) *reinterpret_cast<uint4 *>(out + i * 16) = o4;
+            else {
+                const uint32_t o[4] = {o4.x, o4.y, o4.z, o4.w};
+                for (uint64_t t = i * 16; t < n_bases; t++) out[t] = (uint8_t) (o[(t >> 2) & 3] >> (8 * (t & 3)));
+            }
+        }
     }
 }
 
