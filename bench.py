@@ -470,8 +470,11 @@ def main():
             if cfg["count"] and use_comm:
                 counter.finalize()
 
-        h_el, _ = timed(step_host, False)
+        h_el, _ = timed(step_host, True)
+        hstats = ctx.profile_get()
         host = {"value": job_bases * args.steps / h_el / 1e9, "unit": "Gbases/s", "ms_per_step": h_el / args.steps * 1e3,
+                # the library's own timers over the leg: a kernel's launches of one step (one per chunk of the upload) summed
+                "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(hstats.items())},
                 "what": "bases in pinned host memory -> signatures in pinned host memory + counts on the device: one chunked "
                         "upload overlapped with the sketch kernels, rows downloaded under the count build (kmu_sketch_count)",
                 "bytes_up": total_bases, "bytes_down": n_reads * cfg["m"] * h_sig.element_size()}
