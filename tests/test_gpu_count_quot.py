@@ -139,13 +139,20 @@ def test_table_load_factor_switch(ctx, oracle, monkeypatch):
     o.add_reads(bases, off)
     wk, wc = o.dump(1)
     monkeypatch.setenv("KMU_COUNT_PATH", "partitioned")
-    for load in ("85", "40"):
+    o.add_reads(bases, off)
+    wk2, wc2 = o.dump(1)
+    for load in ("85", "40", "90"):
         monkeypatch.setenv("KMU_COUNT_LOAD", load)
         c = ctx.counter(A.KMER64BIT, 31, 8, wk.size)
         assert abs(c.table_info()["nslots"] - wk.size / (int(load) / 100)) <= 4096
         c.add_reads(bases, off)
         gk, gc = c.dump(1)
         assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        # the same reads onto the full table: the region build starts from the slab, every item walks to its key -- at a load of 0.9
+        # more items of a wave are left after the batched probes than its pool holds (k_part_build_q: the in-lane walk)
+        c.add_reads(bases, off)
+        gk, gc = c.dump(1)
+        assert np.array_equal(gk, wk2) and np.array_equal(gc, wc2), load
         c.close()
 
 
