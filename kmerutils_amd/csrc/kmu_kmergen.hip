@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "kmu_ctx.hpp"
+#include "kmu_smer.hpp"
 #include "kmu_stream.h"
 
 namespace kmu {
@@ -203,6 +204,7 @@ struct NtArgs {
     uint64_t *out;
     uint8_t *strand; // may be null
     uint32_t *err;
+    const uint16_t *novalid; // k_nthash_flat: bit p of word w set = position 16 w + p starts no k-mer (flat_novalid, kmu_smer.hpp)
 };
 
 // A wave step covers 64 code words but emits the k-mers that start in the first 62 (the window of a k-mer, k <= 32, ends at
@@ -297,8 +299,15 @@ __global__ void __launch_bounds__(256) k_nthash(NtArgs a) {
 // array wherever the reads begin and end -- 150 bp reads fill the lanes like 100 kb reads do -- and a k-mer is emitted
 // when it lies inside one read.  The hash of a k-mer only involves its own k bases (the prefixes cancel outside), so
 // nothing has to be restarted at a read boundary; out is indexed by the absolute base position.
-template <bool T8>
+// ONE (n_hashes == 1): a lane's sixteen hashes lie 128 bytes apart in `out`, and stored from the registers every store of a wave is
+// 64 requests of 8 bytes; they go through LDS (lane rows padded to 17 words: no bank is hit twice by a quarter-wave) and leave as
+// 512 contiguous bytes per instruction.  A position without a k-mer is not written, as before.
+template <bool T8, bool ONE>
 __global__ void __launch_bounds__(256) k_nthash_flat(NtArgs a) {
+    __shared__ uint64_t stage_all[ONE ? 4 : 1][ONE ? 64 * 17 : 1];
+    __shared__ uint32_t nvs_all[ONE ? 4 : 1][ONE ? 64 : 1];
+    uint64_t *stage = stage_all[ONE ? threadIdx.x >> 6 : 0];
+    uint32_t *nvs = nvs_all[ONE ? threadIdx.x >> 6 : 0];
     const int lane = lane_id();
     const int k = a.k;
     const uint32_t m = (uint32_t) k & 15u;
@@ -310,7 +319,7 @@ __global__ void __launch_bounds__(256) k_nthash_flat(NtArgs a) {
     const uint64_t w_first = start / 16, nwords = (total + 15) / 16 - w_first, nsteps = (nwords + 61) / 62;
     const uint64_t wave_global = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves_global = ((uint64_t) gridDim.x * blockDim.x) >> 6;
-    uint32_t bad = 0, r_hint = 0xFFFFFFFFu;
+    uint32_t bad = 0;
     for (uint64_t st = wave_global; st < nsteps; st += nwaves_global) {
         const uint64_t widx = w_first + st * 62 + (uint64_t) lane;
         uint32_t b;
@@ -320,7 +329,7 @@ __global__ void __launch_bounds__(256) k_nthash_flat(NtArgs a) {
         bad |= b;
         const uint32_t w1 = shfl_down_u32(w0, 1), w2 = shfl_down_u32(w0, 2);
         uint64_t pf = 0, pr = 0, xf = 0, xr = 0;
-#pragma unroll
+#pragma unroll 4
         for (int j = 0; j < 16; j++) {
             const uint32_t code = (w0 >> (30 - 2 * j)) & 3u;
             const unsigned t = (unsigned) (16 * lane + j) & 63u;
@@ -332,41 +341,15 @@ __global__ void __launch_bounds__(256) k_nthash_flat(NtArgs a) {
         const uint64_t kf = shfl_down_u64(ef ^ xf, d), kr = shfl_down_u64(er ^ xr, d);
         uint64_t F = rotl64(kf ^ ef, (unsigned) (16 * lane + k - 1) & 63u);
         uint64_t R = rotr64(kr ^ er, (unsigned) (16 * lane) & 63u);
-        // the read of this lane's first base (wave-wide 64-ary search, hinted by the previous step)
-        const uint64_t gw = (w_first + st * 62) * 16;
-        uint32_t r = 0;
-        {
-            const uint64_t probe = gw < start ? start : (gw < total ? gw : total - 1);
-            uint32_t lo = 0;
-            if (r_hint < a.n_seq && a.offsets[r_hint] <= probe) {
-                const uint64_t idx = (uint64_t) r_hint + 1 + (uint32_t) lane;
-                const uint32_t c = (uint32_t) __popcll(__ballot(idx < a.n_seq && a.offsets[idx] <= probe));
-                lo = c < 64u ? r_hint + c : 0xFFFFFFFFu;
-            } else lo = 0xFFFFFFFFu;
-            if (lo == 0xFFFFFFFFu) { // full search
-                uint32_t l = 0, h = a.n_seq;
-                while (h - l > 1) {
-                    const uint32_t stp = (h - l + 63) / 64;
-                    const uint64_t idx = (uint64_t) l + (uint64_t) (lane + 1) * stp;
-                    const uint32_t c = (uint32_t) __popcll(__ballot(idx < h && a.offsets[idx] <= probe));
-                    const uint64_t nh = (uint64_t) l + (uint64_t) (c + 1) * stp;
-                    l = l + c * stp;
-                    h = nh < h ? (uint32_t) nh : h;
-                }
-                lo = l;
-            }
-            r_hint = lo;
-            r = lo;
-        }
+        // which of the lane's positions start a k-mer is looked up (one 16-bit load next to the lane's bases), not derived from the
+        // read offsets: a wave-wide search of the lane's read and a dependent look-up at every read boundary made a step a chain of
+        // ~20 loads (config 2's 150 bp reads: 1.16 ms for 150 M positions, the waves waiting for them whatever their number)
         const bool in = g0 < total && g0 + 16 > start && lane < 62;
-        uint64_t rend = 0;
-        if (in) {
-            rend = a.offsets[r + 1];
-            while (g0 >= rend && r + 1 < a.n_seq) { r++; rend = a.offsets[r + 1]; }
-        }
+        const uint32_t nv = in ? (uint32_t) a.novalid[widx] : 0xFFFFu;
         const uint64_t hi = ((uint64_t) w0 << 32) | w1;
         const int sh = 64 - 2 * k;
-#pragma unroll
+        uint32_t sdm = 0; // ONE: bit j = position j's hash is the reverse strand's
+#pragma unroll 4
         for (int j = 0; j < 16; j++) {
             const uint64_t v = (hi << (2 * j)) | (((uint64_t) w2 << (2 * j)) >> 32);
             const uint64_t val = v >> sh;
@@ -375,26 +358,43 @@ __global__ void __launch_bounds__(256) k_nthash_flat(NtArgs a) {
                 F = rotl64(F, 1) ^ rotl64(nt_fwd<T8>(oldb), (unsigned) k) ^ nt_fwd<T8>(newb);
                 R = rotr64(R, 1) ^ rotr64(nt_rev<T8>(oldb), 1) ^ rotl64(nt_rev<T8>(newb), (unsigned) (k - 1));
             }
-            if (in) {
+            uint64_t h0;
+            uint32_t sd;
+            if (a.mode == KMU_NTHASH_FORWARD) { h0 = F; sd = 0; }
+            else if (a.mode == KMU_NTHASH_RCOMP) { h0 = R; sd = 1; }
+            else if (F <= R) { h0 = F; sd = 0; }
+            else { h0 = R; sd = 1; }
+            if (ONE) {
+                stage[17 * lane + j] = h0;
+                sdm |= sd << j;
+            } else if (!((nv >> j) & 1u)) {
                 const uint64_t g = g0 + j;
-                while (g >= rend && r + 1 < a.n_seq) { r++; rend = a.offsets[r + 1]; }
-                if (g >= start && g + k <= rend) {
-                    uint64_t h0;
-                    uint8_t sd;
-                    if (a.mode == KMU_NTHASH_FORWARD) { h0 = F; sd = 0; }
-                    else if (a.mode == KMU_NTHASH_RCOMP) { h0 = R; sd = 1; }
-                    else if (F <= R) { h0 = F; sd = 0; }
-                    else { h0 = R; sd = 1; }
-                    uint64_t *op = a.out + g * (uint64_t) a.n_hashes;
-                    op[0] = h0;
-                    for (int q = 1; q < a.n_hashes; q++) {
-                        uint64_t t = h0 * ((uint64_t) q ^ mult);
-                        t ^= t >> 27;
-                        op[q] = t;
-                    }
-                    if (a.strand) a.strand[g] = sd;
+                uint64_t *op = a.out + g * (uint64_t) a.n_hashes;
+                op[0] = h0;
+                for (int q = 1; q < a.n_hashes; q++) {
+                    uint64_t t = h0 * ((uint64_t) q ^ mult);
+                    t ^= t >> 27;
+                    op[q] = t;
+                }
+                if (a.strand) a.strand[g] = (uint8_t) sd;
+            }
+        }
+        if (ONE) { // (the wave's own rows: its LDS requests are served in order)
+            nvs[lane] = nv | (sdm << 16);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint64_t gbase = (w_first + st * 62) * 16; // position of lane 0's first base
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t q = (uint32_t) i * 64u + (uint32_t) lane, src = q >> 4, jj = q & 15u;
+                const uint32_t mk = nvs[src];
+                if (!((mk >> jj) & 1u)) {
+                    a.out[gbase + q] = stage[17u * src + jj];
+                    if (a.strand) a.strand[gbase + q] = (uint8_t) ((mk >> (16u + jj)) & 1u);
                 }
             }
+            __builtin_amdgcn_wave_barrier(); // (the next step's rows overwrite these)
         }
     }
     if (bad) atomicOr(a.err, DERR_NON_ACGT);
@@ -436,12 +436,21 @@ extern "C" int kmu_nthash(kmu_ctx *ctx, const kmu_nthash_params *p, const uint8_
     KMU_TRY(get_err_word(ctx, &d_err));
     if (n_seq) {
         NtArgs a{ds.bases, ds.offsets, ds.packed_offsets, n_seq, ds.packed, ds.total_bytes, p->kmer_size, p->mode, p->n_hashes,
-                 d_out, d_strand, d_err};
+                 d_out, d_strand, d_err, nullptr};
+        if (!ds.packed) { // the positions that start no k-mer, once per call (the end of the stream as the kernel sees it: offsets[n_seq])
+            uint64_t end = 0;
+            KMU_HIP(ctx, hipMemcpyAsync(&end, ds.offsets + n_seq, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KMU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            void *nvp;
+            KMU_TRY(flat_novalid(ctx, ds, end, p->kmer_size, (end + 15) / 16 + 128, "nt.novalid", &nvp));
+            a.novalid = (const uint16_t *) nvp;
+        }
         KernelTimer t(ctx, "k_nthash");
         if (!ds.packed) { // one flat stream: the lanes are full whatever the read lengths
             const int grid = ctx->num_cus * 8;
-            if (p->table == KMU_NTHASH_TABLE_8B) hipLaunchKernelGGL(k_nthash_flat<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
-            else hipLaunchKernelGGL(k_nthash_flat<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+            const bool t8 = p->table == KMU_NTHASH_TABLE_8B, one = p->n_hashes == 1;
+            const auto kern = t8 ? (one ? k_nthash_flat<true, true> : k_nthash_flat<true, false>) : (one ? k_nthash_flat<false, true> : k_nthash_flat<false, false>);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream, a);
         } else {
             const int grid = (int) std::min<uint32_t>(n_seq, (uint32_t) ctx->num_cus * 8);
             hipLaunchKernelGGL(k_nthash<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
