@@ -148,7 +148,7 @@ def launch_ranks(args, argv=None, runner=_run_child, environ=None):
     runs with the next transport of the exchange -- the library's COPY transport first, then its RCCL all-to-all, then torch's
     process group as carrier (KMU_BENCH_TRANSPORT = copy | rccl | torch names where the chain starts) --, and last one with the
     sketch-only workload (no collective at all); the line that comes out says which attempt it is (`fallback_from`).  An attempt
-    that is still running after KMU_BENCH_ATTEMPT_TIMEOUT seconds (default 900) is ended and counts as failed."""
+    that is still running after KMU_BENCH_ATTEMPT_TIMEOUT seconds (default 420) is ended and counts as failed."""
     import socket
     argv = list(sys.argv[1:] if argv is None else argv)
     environ = dict(os.environ if environ is None else environ)
@@ -184,7 +184,7 @@ def launch_ranks(args, argv=None, runner=_run_child, environ=None):
         env.update(envo)
         # (an attempt that hangs -- a transport that has never met this hardware -- must not take the others with it)
         try:
-            rc, out = runner(cmd, env, timeout=float(environ.get("KMU_BENCH_ATTEMPT_TIMEOUT", "900")))
+            rc, out = runner(cmd, env, timeout=float(environ.get("KMU_BENCH_ATTEMPT_TIMEOUT", "420")))
         except TypeError:  # (a runner without a timeout of its own: the tests' stand-ins)
             rc, out = runner(cmd, env)
         line = _last_json_line(out)
