@@ -1,6 +1,6 @@
 #!/bin/bash
 # the product library against variant libraries (scripts/build_variant.sh <tag> ...: kmerutils_amd/libkmu_<tag>.so), same box, alternating processes;
-# count-only headline (ont_k31_count), ms per kernel.  usage: scripts/r05_rbits.sh <tag> [<tag> ...]   (rb13: regions of 8192 slots, -DKMU_REGION_BITS=13 at the time)
+# count-only headline (ont_k31_count), ms per kernel.  usage: scripts/r05_rbits.sh <tag> [<tag> ...]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05rb
 for rep in 1 2; do
 for v in "" "$@"; do
