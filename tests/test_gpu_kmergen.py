@@ -212,6 +212,24 @@ def test_nthash_vs_oracle(ctx, oracle, k):
         assert np.array_equal(ctx.kmer_hashes(bases, off, kt, k, A.FHASH_CANON_NTHASH), wh[:, 0])
 
 
+@pytest.mark.parametrize("pre", [37, 1024 + 16])
+def test_nthash_of_reads_that_start_inside_the_device_buffer(ctx, oracle, pre):
+    """offsets[0] > 0 (a range of a larger read set in HBM): the output is indexed by the absolute position, what lies before the
+    first read is neither looked at (non-ACGT bytes there are no error) nor written -- the positions that start a k-mer come from
+    the bit mask of flat_novalid, which marks everything before offsets[0]"""
+    import torch
+    seqs = ragged_dna(700, RAGGED)
+    bases, off = oracle.concat(seqs)
+    buf = np.concatenate([np.full(pre, ord("N"), np.uint8), bases])
+    off2 = (off.astype(np.int64) + pre)
+    for k, nh in ((21, 1), (31, 2)):
+        wh, ws = oracle.nthash(bases, off, k, nh)
+        gh, gs = ctx.nthash(torch.from_numpy(buf).cuda(), torch.from_numpy(off2).cuda(), k, nh)
+        gh, gs = gh.cpu().numpy().view(np.uint64), gs.cpu().numpy()
+        assert np.array_equal(gh[pre:], wh) and np.array_equal(gs[pre:], ws), (k, nh)
+        assert not gh[:pre].any() and not gs[:pre].any()
+
+
 def test_nthash_errors(ctx):
     from kmerutils_amd.lib import KmuError
     bases = np.frombuffer(b"ACGTNACGTACGT", np.uint8).copy()
