@@ -922,9 +922,19 @@ __global__ void __launch_bounds__(64) k_spill_header(uint32_t *ovf, uint32_t cap
 }
 
 // "no k-mer" marks from the fill of every (set, bin) stream of level 1 to its capacity (level 2 reads whole streams)
-__global__ void __launch_bounds__(256) k_seg_tails(const uint32_t *cursor, uint32_t cap, uint64_t *out) {
-    const uint32_t n = cursor[blockIdx.x] < cap ? cursor[blockIdx.x] : cap;
-    for (uint32_t i = n + threadIdx.x; i < cap; i += blockDim.x) out[(uint64_t) blockIdx.x * cap + i] = CKEY_EMPTY;
+// (a few workgroups per CU, each over many streams, 16 bytes per lane: one workgroup per stream -- 32 768 launches of 15 KB at the
+//  bench size -- took 0.7 ms for 0.5 GB)
+__global__ void __launch_bounds__(256) k_seg_tails(const uint32_t *cursor, uint32_t n_streams, uint32_t cap, uint64_t *out) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    for (uint32_t s = blockIdx.x; s < n_streams; s += gridDim.x) {
+        uint32_t n = cursor[s] < cap ? cursor[s] : cap;
+        uint64_t *o = out + (uint64_t) s * cap;
+        if ((n & 1u) && n < cap) { // (cap is even: pairs from an even position on)
+            if (threadIdx.x == 0) o[n] = CKEY_EMPTY;
+            n++;
+        }
+        for (uint32_t i = n + 2u * threadIdx.x; i < cap; i += 2u * blockDim.x) *reinterpret_cast<u64x2 *>(o + i) = u64x2{CKEY_EMPTY, CKEY_EMPTY};
+    }
 }
 
 // the spill list of a single-pass partition (khash values) into the finished table, by direct insertion
@@ -1424,8 +1434,8 @@ static int seg_level1(kmu_counter *c, SegRun *run, uint64_t bases_ready) {
     run->steps_done += n_new;
     if (last) {
         run->l1_done = true;
-        hipLaunchKernelGGL(k_seg_tails, dim3(run->sp.sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) run->state,
-                           (uint32_t) run->sp.cap1, (uint64_t *) run->A);
+        hipLaunchKernelGGL(k_seg_tails, dim3(std::min<uint32_t>(run->sp.sets * bins1, (uint32_t) ctx->num_cus * 8u)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *) run->state, run->sp.sets * bins1, (uint32_t) run->sp.cap1, (uint64_t *) run->A);
         KMU_HIP(ctx, hipGetLastError());
     }
     return KMU_OK;
@@ -1648,7 +1658,8 @@ int seg_partitioned_add_kmers(kmu_counter *c, const uint64_t *d_kmers, uint64_t 
         hipLaunchKernelGGL((k_arr_scatter_seg<IT_KEY_TO_HASH, false>), dim3(chunks1), dim3(SCATTER_THREADS), seg_lds_bytes(bins1), ctx->stream, d_kmers,
                            (const uint64_t *) b0, ap1, (uint64_t *) A, cap1, (uint32_t *) ovf, (uint32_t *) cur1, (const uint32_t *) nullptr);
     }
-    hipLaunchKernelGGL(k_seg_tails, dim3(sets * bins1), dim3(256), 0, ctx->stream, (const uint32_t *) cur1, (uint32_t) cap1, (uint64_t *) A);
+    hipLaunchKernelGGL(k_seg_tails, dim3(std::min<uint32_t>(sets * bins1, (uint32_t) ctx->num_cus * 8u)), dim3(256), 0, ctx->stream, (const uint32_t *) cur1,
+                       sets * bins1, (uint32_t) cap1, (uint64_t *) A);
     KMU_HIP(ctx, hipGetLastError());
     const bool leaf6 = leaf6_wanted(c);
     const ArrPlan ap2{plan_digit2(pl), pl.n2, bins1, SEG_L2_UNITS, sets, (uint32_t) cap1, bins1, 0u};
