@@ -1190,7 +1190,10 @@ __global__ void __launch_bounds__(UQ_THREADS, MINW) k_multiset_uq(SketchArgs a) 
     uint32_t *misc = wtot + UQ_THREADS / 64;
     // the next read's chunks land here straight from HBM (global_load_lds: no register is held while they are in flight):
     // chunk t of the read at byte 16 t, i.e. lane l of the wave instruction that fetches chunks 64 j .. 64 j + 63 at 1024 j + 16 l
-    uint8_t *rawp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(misc + 16) + 15) & ~(uintptr_t) 15);
+    // (its place as an offset from the 16-byte aligned base: a pointer that went through an integer is a FLAT pointer to the compiler --
+    //  64-bit address arithmetic kept in registers the kernel does not have, spilled, and FLAT instead of LDS accesses)
+    constexpr uint32_t RAW_OFF = ((8u * UQ_BM_WORDS + 20u * UQ_COLL + 4u * (UQ_BUCKETS + 1u + UQ_TILE + (uint32_t) UQ_THREADS / 64u) + 64u) + 15u) & ~15u;
+    uint8_t *rawp = smem + RAW_OFF;
     const KmerCfg cfg = a.cfg;
     const int k = cfg.k, tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     for (uint32_t i = tid; i < UQ_BUCKETS + 1; i += UQ_THREADS) bst[i] = 0;
