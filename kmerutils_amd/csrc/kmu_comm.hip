@@ -97,6 +97,8 @@ int comm_allgather_host(kmu_ctx *ctx, const void *send, void *recv, uint64_t byt
 // finished (each rank drains its stream before it publishes: a peer writes into memory this rank may still have been reading).
 // Then N - 1 device-to-device copies on the exchange stream (+ the rank's own share), closed by comm_wait's barrier.
 #include <unistd.h>
+static int carrier_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
+                             const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s);
 static int copy_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
                           const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s) {
     kmu_comm *c = ctx->comm;
@@ -120,10 +122,28 @@ static int copy_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *se
         if (hipIpcGetMemHandle(&h, recv_dev) == hipSuccess) {
             mine[2] = 1;
             memcpy(&mine[3 + N], &h, sizeof h);
-        } else (void) hipGetLastError(); // (peers in this process need no handle; the others will report it)
+        } else {
+            (void) hipGetLastError();
+            mine[2] = 2; // wanted and not to be had (seen once in five runs of the two-process test, in the second exchange of a finalize)
+        }
     }
     for (int p = 0; p < N; p++) mine[3 + p] = recv_displs[p] * elem_bytes;
     KMU_TRY(comm_allgather_host(ctx, mine.data(), all.data(), (uint64_t) row_words * 8));
+    // A rank that could not export its buffer: every rank reads the same rows, so all of them take THIS exchange through the
+    // communicator's other data path (the host's all-to-all or RCCL) where it has one -- unless every peer of that rank is a thread of
+    // its process (its plain pointer will do).
+    for (int q = 0; q < N; q++) {
+        const uint64_t *row = &all[row_words * (size_t) q];
+        if (row[2] != 2) continue;
+        bool needed = false;
+        for (int p = 0; p < N; p++) needed = needed || all[row_words * (size_t) p] != row[0];
+        if (!needed) continue;
+        if (c->a2a || c->nccl) {
+            c->carrier_pending = true;
+            return carrier_alltoallv(ctx, send_dev, send_counts, send_displs, recv_dev, recv_counts, recv_displs, elem_bytes, s);
+        }
+        return fail(ctx, KMU_E_RCCL, "rank %d could not export its receive buffer (hipIpcGetMemHandle) and the communicator has no other data path", q);
+    }
     hipEvent_t t_a = nullptr, t_b = nullptr;
     auto take_event = [&]() -> hipEvent_t {
         hipEvent_t e = nullptr;
@@ -148,7 +168,7 @@ static int copy_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *se
         else if (row[0] == mine[0]) dst = (uint8_t *) (uintptr_t) row[1]; // a thread of this process: its pointer is good here
         else {
             kmu_comm::Peer &pe = c->peers[(size_t) q];
-            if (!row[2]) { give_back(); return fail(ctx, KMU_E_RCCL, "rank %d could not export its receive buffer (hipIpcGetMemHandle)", q); }
+            if (row[2] != 1) { give_back(); return fail(ctx, KMU_E_RCCL, "rank %d published no handle of its receive buffer", q); }
             if (!pe.opened || memcmp(&pe.handle, &row[3 + N], sizeof pe.handle) != 0) { // the peer's buffer is new (or has grown)
                 if (pe.opened) (void) hipIpcCloseMemHandle(pe.base);
                 pe.opened = false;
@@ -182,6 +202,10 @@ int comm_wait(kmu_ctx *ctx) {
     kmu_comm *c = ctx->comm;
     if (!c) return fail(ctx, KMU_E_BAD_ARG, "the context has no communicator (kmu_comm_init)");
     if (c->copy) {
+        if (c->carrier_pending) { // (an exchange of the COPY transport that went through the other data path)
+            c->carrier_pending = false;
+            if (!c->a2a) KMU_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_b, 0));
+        }
         if (!c->copy_pending) return KMU_OK;
         c->copy_pending = false;
         KMU_HIP(ctx, hipStreamSynchronize(c->stream)); // this rank's copies have landed at its peers ...
@@ -204,6 +228,13 @@ int comm_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_coun
     c->stats.bytes_received += in;
     c->stats.exchanges++;
     if (c->copy) return copy_alltoallv(ctx, send_dev, send_counts, send_displs, recv_dev, recv_counts, recv_displs, elem_bytes, s);
+    return carrier_alltoallv(ctx, send_dev, send_counts, send_displs, recv_dev, recv_counts, recv_displs, elem_bytes, s);
+}
+
+// the exchange through the host's all-to-all (kmu_comm_init_custom) or RCCL
+static int carrier_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *send_counts, const uint64_t *send_displs, void *recv_dev,
+                             const uint64_t *recv_counts, const uint64_t *recv_displs, uint32_t elem_bytes, hipStream_t s) {
+    kmu_comm *c = ctx->comm;
     if (c->a2a) {
         KMU_HIP(ctx, hipStreamSynchronize(s));
         const auto t0 = std::chrono::steady_clock::now();

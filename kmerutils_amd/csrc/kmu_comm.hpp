@@ -28,6 +28,7 @@ struct kmu_comm {
     // to find a CU under the persistent sketch kernels; the host's all-gather (or RCCL's) carries the handles and closes the exchange
     bool copy = false;
     bool copy_pending = false; // copies of an exchange are enqueued, the closing barrier has not run yet
+    bool carrier_pending = false; // an exchange of the COPY transport went through the other data path (a rank could not export its buffer)
     struct Peer {
         hipIpcMemHandle_t handle{};
         void *base = nullptr; // the peer's receive buffer as this process sees it
