@@ -428,7 +428,9 @@ int kmu_comm_init_custom(kmu_ctx *ctx, int rank, int nranks, kmu_alltoallv_fn al
  * a CU under the persistent sketch kernels a step runs the exchange under (RCCL's send / receive kernels do: measured on one GPU,
  * profiles/r05_reserve.txt).  The communicator's all-gather (RCCL's, or the host's) carries the handles and closes the exchange with
  * a host barrier.  One node only.  kmu_comm_set_transport(ctx, KMU_TRANSPORT_COPY) switches an existing communicator over (every
- * rank alike, between exchanges); kmu_comm_init_custom with alltoallv == NULL creates one that has only this transport. */
+ * rank alike, between exchanges); kmu_comm_init_custom with alltoallv == NULL creates one that has only this transport.  An exchange
+ * for which some rank cannot export its receive buffer goes -- on every rank: all read the same published rows -- through the
+ * communicator's other data path (RCCL, or the host's all-to-all) if it has one, and fails with KMU_E_RCCL otherwise. */
 typedef enum kmu_transport { KMU_TRANSPORT_DEFAULT = 0 /* RCCL, or the host's all-to-all function */, KMU_TRANSPORT_COPY = 1 } kmu_transport;
 int kmu_comm_set_transport(kmu_ctx *ctx, int transport);
 int kmu_comm_transport(const kmu_ctx *ctx); /* kmu_transport of the context's communicator */
