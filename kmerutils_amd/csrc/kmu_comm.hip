@@ -119,7 +119,8 @@ static int copy_alltoallv(kmu_ctx *ctx, const void *send_dev, const uint64_t *se
     mine[1] = (uint64_t) (uintptr_t) recv_dev;
     if (n_in && recv_dev) {
         hipIpcMemHandle_t h;
-        if (hipIpcGetMemHandle(&h, recv_dev) == hipSuccess) {
+        const char *nx = getenv("KMU_COMM_NO_EXPORT"); // tests: this rank's export "fails"
+        if (!(nx && atoi(nx) == c->rank) && hipIpcGetMemHandle(&h, recv_dev) == hipSuccess) {
             mine[2] = 1;
             memcpy(&mine[3 + N], &h, sizeof h);
         } else {

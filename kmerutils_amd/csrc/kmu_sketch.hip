@@ -396,8 +396,7 @@ static int launch_pmh3a(kmu_ctx *ctx, const kmu_sketch_params *p, const DevSeqs 
             for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double) ph[i] / (tot > 0 ? tot : 1));
             fprintf(stderr, "  (%.3g clocks)\n", tot);
         }
-        const char *uq2_env = getenv("KMU_PMH_UQ2"); // 0: no second shape (A/B)
-        if (n_long && !(uq2_env && atoi(uq2_env) == 0)) { // the second shape: reads of up to 20 480 k-mers, from the first one's list
+        if (n_long) { // the second shape: reads of up to 20 480 k-mers, from the first one's list
             const auto kb = k_multiset_uq<1024, UQ2_BM, UQ2_COLL, 4>;
             const size_t lds_b = UqShape<1024, UQ2_BM, UQ2_COLL>::LDS;
             void *rl2;

@@ -313,7 +313,10 @@ def init_comm(ctx, group=None, transport=None):
     elif transport == "copy+torch":  # the copy transport over the process group's all-gather (ranks that share a GPU: RCCL refuses those)
         tt = TorchTransport(group, torch.device("cuda", ctx.device_id))
         ctx._transport = tt
-        ctx.comm_init_custom(rank, world, None, tt.allgather)
+        # (the group's all-to-all stays the communicator's other data path: an exchange whose buffers cannot be exported takes it)
+        ctx.comm_init_custom(rank, world, tt.alltoallv, tt.allgather)
+        from . import _abi as A
+        ctx.comm_set_transport(A.TRANSPORT_COPY)
     else:
         tt = TorchTransport(group, torch.device("cuda", ctx.device_id))
         ctx._transport = tt
