@@ -60,9 +60,13 @@ __device__ __forceinline__ uint32_t pack16_ascii(uint4 v, uint32_t &bad) {
 // amino acids (src/aautils/kmeraa.rs:85-109): 5-bit codes, upper case only, Q = 15, no 14; 0 = invalid
 __device__ __forceinline__ uint32_t code_aa(uint32_t c) {
     // index by (c - 'A'): A B C D E F G H I J K L M N O P Q R S T U V W X Y Z
-    const uint8_t tab[26] = {1, 0, 2, 3, 4, 5, 6, 7, 8, 0, 9, 10, 11, 12, 0, 13, 15, 16, 17, 18, 0, 19, 20, 0, 21, 0};
-    uint32_t i = c - 'A';
-    return i < 26u ? tab[i] : 0u;
+    //                     1 0 2 3 4 5 6 7 8 0 9 10 11 12 0 13 15 16 17 18 0 19 20 0 21 0
+    // as 5-bit fields of three constants (twelve letters each): a table in memory is a load per residue with a per-lane address --
+    // twelve of them per k-mer in wave_step_kmers_aa, next to the twelve loads of the residues themselves
+    const uint32_t i = c - 'A';
+    const uint64_t t = i < 12u ? 0x52408398a418801ull : i < 24u ? 0x52609460f6818bull : 0x15ull;
+    const uint32_t f = i < 12u ? i : i < 24u ? i - 12u : (i - 24u) & 1u; // (a shift below 64 whatever the byte)
+    return i < 26u ? (uint32_t) (t >> (5u * f)) & 31u : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------------
